@@ -1,0 +1,232 @@
+/*
+ * imgenv.h -- C ABI of the MI355X-native batched img_env step() path.
+ *
+ * This is the drop-in boundary.  In the reference the step() path sits behind four ROS
+ * services advertised by EnvService (reference src/img_env/src/img_env.cpp:716-754):
+ *
+ *   ~init_image_env   (src/comn_pkg/srv/InitEnv.srv:1-21)   -> imgenv_create()
+ *   ~reset_image_env  (src/comn_pkg/srv/ResetEnv.srv:1-8)   -> imgenv_reset()
+ *   ~step_image_env   (src/comn_pkg/srv/StepEnv.srv:1-5)    -> imgenv_step()
+ *   ~ep_end_image_env (src/comn_pkg/srv/EndEp.srv)          -> (episode recording: out of scope)
+ *
+ * and the Python post-processing of the response (reference envs/env/yaml_env.py:392-481,
+ * envs/wrapper/base.py:153-254) which this library also performs on the device, so the
+ * outputs are the fields of ImageState (envs/state/state.py:4-28) plus rewards/dones.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*
+ *    (NULL = default stream).
+ *  - every function returns 0 on success, a negative IMGENV_E* code on error; it never
+ *    aborts.  imgenv_last_error() gives a thread-local message.  (The reference handlers
+ *    always `return true`, img_env.cpp:726-754; Python raises on ServiceException,
+ *    yaml_env.py:304-311, 367-370.)
+ *  - all *input* pointers are HOST pointers and are copied during the call, except
+ *    `actions` of the step functions and `records` (see below) which are DEVICE pointers.
+ *  - all *output* pointers handed out by imgenv_outputs() are DEVICE pointers owned by the
+ *    handle, valid until imgenv_destroy(); their contents are valid after the stream work of
+ *    the last reset/step has completed and are overwritten by the next step.
+ *  - one handle is one world (one ImgEnv node, img_env.h:171-172) and is single-threaded
+ *    like the node (ros::spin, img_env_node.cpp:8); distinct handles are independent.
+ *  - fields that are float32 in the ROS messages are `float` here and are promoted to
+ *    double inside exactly where the node reads them (img_env.cpp:58-81, 113-160), so the
+ *    wire rounding of the reference is reproduced by construction.
+ */
+#ifndef IMGENV_H_
+#define IMGENV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMGENV_ABI_VERSION 1
+
+/* error codes */
+#define IMGENV_OK 0
+#define IMGENV_EINVAL (-1)    /* bad argument / unsupported configuration */
+#define IMGENV_ENOMEM (-2)    /* host or device allocation failed */
+#define IMGENV_EDEVICE (-3)   /* HIP runtime error (no device, launch failure, ...) */
+#define IMGENV_ESTATE (-4)    /* call out of order (step before reset, ...) */
+
+/* Agent.msg `shape` (src/comn_pkg/msg/Agent.msg:5; agent.cpp:64-77, 666-685) */
+#define IMGENV_SHAPE_CIRCLE 0    /* size = [cx, cy, r]            agent.cpp:18-30  */
+#define IMGENV_SHAPE_RECTANGLE 1 /* size = [xmin, xmax, ymin, ymax] agent.cpp:51-62 */
+#define IMGENV_SHAPE_LEG 2       /* size = [lx, ly, lr, rx, ry, rr] agent.cpp:666-680 */
+
+/* Env.msg `ped_scene_type` (scenefactory.h:8-24) */
+#define IMGENV_SCENE_EMPTY 0
+#define IMGENV_SCENE_RVO 1     /* "rvoscene"  rvoscene.h  */
+#define IMGENV_SCENE_ERVO 2    /* "ervoscene" ervoscene.h */
+#define IMGENV_SCENE_PEDSIM 3  /* "pedscene"  pedscene.h  */
+
+/* Agent.msg `ktype` of robots (agent.cpp:198, 238) */
+#define IMGENV_KTYPE_DIFF 0
+#define IMGENV_KTYPE_OMNI 1
+
+/* comn_pkg/msg/SpeedLimiter.msg:1-9 (speed_limit.cpp:56-65) */
+typedef struct imgenv_limiter {
+    int32_t has_velocity_limits;
+    int32_t has_acceleration_limits;
+    int32_t has_jerk_limits;
+    float min_velocity, max_velocity;
+    float min_acceleration, max_acceleration;
+    float min_jerk, max_jerk;
+} imgenv_limiter;
+
+/*
+ * Everything InitEnv.srv carries plus the static ImageEnv / wrapper parameters that the
+ * Python side of the reference keeps (yaml_env.py:133-181, base.py:153-231).
+ */
+typedef struct imgenv_cfg {
+    int32_t abi_version;          /* must be IMGENV_ABI_VERSION */
+    int32_t struct_size;          /* sizeof(imgenv_cfg), ABI guard */
+
+    /* ---- InitEnv.srv:1-20 (img_env.cpp:58-81) ---- */
+    float view_resolution;        /* metres / cell of BOTH grids after load (grid_map.cpp:28-38) */
+    float view_width, view_height;/* view extent in metres (agent.cpp:79-90) */
+    float step_hz;                /* YAML control_hz: the step dt in seconds (img_env.cpp:80) */
+    int32_t state_dim;            /* 3 | 4 | 5 (agent.cpp:163-183) */
+    int32_t use_laser;
+    int32_t range_total;          /* number of beams */
+    float view_angle_begin, view_angle_end;
+    float view_min_dist, view_max_dist;
+    float beep_r, ped_ca_p;       /* never forwarded by yaml_env.py:183-200 => 0 */
+    int32_t relation_ped_robo;    /* 1: robots are agents of the pedestrian simulator */
+
+    /* ---- Env.msg ---- */
+    float global_resolution;      /* must equal view_resolution (identity load resize) */
+    int32_t ped_scene_type;       /* IMGENV_SCENE_* */
+    int32_t n_robots;             /* robots of the WORLD (all shards) */
+    int32_t n_peds;
+    int32_t robot_ktype;          /* IMGENV_KTYPE_* */
+    const int32_t* robot_shape;   /* [n_robots] IMGENV_SHAPE_* */
+    const float* robot_size;      /* [n_robots][4]  Agent.msg size[] */
+    const float* robot_sensor_cfg;/* [n_robots][2]  Agent.msg sensor_cfg[] */
+    imgenv_limiter limiter_v, limiter_w;
+    const int32_t* ped_shape;     /* [n_peds] */
+    const float* ped_size;        /* [n_peds][6] */
+    const float* ped_max_speed;   /* [n_peds] */
+
+    /* ---- Python-side ImageEnv parameters (yaml_env.py:133-181) ---- */
+    int32_t image_size[2];        /* must equal the native view size (identity cv2.resize) */
+    int32_t ped_image_size[2];
+    int32_t max_ped;              /* ped vector has 1 + ped_vec_dim*max_ped entries; n_peds <= max_ped */
+    int32_t ped_vec_dim;          /* 7 */
+    double ped_image_r;
+    double laser_max;
+    int32_t laser_norm;
+    const double* robot_size_last;/* [n_robots] YAML robot.size[i][-1] as the Python float (yaml_env.py:407) */
+
+    /* ---- wrapper parameters (base.py:153-231) ---- */
+    double ped_safety_space;
+    int32_t time_max;
+
+    /* ---- robot shard owned by this handle (multi-GPU, one process per GPU) ---- */
+    int32_t robot_begin, robot_end; /* [begin, end) within the world's robots; 0,n_robots = unsharded */
+
+    /* ---- implementation knobs ---- */
+    int32_t device;               /* HIP device ordinal */
+    int32_t flags;                /* IMGENV_FLAG_* */
+} imgenv_cfg;
+
+#define IMGENV_FLAG_PRIVATE_GRIDS 1 /* oracle only: literal per-robot grid copies (img_env.cpp:620-629) */
+
+/* ResetEnv.srv:1-6 (img_env.cpp:162-292).  Poses are (x, y, qz, qw): geometry_msgs/Pose with a
+ * planar orientation; yaw is recovered with tf::Matrix3x3(q).getRPY as the node does. */
+typedef struct imgenv_reset_batch {
+    int32_t struct_size;
+    int32_t n_obstacles;
+    const int32_t* obs_shape;     /* [n_obstacles] */
+    const float* obs_size;        /* [n_obstacles][4] */
+    const double* obs_pose;       /* [n_obstacles][4] */
+    const double* robot_pose;     /* [n_robots][4]  (whole world) */
+    const double* robot_goal;     /* [n_robots][2] */
+    const double* ped_pose;       /* [n_peds][4] */
+    const double* ped_goal;       /* [n_peds][2] */
+    const int32_t* ped_traj_len;  /* [n_peds] */
+    const double* ped_traj;       /* [n_peds][ped_traj_cap][3]  Agent.msg trajectory (x, y, z) */
+    int32_t ped_traj_cap;
+    int32_t ignore_obstacle;
+} imgenv_reset_batch;
+
+/* Device pointers of the per-robot outputs, R = robot_end - robot_begin local robots.
+ * Field meaning follows ImageState (envs/state/state.py:4-28) and _get_states
+ * (yaml_env.py:446-481). */
+typedef struct imgenv_out {
+    int32_t struct_size;
+    int32_t n_local;              /* R */
+    int32_t view_h, view_w;       /* Hv, Wv */
+    int32_t n_beams;              /* B (0 when !use_laser) */
+    int32_t state_dim;
+    int32_t ped_vec_len;          /* 1 + ped_vec_dim*max_ped */
+    float* vector_states;         /* [R][state_dim]      AgentState.state (float32 wire) */
+    uint8_t* view_maps;           /* [R][Hv][Wv]         AgentState.view_map (8UC1) */
+    uint16_t* sensor_maps;        /* [R][Hv][Wv] float16 bits = view/255 (yaml_env.py:431-438) */
+    float* lasers_raw;            /* [R][B]              AgentState.laser */
+    double* lasers;               /* [R][B]              _norm_lasers (yaml_env.py:440-444) */
+    float* ped_vector_states;     /* [R][ped_vec_len] */
+    float* ped_maps;              /* [R][3][Hp][Wp] */
+    int8_t* is_collisions;        /* [R]  AgentState.is_collision 0..3 */
+    uint8_t* is_arrives;          /* [R] */
+    double* step_ds;              /* [R] */
+    double* ped_min_dists;        /* [R] (+inf until a ped has been seen) */
+    /* ImageEnv.step base outputs (yaml_env.py:372-377) */
+    int32_t* base_rewards;        /* [R] arrive - collision code */
+    uint8_t* base_dones;          /* [R] */
+    /* wrapper stack outputs (base.py:153-254, 69-93) */
+    double* rewards;              /* [R] SensorsPaperRewardWrapper, zeroed where !is_clean */
+    uint8_t* dones;               /* [R] after TimeLimitWrapper */
+    int32_t* dones_info;          /* [R] 0 | 1..3 collision class | 5 arrive | 10 time-out */
+    uint8_t* is_clean;            /* [R] MultiRobotCleanWrapper mask used for this step */
+    /* simulator state mirrors, handy for tests and GUIs */
+    double* robot_pose;           /* [R][3] x, y, theta */
+    double* ped_state;            /* [n_peds][4] x, y, vx, vy (world copy) */
+    int32_t* counters;            /* [4]: steps since reset, #done robots (local), #frozen views (local), reserved */
+} imgenv_out;
+
+typedef struct imgenv imgenv_t;
+
+/* library / build identification: "hip-gfx950" for the product library */
+const char* imgenv_backend(void);
+int32_t imgenv_abi_version(void);
+const char* imgenv_last_error(void);
+
+/* init_image_env: builds all per-class static tables (footprints, FOV mask, ray tables) and
+ * uploads the static occupancy grid (uint8, row-major [Hg][Wg], rows <-> world x;
+ * grid_map.cpp:40-55). */
+int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, int32_t Wg,
+                  imgenv_t** out);
+void imgenv_destroy(imgenv_t* h);
+
+/* reset_image_env: obstacles raster + ORCA obstacle tree + poses, then view + states. */
+int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* batch, void* stream);
+
+/* step_image_env + Python post-processing.  actions: DEVICE float[R][3] = (v, w, beep) of the
+ * local robots (ContinuousAction, envs/action/action.py:8-20).  Dead robots are zeroed
+ * inside (yaml_env.py:319-331). */
+int imgenv_step(imgenv_t* h, const float* actions, void* stream);
+
+/* The same step split around the one exchange a robot-sharded world needs:
+ *   step_begin : pedestrian advance + pose integrate of the local robots, publishes their
+ *                records into records[robot_begin:robot_end]
+ *   (caller all-gathers `records` in place across ranks, e.g. RCCL ncclAllGather)
+ *   step_end   : rasters + per-robot view/observation/reward kernels
+ * imgenv_step == step_begin; step_end when the handle owns the whole world. */
+int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream);
+int imgenv_step_end(imgenv_t* h, void* stream);
+/* records: DEVICE double[n_robots][IMGENV_RECORD_DOUBLES] = x, y, theta, vx, vy, (pad) */
+#define IMGENV_RECORD_DOUBLES 6
+int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_robot);
+/* reset counterpart of the exchange (robots' initial records are known to every rank from the
+ * batch, so reset needs no collective). */
+
+int imgenv_outputs(imgenv_t* h, imgenv_out* out);
+
+/* number of kernels launched by the last step and the name of the dominant one (bench / profiling aid) */
+int imgenv_step_launches(imgenv_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMGENV_H_ */
