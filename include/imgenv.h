@@ -128,6 +128,11 @@ typedef struct imgenv_cfg {
     /* ---- implementation knobs ---- */
     int32_t device;               /* HIP device ordinal */
     int32_t flags;                /* IMGENV_FLAG_* */
+    /* Optional caller-owned DEVICE arena for every output buffer and the records buffer, so a
+     * host framework can alias them zero-copy (e.g. slices of one torch uint8 tensor).  Size it
+     * with imgenv_arena_bytes(); NULL = the library allocates (and frees) its own. */
+    void* out_arena;
+    int64_t out_arena_bytes;
 } imgenv_cfg;
 
 #define IMGENV_FLAG_PRIVATE_GRIDS 1 /* oracle only: literal per-robot grid copies (img_env.cpp:620-629) */
@@ -197,6 +202,8 @@ const char* imgenv_last_error(void);
  * grid_map.cpp:40-55). */
 int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, int32_t Wg,
                   imgenv_t** out);
+/* bytes of output arena a handle created from `cfg` needs (256-byte aligned carve-outs) */
+int64_t imgenv_arena_bytes(const imgenv_cfg* cfg);
 void imgenv_destroy(imgenv_t* h);
 
 /* reset_image_env: obstacles raster + ORCA obstacle tree + poses, then view + states. */

@@ -27,6 +27,7 @@ int oracle_step_begin(oracle_world* w, const float* actions);
 int oracle_step_end(oracle_world* w);
 int oracle_records(oracle_world* w, double** records, int64_t* bytes_per_robot);
 int oracle_outputs(oracle_world* w, imgenv_out* out); /* host pointers */
+int oracle_pedinfo(oracle_world* w, float** pedinfo); /* [n_local][n_peds][5] px py vx vy r_ */
 /* class layer as robot `i` (world index) sees it: peds_map + other robots (img_env.cpp:620-629) */
 int oracle_private_grid(oracle_world* w, int32_t robot, uint8_t* dst);
 /* obs_map_ / peds_map_ (img_env.h:43-46) */

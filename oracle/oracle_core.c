@@ -89,7 +89,7 @@ struct oracle_world {
     double *gx, *gy, *l0v, *l0w, *l1v, *l1w;
     tf2d* world_target;
     int32_t* is_coll;
-    uint8_t *is_arr, *py_done;
+    uint8_t *is_arr, *py_done, *clean_state;
     uint8_t* view;
     double* hits;
     /* peds */
@@ -108,6 +108,7 @@ struct oracle_world {
     /* outputs */
     imgenv_out out;
     uint16_t f16_lut[256];
+    float* pedinfo; /* [RL][P][5] AgentState.pedinfo (px, py, vx, vy, r_) in pedestrian order, pre-sort */
 };
 
 /* ------------------------------------------------------------------ helpers */
@@ -464,6 +465,7 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     ALLOC(w->l0v, double, RL); ALLOC(w->l0w, double, RL); ALLOC(w->l1v, double, RL); ALLOC(w->l1w, double, RL);
     ALLOC(w->world_target, tf2d, RL);
     ALLOC(w->is_coll, int32_t, RL); ALLOC(w->is_arr, uint8_t, RL); ALLOC(w->py_done, uint8_t, RL);
+    ALLOC(w->clean_state, uint8_t, RL);
     ALLOC(w->view, uint8_t, (size_t)RL * w->Hv * w->Wv);
     ALLOC(w->hits, double, (size_t)RL * (w->B > 0 ? w->B : 1));
     int P = w->P;
@@ -510,9 +512,11 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     for (int l = 0; l < RL; l++) {
         o->ped_min_dists[l] = INFINITY; /* NearbyPed (reset_helper.py:85-99), never re-initialised */
         o->is_clean[l] = 1;
+        w->clean_state[l] = 1;
     }
     /* numpy: uint8.astype('float16') / 255.0 evaluates in float32 and rounds to float16 */
     for (int v = 0; v < 256; v++) w->f16_lut[v] = f32_to_f16((float)v / 255.0f);
+    ALLOC(w->pedinfo, float, (size_t)RL * P * 5);
     *out = w;
     return IMGENV_OK;
 }
@@ -528,11 +532,12 @@ void oracle_destroy(oracle_world* w) {
     free(w->rcls); free(w->pcls); free(w->robot_cls); free(w->ped_cls); free(w->robot_size_last);
     free(w->static_map); free(w->obs_map); free(w->peds_map); free(w->priv); free(w->own_lo); free(w->own_hi);
     free(w->rec); free(w->gx); free(w->gy); free(w->l0v); free(w->l0w); free(w->l1v); free(w->l1w);
-    free(w->world_target); free(w->is_coll); free(w->is_arr); free(w->py_done); free(w->view); free(w->hits);
+    free(w->world_target); free(w->is_coll); free(w->is_arr); free(w->py_done); free(w->clean_state); free(w->view); free(w->hits);
     free(w->ppx); free(w->ppy); free(w->pyaw); free(w->plx); free(w->ply); free(w->pvx); free(w->pvy);
     free(w->prem); free(w->llx); free(w->lly); free(w->rlx); free(w->rly); free(w->pr_round);
     free(w->pstate); free(w->ptraj_idx); free(w->ptraj_len); free(w->ptraj); free(w->pmax_speed);
     free(w->tmp_dist);
+    free(w->pedinfo);
     rvo_destroy(w->rvo);
     sfm_destroy(w->sfm);
     imgenv_out* o = &w->out;
@@ -887,6 +892,8 @@ static void get_states(oracle_world* w) {
             pi[j].r = (float)w->pcls[w->ped_cls[j]].sizes[2];
             pi[j].key = pow((double)pi[j].px, 2.0) + pow((double)pi[j].py, 2.0); /* yaml_env.py:451 */
             pi[j].idx = j;
+            float* dbg = w->pedinfo + ((size_t)l * P + j) * 5;
+            dbg[0] = pi[j].px; dbg[1] = pi[j].py; dbg[2] = pi[j].vx; dbg[3] = pi[j].vy; dbg[4] = pi[j].r;
         }
         qsort(pi, (size_t)P, sizeof(pedinfo), cmp_pedinfo);
         /* _draw_ped_map (yaml_env.py:392-429) */
@@ -1026,7 +1033,8 @@ int oracle_reset(oracle_world* w, const imgenv_reset_batch* b) {
             w->is_coll[l] = 0;
             w->is_arr[l] = 0;
             w->py_done[l] = 0;       /* self.dones = zeros (yaml_env.py:316) */
-            w->out.is_clean[l] = 1;  /* MultiRobotCleanWrapper.reset (base.py:90-93) */
+            w->clean_state[l] = 1;   /* MultiRobotCleanWrapper.reset (base.py:90-93) */
+            w->out.is_clean[l] = 1;
             w->out.base_rewards[l] = 0;
             w->out.base_dones[l] = 0;
             w->out.rewards[l] = 0;
@@ -1258,13 +1266,14 @@ static void wrappers(oracle_world* w) {
         if (coll > 0) info = coll;
         if (arr == 1) info = 5;
         /* MultiRobotCleanWrapper.step (base.py:79-88): mask uses is_clean from BEFORE this step */
-        uint8_t clean_before = o->is_clean[l];
+        uint8_t clean_before = w->clean_state[l];
         if (!clean_before) reward = 0;
         o->rewards[l] = reward;
         o->dones[l] = (uint8_t)done;
         o->dones_info[l] = info;
-        /* is_clean reported = mask used for this step; state updated for the next one */
-        o->is_clean[l] = done > 0 ? 0 : clean_before;
+        /* info['is_clean'] = the mask used for this step; the state is updated for the next one */
+        o->is_clean[l] = clean_before;
+        w->clean_state[l] = done > 0 ? 0 : clean_before;
         if (done > 0) ndone++;
     }
     o->counters[0] = w->elapsed;
@@ -1303,6 +1312,13 @@ int oracle_records(oracle_world* w, double** records, int64_t* bytes_per_robot) 
     if (!w) FAIL(IMGENV_EINVAL, "null argument");
     if (records) *records = w->rec;
     if (bytes_per_robot) *bytes_per_robot = IMGENV_RECORD_DOUBLES * (int64_t)sizeof(double);
+    return IMGENV_OK;
+}
+
+/* AgentState.pedinfo of the local robots as the node would send it (img_env.cpp:568-584) */
+int oracle_pedinfo(oracle_world* w, float** pedinfo) {
+    if (!w || !pedinfo) FAIL(IMGENV_EINVAL, "null argument");
+    *pedinfo = w->pedinfo;
     return IMGENV_OK;
 }
 

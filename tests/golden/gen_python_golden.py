@@ -1,0 +1,150 @@
+"""Generate tests/golden/python_post_*.npz: golden vectors for the PYTHON half of the step() path.
+
+Run in the build container only (needs /root/reference):  python tests/golden/gen_python_golden.py
+
+The reference's own, unmodified Python runs here: ``envs.make_env(cfg)`` builds ``ImageEnv`` and its
+wrapper stack (VelAction, TimeLimit, SensorsPaperReward, InfoLog, MultiRobotClean); ``reset()`` and
+``step()`` execute ``_step_req``, ``_get_states``, ``_draw_ped_map``, reward / done logic exactly as
+shipped (envs/env/yaml_env.py:296-481, envs/wrapper/base.py:37-254).  The only thing replaced is the
+ROS service behind them: its part (the C++ node) is played by this repo's CPU oracle, whose
+AgentState outputs (state, laser, view_map, is_collision, is_arrive, pedinfo -- float32 on the wire)
+are recorded as the fixture's INPUTS.  The fixture's EXPECTED values are what the reference Python
+made of those inputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+from img_env_amd import config, worldgen  # noqa: E402
+from oracle_binding import OracleWorld  # noqa: E402
+
+
+def agent_states(world):
+    """AgentState[] as the node would serialise them (float32 fields -> python floats)"""
+    o = world.out
+    pi = world.pedinfo()
+    msgs = []
+    for l in range(world.n_local):
+        m = ref_import.Msg()
+        m.state = tuple(float(x) for x in o["vector_states"][l])
+        m.laser = tuple(float(x) for x in o["lasers_raw"][l]) if world.cfg.use_laser else ()
+        m.view_map = o["view_maps"][l].copy()
+        m.is_collision = int(o["is_collisions"][l])
+        m.is_arrive = bool(o["is_arrives"][l])
+        m.pedinfo = [ref_import.Msg(px=float(a[0]), py=float(a[1]), vx=float(a[2]), vy=float(a[3]), r_=float(a[4]))
+                     for a in pi[l]]
+        msgs.append(m)
+    return msgs
+
+
+def run(name, n_robots, n_peds, steps, seed, time_max, ped_shape="circle", state_dim=3, n_obstacles=2,
+        near_goals=False):
+    envs = ref_import.import_reference_envs()
+    grid = worldgen.make_grid(200, seed)
+    cfg = worldgen.make_yaml_cfg(n_robots, n_peds, grid, time_max=time_max, ped_shape=ped_shape, state_dim=state_dim,
+                                 n_obstacles=n_obstacles)
+    world = OracleWorld(config.params_from_cfg(cfg), grid)
+    layout = worldgen.make_layout(grid, 0.125, n_robots, n_peds, seed=seed + 100, n_obstacles=n_obstacles)
+    if near_goals:  # goals 0.9 m ahead of each robot so that arrivals (and the +500 reward) occur
+        yaw = 2.0 * np.arctan2(layout.robot_pose[:, 2], layout.robot_pose[:, 3])
+        layout.robot_goal = layout.robot_pose[:, :2] + 0.9 * np.stack([np.cos(yaw), np.sin(yaw)], 1)
+    rec_in, rec_alive = [], []
+
+    def record_inputs():
+        o = world.out
+        rec_in.append(dict(vector_states=o["vector_states"].copy(), lasers_raw=o["lasers_raw"].copy(),
+                           view_maps=o["view_maps"].copy(), is_collisions=o["is_collisions"].copy(),
+                           is_arrives=o["is_arrives"].copy(), pedinfo=world.pedinfo()))
+
+    def init_srv(req):
+        return ref_import.Msg()
+
+    def reset_srv(req):
+        world.reset(layout)
+        record_inputs()
+        return ref_import.Msg(robot_states=agent_states(world))
+
+    def step_srv(req):
+        # Agent.msg v / w / v_y are float32 on the wire
+        a = np.array([[np.float32(r.v), np.float32(r.w), np.float32(r.v_y)] for r in req.robots], np.float32)
+        rec_alive.append(np.array([bool(r.alive) for r in req.robots]))
+        world.step(a)
+        record_inputs()
+        return ref_import.Msg(robot_states=agent_states(world))
+
+    ref_import.SERVICES.update(init_image_env=init_srv, reset_image_env=reset_srv, step_image_env=step_srv)
+    ref_cfg = dict(cfg)
+    ref_cfg["global_map"] = dict(cfg["global_map"], map_array=None)
+    env = envs.make_env(ref_cfg)
+    keys = ("vector_states", "sensor_maps", "is_collisions", "is_arrives", "lasers", "ped_vector_states", "ped_maps",
+            "step_ds", "ped_min_dists")
+    exp = {k: [] for k in keys}
+    for k in ("rewards", "dones", "dones_info", "is_clean", "all_down", "speeds"):
+        exp[k] = []
+    ora = {k: [] for k in ("rewards", "dones", "dones_info", "is_clean", "step_ds", "ped_min_dists", "ped_maps",
+                           "ped_vector_states", "lasers", "sensor_maps", "base_rewards", "base_dones")}
+
+    def grab_state(st):
+        for k in keys:
+            exp[k].append(np.array(getattr(st, k)))
+
+    def grab_oracle():
+        for k in ora:
+            ora[k].append(world.out[k].copy())
+
+    st = env.reset()
+    grab_state(st)
+    grab_oracle()
+    rng = np.random.default_rng(seed + 7)
+    actions_all = []
+    for s in range(steps):
+        act = np.stack([rng.uniform(-0.1, 0.7, n_robots), rng.uniform(-1.0, 1.0, n_robots)], 1)
+        if near_goals:
+            act = np.stack([rng.uniform(0.2, 0.6, n_robots), rng.uniform(-0.2, 0.2, n_robots)], 1)
+        actions_all.append(act)
+        st, rew, done, info = env.step(act)
+        grab_state(st)
+        grab_oracle()
+        exp["rewards"].append(np.array(rew, np.float64))
+        exp["dones"].append(np.array(done))
+        exp["dones_info"].append(np.array(info["dones_info"]))
+        exp["is_clean"].append(np.array(info["is_clean"]))
+        exp["all_down"].append(np.array(info["all_down"]))
+        exp["speeds"].append(np.array(info["speeds"], np.float64))
+    out = {"in_" + k: np.stack([r[k] for r in rec_in]) for k in rec_in[0]}
+    out["in_alive"] = np.stack(rec_alive)
+    out["actions"] = np.stack(actions_all)
+    for k, v in exp.items():
+        out["exp_" + k] = np.stack(v)
+    # how far the oracle's own Python-half restatement is from the reference Python, for the log
+    for k in ("step_ds", "ped_min_dists", "ped_maps", "ped_vector_states", "lasers", "sensor_maps"):
+        a, b = np.stack(ora[k]).astype(np.float64), out["exp_" + k].astype(np.float64)
+        fin = np.isfinite(a) & np.isfinite(b)
+        print("  %-18s max|oracle-ref| = %.3g   (inf pattern equal: %s)" % (k, np.abs(a[fin] - b[fin]).max() if fin.any() else 0,
+                                                                           np.array_equal(np.isfinite(a), np.isfinite(b))))
+    for k in ("rewards", "dones", "dones_info", "is_clean"):
+        a, b = np.stack(ora[k][1:]).astype(np.float64), out["exp_" + k].astype(np.float64)
+        print("  %-18s max|oracle-ref| = %.3g" % (k, np.abs(a - b).max()))
+    meta = dict(n_robots=n_robots, n_peds=n_peds, steps=steps, seed=seed, time_max=time_max, ped_shape=ped_shape,
+                state_dim=state_dim, n_obstacles=n_obstacles, near_goals=near_goals)
+    out["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, "python_post_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KiB) collisions=%s arrives=%s" % (path, os.path.getsize(path) / 1024,
+                                                           out["in_is_collisions"][-1], out["in_is_arrives"][-1]))
+    world.close()
+
+
+if __name__ == "__main__":
+    run("a", n_robots=6, n_peds=5, steps=30, seed=3, time_max=24)
+    run("b", n_robots=4, n_peds=7, steps=16, seed=11, time_max=100, ped_shape="leg", state_dim=5)
+    run("c", n_robots=3, n_peds=0, steps=8, seed=5, time_max=100, state_dim=4, n_obstacles=0)
+    run("d", n_robots=5, n_peds=3, steps=12, seed=21, time_max=100, near_goals=True)
