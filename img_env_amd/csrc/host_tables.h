@@ -1,0 +1,411 @@
+// host_tables.h -- pose-independent tables of a robot / pedestrian class, computed once on the
+// host at imgenv_create() with the host libm (the same glibc the reference node links), and the
+// host part of reset (obstacle raster, RVO obstacle BSP).
+//
+// Why tables: in Agent::view (agent.cpp:356-509) the field-of-view gate of the crop, the
+// Bresenham path of every beam and the cells of the robot's own footprint depend only on the
+// view geometry, the sensor offset and the footprint -- not on the pose.  The reference recomputes
+// them per robot per step (one atan2 per view cell, one sin/cos + line walk per beam); here they are
+// evaluated once with the reference's formulas and the kernels replay them.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/imgenv.h"
+#include "tfm.h"
+
+struct Pts {
+    std::vector<double> x, y;
+    int n() const { return (int)x.size(); }
+};
+
+// Agent::init_shape_circle (agent.cpp:18-30)
+static Pts shape_circle(double cx, double cy, double r) {
+    Pts p;
+    const double resolution = 0.01;
+    const int bb = (int)ceil(r / resolution);
+    for (int m = -bb; m <= bb; m++)
+        for (int n = -bb; n <= bb; n++)
+            if (sqrt(m * resolution * m * resolution + n * resolution * n * resolution) <= r) {
+                p.x.push_back(m * resolution + cx);
+                p.y.push_back(n * resolution + cy);
+            }
+    return p;
+}
+
+// Agent::init_shape_rectangle (agent.cpp:51-62)
+static Pts shape_rectangle(const double* s) {
+    Pts p;
+    const double resolution = 0.01;
+    const int x_min = (int)floor(s[0] / resolution), x_max = (int)ceil(s[1] / resolution);
+    const int y_min = (int)floor(s[2] / resolution), y_max = (int)ceil(s[3] / resolution);
+    for (int m = x_min; m <= x_max; m++)
+        for (int n = y_min; n <= y_max; n++) {
+            p.x.push_back(m * resolution);
+            p.y.push_back(n * resolution);
+        }
+    return p;
+}
+
+struct ViewGeom {
+    double res, view_w, view_h, a_begin, a_end, min_d, max_d;
+    int Hv, Wv, B, use_laser, range_total;
+    Tf2 view_base, base_view;
+};
+
+// Agent::init_view_map (agent.cpp:79-90)
+static ViewGeom make_view_geom(const imgenv_cfg& c) {
+    ViewGeom g;
+    g.res = (double)c.view_resolution;
+    g.view_w = (double)c.view_width;
+    g.view_h = (double)c.view_height;
+    g.a_begin = (double)c.view_angle_begin;
+    g.a_end = (double)c.view_angle_end;
+    g.min_d = (double)c.view_min_dist;
+    g.max_d = (double)c.view_max_dist;
+    g.Wv = (int)(g.view_w / g.res);
+    g.Hv = (int)(g.view_h / g.res);
+    g.use_laser = c.use_laser;
+    g.range_total = c.range_total;
+    g.B = c.use_laser ? c.range_total : 0;
+    g.view_base.ox = g.view_h / 2;
+    g.view_base.oy = g.view_w / 2;
+    const double half = 3.14159 * 0.5;
+    tf_set_rotation_zw(g.view_base, sin(half), cos(half));
+    g.base_view = tf_inverse(g.view_base);
+    return g;
+}
+
+struct RobotClassHost {
+    int shape;
+    float size[4], sensor[2];
+    double sizes[4], sx, sy;
+    Pts fp;
+    std::vector<uint32_t> fov_bits, stamp_bits;
+    int ray_maxlen = 0, ray_stride = 0, box_rad = 0;
+    std::vector<uint16_t> ray_cells, ray_len;
+    std::vector<float> ray_dist;
+    std::vector<uint32_t> inv_off, inv_ent;
+};
+
+static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
+    for (int j = 0; j < 4; j++) k.sizes[j] = (double)k.size[j];
+    k.sx = (double)k.sensor[0];
+    k.sy = (double)k.sensor[1];
+    k.fp = k.shape == IMGENV_SHAPE_CIRCLE ? shape_circle(k.sizes[0], k.sizes[1], k.sizes[2]) : shape_rectangle(k.sizes);
+    const int Hv = g.Hv, Wv = g.Wv, NC = Hv * Wv, NW = (NC + 31) / 32;
+    const double res = g.res;
+    // crop gate (agent.cpp:373-386)
+    k.fov_bits.assign(NW, 0);
+    for (int a = 0; a < Hv; a++)
+        for (int b = 0; b < Wv; b++) {
+            double xb, yb;
+            tf_apply(g.view_base, a * res, b * res, xb, yb);
+            const double ang = atan2(yb - k.sy, xb - k.sx);
+            if (ang <= g.a_begin || ang >= g.a_end || xb < g.min_d || xb > g.max_d) continue;
+            const int c = a * Wv + b;
+            k.fov_bits[c >> 5] |= 1u << (c & 31);
+        }
+    // own footprint in the view (agent.cpp:503, 307-312)
+    k.stamp_bits.assign(NW, 0);
+    double ext = 0;
+    for (int q = 0; q < k.fp.n(); q++) {
+        double vx, vy;
+        tf_apply(g.base_view, k.fp.x[q], k.fp.y[q], vx, vy);
+        const int m = w2m(vx, res), n = w2m(vy, res);
+        if (m >= 0 && m < Hv && n >= 0 && n < Wv) {
+            const int c = m * Wv + n;
+            k.stamp_bits[c >> 5] |= 1u << (c & 31);
+        }
+        ext = std::max(ext, sqrt(k.fp.x[q] * k.fp.x[q] + k.fp.y[q] * k.fp.y[q]));
+    }
+    k.box_rad = (int)ceil(ext / res) + 2;
+    // laser ray paths (agent.cpp:366-369, 405-438, 511-624)
+    const int B = g.B;
+    k.ray_stride = ((B + WAVE_SZ - 1) / WAVE_SZ) * WAVE_SZ;
+    if (k.ray_stride == 0) k.ray_stride = WAVE_SZ;
+    k.ray_len.assign(k.ray_stride, 0);
+    std::vector<std::vector<uint16_t>> cells(B);
+    std::vector<std::vector<float>> dists(B);
+    if (B > 0) {
+        double sxv, syv;
+        tf_apply(g.base_view, k.sx, k.sy, sxv, syv);
+        const int x1 = w2m(sxv, res), y1 = w2m(syv, res);
+        const double x0w = x1 * res, y0w = y1 * res;
+        const double map_width = g.base_view.ox, map_height = g.base_view.oy;
+        const double max_range = sqrt(map_width * map_width + map_height * map_height);
+        const double angle_step = fabs(g.a_end - g.a_begin) / g.range_total;
+        for (int b = 0; b < B; b++) {
+            const double cur = g.a_begin + angle_step * b;
+            const double x = max_range * cos(cur), y = max_range * sin(cur);
+            double vx, vy;
+            tf_apply(g.base_view, x, y, vx, vy);
+            const int x2 = w2m(vx, res), y2 = w2m(vy, res);
+            int wv = x2 - x1, hv = y2 - y1;
+            const int dx = ((wv > 0) << 1) - 1, dy = ((hv > 0) << 1) - 1;
+            wv = abs(wv);
+            hv = abs(hv);
+            const bool steep = !(wv > hv);
+            int f, d1, d2;
+            if (!steep) {
+                f = 2 * hv - wv; d1 = 2 * hv; d2 = (hv - wv) * 2;
+            } else {
+                f = 2 * wv - hv; d1 = wv * 2; d2 = (wv - hv) * 2;
+            }
+            int xx = x1, yy = y1;
+            while (steep ? (yy != y2) : (xx != x2)) {
+                if (!(xx >= 0 && xx < Hv && yy >= 0 && yy < Wv)) break;  // "else return hit"
+                cells[b].push_back((uint16_t)(xx * Wv + yy));
+                const double cx = xx * res, cy = yy * res;
+                dists[b].push_back((float)sqrt((x0w - cx) * (x0w - cx) + (y0w - cy) * (y0w - cy)));
+                if (f < 0) {
+                    f += d1;
+                } else {
+                    if (steep) xx += dx; else yy += dy;
+                    f += d2;
+                }
+                if (steep) yy += dy; else xx += dx;
+            }
+            k.ray_len[b] = (uint16_t)cells[b].size();
+            k.ray_maxlen = std::max(k.ray_maxlen, (int)cells[b].size());
+        }
+    }
+    if (k.ray_maxlen == 0) k.ray_maxlen = 1;
+    k.ray_cells.assign((size_t)k.ray_maxlen * k.ray_stride, 0xFFFF);
+    k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
+    std::vector<std::vector<uint32_t>> inv(NC);
+    for (int b = 0; b < B; b++)
+        for (size_t q = 0; q < cells[b].size(); q++) {
+            k.ray_cells[q * k.ray_stride + b] = cells[b][q];
+            k.ray_dist[q * k.ray_stride + b] = dists[b][q];
+            inv[cells[b][q]].push_back(((uint32_t)b << 16) | (uint32_t)q);
+        }
+    k.inv_off.assign(NC + 1, 0);
+    for (int c = 0; c < NC; c++) {
+        std::sort(inv[c].begin(), inv[c].end(), [](uint32_t a, uint32_t b) { return a > b; });  // beam descending
+        k.inv_off[c + 1] = k.inv_off[c] + (uint32_t)inv[c].size();
+    }
+    k.inv_ent.reserve(k.inv_off[NC] + 1);
+    for (int c = 0; c < NC; c++) k.inv_ent.insert(k.inv_ent.end(), inv[c].begin(), inv[c].end());
+    if (k.inv_ent.empty()) k.inv_ent.push_back(0);
+}
+
+struct PedClassHost {
+    int shape;
+    float size[6];
+    double sizes[6];
+    Pts bbox, left, right;
+};
+
+// PedAgent::init_shape (agent.cpp:666-685)
+static void build_ped_class(PedClassHost& k) {
+    for (int j = 0; j < 6; j++) k.sizes[j] = (double)k.size[j];
+    if (k.shape == IMGENV_SHAPE_LEG) {
+        k.left = shape_circle(0, 0, k.sizes[2]);
+        k.right = shape_circle(0, 0, k.sizes[5]);
+    } else if (k.shape == IMGENV_SHAPE_CIRCLE) {
+        k.bbox = shape_circle(k.sizes[0], k.sizes[1], k.sizes[2]);
+    } else {
+        k.bbox = shape_rectangle(k.sizes);
+    }
+}
+
+// Python round(x, 2) (float.__round__ is a correctly rounded decimal rounding)
+static double py_round2(double x) {
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%.2f", x);
+    return strtod(buf, nullptr);
+}
+
+// numpy float32 -> float16, round to nearest even
+static uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const uint32_t shift = (uint32_t)(14 - e);
+        uint32_t hm = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    const uint32_t hm = m >> 13, rem = m & 0x1fffu;
+    uint16_t h = (uint16_t)(sign | ((uint32_t)e << 10) | hm);
+    if (rem > 0x1000u || (rem == 0x1000u && (hm & 1))) h++;
+    return h;
+}
+
+// Agent::draw(obs_map, 0, "world_map") for an obstacle at reset (img_env.cpp:169-193, agent.cpp:285-327)
+static void draw_obstacle(uint8_t* grid, int Hg, int Wg, double res, const Tf2& bw, const Pts& bb) {
+    for (int q = 0; q < bb.n(); q++) {
+        double wx, wy;
+        tf_apply(bw, bb.x[q], bb.y[q], wx, wy);
+        const int m = w2m(wx, res), n = w2m(wy, res);
+        if (m >= 0 && m < Hg && n >= 0 && n < Wg) {
+            uint8_t& c = grid[(size_t)m * Wg + n];
+            if (c != 0 && c != 1 && c != 2) c = 0;
+        }
+    }
+}
+
+// Agent::get_corners (agent.cpp:626-651)
+static void get_corners(int shape, const double* s, const Tf2& bw, double& pax, double& pay, double& pbx, double& pby) {
+    if (shape == IMGENV_SHAPE_CIRCLE) {
+        tf_apply(bw, s[0] - s[2], s[1] - s[2], pax, pay);
+        tf_apply(bw, s[0] + s[2], s[1] + s[2], pbx, pby);
+    } else {
+        tf_apply(bw, s[0], s[2], pax, pay);
+        tf_apply(bw, s[1], s[3], pbx, pby);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RVO2 obstacle list + BSP tree, host side (RVOSimulator::addObstacle RVOSimulator.cpp:130-170,
+// KdTree::buildObstacleTree KdTree.cpp:119-257), float32 like the reference.  Built at reset,
+// uploaded as flat arrays; the device replays KdTree::queryObstacleTreeRecursive on them.
+struct RvoObstHost {
+    float px, py, ux, uy;
+    int is_convex, next, prev;
+};
+struct RvoNodeHost {
+    int obstacle, left, right;
+};
+
+struct RvoObstacles {
+    std::vector<RvoObstHost> ob;
+    std::vector<RvoNodeHost> nodes;
+    int root = -1;
+
+    static float det(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+    float left_of(int a, int b, int c) const {  // leftOf(a, b, c) = det(a - c, b - a)
+        return det(ob[a].px - ob[c].px, ob[a].py - ob[c].py, ob[b].px - ob[a].px, ob[b].py - ob[a].py);
+    }
+
+    void clear() {
+        ob.clear();
+        nodes.clear();
+        root = -1;
+    }
+
+    void add(const float* xy, int n) {
+        const int first = (int)ob.size();
+        for (int i = 0; i < n; i++) {
+            RvoObstHost o;
+            o.px = xy[2 * i];
+            o.py = xy[2 * i + 1];
+            o.next = o.prev = -1;
+            const int k = (int)ob.size();
+            if (i != 0) {
+                o.prev = k - 1;
+                ob[k - 1].next = k;
+            }
+            const int inext = (i == n - 1 ? 0 : i + 1), iprev = (i == 0 ? n - 1 : i - 1);
+            const float dx = xy[2 * inext] - xy[2 * i], dy = xy[2 * inext + 1] - xy[2 * i + 1];
+            const float inv = 1.0f / sqrtf(dx * dx + dy * dy);  // normalize(): v / abs(v) multiplies by 1/|v|
+            o.ux = dx * inv;
+            o.uy = dy * inv;
+            if (n == 2) {
+                o.is_convex = 1;
+            } else {
+                // leftOf(prev, cur, next) >= 0
+                const float ax = xy[2 * iprev] - xy[2 * inext], ay = xy[2 * iprev + 1] - xy[2 * inext + 1];
+                const float bx = xy[2 * i] - xy[2 * iprev], by = xy[2 * i + 1] - xy[2 * iprev + 1];
+                o.is_convex = det(ax, ay, bx, by) >= 0.0f;
+            }
+            ob.push_back(o);
+            if (i == n - 1) {
+                ob[k].next = first;
+                ob[first].prev = k;
+            }
+        }
+    }
+
+    static bool pair_ge(size_t a1, size_t a2, size_t b1, size_t b2) { return (a1 > b1) || (a1 == b1 && a2 >= b2); }
+
+    int build(const std::vector<int>& obs) {
+        const float EPS = 0.00001f;
+        const size_t n = obs.size();
+        if (n == 0) return -1;
+        const int node = (int)nodes.size();
+        nodes.push_back(RvoNodeHost{-1, -1, -1});
+        size_t optimal = 0, min_left = n, min_right = n;
+        for (size_t i = 0; i < n; i++) {
+            size_t ls = 0, rs = 0;
+            const int i1 = obs[i], i2 = ob[i1].next;
+            for (size_t j = 0; j < n; j++) {
+                if (i == j) continue;
+                const int j1 = obs[j], j2 = ob[j1].next;
+                const float a = left_of(i1, i2, j1), b = left_of(i1, i2, j2);
+                if (a >= -EPS && b >= -EPS) ++ls;
+                else if (a <= EPS && b <= EPS) ++rs;
+                else { ++ls; ++rs; }
+                if (pair_ge(std::max(ls, rs), std::min(ls, rs), std::max(min_left, min_right), std::min(min_left, min_right))) break;
+            }
+            if (!pair_ge(std::max(ls, rs), std::min(ls, rs), std::max(min_left, min_right), std::min(min_left, min_right))) {
+                min_left = ls;
+                min_right = rs;
+                optimal = i;
+            }
+        }
+        std::vector<int> L, Rr;
+        const int i1 = obs[optimal], i2 = ob[i1].next;
+        for (size_t j = 0; j < n; j++) {
+            if (j == optimal) continue;
+            const int j1 = obs[j], j2 = ob[j1].next;
+            const float a = left_of(i1, i2, j1), b = left_of(i1, i2, j2);
+            if (a >= -EPS && b >= -EPS) {
+                L.push_back(j1);
+            } else if (a <= EPS && b <= EPS) {
+                Rr.push_back(j1);
+            } else {
+                const float ex = ob[i2].px - ob[i1].px, ey = ob[i2].py - ob[i1].py;
+                const float t = det(ex, ey, ob[j1].px - ob[i1].px, ob[j1].py - ob[i1].py) /
+                                det(ex, ey, ob[j1].px - ob[j2].px, ob[j1].py - ob[j2].py);
+                RvoObstHost no;
+                no.px = ob[j1].px + t * (ob[j2].px - ob[j1].px);
+                no.py = ob[j1].py + t * (ob[j2].py - ob[j1].py);
+                no.prev = j1;
+                no.next = j2;
+                no.is_convex = 1;
+                no.ux = ob[j1].ux;
+                no.uy = ob[j1].uy;
+                const int nn = (int)ob.size();
+                ob.push_back(no);
+                ob[j1].next = nn;
+                ob[j2].prev = nn;
+                if (a > 0.0f) {
+                    L.push_back(j1);
+                    Rr.push_back(nn);
+                } else {
+                    Rr.push_back(j1);
+                    L.push_back(nn);
+                }
+            }
+        }
+        nodes[node].obstacle = i1;
+        const int l = build(L);
+        const int r = build(Rr);
+        nodes[node].left = l;
+        nodes[node].right = r;
+        return node;
+    }
+
+    void process() {
+        nodes.clear();
+        std::vector<int> all(ob.size());
+        for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+        root = build(all);
+    }
+};

@@ -1,0 +1,645 @@
+// imgenv_hip.hip -- C ABI (include/imgenv.h) of the MI355X-native img_env step() path.
+// Host orchestration of ImgEnv::_init/_reset/_step (img_env.cpp:83-160, 162-292, 421-525) as a fixed
+// sequence of HIP kernels on one stream; all simulator state lives in HBM for the life of the handle.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off (see __graft_entry__.py)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#define WAVE_SZ 64
+#include "../../include/imgenv.h"
+#include "host_tables.h"
+#include "kernels.h"
+#include "world.h"
+
+static thread_local char g_err[512] = "";
+#define FAIL(code, ...)                              \
+    do {                                             \
+        snprintf(g_err, sizeof(g_err), __VA_ARGS__); \
+        return (code);                               \
+    } while (0)
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) FAIL(IMGENV_EDEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct imgenv {
+    imgenv_cfg cfg;
+    ViewGeom geom;
+    int R = 0, P = 0, r0 = 0, r1 = 0, RL = 0, NA = 0, Hg = 0, Wg = 0, PP = 2;
+    std::vector<RobotClassHost> rcls;
+    std::vector<PedClassHost> pcls;
+    std::vector<int> robot_cls, ped_cls;
+    std::vector<uint8_t> static_map;
+    std::vector<double> rsl;
+    std::vector<float> pmax;
+    DevWorld d;
+    std::vector<void*> allocs;
+    unsigned char* arena = nullptr;
+    bool own_arena = false;
+    imgenv_out out;
+    uint8_t* d_obs_map = nullptr;
+    RvoObstDev* d_obst = nullptr;
+    RvoNodeDev* d_nodes = nullptr;
+    int cap_obst = 0, cap_nodes = 0;
+    double* d_traj = nullptr;
+    int* d_traj_len = nullptr;
+    int traj_cap = 0;
+    int elapsed = 0;
+    bool has_reset = false;
+    int launches = 0;
+    size_t lds_view = 0, lds_obs = 0;
+    RvoObstacles rvo;
+};
+
+extern "C" const char* imgenv_backend(void) { return "hip-gfx950"; }
+extern "C" int32_t imgenv_abi_version(void) { return IMGENV_ABI_VERSION; }
+extern "C" const char* imgenv_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------- arena
+struct OutField {
+    size_t offset, bytes;
+};
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct ArenaPlan {
+    size_t total = 0;
+    size_t off[32];
+    int n = 0;
+    size_t add(size_t bytes) {
+        off[n] = total;
+        total = align256(total + (bytes ? bytes : 1));
+        return off[n++];
+    }
+};
+
+static void plan_arena(const imgenv_cfg& c, const ViewGeom& g, int RL, ArenaPlan& p) {
+    const size_t R = (size_t)RL, NC = (size_t)g.Hv * g.Wv, B = (size_t)(g.B > 0 ? g.B : 1);
+    const size_t PV = 1 + (size_t)c.ped_vec_dim * c.max_ped, NP = (size_t)c.ped_image_size[0] * c.ped_image_size[1];
+    const size_t P = (size_t)(c.n_peds > 0 ? c.n_peds : 1);
+    p.add(R * c.state_dim * 4);  // 0 vector_states
+    p.add(R * NC);               // 1 view_maps
+    p.add(R * NC * 2);           // 2 sensor_maps
+    p.add(R * B * 4);            // 3 lasers_raw
+    p.add(R * B * 8);            // 4 lasers
+    p.add(R * PV * 4);           // 5 ped_vector_states
+    p.add(R * 3 * NP * 4);       // 6 ped_maps
+    p.add(R);                    // 7 is_collisions
+    p.add(R);                    // 8 is_arrives
+    p.add(R * 8);                // 9 step_ds
+    p.add(R * 8);                // 10 ped_min_dists
+    p.add(R * 4);                // 11 base_rewards
+    p.add(R);                    // 12 base_dones
+    p.add(R * 8);                // 13 rewards
+    p.add(R);                    // 14 dones
+    p.add(R * 4);                // 15 dones_info
+    p.add(R);                    // 16 is_clean
+    p.add(R * 24);               // 17 robot_pose
+    p.add(P * 32);               // 18 ped_state
+    p.add(16);                   // 19 counters
+    p.add((size_t)c.n_robots * IMGENV_RECORD_DOUBLES * 8);  // 20 records
+}
+
+static int shard_of(const imgenv_cfg& c, int& r0, int& r1) {
+    r0 = c.robot_begin;
+    r1 = c.robot_end;
+    if (r0 == 0 && r1 == 0) r1 = c.n_robots;
+    if (r0 < 0 || r1 > c.n_robots || r0 >= r1) return -1;
+    return 0;
+}
+
+extern "C" int64_t imgenv_arena_bytes(const imgenv_cfg* cfg) {
+    if (!cfg || cfg->struct_size != (int32_t)sizeof(imgenv_cfg)) return -1;
+    int r0, r1;
+    if (shard_of(*cfg, r0, r1)) return -1;
+    ArenaPlan p;
+    plan_arena(*cfg, make_view_geom(*cfg), r1 - r0, p);
+    return (int64_t)p.total;
+}
+
+// ---------------------------------------------------------------------------------------- helpers
+template <typename T>
+static int dev_alloc(imgenv* h, T** out, size_t n, int fill = 0) {
+    void* p = nullptr;
+    const size_t bytes = sizeof(T) * (n ? n : 1);
+    HIPCHK(hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    HIPCHK(hipMemset(p, fill, bytes));
+    *out = (T*)p;
+    return 0;
+}
+template <typename T>
+static int dev_upload(imgenv* h, const T** out, const std::vector<T>& v) {
+    T* p = nullptr;
+    if (int rc = dev_alloc(h, &p, v.size())) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+#define TRY(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_) {             \
+            imgenv_destroy(h); \
+            return rc_;        \
+        }                      \
+    } while (0)
+
+extern "C" void imgenv_destroy(imgenv_t* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->own_arena && h->arena) (void)hipFree(h->arena);
+    delete h;
+}
+
+// ---------------------------------------------------------------------------------------- create
+extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, int32_t Wg,
+                             imgenv_t** out) {
+    if (!cfg || !static_map || !out) FAIL(IMGENV_EINVAL, "null argument");
+    if (cfg->abi_version != IMGENV_ABI_VERSION || cfg->struct_size != (int32_t)sizeof(imgenv_cfg))
+        FAIL(IMGENV_EINVAL, "imgenv_cfg ABI mismatch (version %d size %d, want %d %d)", cfg->abi_version,
+             cfg->struct_size, IMGENV_ABI_VERSION, (int)sizeof(imgenv_cfg));
+    if (cfg->n_robots < 1 || cfg->n_peds < 0 || Hg < 1 || Wg < 1) FAIL(IMGENV_EINVAL, "bad sizes");
+    if (cfg->n_peds > cfg->max_ped)
+        FAIL(IMGENV_EINVAL, "n_peds %d > max_ped %d (IndexError in yaml_env.py:401)", cfg->n_peds, cfg->max_ped);
+    if (cfg->n_peds > 65000) FAIL(IMGENV_EINVAL, "n_peds > 65000 unsupported");
+    if (cfg->global_resolution != cfg->view_resolution)
+        FAIL(IMGENV_EINVAL, "global_resolution != view_resolution: load-time cv::resize not supported");
+    if (cfg->state_dim < 3 || cfg->state_dim > 5) FAIL(IMGENV_EINVAL, "state_dim must be 3, 4 or 5");
+    if (cfg->ped_vec_dim != 7) FAIL(IMGENV_EINVAL, "ped_vec_dim must be 7");
+    if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM && cfg->n_peds > 0)
+        FAIL(IMGENV_EINVAL, "pedscene (social force) is not implemented in the HIP path yet");
+    int r0, r1;
+    if (shard_of(*cfg, r0, r1)) FAIL(IMGENV_EINVAL, "bad robot shard [%d,%d)", cfg->robot_begin, cfg->robot_end);
+    const ViewGeom g = make_view_geom(*cfg);
+    if (cfg->image_size[0] != g.Wv || cfg->image_size[1] != g.Hv)
+        FAIL(IMGENV_EINVAL, "image_size (%d,%d) != native view (%d,%d): cv2.resize INTER_CUBIC not supported",
+             cfg->image_size[0], cfg->image_size[1], g.Wv, g.Hv);
+    if ((size_t)g.Hv * g.Wv > 65535) FAIL(IMGENV_EINVAL, "view larger than 65535 cells unsupported");
+    if (g.B > 65535) FAIL(IMGENV_EINVAL, "more than 65535 beams unsupported");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(IMGENV_EDEVICE, "no HIP device available");
+    if (cfg->device < 0 || cfg->device >= ndev) FAIL(IMGENV_EDEVICE, "device %d out of range (%d)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+
+    imgenv* h = new imgenv();
+    h->cfg = *cfg;
+    h->geom = g;
+    h->R = cfg->n_robots;
+    h->P = cfg->n_peds;
+    h->r0 = r0;
+    h->r1 = r1;
+    h->RL = r1 - r0;
+    h->Hg = Hg;
+    h->Wg = Wg;
+    const bool rvo = (cfg->ped_scene_type == IMGENV_SCENE_RVO || cfg->ped_scene_type == IMGENV_SCENE_ERVO);
+    h->NA = rvo ? h->P + (cfg->relation_ped_robo == 1 ? h->R : 0) : 0;
+    h->static_map.assign(static_map, static_map + (size_t)Hg * Wg);
+    const int R = h->R, P = h->P, RL = h->RL;
+
+    // classes
+    h->robot_cls.resize(R);
+    h->rsl.resize(R);
+    for (int i = 0; i < R; i++) {
+        const int shape = cfg->robot_shape[i];
+        if (shape != IMGENV_SHAPE_CIRCLE && shape != IMGENV_SHAPE_RECTANGLE) {
+            delete h;
+            FAIL(IMGENV_EINVAL, "robot %d: unsupported shape %d", i, shape);
+        }
+        int found = -1;
+        for (size_t c = 0; c < h->rcls.size(); c++)
+            if (h->rcls[c].shape == shape && !memcmp(h->rcls[c].size, cfg->robot_size + 4 * i, 16) &&
+                !memcmp(h->rcls[c].sensor, cfg->robot_sensor_cfg + 2 * i, 8))
+                found = (int)c;
+        if (found < 0) {
+            RobotClassHost k;
+            k.shape = shape;
+            memcpy(k.size, cfg->robot_size + 4 * i, 16);
+            memcpy(k.sensor, cfg->robot_sensor_cfg + 2 * i, 8);
+            build_robot_class(k, g);
+            h->rcls.push_back(std::move(k));
+            found = (int)h->rcls.size() - 1;
+        }
+        h->robot_cls[i] = found;
+        h->rsl[i] = cfg->robot_size_last ? cfg->robot_size_last[i] : 0.0;
+    }
+    h->ped_cls.resize(P);
+    h->pmax.resize(P);
+    std::vector<double> pr_round(P);
+    std::vector<float> pr32(P);
+    for (int j = 0; j < P; j++) {
+        int found = -1;
+        for (size_t c = 0; c < h->pcls.size(); c++)
+            if (h->pcls[c].shape == cfg->ped_shape[j] && !memcmp(h->pcls[c].size, cfg->ped_size + 6 * j, 24)) found = (int)c;
+        if (found < 0) {
+            PedClassHost k;
+            k.shape = cfg->ped_shape[j];
+            memcpy(k.size, cfg->ped_size + 6 * j, 24);
+            build_ped_class(k);
+            h->pcls.push_back(std::move(k));
+            found = (int)h->pcls.size() - 1;
+        }
+        h->ped_cls[j] = found;
+        h->pmax[j] = cfg->ped_max_speed[j];
+        pr32[j] = (float)h->pcls[found].sizes[2];
+        pr_round[j] = py_round2((double)pr32[j]);
+    }
+    h->cfg.robot_shape = nullptr; h->cfg.robot_size = nullptr; h->cfg.robot_sensor_cfg = nullptr;
+    h->cfg.ped_shape = nullptr; h->cfg.ped_size = nullptr; h->cfg.ped_max_speed = nullptr;
+    h->cfg.robot_size_last = nullptr;
+
+    DevWorld& d = h->d;
+    memset(&d, 0, sizeof(d));
+    d.R = R; d.RL = RL; d.r0 = r0; d.P = P; d.NA = h->NA;
+    d.Hg = Hg; d.Wg = Wg; d.Hv = g.Hv; d.Wv = g.Wv; d.B = g.B;
+    d.Hp = cfg->ped_image_size[0]; d.Wp = cfg->ped_image_size[1];
+    d.SD = cfg->state_dim; d.PV = 1 + cfg->ped_vec_dim * cfg->max_ped;
+    d.scene = cfg->ped_scene_type; d.relation = cfg->relation_ped_robo; d.ktype = cfg->robot_ktype;
+    d.use_laser = cfg->use_laser ? 1 : 0; d.laser_norm = cfg->laser_norm; d.time_max = cfg->time_max;
+    d.res = g.res; d.step_hz = (double)cfg->step_hz; d.laser_max = cfg->laser_max;
+    d.ped_safety_space = cfg->ped_safety_space; d.ped_image_r = cfg->ped_image_r;
+    d.ped_image_r2 = pow(cfg->ped_image_r, 2.0);        // self.ped_image_r ** 2 (yaml_env.py:425)
+    d.ped_res = 6.0 / cfg->ped_image_size[0];            // yaml_env.py:164
+    d.view_base = g.view_base; d.base_view = g.base_view;
+    {   // SpeedLimiter(msg) (speed_limit.cpp:56-65): max_jerk <- msg.min_jerk, min_jerk uninitialised (0 here)
+        const imgenv_limiter& v = cfg->limiter_v; const imgenv_limiter& ww = cfg->limiter_w;
+        d.lv_has_v = v.has_velocity_limits; d.lv_has_a = v.has_acceleration_limits; d.lv_has_j = v.has_jerk_limits;
+        d.lv_min_v = v.min_velocity; d.lv_max_v = v.max_velocity; d.lv_min_a = v.min_acceleration;
+        d.lv_max_a = v.max_acceleration; d.lv_min_j = 0.0; d.lv_max_j = v.min_jerk;
+        d.lw_has_v = ww.has_velocity_limits; d.lw_has_a = ww.has_acceleration_limits; d.lw_has_j = ww.has_jerk_limits;
+        d.lw_min_v = ww.min_velocity; d.lw_max_v = ww.max_velocity; d.lw_min_a = ww.min_acceleration;
+        d.lw_max_a = ww.max_acceleration; d.lw_min_j = 0.0; d.lw_max_j = ww.min_jerk;
+    }
+    const size_t G = (size_t)Hg * Wg, Gp = (G + 15) & ~(size_t)15;
+
+    // grids
+    TRY(dev_alloc(h, &h->d_obs_map, Gp));
+    HIPCHK(hipMemcpy(h->d_obs_map, static_map, G, hipMemcpyHostToDevice));
+    d.obs_map = h->d_obs_map;
+    TRY(dev_alloc(h, &d.ped_layer, Gp));
+    TRY(dev_alloc(h, &d.own_lo, Gp, 0xFF));
+    TRY(dev_alloc(h, &d.own_hi, Gp));
+    TRY(dev_alloc(h, &d.cls, Gp));
+    TRY(dev_alloc(h, &d.owner, Gp));
+
+    // class tables
+    size_t max_stride = WAVE;
+    {
+        std::vector<RobotClassDev> rc(h->rcls.size());
+        for (size_t c = 0; c < h->rcls.size(); c++) {
+            const RobotClassHost& k = h->rcls[c];
+            RobotClassDev& o = rc[c];
+            o.n_fp = k.fp.n();
+            TRY(dev_upload(h, &o.fp_x, k.fp.x));
+            TRY(dev_upload(h, &o.fp_y, k.fp.y));
+            TRY(dev_upload(h, &o.fov_bits, k.fov_bits));
+            TRY(dev_upload(h, &o.stamp_bits, k.stamp_bits));
+            o.ray_maxlen = k.ray_maxlen;
+            o.ray_stride = k.ray_stride;
+            TRY(dev_upload(h, &o.ray_cells, k.ray_cells));
+            TRY(dev_upload(h, &o.ray_len, k.ray_len));
+            TRY(dev_upload(h, &o.ray_dist, k.ray_dist));
+            TRY(dev_upload(h, &o.inv_off, k.inv_off));
+            TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
+            o.box_rad = k.box_rad;
+            max_stride = std::max(max_stride, (size_t)k.ray_stride);
+        }
+        TRY(dev_upload(h, &d.rclass, rc));
+        std::vector<PedClassDev> pc(h->pcls.size());
+        for (size_t c = 0; c < h->pcls.size(); c++) {
+            const PedClassHost& k = h->pcls[c];
+            PedClassDev& o = pc[c];
+            memset(&o, 0, sizeof(o));
+            o.shape = k.shape;
+            o.n_bbox = k.bbox.n();
+            o.n_left = k.left.n();
+            o.n_right = k.right.n();
+            TRY(dev_upload(h, &o.bx, k.bbox.x));
+            TRY(dev_upload(h, &o.by, k.bbox.y));
+            TRY(dev_upload(h, &o.lx, k.left.x));
+            TRY(dev_upload(h, &o.ly, k.left.y));
+            TRY(dev_upload(h, &o.rx, k.right.x));
+            TRY(dev_upload(h, &o.ry, k.right.y));
+            memcpy(o.sizes, k.sizes, sizeof(o.sizes));
+        }
+        if (pc.empty()) pc.resize(1);
+        TRY(dev_upload(h, &d.pclass, pc));
+    }
+    TRY(dev_upload(h, &d.robot_cls, h->robot_cls));
+    TRY(dev_upload(h, &d.ped_cls, h->ped_cls));
+    TRY(dev_upload(h, &d.robot_size_last, h->rsl));
+    TRY(dev_upload(h, &d.ped_r_round, pr_round));
+    TRY(dev_upload(h, &d.ped_r32, pr32));
+    {
+        std::vector<uint16_t> lut(256);
+        for (int v = 0; v < 256; v++) lut[v] = f32_to_f16((float)v / 255.0f);  // numpy: f16(f32(v)/255)
+        TRY(dev_upload(h, &d.f16_lut, lut));
+    }
+
+    // robot / ped state
+    TRY(dev_alloc(h, &d.gx, RL)); TRY(dev_alloc(h, &d.gy, RL));
+    TRY(dev_alloc(h, &d.l0v, RL)); TRY(dev_alloc(h, &d.l0w, RL)); TRY(dev_alloc(h, &d.l1v, RL)); TRY(dev_alloc(h, &d.l1w, RL));
+    TRY(dev_alloc(h, &d.world_target, RL));
+    TRY(dev_alloc(h, &d.is_coll, RL)); TRY(dev_alloc(h, &d.is_arr, RL)); TRY(dev_alloc(h, &d.py_done, RL));
+    TRY(dev_alloc(h, &d.clean_state, RL, 1));
+    TRY(dev_alloc(h, &d.tmp_dist, RL));
+    TRY(dev_alloc(h, &d.ppx, P)); TRY(dev_alloc(h, &d.ppy, P)); TRY(dev_alloc(h, &d.pyaw, P));
+    TRY(dev_alloc(h, &d.plx, P)); TRY(dev_alloc(h, &d.ply, P)); TRY(dev_alloc(h, &d.pvx, P)); TRY(dev_alloc(h, &d.pvy, P));
+    TRY(dev_alloc(h, &d.prem, P)); TRY(dev_alloc(h, &d.llx, P)); TRY(dev_alloc(h, &d.lly, P));
+    TRY(dev_alloc(h, &d.rlx, P)); TRY(dev_alloc(h, &d.rly, P));
+    TRY(dev_alloc(h, &d.pstate, P)); TRY(dev_alloc(h, &d.ptraj_idx, P));
+    TRY(dev_alloc(h, &h->d_traj_len, P));
+    d.ptraj_len = h->d_traj_len;
+    const int NA = h->NA;
+    TRY(dev_alloc(h, &d.apx, NA)); TRY(dev_alloc(h, &d.apy, NA)); TRY(dev_alloc(h, &d.avx, NA)); TRY(dev_alloc(h, &d.avy, NA));
+    TRY(dev_alloc(h, &d.anvx, NA)); TRY(dev_alloc(h, &d.anvy, NA));
+    {
+        std::vector<float> ms(NA > 0 ? NA : 1, 0.6f);  // robots: maxSpeed 0.6 (rvoscene.h:63)
+        for (int j = 0; j < P && j < NA; j++) ms[j] = (float)(double)h->pmax[j];
+        TRY(dev_upload(h, &d.amax_speed, ms));
+    }
+    TRY(dev_alloc(h, &d.err, 4));
+
+    // output arena
+    ArenaPlan plan;
+    plan_arena(*cfg, g, RL, plan);
+    if (cfg->out_arena) {
+        if (cfg->out_arena_bytes < (int64_t)plan.total) {
+            imgenv_destroy(h);
+            FAIL(IMGENV_EINVAL, "out_arena too small: %lld < %zu", (long long)cfg->out_arena_bytes, plan.total);
+        }
+        h->arena = (unsigned char*)cfg->out_arena;
+    } else {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, plan.total);
+        if (e != hipSuccess) {
+            imgenv_destroy(h);
+            FAIL(IMGENV_ENOMEM, "hipMalloc(%zu) for the output arena failed: %s", plan.total, hipGetErrorString(e));
+        }
+        h->arena = (unsigned char*)p;
+        h->own_arena = true;
+    }
+    HIPCHK(hipMemset(h->arena, 0, plan.total));
+    unsigned char* A = h->arena;
+    imgenv_out& o = h->out;
+    o.struct_size = (int32_t)sizeof(imgenv_out);
+    o.n_local = RL; o.view_h = g.Hv; o.view_w = g.Wv; o.n_beams = g.B; o.state_dim = cfg->state_dim; o.ped_vec_len = d.PV;
+    o.vector_states = (float*)(A + plan.off[0]);
+    o.view_maps = (uint8_t*)(A + plan.off[1]);
+    o.sensor_maps = (uint16_t*)(A + plan.off[2]);
+    o.lasers_raw = (float*)(A + plan.off[3]);
+    o.lasers = (double*)(A + plan.off[4]);
+    o.ped_vector_states = (float*)(A + plan.off[5]);
+    o.ped_maps = (float*)(A + plan.off[6]);
+    o.is_collisions = (int8_t*)(A + plan.off[7]);
+    o.is_arrives = (uint8_t*)(A + plan.off[8]);
+    o.step_ds = (double*)(A + plan.off[9]);
+    o.ped_min_dists = (double*)(A + plan.off[10]);
+    o.base_rewards = (int32_t*)(A + plan.off[11]);
+    o.base_dones = (uint8_t*)(A + plan.off[12]);
+    o.rewards = (double*)(A + plan.off[13]);
+    o.dones = (uint8_t*)(A + plan.off[14]);
+    o.dones_info = (int32_t*)(A + plan.off[15]);
+    o.is_clean = (uint8_t*)(A + plan.off[16]);
+    o.robot_pose = (double*)(A + plan.off[17]);
+    o.ped_state = (double*)(A + plan.off[18]);
+    o.counters = (int32_t*)(A + plan.off[19]);
+    d.rec = (double*)(A + plan.off[20]);
+    d.vector_states = o.vector_states; d.view_maps = o.view_maps; d.sensor_maps = o.sensor_maps;
+    d.lasers_raw = o.lasers_raw; d.lasers = o.lasers; d.ped_vector_states = o.ped_vector_states;
+    d.ped_maps = o.ped_maps; d.is_collisions = o.is_collisions; d.is_arrives = o.is_arrives;
+    d.step_ds = o.step_ds; d.ped_min_dists = o.ped_min_dists; d.base_rewards = o.base_rewards;
+    d.base_dones = o.base_dones; d.rewards = o.rewards; d.dones = o.dones; d.dones_info = o.dones_info;
+    d.is_clean = o.is_clean; d.robot_pose = o.robot_pose; d.ped_state = o.ped_state; d.counters = o.counters;
+    {   // NearbyPed starts at +inf and is never re-initialised (reset_helper.py:85-99); is_clean starts True
+        std::vector<double> inf(RL, INFINITY);
+        HIPCHK(hipMemcpy(o.ped_min_dists, inf.data(), sizeof(double) * RL, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(o.is_clean, 1, RL));
+    }
+    h->PP = 2;
+    while (h->PP < P) h->PP <<= 1;
+    const size_t NC = (size_t)g.Hv * g.Wv;
+    h->lds_view = ((NC + 15) & ~(size_t)15) + 2 * max_stride + 16;
+    h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)d.Hp * d.Wp * 4 + (size_t)h->PP * 2 + 16;
+    if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
+        imgenv_destroy(h);
+        FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
+    }
+    if (h->lds_view > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)k_view, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+    if (h->lds_obs > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)k_obs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+    HIPCHK(hipDeviceSynchronize());
+    *out = h;
+    return IMGENV_OK;
+}
+
+// ---------------------------------------------------------------------------------------- reset
+struct ResetRobot {  // per local robot
+    double gx, gy;
+    Tf2 world_target;
+};
+
+__global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, const ResetRobot* __restrict__ rr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.R) return;
+    double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    r[0] = pose3[3 * i];  // init_pose (agent.cpp:133-142); Agent::vx, vy persist across resets
+    r[1] = pose3[3 * i + 1];
+    r[2] = pose3[3 * i + 2];
+    const int l = i - w.r0;
+    if (l >= 0 && l < w.RL) {
+        w.l0v[l] = 0;  // last0_vw_ = (0,0); last1_vw_ is not touched by init_pose
+        w.l0w[l] = 0;
+        w.gx[l] = rr[l].gx;
+        w.gy[l] = rr[l].gy;
+        w.world_target[l] = rr[l].world_target;
+        w.is_coll[l] = 0;
+        w.is_arr[l] = 0;
+    }
+}
+
+__global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= w.P) return;
+    w.ppx[j] = pose3[3 * j];
+    w.ppy[j] = pose3[3 * j + 1];
+    w.pyaw[j] = pose3[3 * j + 2];
+    w.ptraj_idx[j] = 0;
+    if (w.NA > 0) {  // setPedPos (rvoscene.h:32-34); the agent's velocity persists
+        w.apx[j] = (float)pose3[3 * j];
+        w.apy[j] = (float)pose3[3 * j + 1];
+    }
+    w.ped_state[4 * j] = pose3[3 * j];
+    w.ped_state[4 * j + 1] = pose3[3 * j + 1];
+    w.ped_state[4 * j + 2] = w.pvx[j];
+    w.ped_state[4 * j + 3] = w.pvy[j];
+}
+
+static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
+    DevWorld& d = h->d;
+    const size_t G = (size_t)h->Hg * h->Wg;
+    k_raster<<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset);
+    k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d);
+    k_view<<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d);
+    k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, st>>>(d, is_reset, h->elapsed, h->PP);
+    h->launches += 4;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stream) {
+    if (!h || !b) FAIL(IMGENV_EINVAL, "null argument");
+    if (b->struct_size != (int32_t)sizeof(imgenv_reset_batch)) FAIL(IMGENV_EINVAL, "reset batch ABI mismatch");
+    if (b->n_obstacles < 0 || (h->P > 0 && b->ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    DevWorld& d = h->d;
+    const int R = h->R, P = h->P, RL = h->RL;
+    const double res = h->geom.res;
+    // obstacles -> obs_map_ and the pedestrian simulator (img_env.cpp:166-193)
+    std::vector<uint8_t> obs(h->static_map);
+    h->rvo.clear();
+    for (int q = 0; q < b->n_obstacles; q++) {
+        double sizes[4];
+        for (int j = 0; j < 4; j++) sizes[j] = (double)b->obs_size[4 * q + j];
+        const Pts bb = b->obs_shape[q] == IMGENV_SHAPE_CIRCLE ? shape_circle(sizes[0], sizes[1], sizes[2]) : shape_rectangle(sizes);
+        const double* p = b->obs_pose + 4 * q;
+        const Tf2 bw = tf_from_pose(p[0], p[1], tf_yaw_from_quaternion_zw(p[2], p[3]));
+        draw_obstacle(obs.data(), h->Hg, h->Wg, res, bw, bb);
+        double pax, pay, pbx, pby;
+        get_corners(b->obs_shape[q], sizes, bw, pax, pay, pbx, pby);
+        if (!b->ignore_obstacle && h->NA > 0) {  // RVOScene::addObs (rvoscene.h:19-26)
+            const float v[8] = {(float)pax, (float)pay, (float)pax, (float)pby, (float)pbx, (float)pby, (float)pbx, (float)pay};
+            h->rvo.add(v, 4);
+        }
+    }
+    h->rvo.process();  // processObs (img_env.cpp:283)
+    HIPCHK(hipMemcpyAsync(h->d_obs_map, obs.data(), obs.size(), hipMemcpyHostToDevice, st));
+    if ((int)h->rvo.ob.size() > h->cap_obst) {
+        h->cap_obst = (int)h->rvo.ob.size() * 2;
+        if (int rc = dev_alloc(h, &h->d_obst, h->cap_obst)) return rc;
+    }
+    if ((int)h->rvo.nodes.size() > h->cap_nodes) {
+        h->cap_nodes = (int)h->rvo.nodes.size() * 2;
+        if (int rc = dev_alloc(h, &h->d_nodes, h->cap_nodes)) return rc;
+    }
+    static_assert(sizeof(RvoObstHost) == sizeof(RvoObstDev) && sizeof(RvoNodeHost) == sizeof(RvoNodeDev), "layout");
+    if (!h->rvo.ob.empty())
+        HIPCHK(hipMemcpyAsync(h->d_obst, h->rvo.ob.data(), sizeof(RvoObstDev) * h->rvo.ob.size(), hipMemcpyHostToDevice, st));
+    if (!h->rvo.nodes.empty())
+        HIPCHK(hipMemcpyAsync(h->d_nodes, h->rvo.nodes.data(), sizeof(RvoNodeDev) * h->rvo.nodes.size(), hipMemcpyHostToDevice, st));
+    d.obst = h->d_obst;
+    d.onodes = h->d_nodes;
+    d.n_obst = (int)h->rvo.ob.size();
+    d.n_onodes = (int)h->rvo.nodes.size();
+    d.oroot = h->rvo.root;
+    // pedestrians (img_env.cpp:220-250)
+    std::vector<double> ped3((size_t)(P > 0 ? P : 1) * 3);
+    std::vector<int> tlen(P > 0 ? P : 1);
+    if (P > 0) {
+        if (b->ped_traj_cap > h->traj_cap) {
+            h->traj_cap = b->ped_traj_cap;
+            if (int rc = dev_alloc(h, &h->d_traj, (size_t)P * h->traj_cap * 3)) return rc;
+        }
+        std::vector<double> traj((size_t)P * h->traj_cap * 3, 0.0);
+        for (int j = 0; j < P; j++) {
+            const double* p = b->ped_pose + 4 * j;
+            ped3[3 * j] = p[0];
+            ped3[3 * j + 1] = p[1];
+            ped3[3 * j + 2] = tf_yaw_from_quaternion_zw(p[2], p[3]);
+            tlen[j] = b->ped_traj_len[j];
+            if (tlen[j] < 1 || tlen[j] > b->ped_traj_cap) FAIL(IMGENV_EINVAL, "ped %d: bad trajectory length %d", j, tlen[j]);
+            for (int q = 0; q < tlen[j]; q++)
+                memcpy(&traj[((size_t)j * h->traj_cap + q) * 3], b->ped_traj + ((size_t)j * b->ped_traj_cap + q) * 3, 24);
+        }
+        HIPCHK(hipMemcpyAsync(h->d_traj, traj.data(), traj.size() * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->d_traj_len, tlen.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
+        d.ptraj = h->d_traj;
+        d.traj_cap = h->traj_cap;
+    }
+    // robots (img_env.cpp:252-282)
+    std::vector<double> rob3((size_t)R * 3);
+    std::vector<ResetRobot> rr(RL);
+    for (int i = 0; i < R; i++) {
+        const double* p = b->robot_pose + 4 * i;
+        const double yaw = tf_yaw_from_quaternion_zw(p[2], p[3]);
+        rob3[3 * i] = p[0];
+        rob3[3 * i + 1] = p[1];
+        rob3[3 * i + 2] = yaw;
+        if (i >= h->r0 && i < h->r1) {  // set_goal (agent.cpp:144-154)
+            ResetRobot& q = rr[i - h->r0];
+            q.gx = b->robot_goal[2 * i];
+            q.gy = b->robot_goal[2 * i + 1];
+            q.world_target = tf_inverse(tf_from_pose(q.gx, q.gy, yaw));
+        }
+    }
+    double *d_rob3 = nullptr, *d_ped3 = nullptr;
+    ResetRobot* d_rr = nullptr;
+    HIPCHK(hipMallocAsync((void**)&d_rob3, rob3.size() * 8, st));
+    HIPCHK(hipMallocAsync((void**)&d_ped3, ped3.size() * 8, st));
+    HIPCHK(hipMallocAsync((void**)&d_rr, rr.size() * sizeof(ResetRobot), st));
+    HIPCHK(hipMemcpyAsync(d_rob3, rob3.data(), rob3.size() * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ped3, ped3.data(), ped3.size() * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_rr, rr.data(), rr.size() * sizeof(ResetRobot), hipMemcpyHostToDevice, st));
+    k_reset_robots<<<dim3((R + 255) / 256), dim3(256), 0, st>>>(d, d_rob3, d_rr);
+    if (P > 0) k_reset_peds<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(d, d_ped3);
+    h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
+    h->launches = 2;
+    if (int rc = launch_views(h, st, 1)) return rc;  // view_agent + get_states (img_env.cpp:285-286)
+    HIPCHK(hipFreeAsync(d_rob3, st));
+    HIPCHK(hipFreeAsync(d_ped3, st));
+    HIPCHK(hipFreeAsync(d_rr, st));
+    HIPCHK(hipStreamSynchronize(st));  // host staging buffers die with this frame
+    h->has_reset = true;
+    return IMGENV_OK;
+}
+
+// ---------------------------------------------------------------------------------------- step
+extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream) {
+    if (!h || !actions) FAIL(IMGENV_EINVAL, "null argument");
+    if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
+    hipStream_t st = (hipStream_t)stream;
+    DevWorld& d = h->d;
+    h->launches = 0;
+    if (h->P > 0 && h->NA > 0) {  // _step_ped_normal (img_env.cpp:304-359)
+        k_orca<<<dim3(h->P), dim3(WAVE), 0, st>>>(d);
+        k_ped_update<<<dim3((h->P + 63) / 64), dim3(64), 0, st>>>(d);
+        h->launches += 2;
+    }
+    k_integrate<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, actions);  // _step_robot (img_env.cpp:388-410)
+    h->launches += 1;
+    HIPCHK(hipGetLastError());
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_step_end(imgenv_t* h, void* stream) {
+    if (!h) FAIL(IMGENV_EINVAL, "null argument");
+    if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
+    h->elapsed += 1;  // TimeLimitWrapper._elapsed_steps (base.py:224)
+    return launch_views(h, (hipStream_t)stream, 0);
+}
+
+extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) {
+    if (int rc = imgenv_step_begin(h, actions, stream)) return rc;
+    return imgenv_step_end(h, stream);
+}
+
+extern "C" int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_robot) {
+    if (!h) FAIL(IMGENV_EINVAL, "null argument");
+    if (records) *records = h->d.rec;
+    if (bytes_per_robot) *bytes_per_robot = IMGENV_RECORD_DOUBLES * (int64_t)sizeof(double);
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_outputs(imgenv_t* h, imgenv_out* out) {
+    if (!h || !out) FAIL(IMGENV_EINVAL, "null argument");
+    *out = h->out;
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_step_launches(imgenv_t* h) { return h ? h->launches : 0; }

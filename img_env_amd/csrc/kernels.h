@@ -1,0 +1,789 @@
+// kernels.h -- the HIP kernels of one img_env step, one kernel per stage, gfx950 (wave64).
+//
+//   k_orca        1 wave / pedestrian   waypoint logic + ORCA half-planes + LP   (img_env.cpp:304-343)
+//   k_ped_update  1 thread / pedestrian Agent::update + write-back + leg gait    (img_env.cpp:344-358)
+//   k_integrate   1 thread / robot      Agent::cmd                               (agent.cpp:186-283)
+//   k_raster      1 wave / ped | robot  view_ped + the shared robot-owner layer  (img_env.cpp:594-629)
+//   k_compose     1 thread / 4 cells    class layer = obstacles + peds + robots
+//   k_view        1 wave / robot        Agent::view: collision, crop, laser, stamp (agent.cpp:356-509)
+//   k_obs         1 wave / robot        get_state, PedInfo, ped_map, reward/done (img_env.cpp:547-587,
+//                                       yaml_env.py:392-481, base.py:153-254)
+//
+// This is gather / raster / scan work on bytes and small integers: no MFMA.  What matters is
+// wave-per-robot decomposition, LDS staging of the 48x48 windows and pedestrian lists, coalesced
+// dword stores of the outputs, and no atomics on the hot per-robot path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "orca_device.h"
+#include "world.h"
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// ------------------------------------------------------------------------------------------------
+// Pedestrian advance (ORCA)
+
+// PedAgent::arrive + _get_cur_goal + RVOScene::step pref velocity (img_env.cpp:306-319, rvoscene.h:36-46),
+// then Agent::computeNeighbors + computeNewVelocity for pedestrian j = blockIdx.x.
+__global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
+    __shared__ OrcaScratch s;
+    const int j = blockIdx.x;
+    const int lane = lane_id();
+    // pref velocity: every lane computes the same (uniform) values
+    int idx = w.ptraj_idx[j];
+    const int len = w.ptraj_len[j];
+    const double px = w.ppx[j], py = w.ppy[j];
+    if (idx < len) {  // an index past the end (UB in the reference) never "arrives"
+        const double* tp = w.ptraj + ((size_t)j * w.traj_cap + idx) * 3;
+        if ((tp[0] - px) * (tp[0] - px) + (tp[1] - py) * (tp[1] - py) < 0.04) idx++;
+    }
+    const double* g = w.ptraj + ((size_t)j * w.traj_cap + (len > 0 ? idx % len : 0)) * 3;
+    const f2 pos = F2(w.apx[j], w.apy[j]);
+    f2 pref = F2((float)g[0], (float)g[1]) - pos;
+    if (abs_sq(pref) > 1.0f) pref = normalize(pref);
+    if (lane == 0) {
+        w.ptraj_idx[j] = idx;
+        s.n_an = 0;
+        s.n_on = 0;
+    }
+    __syncthreads();
+    // agent neighbours: brute-force scan in index order, 64 agents per round
+    float range_sq = sqr(0.5f);  // neighborDist (rvoscene.h:57)
+    for (int base = 0; base < w.NA; base += WAVE) {
+        const int a = base + lane;
+        float dist_sq = 0.0f;
+        bool cand = false;
+        if (a < w.NA && a != j) {
+            dist_sq = abs_sq(pos - F2(w.apx[a], w.apy[a]));
+            cand = dist_sq < range_sq;
+        }
+        unsigned long long mask = __ballot(cand);
+        if (mask != 0ull) {  // rare: resolve in index order on lane 0 with the shrinking range
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const float d = __shfl(dist_sq, src);
+                if (lane == 0) insert_agent_neighbor(s, d, base + src, range_sq);
+            }
+            range_sq = __shfl(range_sq, 0);
+        }
+    }
+    if (lane == 0) {
+        if (w.n_obst > 0) {
+            const float obst_range_sq = sqr(5.0f * w.amax_speed[j] + 0.5f);  // timeHorizonObst*maxSpeed + radius
+            query_obstacle_tree(w, s, pos, obst_range_sq);
+        }
+        const f2 nv = compute_new_velocity(w, s, j, pref);
+        // ERVO: every beep source is ((0,0), 0) through the Python API (yaml_env.py:183-200 never
+        // forwards beep_r / ped_ca_p), for which addEvacVelocity (Agent.cpp:63-69) returns early.
+        w.anvx[j] = nv.x;
+        w.anvy[j] = nv.y;
+    }
+}
+
+// Agent::update (Agent.cpp:840-843), getNewPosAndVel (rvoscene.h:72-82), set_position + update_bbox
+// (agent.cpp:691-735)
+__global__ void k_ped_update(DevWorld w) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= w.P) return;
+    const float ts = (float)w.step_hz;
+    const float vx = w.anvx[j], vy = w.anvy[j];
+    w.avx[j] = vx;
+    w.avy[j] = vy;
+    const float nx = w.apx[j] + vx * ts, ny = w.apy[j] + vy * ts;
+    w.apx[j] = nx;
+    w.apy[j] = ny;
+    const double ox = w.ppx[j], oy = w.ppy[j];
+    w.plx[j] = ox;
+    w.ply[j] = oy;
+    const double x = (double)nx, y = (double)ny;
+    w.ppx[j] = x;
+    w.ppy[j] = y;
+    w.pyaw[j] = 0.0;  // uninitialised local `yaw` in the reference (img_env.cpp:346-349)
+    w.pvx[j] = (double)vx;
+    w.pvy[j] = (double)vy;
+    w.ped_state[4 * j] = x;
+    w.ped_state[4 * j + 1] = y;
+    w.ped_state[4 * j + 2] = (double)vx;
+    w.ped_state[4 * j + 3] = (double)vy;
+    const PedClassDev& k = w.pclass[w.ped_cls[j]];
+    if (k.shape == IMGENV_SHAPE_LEG) {
+        const double step_len = 0.3;
+        const double move = sqrt((x - ox) * (x - ox) + (y - oy) * (y - oy));
+        const int last = w.pstate[j];
+        int st = (int)((move + w.prem[j]) / step_len + last);
+        w.prem[j] = move + w.prem[j] - (st - last) * step_len;
+        st %= 7;
+        w.pstate[j] = st;
+        if (st == 0 || st == 4) {
+            w.llx[j] = k.sizes[0];
+            w.lly[j] = k.sizes[1];
+            w.rlx[j] = k.sizes[3];
+            w.rly[j] = k.sizes[4];
+        } else if (st == 1 || st == 3) {
+            w.llx[j] = -step_len / 2;
+            w.rlx[j] = step_len / 2;
+        } else if (st == 2) {
+            w.llx[j] = -step_len;
+            w.rlx[j] = step_len;
+        } else if (st == 5) {
+            w.llx[j] = step_len / 2;
+            w.rlx[j] = -step_len / 2;
+        } else if (st == 6) {
+            w.llx[j] = step_len;
+            w.rlx[j] = -step_len;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pose integrate
+
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(lo, x), hi); }
+__device__ __forceinline__ int signd(double x) { return x == 0 ? 0 : (int)(x / fabs(x)); }
+
+// SpeedLimiter::limit (speed_limit.cpp:92-173); max_jerk = msg.min_jerk, min_jerk = 0 (speed_limit.cpp:56-65)
+__device__ void limiter_limit(bool has_v, bool has_a, bool has_j, double min_v, double max_v, double min_a, double max_a,
+                              double min_j, double max_j, double& v, double v0, double v1, double dt) {
+    if (has_j) {
+        const double dv = v - v0, dv0 = v0 - v1;
+        const double dt2 = 2. * dt * dt;
+        const double da = clampd(dv - dv0, min_j * dt2, max_j * dt2);
+        v = v0 + dv0 + da;
+    }
+    if (has_a) {
+        const double tmp = v;
+        const int v_sign = signd(v), v0_sign = signd(v0);
+        if (v_sign + v0_sign != 0) {
+            const double dv_min = min_a * dt, dv_max = max_a * dt;
+            double dv = v - v0;
+            const int dv_sign = signd(dv);
+            if (dv_sign == v0_sign || dv_sign == v_sign)
+                dv = dv_sign * clampd(fabs(dv), dv_min, dv_max);
+            else
+                dv = dv_sign * fabs(clampd(-fabs(dv), dv_min, dv_max));
+            v = v0 + dv;
+        } else {
+            const double zero_dt = fabs(v0 / min_a);
+            if (zero_dt >= dt)
+                v = v0_sign * (fabs(v0) - fabs(min_a) * dt);
+            else {
+                const double v_dt = fabs(v / max_a);
+                if (zero_dt + v_dt >= dt)
+                    v = v_sign * fabs(max_a * (dt - zero_dt));
+                else
+                    v = tmp;
+            }
+        }
+    }
+    if (has_v) v = clampd(v, min_v, max_v);
+}
+
+// _step_req (yaml_env.py:319-331) + Agent::cmd (agent.cpp:186-283)
+__global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= w.RL) return;
+    if (w.py_done[l]) return;  // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
+    double* r = w.rec + (size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES;
+    double v = (double)actions[3 * l], wv = (double)actions[3 * l + 1];
+    const double v_y = (double)actions[3 * l + 2];
+    const double step_hz = w.step_hz, control_hz = 0.05;
+    limiter_limit(w.lv_has_v, w.lv_has_a, w.lv_has_j, w.lv_min_v, w.lv_max_v, w.lv_min_a, w.lv_max_a, w.lv_min_j,
+                  w.lv_max_j, v, w.l0v[l], w.l1v[l], step_hz);
+    limiter_limit(w.lw_has_v, w.lw_has_a, w.lw_has_j, w.lw_min_v, w.lw_max_v, w.lw_min_a, w.lw_max_a, w.lw_min_j,
+                  w.lw_max_j, wv, w.l0w[l], w.l1w[l], step_hz);
+    w.l1v[l] = w.l0v[l];
+    w.l1w[l] = w.l0w[l];
+    w.l0v[l] = v;
+    w.l0w[l] = wv;
+    bool is_arrive = false;
+    const double gx = w.gx[l], gy = w.gy[l];
+    double ox = r[0], oy = r[1], oz = r[2];
+    double vx = r[3], vy = r[4];
+    const bool omni = w.ktype == IMGENV_KTYPE_OMNI;
+    double cur_control = 0;
+    while (cur_control <= step_hz) {
+        const double c = cos(oz), s = sin(oz);
+        if (!omni) {
+            ox += v * control_hz * c;
+            oy += v * control_hz * s;
+            vx = v * c;
+            vy = v * s;
+        } else {
+            ox += v * control_hz * c - v_y * control_hz * s;
+            oy += v * control_hz * s + v_y * control_hz * c;
+        }
+        oz += wv * control_hz;
+        const double cur_dist = sqrt((ox - gx) * (ox - gx) + (oy - gy) * (oy - gy));
+        if (cur_dist <= 0.3) {
+            is_arrive = true;
+            break;
+        }
+        cur_control += control_hz;
+    }
+    const double theta = r[2], dt = step_hz;
+    double x = r[0], y = r[1];
+    if (wv == 0) {
+        if (!omni) {
+            x += v * dt * cos(theta);
+            y += v * dt * sin(theta);
+        } else {
+            x += v * dt * cos(theta) - v_y * dt * sin(theta);
+            y += v * dt * sin(theta) + v_y * dt * cos(theta);
+        }
+    } else {
+        const double vw = v / wv;
+        x += -vw * sin(theta) + vw * sin(theta + wv * dt);
+        y += vw * cos(theta) - vw * cos(theta + wv * dt);
+        if (omni) {
+            const double v_yw = v_y / wv;
+            x += -v_yw * cos(theta) + v_yw * cos(theta + wv * dt);
+            y += -v_yw * sin(theta) + v_yw * sin(theta + wv * dt);
+        }
+    }
+    const double th = theta + wv * dt;
+    const double cur_dist = sqrt((x - gx) * (x - gx) + (y - gy) * (y - gy));
+    if (cur_dist <= 0.3) is_arrive = true;
+    r[0] = x;
+    r[1] = y;
+    r[2] = th;
+    r[3] = vx;
+    r[4] = vy;
+    w.is_arr[l] = is_arrive ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rasters: blocks [0, P) draw pedestrians, blocks [P, P + R) draw robots.
+
+// view_ped (img_env.cpp:594-618).  Agent::draw(...,1) and PedAgent::draw_leg only ever write the
+// value 1 and their skip rules depend on the UNDERLYING obstacle value alone:
+//   circle sample : writes unless the cell is 0 / 1 / 2          (agent.cpp:315-322)
+//   left leg      : writes unless the cell is 0                   (agent.cpp:751-754)
+//   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
+// so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
+__device__ void raster_ped(const DevWorld& w, int j) {
+    const PedClassDev& k = w.pclass[w.ped_cls[j]];
+    const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
+    const int lane = lane_id();
+    if (k.shape == IMGENV_SHAPE_CIRCLE) {
+        for (int q = lane; q < k.n_bbox; q += WAVE) {
+            double wx, wy;
+            tf_apply(bw, k.bx[q], k.by[q], wx, wy);
+            const int m = w2m(wx, w.res), n = w2m(wy, w.res);
+            if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+                const size_t c = (size_t)m * w.Wg + n;
+                if (w.obs_map[c] > 2) w.ped_layer[c] = 1;
+            }
+        }
+    } else if (k.shape == IMGENV_SHAPE_LEG) {
+        for (int leg = 0; leg < 2; leg++) {
+            Tf2 lb;  // get_leg_base: Quaternion(0,0,0,1), origin = leg (agent.cpp:815-821)
+            tf_set_rotation_zw(lb, 0.0, 1.0);
+            lb.ox = leg == 0 ? w.llx[j] : w.rlx[j];
+            lb.oy = leg == 0 ? w.lly[j] : w.rly[j];
+            const int n_s = leg == 0 ? k.n_left : k.n_right;
+            const double* sx = leg == 0 ? k.lx : k.rx;
+            const double* sy = leg == 0 ? k.ly : k.ry;
+            for (int q = lane; q < n_s; q += WAVE) {
+                double bx, by, wx, wy;
+                tf_apply(lb, sx[q], sy[q], bx, by);
+                tf_apply(bw, bx, by, wx, wy);
+                const int m = w2m(wx, w.res), n = w2m(wy, w.res);
+                if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+                    const size_t c = (size_t)m * w.Wg + n;
+                    if (leg == 1 || w.obs_map[c] != 0) w.ped_layer[c] = 1;
+                }
+            }
+        }
+    }
+}
+
+#define RASTER_BOX_WORDS 64  // LDS bitmap: up to 2048 cells = 45 x 45 box
+
+// view_robot's inner loop (img_env.cpp:624-628) for ALL robots at once: instead of stamping every
+// other robot into a private copy of the grid per robot (O(R * Hg*Wg + R^2 * F)), each robot records
+// itself in two shared layers, own_lo = min id and own_hi = max id covering a cell.  Robot i then
+// sees "another robot" in a cell iff (lo != i or hi != i).  The 901 footprint samples fall on a few
+// cells, so they are de-duplicated in an LDS bitmap first: ~10-20 global atomics per robot.
+__device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel) {
+    const RobotClassDev& k = w.rclass[w.robot_cls[i]];
+    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    const int lane = lane_id();
+    const Tf2 bw = tf_from_pose(r[0], r[1], r[2]);
+    const uint32_t id = (uint32_t)i + 1;
+    const int rad = k.box_rad, side = 2 * rad + 1;
+    const bool use_box = side * side <= RASTER_BOX_WORDS * 32;
+    const int cm = w2m(r[0], w.res), cn = w2m(r[1], w.res);
+    if (use_box) {
+        for (int q = lane; q < RASTER_BOX_WORDS; q += WAVE) box[q] = 0;
+        __syncthreads();
+    }
+    for (int q = lane; q < k.n_fp; q += WAVE) {
+        double wx, wy;
+        tf_apply(bw, k.fp_x[q], k.fp_y[q], wx, wy);
+        const int m = w2m(wx, w.res), n = w2m(wy, w.res);
+        if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+            const int dm = m - cm + rad, dn = n - cn + rad;
+            if (use_box && dm >= 0 && dm < side && dn >= 0 && dn < side) {
+                const int b = dm * side + dn;
+                atomicOr(&box[b >> 5], 1u << (b & 31));
+            } else {
+                const size_t c = (size_t)m * w.Wg + n;
+                atomicMin(&w.own_lo[c], id);
+                atomicMax(&w.own_hi[c], id);
+            }
+        }
+    }
+    if (use_box) {
+        __syncthreads();
+        for (int b = lane; b < side * side; b += WAVE) {
+            if (box[b >> 5] & (1u << (b & 31))) {
+                const int m = cm - rad + b / side, n = cn - rad + b % side;
+                const size_t c = (size_t)m * w.Wg + n;
+                atomicMin(&w.own_lo[c], id);
+                atomicMax(&w.own_hi[c], id);
+            }
+        }
+    }
+    // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417, rvoscene.h:47-51)
+    if (lane == 0 && w.relation == 1 && (w.scene == IMGENV_SCENE_RVO || w.scene == IMGENV_SCENE_ERVO)) {
+        const int a = w.P + i;
+        w.apx[a] = (float)r[0];
+        w.apy[a] = (float)r[1];
+        w.avx[a] = zero_vel ? 0.0f : (float)r[3];
+        w.avy[a] = zero_vel ? 0.0f : (float)r[4];
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
+    __shared__ uint32_t box[RASTER_BOX_WORDS];
+    const int b = blockIdx.x;
+    if (b < w.P)
+        raster_ped(w, b);
+    else
+        raster_robot(w, b - w.P, box, zero_vel != 0);
+}
+
+// class layer: one byte per cell that a robot's view kernel can decode without touching the three
+// raster layers; also re-arms the raster layers for the next step (saves two memsets per step).
+__global__ void k_compose(DevWorld w) {
+    const size_t G = (size_t)w.Hg * w.Wg;
+    const size_t c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.counters[1] = 0;
+        w.counters[2] = 0;
+    }
+    if (c0 >= G) return;
+    if (c0 + 4 <= G) {
+        const uint32_t obs = *(const uint32_t*)(w.obs_map + c0);
+        const uint32_t ped = *(const uint32_t*)(w.ped_layer + c0);
+        const uint4 lo = *(const uint4*)(w.own_lo + c0);
+        const uint4 hi = *(const uint4*)(w.own_hi + c0);
+        const uint32_t los[4] = {lo.x, lo.y, lo.z, lo.w}, his[4] = {hi.x, hi.y, hi.z, hi.w};
+        uint32_t out = 0, any_robot = 0;
+        uint32_t own[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t o = (obs >> (8 * q)) & 0xff, p = (ped >> (8 * q)) & 0xff;
+            const uint32_t base = p ? 1u : o;
+            uint32_t b = base <= 2 ? base : (base < 250 ? CLS_LOW : CLS_HIGH);
+            own[q] = 0;
+            if (b >= CLS_LOW && his[q] != 0) {
+                b |= CLS_ROBOT;
+                own[q] = (los[q] == his[q]) ? los[q] - 1 : OWNER_MULTI;
+                any_robot = 1;
+            }
+            out |= b << (8 * q);
+        }
+        *(uint32_t*)(w.cls + c0) = out;
+        if (any_robot) *(uint4*)(w.owner + c0) = make_uint4(own[0], own[1], own[2], own[3]);
+        if (ped) *(uint32_t*)(w.ped_layer + c0) = 0;
+        if (his[0] | his[1] | his[2] | his[3]) {
+            *(uint4*)(w.own_lo + c0) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            *(uint4*)(w.own_hi + c0) = make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        for (size_t c = c0; c < G; c++) {
+            const uint32_t base = w.ped_layer[c] ? 1u : w.obs_map[c];
+            uint32_t b = base <= 2 ? base : (base < 250 ? CLS_LOW : CLS_HIGH);
+            if (b >= CLS_LOW && w.own_hi[c] != 0) {
+                b |= CLS_ROBOT;
+                w.owner[c] = (w.own_lo[c] == w.own_hi[c]) ? w.own_lo[c] - 1 : OWNER_MULTI;
+            }
+            w.cls[c] = (uint8_t)b;
+            w.ped_layer[c] = 0;
+            w.own_lo[c] = 0xFFFFFFFFu;
+            w.own_hi[c] = 0;
+        }
+    }
+}
+
+// value of cell c in robots_[i].global_map_ (img_env.cpp:623-628), as a small class code
+__device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, size_t c) {
+    const uint32_t b = w.cls[c];
+    if (b & CLS_ROBOT) {
+        const uint32_t o = w.owner[c];
+        if (o != i) return CLS_TWO;  // another robot (or several): value 2
+        return b & 7;
+    }
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Agent::view (agent.cpp:356-509) for local robot l = blockIdx.x, one wavefront.
+//   LDS: src[Hv*Wv] cropped view (0 / 255 / 200), hitk[B] first-hit step of each beam.
+__global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int l = blockIdx.x;
+    const int lane = lane_id();
+    if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value
+        if (lane == 0) atomicAdd(&w.counters[2], 1);
+        return;
+    }
+    const int i = w.r0 + l;
+    const RobotClassDev& k = w.rclass[w.robot_cls[i]];
+    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    const Tf2 bw = tf_from_pose(r[0], r[1], r[2]);
+    const int Hv = w.Hv, Wv = w.Wv, NC = Hv * Wv;
+    const double res = w.res;
+    uint8_t* src = smem;
+    uint16_t* hitk = (uint16_t*)(smem + ((NC + 15) & ~15));
+
+    // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits
+    //     decides the code (agent.cpp:294-326) -> max over (sample index, code)
+    uint32_t best = 0;
+    for (int q = lane; q < k.n_fp; q += WAVE) {
+        double wx, wy;
+        tf_apply(bw, k.fp_x[q], k.fp_y[q], wx, wy);
+        const int m = w2m(wx, res), n = w2m(wy, res);
+        if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+            const uint32_t v = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n);
+            if (v <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (v + 1));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
+    const int code = (int)(best & 3);
+
+    // (2) egocentric crop (agent.cpp:373-404): 4 view cells per lane per round -> one LDS dword
+    const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
+    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = c4 + q;
+            uint32_t val = 200;
+            if (c < NC && ((k.fov_bits[c >> 5] >> (c & 31)) & 1u)) {
+                const int a = c / Wv, b = c - a * Wv;
+                double wx, wy;
+                tf_apply(vw, a * res, b * res, wx, wy);
+                const int m = w2m(wx, res), n = w2m(wy, res);
+                if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg)
+                    val = (cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n) == CLS_HIGH) ? 255u : 0u;
+            }
+            packed |= val << (8 * q);
+        }
+        *(uint32_t*)(src + c4) = packed;
+    }
+    __syncthreads();
+
+    // (3) laser (agent.cpp:405-438, bresenhamLine 511-624): one lane per beam walks the precomputed
+    //     Bresenham path until the first occupied cell of the crop
+    if (w.use_laser) {
+        for (int b = lane; b < k.ray_stride; b += WAVE) {
+            uint32_t hk = 0xFFFF;
+            if (b < w.B) {
+                const int len = k.ray_len[b];
+                for (int q = 0; q < len; q++) {
+                    const uint32_t c = k.ray_cells[(size_t)q * k.ray_stride + b];
+                    if (src[c] == 0) {
+                        hk = q;
+                        break;
+                    }
+                }
+                const float hit = hk != 0xFFFF ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
+                w.lasers_raw[(size_t)l * w.B + b] = hit;
+                w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hit / w.laser_max : (double)hit;
+            }
+            hitk[b] = (uint16_t)hk;
+        }
+        __syncthreads();
+    }
+
+    // (4) laser_map replaces the view (agent.cpp:437): start from 200; beams write in index order and
+    //     later beams win, so each cell takes the value of the HIGHEST beam that writes it.  A beam
+    //     writes 255 before its hit, 0 at the hit and 200 behind it unless the cell shares a row or
+    //     column with the hit cell (agent.cpp:538-560).  Then the own footprint is stamped 100
+    //     (agent.cpp:503) and the result is stored as uint8 and as float16(v/255).
+    uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
+    uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;
+    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
+        uint32_t packed = 0;
+        uint32_t h[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = c4 + q;
+            uint32_t val = 200;
+            if (c < NC) {
+                if (w.use_laser) {
+                    const uint32_t e0 = k.inv_off[c], e1 = k.inv_off[c + 1];
+                    for (uint32_t e = e0; e < e1; e++) {
+                        const uint32_t ent = k.inv_ent[e];
+                        const uint32_t b = ent >> 16, kk = ent & 0xFFFF;
+                        const uint32_t hk = hitk[b];
+                        if (hk == 0xFFFF || kk < hk) {
+                            val = 255;
+                            break;
+                        }
+                        if (kk == hk) {
+                            val = 0;
+                            break;
+                        }
+                        const uint32_t hc = k.ray_cells[(size_t)hk * k.ray_stride + b];
+                        const int hx = hc / Wv, hy = hc - hx * Wv;
+                        const int cx = c / Wv, cy = c - cx * Wv;
+                        if (cx != hx && cy != hy) break;  // writes 200
+                        // same row / column as the hit: this beam leaves the cell alone
+                    }
+                } else {
+                    val = src[c];
+                }
+                if (((k.stamp_bits[c >> 5] >> (c & 31)) & 1u) && val > 2) val = 100;
+            }
+            packed |= val << (8 * q);
+            h[q] = w.f16_lut[val];
+        }
+        if (c4 + 4 <= NC) {
+            *(uint32_t*)(out_u8 + c4) = packed;
+            *(uint2*)(out_f16 + c4) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        } else {
+            for (int q = 0; q < 4 && c4 + q < NC; q++) {
+                out_u8[c4 + q] = (uint8_t)(packed >> (8 * q));
+                out_f16[c4 + q] = (uint16_t)h[q];
+            }
+        }
+    }
+    if (lane == 0) w.is_coll[l] = code;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Observation + reward / done for local robot l = blockIdx.x, one wavefront.
+//   LDS: key[PP] f64 sort keys, ord[PP] pedestrian index, info[P] float4 (px,py,vx,vy), rank[Hp*Wp]
+
+// Python float floor division (CPython float_floor_div / _float_div_mod)
+__device__ double py_floordiv(double vx, double wx) {
+    double mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod != 0.0) {
+        if ((wx < 0) != (mod < 0)) {
+            mod += wx;
+            div -= 1.0;
+        }
+    }
+    double floordiv;
+    if (div != 0.0) {
+        floordiv = floor(div);
+        if (div - floordiv > 0.5) floordiv += 1.0;
+    } else {
+        floordiv = copysign(0.0, vx / wx);
+    }
+    return floordiv;
+}
+
+__global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elapsed, int PP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int l = blockIdx.x, lane = lane_id();
+    const int i = w.r0 + l;
+    const int P = w.P, Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
+    double* key = (double*)smem;
+    float4* info = (float4*)(smem + (size_t)PP * 8);
+    uint32_t* rank = (uint32_t*)(smem + (size_t)PP * 8 + (size_t)(P > 0 ? P : 1) * 16);
+    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)NP * 4);
+
+    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    const Tf2 bw = tf_from_pose(r[0], r[1], r[2]);
+    // Agent::get_state (agent.cpp:156-184)
+    const Tf2 t = tf_mul(w.world_target[l], bw);
+    const Tf2 target_base = tf_inverse(t);
+    const float s0 = (float)target_base.ox, s1 = (float)target_base.oy;
+    if (lane == 0) {
+        float* vs = w.vector_states + (size_t)l * w.SD;
+        vs[0] = s0;
+        vs[1] = s1;
+        if (w.SD == 3) {
+            vs[2] = (float)tf_basis_yaw_via_quaternion(target_base);
+        } else if (w.SD == 4) {
+            vs[2] = (float)w.l0v[l];
+            vs[3] = (float)w.l0w[l];
+        } else {
+            vs[2] = (float)tf_basis_yaw_via_quaternion(target_base);
+            vs[3] = (float)w.l0v[l];
+            vs[4] = (float)w.l0w[l];
+        }
+        w.robot_pose[3 * l] = r[0];
+        w.robot_pose[3 * l + 1] = r[1];
+        w.robot_pose[3 * l + 2] = r[2];
+    }
+    double min_dist = w.ped_min_dists[l];
+    if (P > 0) {
+        // PedInfo in the robot base frame, float32 on the wire (img_env.cpp:568-584)
+        const Tf2 wb = tf_inverse(bw);
+        for (int j = lane; j < PP; j += WAVE) {
+            if (j < P) {
+                double px, py;
+                tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
+                const double vx = (wb.m00 * w.pvx[j] + wb.m01 * w.pvy[j]) + 0.0;
+                const double vy = (wb.m10 * w.pvx[j] + wb.m11 * w.pvy[j]) + 0.0;
+                const float fx = (float)px, fy = (float)py;
+                info[j] = make_float4(fx, fy, (float)vx, (float)vy);
+                key[j] = (double)fx * (double)fx + (double)fy * (double)fy;  // yaml_env.py:451
+                ord[j] = (uint16_t)j;
+            } else {
+                key[j] = __builtin_huge_val();
+                ord[j] = 0xFFFF;
+            }
+        }
+        for (int c = lane; c < NP; c += WAVE) rank[c] = 0;
+        __syncthreads();
+        // stable sort by (key, index): bitonic network over PP = 2^k entries in LDS
+        for (int kk = 2; kk <= PP; kk <<= 1) {
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int t2 = lane; t2 < PP / 2; t2 += WAVE) {
+                    const int a = ((t2 / jj) * 2 * jj) + (t2 % jj);
+                    const int b = a + jj;
+                    const bool up = ((a & kk) == 0);
+                    const double ka = key[a], kb = key[b];
+                    const uint16_t oa = ord[a], ob = ord[b];
+                    const bool a_gt_b = (ka > kb) || (ka == kb && oa > ob);
+                    if (a_gt_b == up) {
+                        key[a] = kb;
+                        key[b] = ka;
+                        ord[a] = ob;
+                        ord[b] = oa;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ped_tmp vector + disc raster (yaml_env.py:392-429): rank r overwrites ranks < r
+        float* pt = w.ped_vector_states + (size_t)l * w.PV;
+        if (lane == 0) pt[0] = (float)P;
+        const double rsl = w.robot_size_last[i];
+        const double pres = w.ped_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
+        for (int q = lane; q < P; q += WAVE) {
+            const int j = ord[q];
+            const float4 f = info[j];
+            const double dpx = f.x, dpy = f.y;
+            const double ped_r = w.ped_r_round[j];
+            float* o = pt + 1 + 7 * q;
+            o[0] = f.x;
+            o[1] = f.y;
+            o[2] = f.z;
+            o[3] = f.w;
+            o[4] = (float)ped_r;
+            o[5] = (float)(ped_r + rsl);
+            const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
+            o[6] = dist;
+            if (q == 0) min_dist = (double)(float)(dist - (float)(ped_r + rsl));  // yaml_env.py:455-456
+            if (dpx > 3 || dpx < -3 || dpy > 3 || dpy < -3) continue;
+            const double tmx = -dpx + 3, tmy = -dpy + 3;
+            const int ax = (int)py_floordiv(tmx - pr, pres), bx = (int)py_floordiv(tmx + pr, pres);
+            const int ay = (int)py_floordiv(tmy - pr, pres), by = (int)py_floordiv(tmy + pr, pres);
+            for (int jj = ax; jj < bx; jj++)
+                for (int kq = ay; kq < by; kq++) {
+                    if (jj < 0 || jj >= Hp || kq < 0 || kq >= Wp) continue;
+                    const double ddx = (jj + 0.5) * pres - tmx, ddy = (kq + 0.5) * pres - tmy;
+                    if (ddx * ddx + ddy * ddy < pr2) atomicMax(&rank[jj * Wp + kq], (uint32_t)q + 1);
+                }
+        }
+        __syncthreads();
+        min_dist = __shfl(min_dist, 0);
+        float* pm = w.ped_maps + (size_t)l * 3 * NP;
+        for (int c4 = lane * 4; c4 < NP; c4 += WAVE * 4) {
+            float a[4], b[4], c[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t rk = (c4 + q < NP) ? rank[c4 + q] : 0;
+                if (rk) {
+                    const float4 f = info[ord[rk - 1]];
+                    a[q] = 1.0f;
+                    b[q] = f.z;
+                    c[q] = f.w;
+                } else {
+                    a[q] = b[q] = c[q] = 0.0f;
+                }
+            }
+            if (c4 + 4 <= NP) {
+                *(float4*)(pm + c4) = make_float4(a[0], a[1], a[2], a[3]);
+                *(float4*)(pm + NP + c4) = make_float4(b[0], b[1], b[2], b[3]);
+                *(float4*)(pm + 2 * NP + c4) = make_float4(c[0], c[1], c[2], c[3]);
+            } else {
+                for (int q = 0; q < 4 && c4 + q < NP; q++) {
+                    pm[c4 + q] = a[q];
+                    pm[NP + c4 + q] = b[q];
+                    pm[2 * NP + c4 + q] = c[q];
+                }
+            }
+        }
+    }
+    if (lane != 0) return;
+    // ---- scalar tail on lane 0: _get_states distances, ImageEnv.step, wrapper stack ----
+    w.ped_min_dists[l] = min_dist;
+    const int coll = w.is_coll[l];
+    const int arr = w.is_arr[l];
+    w.is_collisions[l] = (int8_t)coll;
+    w.is_arrives[l] = (uint8_t)arr;
+    const double dist = sqrt((double)s0 * (double)s0 + (double)s1 * (double)s1);  // yaml_env.py:467
+    const double step_d = is_reset ? 0.0 : w.tmp_dist[l] - dist;
+    w.step_ds[l] = step_d;
+    w.tmp_dist[l] = dist;
+    if (is_reset) {
+        w.base_rewards[l] = 0;
+        w.base_dones[l] = 0;
+        w.py_done[l] = 0;  // self.dones = zeros (yaml_env.py:316)
+        w.rewards[l] = 0.0;
+        w.dones[l] = 0;
+        w.dones_info[l] = 0;
+        w.is_clean[l] = 1;
+        w.clean_state[l] = 1;
+        if (l == 0) w.counters[0] = 0;
+        return;
+    }
+    // ImageEnv.step (yaml_env.py:372-377)
+    w.base_rewards[l] = arr - coll;
+    int d = (coll > 1 ? 1 : coll) + arr;
+    d = d > 1 ? 1 : d;
+    w.base_dones[l] = (uint8_t)d;
+    w.py_done[l] = (uint8_t)d;
+    // TimeLimitWrapper (base.py:222-227)
+    const bool timeout = elapsed > w.time_max;
+    const int done = timeout ? 1 : d;
+    int dinfo = timeout ? 10 : 0;
+    // SensorsPaperRewardWrapper._each_r (base.py:164-188)
+    double collision_reward = 0, reach_reward = 0, step_reward = 0, distance_reward = 0;
+    if (min_dist <= w.ped_safety_space) collision_reward = -50 * (w.ped_safety_space - min_dist);
+    if (coll > 0) {
+        collision_reward = -500;
+    } else {
+        if (dist < 0.3 || arr) {
+            reach_reward = 500.0;
+        } else {
+            distance_reward = step_d * 200;
+            step_reward = -5;
+        }
+    }
+    double reward = collision_reward + reach_reward + step_reward + distance_reward + 0.0;
+    // InfoLogWrapper (base.py:241-254)
+    if (coll > 0) dinfo = coll;
+    if (arr == 1) dinfo = 5;
+    // MultiRobotCleanWrapper (base.py:79-88)
+    const uint8_t clean_before = w.clean_state[l];
+    if (!clean_before) reward = 0;
+    w.rewards[l] = reward;
+    w.dones[l] = (uint8_t)done;
+    w.dones_info[l] = dinfo;
+    w.is_clean[l] = clean_before;
+    w.clean_state[l] = done > 0 ? 0 : clean_before;
+    if (done > 0) atomicAdd(&w.counters[1], 1);
+    if (l == 0) w.counters[0] = elapsed;
+}

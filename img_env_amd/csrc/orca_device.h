@@ -1,0 +1,420 @@
+// orca_device.h -- ORCA (RVO2 v2.0.x) + ERVO for one pedestrian per wavefront, float32.
+//
+// Reference: src/3rdparty/ervo_ros  Agent::computeNeighbors (src/Agent.cpp:50-61),
+// computeNewVelocity[ForERVO] (72-434, 437-793), insertAgentNeighbor / insertObstacleNeighbor
+// (795-838), linearProgram1/2/3 (845-1001), KdTree::queryObstacleTreeRecursive (src/KdTree.cpp:
+// 310-353), helpers in include/ervo_ros/Vector2.h and Definitions.h.
+//
+// MI355X mapping: the agent-neighbour search is a coalesced brute-force scan of the SoA agent
+// arrays by all 64 lanes (chunks in index order, ballot + ordered insertion by lane 0, with the
+// reference's shrinking range) -- equivalent to the kd-tree query up to the order of exactly
+// equidistant neighbours.  The obstacle BSP tree (built on the host at reset with the reference's
+// algorithm) is walked iteratively in the reference's traversal order.  Half-plane construction
+// and the 2-D linear programs are inherently sequential and tiny (<= 10 agent lines): lane 0 runs
+// them out of LDS.  Every float operation is kept in the reference's order (-ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "world.h"
+
+#define RVO_EPS 0.00001f
+#define ORCA_MAX_ON 118  // obstacle neighbours kept per agent
+#define ORCA_MAX_AN 10   // rvoscene.h:57,63 maxNeighbors
+#define ORCA_MAX_LINES (ORCA_MAX_ON + ORCA_MAX_AN)
+#define ORCA_STACK 128
+
+struct f2 {
+    float x, y;
+};
+__device__ __forceinline__ f2 F2(float x, float y) {
+    f2 r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return F2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return F2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ f2 operator-(f2 a) { return F2(-a.x, -a.y); }
+__device__ __forceinline__ float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ f2 operator*(f2 a, float s) { return F2(a.x * s, a.y * s); }
+__device__ __forceinline__ f2 operator*(float s, f2 a) { return F2(s * a.x, s * a.y); }
+__device__ __forceinline__ f2 vdiv(f2 a, float s) {
+    const float inv = 1.0f / s;
+    return F2(a.x * inv, a.y * inv);
+}
+__device__ __forceinline__ float abs_sq(f2 a) { return dot(a, a); }
+__device__ __forceinline__ float vabs(f2 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ float det(f2 a, f2 b) { return a.x * b.y - a.y * b.x; }
+__device__ __forceinline__ f2 normalize(f2 a) { return vdiv(a, vabs(a)); }
+__device__ __forceinline__ float sqr(float a) { return a * a; }
+__device__ __forceinline__ float left_of(f2 a, f2 b, f2 c) { return det(a - c, b - a); }
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
+
+struct OrcaLine {
+    f2 point, direction;
+};
+
+// LDS scratch of one wave
+struct OrcaScratch {
+    OrcaLine lines[ORCA_MAX_LINES];
+    OrcaLine proj[ORCA_MAX_LINES];
+    float on_dist[ORCA_MAX_ON];
+    int on_idx[ORCA_MAX_ON];
+    float an_dist[ORCA_MAX_AN];
+    int an_idx[ORCA_MAX_AN];
+    int stack[ORCA_STACK];
+    int n_an, n_on;
+};
+
+__device__ float dist_sq_point_segment(f2 a, f2 b, f2 c) {
+    const float r = dot(c - a, b - a) / abs_sq(b - a);
+    if (r < 0.0f) {
+        return abs_sq(c - a);
+    } else if (r > 1.0f) {
+        return abs_sq(c - b);
+    } else {
+        return abs_sq(c - (a + r * (b - a)));
+    }
+}
+
+__device__ __forceinline__ f2 opoint(const DevWorld& w, int i) { return F2(w.obst[i].px, w.obst[i].py); }
+__device__ __forceinline__ f2 ounit(const DevWorld& w, int i) { return F2(w.obst[i].ux, w.obst[i].uy); }
+
+// Agent::insertAgentNeighbor (lane 0)
+__device__ void insert_agent_neighbor(OrcaScratch& s, float dist_sq, int other, float& range_sq) {
+    if (dist_sq < range_sq) {
+        if (s.n_an < ORCA_MAX_AN) {
+            s.an_dist[s.n_an] = dist_sq;
+            s.an_idx[s.n_an] = other;
+            s.n_an++;
+        }
+        int i = s.n_an - 1;
+        while (i != 0 && dist_sq < s.an_dist[i - 1]) {
+            s.an_dist[i] = s.an_dist[i - 1];
+            s.an_idx[i] = s.an_idx[i - 1];
+            --i;
+        }
+        s.an_dist[i] = dist_sq;
+        s.an_idx[i] = other;
+        if (s.n_an == ORCA_MAX_AN) range_sq = s.an_dist[s.n_an - 1];
+    }
+}
+
+// Agent::insertObstacleNeighbor (lane 0)
+__device__ void insert_obstacle_neighbor(const DevWorld& w, OrcaScratch& s, f2 pos, int ob, float range_sq) {
+    const int nx = w.obst[ob].next;
+    const float dist_sq = dist_sq_point_segment(opoint(w, ob), opoint(w, nx), pos);
+    if (dist_sq < range_sq) {
+        if (s.n_on >= ORCA_MAX_ON) {
+            w.err[0] = 1;  // more visible obstacle segments than the scratch holds
+            return;
+        }
+        s.on_dist[s.n_on] = dist_sq;
+        s.on_idx[s.n_on] = ob;
+        s.n_on++;
+        int i = s.n_on - 1;
+        while (i != 0 && dist_sq < s.on_dist[i - 1]) {
+            s.on_dist[i] = s.on_dist[i - 1];
+            s.on_idx[i] = s.on_idx[i - 1];
+            --i;
+        }
+        s.on_dist[i] = dist_sq;
+        s.on_idx[i] = ob;
+    }
+}
+
+// KdTree::queryObstacleTreeRecursive, iteratively, same visiting order (lane 0)
+__device__ void query_obstacle_tree(const DevWorld& w, OrcaScratch& s, f2 pos, float range_sq) {
+    int sp = 0;
+    if (w.oroot < 0) return;
+    s.stack[sp++] = w.oroot << 1;  // (node << 1) | stage
+    while (sp > 0) {
+        const int top = s.stack[sp - 1];
+        const int node = top >> 1;
+        const int o1 = w.onodes[node].obstacle;
+        const int o2 = w.obst[o1].next;
+        const float agent_left = left_of(opoint(w, o1), opoint(w, o2), pos);
+        if ((top & 1) == 0) {
+            s.stack[sp - 1] = top | 1;
+            const int child = (agent_left >= 0.0f ? w.onodes[node].left : w.onodes[node].right);
+            if (child >= 0) {
+                if (sp >= ORCA_STACK) {
+                    w.err[1] = 1;
+                    return;
+                }
+                s.stack[sp++] = child << 1;
+            }
+        } else {
+            sp--;
+            const float dist_sq_line = sqr(agent_left) / abs_sq(opoint(w, o2) - opoint(w, o1));
+            if (dist_sq_line < range_sq) {
+                if (agent_left < 0.0f) insert_obstacle_neighbor(w, s, pos, o1, range_sq);
+                const int child = (agent_left >= 0.0f ? w.onodes[node].right : w.onodes[node].left);
+                if (child >= 0) s.stack[sp++] = child << 1;
+            }
+        }
+    }
+}
+
+__device__ bool linear_program1(const OrcaLine* lines, int line_no, float radius, f2 opt, bool direction_opt,
+                                f2& result) {
+    const f2 lp = lines[line_no].point, ld = lines[line_no].direction;
+    const float dot_product = dot(lp, ld);
+    const float discriminant = sqr(dot_product) + sqr(radius) - abs_sq(lp);
+    if (discriminant < 0.0f) return false;
+    const float sqrt_disc = sqrtf(discriminant);
+    float t_left = -dot_product - sqrt_disc;
+    float t_right = -dot_product + sqrt_disc;
+    for (int i = 0; i < line_no; ++i) {
+        const float denominator = det(ld, lines[i].direction);
+        const float numerator = det(lines[i].direction, lp - lines[i].point);
+        if (fabsf(denominator) <= RVO_EPS) {
+            if (numerator < 0.0f) {
+                return false;
+            } else {
+                continue;
+            }
+        }
+        const float t = numerator / denominator;
+        if (denominator >= 0.0f) {
+            t_right = std_min(t_right, t);
+        } else {
+            t_left = std_max(t_left, t);
+        }
+        if (t_left > t_right) return false;
+    }
+    if (direction_opt) {
+        if (dot(opt, ld) > 0.0f) {
+            result = lp + t_right * ld;
+        } else {
+            result = lp + t_left * ld;
+        }
+    } else {
+        const float t = dot(ld, opt - lp);
+        if (t < t_left) {
+            result = lp + t_left * ld;
+        } else if (t > t_right) {
+            result = lp + t_right * ld;
+        } else {
+            result = lp + t * ld;
+        }
+    }
+    return true;
+}
+
+__device__ int linear_program2(const OrcaLine* lines, int n, float radius, f2 opt, bool direction_opt, f2& result) {
+    if (direction_opt) {
+        result = opt * radius;
+    } else if (abs_sq(opt) > sqr(radius)) {
+        result = normalize(opt) * radius;
+    } else {
+        result = opt;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (det(lines[i].direction, lines[i].point - result) > 0.0f) {
+            const f2 temp = result;
+            if (!linear_program1(lines, i, radius, opt, direction_opt, result)) {
+                result = temp;
+                return i;
+            }
+        }
+    }
+    return n;
+}
+
+__device__ void linear_program3(OrcaScratch& s, int n, int num_obst_lines, int begin_line, float radius, f2& result) {
+    float distance = 0.0f;
+    const OrcaLine* lines = s.lines;
+    for (int i = begin_line; i < n; ++i) {
+        if (det(lines[i].direction, lines[i].point - result) > distance) {
+            int np = 0;
+            for (int k = 0; k < num_obst_lines; ++k) s.proj[np++] = lines[k];
+            for (int j = num_obst_lines; j < i; ++j) {
+                OrcaLine line;
+                const float determinant = det(lines[i].direction, lines[j].direction);
+                if (fabsf(determinant) <= RVO_EPS) {
+                    if (dot(lines[i].direction, lines[j].direction) > 0.0f) {
+                        continue;
+                    } else {
+                        line.point = 0.5f * (lines[i].point + lines[j].point);
+                    }
+                } else {
+                    line.point = lines[i].point +
+                                 (det(lines[j].direction, lines[i].point - lines[j].point) / determinant) * lines[i].direction;
+                }
+                line.direction = normalize(lines[j].direction - lines[i].direction);
+                s.proj[np++] = line;
+            }
+            const f2 temp = result;
+            if (linear_program2(s.proj, np, radius, F2(-lines[i].direction.y, lines[i].direction.x), true, result) < np) {
+                result = temp;
+            }
+            distance = det(lines[i].direction, lines[i].point - result);
+        }
+    }
+}
+
+// Agent::computeNewVelocity for agent `self` given its neighbour lists in the scratch (lane 0)
+__device__ f2 compute_new_velocity(const DevWorld& w, OrcaScratch& s, int self, f2 pref) {
+    const f2 pos = F2(w.apx[self], w.apy[self]);
+    const f2 vel = F2(w.avx[self], w.avy[self]);
+    const float radius = 0.5f, time_horizon = 5.0f, time_horizon_obst = 5.0f;  // rvoscene.h:57,63
+    const float max_speed = w.amax_speed[self];
+    const float inv_tho = 1.0f / time_horizon_obst;
+    int nl = 0;
+    OrcaLine* L = s.lines;
+#define PUSH(P_, D_)              \
+    do {                          \
+        L[nl].point = (P_);       \
+        L[nl].direction = (D_);   \
+        nl++;                     \
+    } while (0)
+    for (int i = 0; i < s.n_on; ++i) {
+        int o1 = s.on_idx[i];
+        int o2 = w.obst[o1].next;
+        const f2 rel1 = opoint(w, o1) - pos;
+        const f2 rel2 = opoint(w, o2) - pos;
+        bool covered = false;
+        for (int j = 0; j < nl; ++j) {
+            if (det(inv_tho * rel1 - L[j].point, L[j].direction) - inv_tho * radius >= -RVO_EPS &&
+                det(inv_tho * rel2 - L[j].point, L[j].direction) - inv_tho * radius >= -RVO_EPS) {
+                covered = true;
+                break;
+            }
+        }
+        if (covered) continue;
+        const float dsq1 = abs_sq(rel1), dsq2 = abs_sq(rel2);
+        const float rsq = sqr(radius);
+        const f2 ovec = opoint(w, o2) - opoint(w, o1);
+        const float sp = dot(-rel1, ovec) / abs_sq(ovec);
+        const float dsq_line = abs_sq(-rel1 - sp * ovec);
+        const f2 u1 = ounit(w, o1);
+        if (sp < 0.0f && dsq1 <= rsq) {
+            if (w.obst[o1].is_convex) PUSH(F2(0.0f, 0.0f), normalize(F2(-rel1.y, rel1.x)));
+            continue;
+        } else if (sp > 1.0f && dsq2 <= rsq) {
+            if (w.obst[o2].is_convex && det(rel2, ounit(w, o2)) >= 0.0f) PUSH(F2(0.0f, 0.0f), normalize(F2(-rel2.y, rel2.x)));
+            continue;
+        } else if (sp >= 0.0f && sp < 1.0f && dsq_line <= rsq) {
+            PUSH(F2(0.0f, 0.0f), -u1);
+            continue;
+        }
+        f2 left_leg, right_leg;
+        if (sp < 0.0f && dsq_line <= rsq) {
+            if (!w.obst[o1].is_convex) continue;
+            o2 = o1;
+            const float leg1 = sqrtf(dsq1 - rsq);
+            left_leg = vdiv(F2(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), dsq1);
+            right_leg = vdiv(F2(rel1.x * leg1 + rel1.y * radius, -rel1.x * radius + rel1.y * leg1), dsq1);
+        } else if (sp > 1.0f && dsq_line <= rsq) {
+            if (!w.obst[o2].is_convex) continue;
+            o1 = o2;
+            const float leg2 = sqrtf(dsq2 - rsq);
+            left_leg = vdiv(F2(rel2.x * leg2 - rel2.y * radius, rel2.x * radius + rel2.y * leg2), dsq2);
+            right_leg = vdiv(F2(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), dsq2);
+        } else {
+            if (w.obst[o1].is_convex) {
+                const float leg1 = sqrtf(dsq1 - rsq);
+                left_leg = vdiv(F2(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), dsq1);
+            } else {
+                left_leg = -u1;
+            }
+            if (w.obst[o2].is_convex) {
+                const float leg2 = sqrtf(dsq2 - rsq);
+                right_leg = vdiv(F2(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), dsq2);
+            } else {
+                right_leg = u1;
+            }
+        }
+        const f2 uo1 = ounit(w, o1), uo2 = ounit(w, o2);
+        const f2 uln = ounit(w, w.obst[o1].prev);
+        bool left_foreign = false, right_foreign = false;
+        if (w.obst[o1].is_convex && det(left_leg, -uln) >= 0.0f) {
+            left_leg = -uln;
+            left_foreign = true;
+        }
+        if (w.obst[o2].is_convex && det(right_leg, uo2) <= 0.0f) {
+            right_leg = uo2;
+            right_foreign = true;
+        }
+        const f2 left_cutoff = inv_tho * (opoint(w, o1) - pos);
+        const f2 right_cutoff = inv_tho * (opoint(w, o2) - pos);
+        const f2 cutoff_vec = right_cutoff - left_cutoff;
+        const float t = (o1 == o2 ? 0.5f : dot(vel - left_cutoff, cutoff_vec) / abs_sq(cutoff_vec));
+        const float t_left = dot(vel - left_cutoff, left_leg);
+        const float t_right = dot(vel - right_cutoff, right_leg);
+        if ((t < 0.0f && t_left < 0.0f) || (o1 == o2 && t_left < 0.0f && t_right < 0.0f)) {
+            const f2 unit_w = normalize(vel - left_cutoff);
+            PUSH(left_cutoff + radius * inv_tho * unit_w, F2(unit_w.y, -unit_w.x));
+            continue;
+        } else if (t > 1.0f && t_right < 0.0f) {
+            const f2 unit_w = normalize(vel - right_cutoff);
+            PUSH(right_cutoff + radius * inv_tho * unit_w, F2(unit_w.y, -unit_w.x));
+            continue;
+        }
+        const float inf = __builtin_huge_valf();
+        const float dsq_cutoff = ((t < 0.0f || t > 1.0f || o1 == o2) ? inf : abs_sq(vel - (left_cutoff + t * cutoff_vec)));
+        const float dsq_left = ((t_left < 0.0f) ? inf : abs_sq(vel - (left_cutoff + t_left * left_leg)));
+        const float dsq_right = ((t_right < 0.0f) ? inf : abs_sq(vel - (right_cutoff + t_right * right_leg)));
+        if (dsq_cutoff <= dsq_left && dsq_cutoff <= dsq_right) {
+            const f2 d = -uo1;
+            PUSH(left_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
+            continue;
+        } else if (dsq_left <= dsq_right) {
+            if (left_foreign) continue;
+            const f2 d = left_leg;
+            PUSH(left_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
+            continue;
+        } else {
+            if (right_foreign) continue;
+            const f2 d = -right_leg;
+            PUSH(right_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
+            continue;
+        }
+    }
+    const int num_obst_lines = nl;
+    const float inv_th = 1.0f / time_horizon;
+    for (int i = 0; i < s.n_an; ++i) {
+        const int other = s.an_idx[i];
+        const f2 rel_pos = F2(w.apx[other], w.apy[other]) - pos;
+        const f2 rel_vel = vel - F2(w.avx[other], w.avy[other]);
+        const float dist_sq = abs_sq(rel_pos);
+        const float comb = radius + 0.5f;  // every agent has radius 0.5
+        const float comb_sq = sqr(comb);
+        f2 dir, u;
+        if (dist_sq > comb_sq) {
+            const f2 ww = rel_vel - inv_th * rel_pos;
+            const float wl_sq = abs_sq(ww);
+            const float dp1 = dot(ww, rel_pos);
+            if (dp1 < 0.0f && sqr(dp1) > comb_sq * wl_sq) {
+                const float wl = sqrtf(wl_sq);
+                const f2 unit_w = vdiv(ww, wl);
+                dir = F2(unit_w.y, -unit_w.x);
+                u = (comb * inv_th - wl) * unit_w;
+            } else {
+                const float leg = sqrtf(dist_sq - comb_sq);
+                if (det(rel_pos, ww) > 0.0f) {
+                    dir = vdiv(F2(rel_pos.x * leg - rel_pos.y * comb, rel_pos.x * comb + rel_pos.y * leg), dist_sq);
+                } else {
+                    dir = vdiv(-F2(rel_pos.x * leg + rel_pos.y * comb, -rel_pos.x * comb + rel_pos.y * leg), dist_sq);
+                }
+                const float dp2 = dot(rel_vel, dir);
+                u = dp2 * dir - rel_vel;
+            }
+        } else {
+            const float inv_ts = 1.0f / (float)w.step_hz;
+            const f2 ww = rel_vel - inv_ts * rel_pos;
+            const float wl = vabs(ww);
+            const f2 unit_w = vdiv(ww, wl);
+            dir = F2(unit_w.y, -unit_w.x);
+            u = (comb * inv_ts - wl) * unit_w;
+        }
+        PUSH(vel + 0.5f * u, dir);
+    }
+#undef PUSH
+    f2 nv = F2(w.anvx[self], w.anvy[self]);
+    const int fail = linear_program2(L, nl, max_speed, pref, false, nv);
+    if (fail < nl) linear_program3(s, nl, num_obst_lines, fail, max_speed, nv);
+    return nv;
+}

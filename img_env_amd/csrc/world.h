@@ -1,0 +1,124 @@
+// world.h -- device-side data layout of one img_env world (SoA in HBM) and the per-class static
+// tables built once at imgenv_create().  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+#include "tfm.h"
+
+#define WAVE 64
+#define OWNER_MULTI 0xFFFFFFFEu
+
+// composed class layer byte (k_compose): low 3 bits = base class, bit 3 = "some robot covers it"
+#define CLS_STATIC 0   // occupancy value 0: static map / obstacle      (collision code 1)
+#define CLS_PED 1      // value 1: pedestrian                           (collision code 2)
+#define CLS_TWO 2      // value 2 already in the static map            (collision code 3)
+#define CLS_LOW 3      // free for collision, occupied for the crop (3..249)
+#define CLS_HIGH 4     // free (>= 250)
+#define CLS_ROBOT 8    // flag: covered by >= 1 robot footprint; owner[] says which
+
+// Everything of a robot class that does not depend on the pose: footprint samples
+// (agent.cpp:18-62), field-of-view mask of the crop (agent.cpp:373-386), Bresenham ray paths of
+// the laser (agent.cpp:405-438, 511-624) and the own-footprint stamp (agent.cpp:503).
+struct RobotClassDev {
+    int n_fp;
+    const double* fp_x;
+    const double* fp_y;
+    const uint32_t* fov_bits;    // [ceil(Hv*Wv/32)] bit = cell passes the angle / distance gate
+    const uint32_t* stamp_bits;  // [ceil(Hv*Wv/32)] bit = own footprint covers the view cell
+    int ray_maxlen;              // longest ray in cells
+    int ray_stride;              // beams padded to a multiple of 64
+    const uint16_t* ray_cells;   // [ray_maxlen][ray_stride] view cell index of step k of beam b
+    const uint16_t* ray_len;     // [ray_stride] number of in-map steps before the ray leaves / ends
+    const float* ray_dist;       // [ray_maxlen][ray_stride] float32(hit distance) if the hit is at step k
+    const uint32_t* inv_off;     // [Hv*Wv+1] CSR offsets: rays through a view cell ...
+    const uint32_t* inv_ent;     // ... as (beam << 16 | k), beam descending
+    int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
+};
+
+struct PedClassDev {
+    int shape;
+    int n_bbox;  // circle / rectangle samples
+    const double* bx;
+    const double* by;
+    int n_left, n_right;  // leg samples (circles of radius lr / rr around 0,0)
+    const double *lx, *ly, *rx, *ry;
+    double sizes[6];
+};
+
+struct RvoObstDev {  // RVO::Obstacle (Obstacle.h) with index links
+    float px, py, ux, uy;
+    int is_convex, next, prev;
+};
+struct RvoNodeDev {  // KdTree::ObstacleTreeNode
+    int obstacle, left, right;
+};
+
+struct DevWorld {
+    // sizes
+    int R, RL, r0, P, NA;  // world robots, local robots, first local robot, peds, RVO agents
+    int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;
+    int scene, relation, ktype, use_laser, laser_norm, time_max;
+    double res, step_hz, laser_max, ped_safety_space, ped_image_r, ped_image_r2, ped_res;
+    Tf2 view_base, base_view;
+    // limiter (speed_limit.cpp)
+    int lv_has_v, lv_has_a, lv_has_j, lw_has_v, lw_has_a, lw_has_j;
+    double lv_min_v, lv_max_v, lv_min_a, lv_max_a, lv_min_j, lv_max_j;
+    double lw_min_v, lw_max_v, lw_min_a, lw_max_a, lw_min_j, lw_max_j;
+    // grids
+    const uint8_t* obs_map;  // static + obstacles (rebuilt at reset)
+    uint8_t* ped_layer;      // 1 where view_ped() would have written a 1 this step
+    uint32_t* own_lo;        // min (robot index + 1) covering the cell, 0xFFFFFFFF = none
+    uint32_t* own_hi;        // max (robot index + 1) covering the cell, 0 = none
+    uint8_t* cls;            // composed class layer
+    uint32_t* owner;         // robot index | OWNER_MULTI where cls has CLS_ROBOT
+    // classes
+    const RobotClassDev* rclass;
+    const PedClassDev* pclass;
+    const int* robot_cls;  // [R]
+    const int* ped_cls;    // [P]
+    const double* robot_size_last;  // [R]
+    const double* ped_r_round;      // [P] round(PedInfo.r_, 2)
+    const float* ped_r32;           // [P] PedInfo.r_
+    const uint16_t* f16_lut;        // [256] float16(v / 255)
+    // robots
+    double* rec;  // [R][6] x y theta vx vy pad
+    double *gx, *gy, *l0v, *l0w, *l1v, *l1w;  // [RL]
+    Tf2* world_target;                        // [RL] tf_world_target_ (agent.cpp:144-154)
+    int* is_coll;                             // [RL]
+    uint8_t *is_arr, *py_done, *clean_state;  // [RL]
+    double* tmp_dist;                         // [RL]
+    // pedestrians
+    double *ppx, *ppy, *pyaw, *plx, *ply, *pvx, *pvy, *prem, *llx, *lly, *rlx, *rly;  // [P]
+    int *pstate, *ptraj_idx;                                                       // [P]
+    const int* ptraj_len;
+    const double* ptraj;  // [P][traj_cap][3]
+    int traj_cap;
+    // RVO (float32)
+    float *apx, *apy, *avx, *avy, *anvx, *anvy;  // [NA]
+    const float* amax_speed;                     // [NA]
+    const RvoObstDev* obst;
+    const RvoNodeDev* onodes;
+    int n_obst, n_onodes, oroot;
+    int* err;  // [4] device-side overflow flags
+    // outputs (imgenv_out)
+    float* vector_states;
+    uint8_t* view_maps;
+    uint16_t* sensor_maps;
+    float* lasers_raw;
+    double* lasers;
+    float* ped_vector_states;
+    float* ped_maps;
+    int8_t* is_collisions;
+    uint8_t* is_arrives;
+    double* step_ds;
+    double* ped_min_dists;
+    int32_t* base_rewards;
+    uint8_t* base_dones;
+    double* rewards;
+    uint8_t* dones;
+    int32_t* dones_info;
+    uint8_t* is_clean;
+    double* robot_pose;
+    double* ped_state;
+    int32_t* counters;
+};

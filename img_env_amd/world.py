@@ -1,0 +1,126 @@
+"""``World``: one img_env world living on one GPU, a thin Python object over the C ABI.
+
+torch is plumbing only: it owns the output arena (so every output is a zero-copy ``torch.Tensor``
+view of library-written HBM), provides the stream, and runs the RCCL all-gather of a robot-sharded
+world.  All simulation work happens in ``csrc/libimgenv_hip.so``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi
+
+_TORCH_DTYPES = None
+
+
+def _torch_dtype(np_dtype):
+    global _TORCH_DTYPES
+    import torch
+    if _TORCH_DTYPES is None:
+        _TORCH_DTYPES = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                         np.dtype(np.float16): torch.float16, np.dtype(np.uint8): torch.uint8,
+                         np.dtype(np.int8): torch.int8, np.dtype(np.int32): torch.int32}
+    return _TORCH_DTYPES[np.dtype(np_dtype)]
+
+
+class World:
+    """create -> reset(layout) -> step(actions) ... ; ``out`` maps output names to device tensors."""
+
+    def __init__(self, params, grid, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("img_env_amd.World needs a ROCm GPU (there is no CPU fallback)")
+        self.lib = _cabi.load_library()
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
+        self.params = dict(params)
+        self.params["device"] = self.device.index
+        self.grid = np.ascontiguousarray(grid, np.uint8)
+        cfg, self._keep = _cabi.make_cfg(self.params)
+        nbytes = self.lib.imgenv_arena_bytes(C.byref(cfg))
+        if nbytes <= 0:
+            raise ValueError("imgenv_arena_bytes rejected the configuration")
+        with torch.cuda.device(self.device):
+            self.arena = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+        cfg.out_arena = self.arena.data_ptr()
+        cfg.out_arena_bytes = nbytes
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.imgenv_create(C.byref(cfg), self.grid.ctypes.data, self.grid.shape[0], self.grid.shape[1],
+                                    C.byref(h))
+        if rc != 0:
+            raise ValueError("imgenv_create: %s" % self.lib.imgenv_last_error().decode())
+        self.h = h
+        self.n_robots, self.n_peds = cfg.n_robots, cfg.n_peds
+        o = _cabi.Out()
+        self._check(self.lib.imgenv_outputs(self.h, C.byref(o)), "imgenv_outputs")
+        self.n_local = o.n_local
+        base = self.arena.data_ptr()
+        self.out = {}
+        for name, (dt, shape) in _cabi.out_layout(o, self.n_peds, cfg.ped_image_size[0], cfg.ped_image_size[1]).items():
+            off = getattr(o, name) - base
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            self.out[name] = self.arena[off:off + n].view(_torch_dtype(dt)).view(*shape)
+        rec, bpr = C.c_void_p(), C.c_int64()
+        self._check(self.lib.imgenv_records(self.h, C.byref(rec), C.byref(bpr)), "imgenv_records")
+        off = rec.value - base
+        n = self.n_robots * _cabi.RECORD_DOUBLES * 8
+        self.records = self.arena[off:off + n].view(torch.float64).view(self.n_robots, _cabi.RECORD_DOUBLES)
+        self.robot_begin = cfg.robot_begin
+        self.robot_end = cfg.robot_end if cfg.robot_end else cfg.n_robots
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.imgenv_last_error().decode()))
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, layout):
+        b, keep = _cabi.make_reset_batch(layout if isinstance(layout, dict) else layout.as_batch(), self.n_robots,
+                                         self.n_peds)
+        self._check(self.lib.imgenv_reset(self.h, C.byref(b), self._stream()), "imgenv_reset")
+        return self.out
+
+    def _actions(self, actions):
+        import torch
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(np.ascontiguousarray(actions, np.float32), device=self.device)
+        if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.numel() != self.n_local * 3:
+            raise ValueError("actions must be [%d, 3] (v, w, beep)" % self.n_local)
+        return actions
+
+    def step(self, actions):
+        a = self._actions(actions)
+        self._check(self.lib.imgenv_step(self.h, C.c_void_p(a.data_ptr()), self._stream()), "imgenv_step")
+        return self.out
+
+    def step_begin(self, actions):
+        a = self._actions(actions)
+        self._check(self.lib.imgenv_step_begin(self.h, C.c_void_p(a.data_ptr()), self._stream()), "imgenv_step_begin")
+
+    def step_end(self):
+        self._check(self.lib.imgenv_step_end(self.h, self._stream()), "imgenv_step_end")
+        return self.out
+
+    def launches(self):
+        return self.lib.imgenv_step_launches(self.h)
+
+    def snapshot(self):
+        """host copies (numpy) of every output, after synchronising the stream"""
+        import torch
+        torch.cuda.synchronize(self.device)
+        return {k: v.cpu().numpy().copy() for k, v in self.out.items()}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.imgenv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
