@@ -205,7 +205,9 @@ def make_reset_batch(b, n_robots, n_peds):
 #: every symbol include/imgenv.h declares
 SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_create", "imgenv_arena_bytes",
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
-           "imgenv_records", "imgenv_outputs", "imgenv_step_launches")
+           "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
+           "imgenv_kernel_name")
+K_COUNT = 7
 
 
 def library_path():
@@ -232,6 +234,10 @@ def bind(lib):
     lib.imgenv_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.imgenv_outputs.argtypes = [C.c_void_p, C.POINTER(Out)]
     lib.imgenv_step_launches.argtypes = [C.c_void_p]
+    lib.imgenv_timing.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.imgenv_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.imgenv_kernel_name.argtypes = [C.c_int]
+    lib.imgenv_kernel_name.restype = C.c_char_p
     return lib
 
 

@@ -54,7 +54,82 @@ struct imgenv {
     int launches = 0;
     size_t lds_view = 0, lds_obs = 0;
     RvoObstacles rvo;
+    // live timing (imgenv_timing)
+    int t_mode = 0, t_which = -1;
+    std::vector<hipEvent_t> t_ev;
+    std::vector<int> t_id;  // kernel id of event pair q
+    size_t t_used = 0;
+    double t_ms[IMGENV_K_COUNT] = {0};
+    int64_t t_cnt[IMGENV_K_COUNT] = {0};
 };
+
+static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster",
+                                                         "k_compose", "k_view", "k_obs"};
+extern "C" const char* imgenv_kernel_name(int id) { return (id >= 0 && id < IMGENV_K_COUNT) ? KERNEL_NAMES[id] : ""; }
+
+static int timing_flush(imgenv* h) {
+    for (size_t q = 0; q < h->t_used; q++) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(h->t_ev[2 * q + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, h->t_ev[2 * q], h->t_ev[2 * q + 1]));
+        h->t_ms[h->t_id[q]] += ms;
+        h->t_cnt[h->t_id[q]] += 1;
+    }
+    h->t_used = 0;
+    return 0;
+}
+static inline bool timing_on(const imgenv* h, int id) { return h->t_mode == 1 || (h->t_mode == 2 && h->t_which == id); }
+static int timing_mark(imgenv* h, int id, hipStream_t st, int end) {
+    if (!end) {
+        if (h->t_used * 2 + 2 > h->t_ev.size()) {
+            if (h->t_ev.size() >= 16384) {
+                if (int rc = timing_flush(h)) return rc;
+            } else {
+                for (int q = 0; q < 2; q++) {
+                    hipEvent_t e;
+                    HIPCHK(hipEventCreate(&e));
+                    h->t_ev.push_back(e);
+                }
+                h->t_id.push_back(id);
+            }
+        }
+        h->t_id[h->t_used] = id;
+        HIPCHK(hipEventRecord(h->t_ev[2 * h->t_used], st));
+    } else {
+        HIPCHK(hipEventRecord(h->t_ev[2 * h->t_used + 1], st));
+        h->t_used++;
+    }
+    return 0;
+}
+// launch wrapper: optional event pair on the launch stream around one kernel
+#define TIMED(h, id, st, launch)                                       \
+    do {                                                               \
+        const bool on_ = timing_on(h, id);                             \
+        if (on_) { if (int rc_ = timing_mark(h, id, st, 0)) return rc_; } \
+        launch;                                                        \
+        if (on_) { if (int rc_ = timing_mark(h, id, st, 1)) return rc_; } \
+    } while (0)
+
+extern "C" int imgenv_timing(imgenv_t* h, int mode, int which) {
+    if (!h || mode < 0 || mode > 2) FAIL(IMGENV_EINVAL, "bad timing mode");
+    if (int rc = timing_flush(h)) return rc;
+    h->t_mode = mode;
+    h->t_which = which;
+    for (int q = 0; q < IMGENV_K_COUNT; q++) {
+        h->t_ms[q] = 0;
+        h->t_cnt[q] = 0;
+    }
+    return IMGENV_OK;
+}
+extern "C" int imgenv_timing_read(imgenv_t* h, double* total_ms, int64_t* launches) {
+    if (!h || !total_ms || !launches) FAIL(IMGENV_EINVAL, "null argument");
+    if (int rc = timing_flush(h)) return rc;
+    for (int q = 0; q < IMGENV_K_COUNT; q++) {
+        total_ms[q] = h->t_ms[q];
+        launches[q] = h->t_cnt[q];
+    }
+    return IMGENV_OK;
+}
 
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950"; }
 extern "C" int32_t imgenv_abi_version(void) { return IMGENV_ABI_VERSION; }
@@ -152,6 +227,7 @@ static int dev_upload(imgenv* h, const T** out, const std::vector<T>& v) {
 extern "C" void imgenv_destroy(imgenv_t* h) {
     if (!h) return;
     for (void* p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->t_ev) (void)hipEventDestroy(e);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     delete h;
 }
@@ -483,10 +559,10 @@ __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const size_t G = (size_t)h->Hg * h->Wg;
-    k_raster<<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset);
-    k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d);
-    k_view<<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d);
-    k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, st>>>(d, is_reset, h->elapsed, h->PP);
+    TIMED(h, IMGENV_K_RASTER, st, (k_raster<<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
+    TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
+    TIMED(h, IMGENV_K_VIEW, st, (k_view<<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d)));
+    TIMED(h, IMGENV_K_OBS, st, (k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, st>>>(d, is_reset, h->elapsed, h->PP)));
     h->launches += 4;
     HIPCHK(hipGetLastError());
     return 0;
@@ -607,11 +683,12 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     DevWorld& d = h->d;
     h->launches = 0;
     if (h->P > 0 && h->NA > 0) {  // _step_ped_normal (img_env.cpp:304-359)
-        k_orca<<<dim3(h->P), dim3(WAVE), 0, st>>>(d);
-        k_ped_update<<<dim3((h->P + 63) / 64), dim3(64), 0, st>>>(d);
+        TIMED(h, IMGENV_K_ORCA, st, (k_orca<<<dim3(h->P), dim3(WAVE), 0, st>>>(d)));
+        TIMED(h, IMGENV_K_PED_UPDATE, st, (k_ped_update<<<dim3((h->P + 63) / 64), dim3(64), 0, st>>>(d)));
         h->launches += 2;
     }
-    k_integrate<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, actions);  // _step_robot (img_env.cpp:388-410)
+    // _step_robot (img_env.cpp:388-410)
+    TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, actions)));
     h->launches += 1;
     HIPCHK(hipGetLastError());
     return IMGENV_OK;

@@ -370,6 +370,7 @@ __global__ void k_compose(DevWorld w) {
     const size_t G = (size_t)w.Hg * w.Wg;
     const size_t c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.counters[3] += w.counters[2];  // cumulative frozen robot-steps since create (bench statistic)
         w.counters[1] = 0;
         w.counters[2] = 0;
     }

@@ -108,6 +108,17 @@ class World:
     def launches(self):
         return self.lib.imgenv_step_launches(self.h)
 
+    def timing(self, mode, which=-1):
+        """0 off, 1 every kernel, 2 only kernel id ``which`` (HIP events on the launch stream)"""
+        self._check(self.lib.imgenv_timing(self.h, mode, which), "imgenv_timing")
+
+    def timing_read(self):
+        """{kernel name: (total ms, launches)} since the last timing() call"""
+        ms = (C.c_double * _cabi.K_COUNT)()
+        n = (C.c_int64 * _cabi.K_COUNT)()
+        self._check(self.lib.imgenv_timing_read(self.h, ms, n), "imgenv_timing_read")
+        return {self.lib.imgenv_kernel_name(q).decode(): (ms[q], n[q]) for q in range(_cabi.K_COUNT)}
+
     def snapshot(self):
         """host copies (numpy) of every output, after synchronising the stream"""
         import torch

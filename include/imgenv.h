@@ -230,8 +230,24 @@ int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_robot);
 
 int imgenv_outputs(imgenv_t* h, imgenv_out* out);
 
-/* number of kernels launched by the last step and the name of the dominant one (bench / profiling aid) */
+/* number of kernels launched by the last step (bench / profiling aid) */
 int imgenv_step_launches(imgenv_t* h);
+
+/* Live per-kernel timing with HIP events recorded on the stream the kernels are launched on.
+ * mode 0: off; 1: every kernel; 2: only kernel `which`.  Kernel ids: */
+#define IMGENV_K_ORCA 0
+#define IMGENV_K_PED_UPDATE 1
+#define IMGENV_K_INTEGRATE 2
+#define IMGENV_K_RASTER 3
+#define IMGENV_K_COMPOSE 4
+#define IMGENV_K_VIEW 5
+#define IMGENV_K_OBS 6
+#define IMGENV_K_COUNT 7
+int imgenv_timing(imgenv_t* h, int mode, int which);
+/* synchronises the recorded events and returns accumulated milliseconds / launch counts per kernel
+ * id since the last imgenv_timing() call; arrays of IMGENV_K_COUNT entries */
+int imgenv_timing_read(imgenv_t* h, double* total_ms, int64_t* launches);
+const char* imgenv_kernel_name(int id);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,8 @@ def compare(g, c, fields=EXACT + CLOSE):
     bad = {}
     for k in fields:
         a, b = g[k], c[k]
+        if k == "counters":  # [3] is a cumulative bench statistic of the HIP library only
+            a, b = a[:3], b[:3]
         if k in EXACT:
             if not np.array_equal(a, b):
                 idx = np.argwhere(np.asarray(a) != np.asarray(b))
