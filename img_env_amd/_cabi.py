@@ -72,7 +72,7 @@ class Out(C.Structure):
         ("ped_maps", C.c_void_p), ("is_collisions", C.c_void_p), ("is_arrives", C.c_void_p),
         ("step_ds", C.c_void_p), ("ped_min_dists", C.c_void_p),
         ("base_rewards", C.c_void_p), ("base_dones", C.c_void_p),
-        ("rewards", C.c_void_p), ("dones", C.c_void_p), ("dones_info", C.c_void_p), ("is_clean", C.c_void_p),
+        ("rewards", C.c_void_p), ("paper_rewards", C.c_void_p), ("dones", C.c_void_p), ("dones_info", C.c_void_p), ("is_clean", C.c_void_p),
         ("robot_pose", C.c_void_p), ("ped_state", C.c_void_p), ("counters", C.c_void_p),
     ]
 
@@ -95,6 +95,7 @@ def out_layout(o, n_peds, hp, wp):
         "base_rewards": (np.int32, (R,)),
         "base_dones": (np.uint8, (R,)),
         "rewards": (np.float64, (R,)),
+        "paper_rewards": (np.float64, (R,)),
         "dones": (np.uint8, (R,)),
         "dones_info": (np.int32, (R,)),
         "is_clean": (np.uint8, (R,)),

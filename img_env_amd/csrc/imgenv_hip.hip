@@ -177,6 +177,7 @@ static void plan_arena(const imgenv_cfg& c, const ViewGeom& g, int RL, ArenaPlan
     p.add(P * 32);               // 18 ped_state
     p.add(16);                   // 19 counters
     p.add((size_t)c.n_robots * IMGENV_RECORD_DOUBLES * 8);  // 20 records
+    p.add(R * 8);                // 21 paper_rewards
 }
 
 static int shard_of(const imgenv_cfg& c, int& r0, int& r1) {
@@ -485,6 +486,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     o.ped_state = (double*)(A + plan.off[18]);
     o.counters = (int32_t*)(A + plan.off[19]);
     d.rec = (double*)(A + plan.off[20]);
+    o.paper_rewards = (double*)(A + plan.off[21]);
+    d.paper_rewards = o.paper_rewards;
     d.vector_states = o.vector_states; d.view_maps = o.view_maps; d.sensor_maps = o.sensor_maps;
     d.lasers_raw = o.lasers_raw; d.lasers = o.lasers; d.ped_vector_states = o.ped_vector_states;
     d.ped_maps = o.ped_maps; d.is_collisions = o.is_collisions; d.is_arrives = o.is_arrives;

@@ -743,6 +743,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
         w.base_dones[l] = 0;
         w.py_done[l] = 0;  // self.dones = zeros (yaml_env.py:316)
         w.rewards[l] = 0.0;
+        w.paper_rewards[l] = 0.0;
         w.dones[l] = 0;
         w.dones_info[l] = 0;
         w.is_clean[l] = 1;
@@ -778,6 +779,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
     if (coll > 0) dinfo = coll;
     if (arr == 1) dinfo = 5;
     // MultiRobotCleanWrapper (base.py:79-88)
+    w.paper_rewards[l] = reward;
     const uint8_t clean_before = w.clean_state[l];
     if (!clean_before) reward = 0;
     w.rewards[l] = reward;

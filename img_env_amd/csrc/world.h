@@ -115,6 +115,7 @@ struct DevWorld {
     int32_t* base_rewards;
     uint8_t* base_dones;
     double* rewards;
+    double* paper_rewards;
     uint8_t* dones;
     int32_t* dones_info;
     uint8_t* is_clean;

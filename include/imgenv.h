@@ -180,7 +180,8 @@ typedef struct imgenv_out {
     int32_t* base_rewards;        /* [R] arrive - collision code */
     uint8_t* base_dones;          /* [R] */
     /* wrapper stack outputs (base.py:153-254, 69-93) */
-    double* rewards;              /* [R] SensorsPaperRewardWrapper, zeroed where !is_clean */
+    double* rewards;              /* [R] SensorsPaperRewardWrapper, zeroed where !is_clean (the full default stack) */
+    double* paper_rewards;        /* [R] SensorsPaperRewardWrapper before the MultiRobotClean mask */
     uint8_t* dones;               /* [R] after TimeLimitWrapper */
     int32_t* dones_info;          /* [R] 0 | 1..3 collision class | 5 arrive | 10 time-out */
     uint8_t* is_clean;            /* [R] MultiRobotCleanWrapper mask used for this step */

@@ -504,7 +504,7 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     ALLOC(o->is_collisions, int8_t, RL); ALLOC(o->is_arrives, uint8_t, RL);
     ALLOC(o->step_ds, double, RL); ALLOC(o->ped_min_dists, double, RL);
     ALLOC(o->base_rewards, int32_t, RL); ALLOC(o->base_dones, uint8_t, RL);
-    ALLOC(o->rewards, double, RL); ALLOC(o->dones, uint8_t, RL); ALLOC(o->dones_info, int32_t, RL);
+    ALLOC(o->rewards, double, RL); ALLOC(o->paper_rewards, double, RL); ALLOC(o->dones, uint8_t, RL); ALLOC(o->dones_info, int32_t, RL);
     ALLOC(o->is_clean, uint8_t, RL);
     ALLOC(o->robot_pose, double, (size_t)RL * 3);
     ALLOC(o->ped_state, double, (size_t)P * 4);
@@ -543,7 +543,7 @@ void oracle_destroy(oracle_world* w) {
     imgenv_out* o = &w->out;
     free(o->vector_states); free(o->view_maps); free(o->sensor_maps); free(o->lasers_raw); free(o->lasers);
     free(o->ped_vector_states); free(o->ped_maps); free(o->is_collisions); free(o->is_arrives);
-    free(o->step_ds); free(o->ped_min_dists); free(o->base_rewards); free(o->base_dones); free(o->rewards);
+    free(o->step_ds); free(o->ped_min_dists); free(o->base_rewards); free(o->base_dones); free(o->rewards); free(o->paper_rewards);
     free(o->dones); free(o->dones_info); free(o->is_clean); free(o->robot_pose); free(o->ped_state);
     free(o->counters);
     free(w);
@@ -1038,6 +1038,7 @@ int oracle_reset(oracle_world* w, const imgenv_reset_batch* b) {
             w->out.base_rewards[l] = 0;
             w->out.base_dones[l] = 0;
             w->out.rewards[l] = 0;
+            w->out.paper_rewards[l] = 0;
             w->out.dones[l] = 0;
             w->out.dones_info[l] = 0;
         }
@@ -1266,6 +1267,7 @@ static void wrappers(oracle_world* w) {
         if (coll > 0) info = coll;
         if (arr == 1) info = 5;
         /* MultiRobotCleanWrapper.step (base.py:79-88): mask uses is_clean from BEFORE this step */
+        o->paper_rewards[l] = reward;
         uint8_t clean_before = w->clean_state[l];
         if (!clean_before) reward = 0;
         o->rewards[l] = reward;

@@ -8,7 +8,7 @@ import numpy as np
 EXACT = ("is_collisions", "is_arrives", "view_maps", "sensor_maps", "base_rewards", "base_dones", "dones",
          "dones_info", "is_clean", "counters")
 CLOSE = ("vector_states", "lasers_raw", "lasers", "ped_vector_states", "ped_maps", "step_ds", "ped_min_dists",
-         "rewards", "robot_pose", "ped_state")
+         "rewards", "paper_rewards", "robot_pose", "ped_state")
 TOL = 1e-4
 
 
