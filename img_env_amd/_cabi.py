@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 ABI_VERSION = 1
-RECORD_DOUBLES = 6
+RECORD_DOUBLES = 8
 
 SHAPE_CIRCLE, SHAPE_RECTANGLE, SHAPE_LEG = 0, 1, 2
 SCENE_EMPTY, SCENE_RVO, SCENE_ERVO, SCENE_PEDSIM = 0, 1, 2, 3

@@ -91,7 +91,7 @@ struct RobotClassHost {
     int ray_maxlen = 0, ray_stride = 0, box_rad = 0;
     std::vector<uint16_t> ray_cells, ray_len;
     std::vector<float> ray_dist;
-    std::vector<uint32_t> inv_off, inv_ent;
+    std::vector<uint32_t> inv_off, inv_ent, top_ent;
 };
 
 static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
@@ -193,6 +193,9 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
     }
     k.inv_ent.reserve(k.inv_off[NC] + 1);
     for (int c = 0; c < NC; c++) k.inv_ent.insert(k.inv_ent.end(), inv[c].begin(), inv[c].end());
+    k.top_ent.assign(NC, 0xFFFFFFFFu);
+    for (int c = 0; c < NC; c++)
+        if (!inv[c].empty()) k.top_ent[c] = inv[c][0];
     if (k.inv_ent.empty()) k.inv_ent.push_back(0);
 }
 

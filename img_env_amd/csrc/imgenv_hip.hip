@@ -53,6 +53,7 @@ struct imgenv {
     bool has_reset = false;
     int launches = 0;
     size_t lds_view = 0, lds_obs = 0;
+    bool pow2 = false;
     RvoObstacles rvo;
     // live timing (imgenv_timing)
     int t_mode = 0, t_which = -1;
@@ -337,7 +338,13 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     d.SD = cfg->state_dim; d.PV = 1 + cfg->ped_vec_dim * cfg->max_ped;
     d.scene = cfg->ped_scene_type; d.relation = cfg->relation_ped_robo; d.ktype = cfg->robot_ktype;
     d.use_laser = cfg->use_laser ? 1 : 0; d.laser_norm = cfg->laser_norm; d.time_max = cfg->time_max;
-    d.res = g.res; d.step_hz = (double)cfg->step_hz; d.laser_max = cfg->laser_max;
+    d.res = g.res; d.inv_res = 1.0 / g.res;
+    {
+        int e = 0;
+        h->pow2 = (frexp(g.res, &e) == 0.5);  // exact power of two: x * (1/res) == x / res bit for bit
+        d.wv_magic = (uint32_t)((0x100000000ull + (uint64_t)g.Wv - 1) / (uint64_t)g.Wv);
+    }
+    d.step_hz = (double)cfg->step_hz; d.laser_max = cfg->laser_max;
     d.ped_safety_space = cfg->ped_safety_space; d.ped_image_r = cfg->ped_image_r;
     d.ped_image_r2 = pow(cfg->ped_image_r, 2.0);        // self.ped_image_r ** 2 (yaml_env.py:425)
     d.ped_res = 6.0 / cfg->ped_image_size[0];            // yaml_env.py:164
@@ -382,6 +389,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.ray_dist, k.ray_dist));
             TRY(dev_upload(h, &o.inv_off, k.inv_off));
             TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
+            TRY(dev_upload(h, &o.top_ent, k.top_ent));
             o.box_rad = k.box_rad;
             max_stride = std::max(max_stride, (size_t)k.ray_stride);
         }
@@ -502,14 +510,16 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->PP = 2;
     while (h->PP < P) h->PP <<= 1;
     const size_t NC = (size_t)g.Hv * g.Wv;
-    h->lds_view = ((NC + 15) & ~(size_t)15) + 2 * max_stride + 16;
+    h->lds_view = 4 * max_stride + (cfg->use_laser ? 0 : ((NC + 15) & ~(size_t)15)) + 16;
     h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)d.Hp * d.Wp * 4 + (size_t)h->PP * 2 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);
         FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
     }
-    if (h->lds_view > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)k_view, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+    if (h->lds_view > 64 * 1024) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_view<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+        HIPCHK(hipFuncSetAttribute((const void*)k_view<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+    }
     if (h->lds_obs > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)k_obs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     HIPCHK(hipDeviceSynchronize());
@@ -527,9 +537,11 @@ __global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, con
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= w.R) return;
     double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    r[0] = pose3[3 * i];  // init_pose (agent.cpp:133-142); Agent::vx, vy persist across resets
-    r[1] = pose3[3 * i + 1];
-    r[2] = pose3[3 * i + 2];
+    r[0] = pose3[5 * i];  // init_pose (agent.cpp:133-142); Agent::vx, vy persist across resets
+    r[1] = pose3[5 * i + 1];
+    r[2] = pose3[5 * i + 2];
+    r[5] = pose3[5 * i + 3];  // sin / cos of yaw/2, evaluated on the host
+    r[6] = pose3[5 * i + 4];
     const int l = i - w.r0;
     if (l >= 0 && l < w.RL) {
         w.l0v[l] = 0;  // last0_vw_ = (0,0); last1_vw_ is not touched by init_pose
@@ -562,9 +574,15 @@ __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const size_t G = (size_t)h->Hg * h->Wg;
-    TIMED(h, IMGENV_K_RASTER, st, (k_raster<<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
+    if (h->pow2)
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
+    else
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
     TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
-    TIMED(h, IMGENV_K_VIEW, st, (k_view<<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d)));
+    if (h->pow2)
+        TIMED(h, IMGENV_K_VIEW, st, (k_view<true><<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d)));
+    else
+        TIMED(h, IMGENV_K_VIEW, st, (k_view<false><<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d)));
     TIMED(h, IMGENV_K_OBS, st, (k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, st>>>(d, is_reset, h->elapsed, h->PP)));
     h->launches += 4;
     HIPCHK(hipGetLastError());
@@ -642,14 +660,16 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         d.traj_cap = h->traj_cap;
     }
     // robots (img_env.cpp:252-282)
-    std::vector<double> rob3((size_t)R * 3);
+    std::vector<double> rob3((size_t)R * 5);
     std::vector<ResetRobot> rr(RL);
     for (int i = 0; i < R; i++) {
         const double* p = b->robot_pose + 4 * i;
         const double yaw = tf_yaw_from_quaternion_zw(p[2], p[3]);
-        rob3[3 * i] = p[0];
-        rob3[3 * i + 1] = p[1];
-        rob3[3 * i + 2] = yaw;
+        rob3[5 * i] = p[0];
+        rob3[5 * i + 1] = p[1];
+        rob3[5 * i + 2] = yaw;
+        rob3[5 * i + 3] = sin(yaw * 0.5);
+        rob3[5 * i + 4] = cos(yaw * 0.5);
         if (i >= h->r0 && i < h->r1) {  // set_goal (agent.cpp:144-154)
             ResetRobot& q = rr[i - h->r0];
             q.gx = b->robot_goal[2 * i];

@@ -249,6 +249,8 @@ __global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
     r[2] = th;
     r[3] = vx;
     r[4] = vy;
+    r[5] = sin(th * 0.5);  // Quaternion::setRPY(0,0,theta) of the new pose, shared by the next kernels
+    r[6] = cos(th * 0.5);
     w.is_arr[l] = is_arrive ? 1 : 0;
 }
 
@@ -261,15 +263,17 @@ __global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
 //   left leg      : writes unless the cell is 0                   (agent.cpp:751-754)
 //   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
+template <bool POW2>
 __device__ void raster_ped(const DevWorld& w, int j) {
     const PedClassDev& k = w.pclass[w.ped_cls[j]];
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id();
+    const double res = w.res, inv = w.inv_res;
     if (k.shape == IMGENV_SHAPE_CIRCLE) {
         for (int q = lane; q < k.n_bbox; q += WAVE) {
             double wx, wy;
             tf_apply(bw, k.bx[q], k.by[q], wx, wy);
-            const int m = w2m(wx, w.res), n = w2m(wy, w.res);
+            const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
             if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
                 const size_t c = (size_t)m * w.Wg + n;
                 if (w.obs_map[c] > 2) w.ped_layer[c] = 1;
@@ -288,7 +292,7 @@ __device__ void raster_ped(const DevWorld& w, int j) {
                 double bx, by, wx, wy;
                 tf_apply(lb, sx[q], sy[q], bx, by);
                 tf_apply(bw, bx, by, wx, wy);
-                const int m = w2m(wx, w.res), n = w2m(wy, w.res);
+                const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
                 if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
                     const size_t c = (size_t)m * w.Wg + n;
                     if (leg == 1 || w.obs_map[c] != 0) w.ped_layer[c] = 1;
@@ -305,15 +309,17 @@ __device__ void raster_ped(const DevWorld& w, int j) {
 // itself in two shared layers, own_lo = min id and own_hi = max id covering a cell.  Robot i then
 // sees "another robot" in a cell iff (lo != i or hi != i).  The 901 footprint samples fall on a few
 // cells, so they are de-duplicated in an LDS bitmap first: ~10-20 global atomics per robot.
+template <bool POW2>
 __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel) {
     const RobotClassDev& k = w.rclass[w.robot_cls[i]];
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id();
-    const Tf2 bw = tf_from_pose(r[0], r[1], r[2]);
+    const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
+    const double res = w.res, inv = w.inv_res;
     const uint32_t id = (uint32_t)i + 1;
     const int rad = k.box_rad, side = 2 * rad + 1;
     const bool use_box = side * side <= RASTER_BOX_WORDS * 32;
-    const int cm = w2m(r[0], w.res), cn = w2m(r[1], w.res);
+    const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
     if (use_box) {
         for (int q = lane; q < RASTER_BOX_WORDS; q += WAVE) box[q] = 0;
         __syncthreads();
@@ -321,7 +327,7 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
     for (int q = lane; q < k.n_fp; q += WAVE) {
         double wx, wy;
         tf_apply(bw, k.fp_x[q], k.fp_y[q], wx, wy);
-        const int m = w2m(wx, w.res), n = w2m(wy, w.res);
+        const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
             const int dm = m - cm + rad, dn = n - cn + rad;
             if (use_box && dm >= 0 && dm < side && dn >= 0 && dn < side) {
@@ -355,13 +361,14 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
     }
 }
 
+template <bool POW2>
 __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     __shared__ uint32_t box[RASTER_BOX_WORDS];
     const int b = blockIdx.x;
     if (b < w.P)
-        raster_ped(w, b);
+        raster_ped<POW2>(w, b);
     else
-        raster_robot(w, b - w.P, box, zero_vel != 0);
+        raster_robot<POW2>(w, b - w.P, box, zero_vel != 0);
 }
 
 // class layer: one byte per cell that a robot's view kernel can decode without touching the three
@@ -432,7 +439,15 @@ __device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, si
 
 // ------------------------------------------------------------------------------------------------
 // Agent::view (agent.cpp:356-509) for local robot l = blockIdx.x, one wavefront.
-//   LDS: src[Hv*Wv] cropped view (0 / 255 / 200), hitk[B] first-hit step of each beam.
+//   LDS: hit[ray_stride] u32 = first-hit step of each beam (0xFFFF = none);
+//        src[Hv*Wv] u8 cropped view, only materialised when the laser is off.
+//
+// With the laser on, the reference overwrites the cropped view with laser_map (agent.cpp:437), so the
+// crop only matters through the first occupied cell on each beam.  Beam paths are static, hence
+//   hit[b] = min { k : crop(cell_k(b)) == 0 }
+// is computed from the OCCUPIED cells (usually a few per cent of the window): each occupied crop cell
+// pushes its step index to every ray through it with an LDS atomicMin.  Nothing walks rays.
+template <bool POW2>
 __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = blockIdx.x;
@@ -444,11 +459,15 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const int i = w.r0 + l;
     const RobotClassDev& k = w.rclass[w.robot_cls[i]];
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    const Tf2 bw = tf_from_pose(r[0], r[1], r[2]);
+    const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
     const int Hv = w.Hv, Wv = w.Wv, NC = Hv * Wv;
-    const double res = w.res;
-    uint8_t* src = smem;
-    uint16_t* hitk = (uint16_t*)(smem + ((NC + 15) & ~15));
+    const double res = w.res, inv = w.inv_res;
+    const uint32_t wv_magic = w.wv_magic;
+    const bool laser = w.use_laser != 0;
+    uint32_t* hit = (uint32_t*)smem;
+    uint8_t* src = smem + (size_t)k.ray_stride * 4;
+    if (laser)
+        for (int b = lane; b < k.ray_stride; b += WAVE) hit[b] = 0xFFFFu;
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits
     //     decides the code (agent.cpp:294-326) -> max over (sample index, code)
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     for (int q = lane; q < k.n_fp; q += WAVE) {
         double wx, wy;
         tf_apply(bw, k.fp_x[q], k.fp_y[q], wx, wy);
-        const int m = w2m(wx, res), n = w2m(wy, res);
+        const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
             const uint32_t v = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n);
             if (v <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (v + 1));
@@ -465,74 +484,81 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
     const int code = (int)(best & 3);
+    __syncthreads();  // hit[] initialised
 
-    // (2) egocentric crop (agent.cpp:373-404): 4 view cells per lane per round -> one LDS dword
+    // (2) egocentric crop (agent.cpp:373-404), 4 view cells per lane per round
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
     for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
-        uint32_t packed = 0;
+        const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds all 4 bits
+        uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
+        if (fov) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = c4 + q;
-            uint32_t val = 200;
-            if (c < NC && ((k.fov_bits[c >> 5] >> (c & 31)) & 1u)) {
-                const int a = c / Wv, b = c - a * Wv;
-                double wx, wy;
-                tf_apply(vw, a * res, b * res, wx, wy);
-                const int m = w2m(wx, res), n = w2m(wy, res);
-                if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg)
-                    val = (cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n) == CLS_HIGH) ? 255u : 0u;
+            for (int q = 0; q < 4; q++) {
+                const int c = c4 + q;
+                if (c < NC && ((fov >> q) & 1u)) {
+                    const int a = (int)__umulhi((uint32_t)c, wv_magic), b = c - a * Wv;
+                    double wx, wy;
+                    tf_apply(vw, a * res, b * res, wx, wy);
+                    const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
+                    if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+                        const bool free_cell = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n) == CLS_HIGH;
+                        packed = (packed & ~(0xFFu << (8 * q))) | ((free_cell ? 255u : 0u) << (8 * q));
+                        if (!free_cell && laser) {  // occupied: first-hit candidate of every ray through this cell
+                            const uint32_t e1 = k.inv_off[c + 1];
+                            for (uint32_t e = k.inv_off[c]; e < e1; e++) {
+                                const uint32_t ent = k.inv_ent[e];
+                                atomicMin(&hit[ent >> 16], ent & 0xFFFFu);
+                            }
+                        }
+                    }
+                }
             }
-            packed |= val << (8 * q);
         }
-        *(uint32_t*)(src + c4) = packed;
+        if (!laser) *(uint32_t*)(src + c4) = packed;
     }
     __syncthreads();
 
-    // (3) laser (agent.cpp:405-438, bresenhamLine 511-624): one lane per beam walks the precomputed
-    //     Bresenham path until the first occupied cell of the crop
-    if (w.use_laser) {
-        for (int b = lane; b < k.ray_stride; b += WAVE) {
-            uint32_t hk = 0xFFFF;
-            if (b < w.B) {
-                const int len = k.ray_len[b];
-                for (int q = 0; q < len; q++) {
-                    const uint32_t c = k.ray_cells[(size_t)q * k.ray_stride + b];
-                    if (src[c] == 0) {
-                        hk = q;
-                        break;
-                    }
-                }
-                const float hit = hk != 0xFFFF ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
-                w.lasers_raw[(size_t)l * w.B + b] = hit;
-                w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hit / w.laser_max : (double)hit;
-            }
-            hitk[b] = (uint16_t)hk;
+    // (3) laser ranges (agent.cpp:405-438): distance between the sensor cell and the hit cell, 6.0 if none
+    if (laser) {
+        for (int b = lane; b < w.B; b += WAVE) {
+            const uint32_t hk = hit[b];
+            const float h = hk != 0xFFFFu ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
+            w.lasers_raw[(size_t)l * w.B + b] = h;
+            w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)h / w.laser_max : (double)h;
         }
-        __syncthreads();
     }
 
-    // (4) laser_map replaces the view (agent.cpp:437): start from 200; beams write in index order and
-    //     later beams win, so each cell takes the value of the HIGHEST beam that writes it.  A beam
-    //     writes 255 before its hit, 0 at the hit and 200 behind it unless the cell shares a row or
-    //     column with the hit cell (agent.cpp:538-560).  Then the own footprint is stamped 100
-    //     (agent.cpp:503) and the result is stored as uint8 and as float16(v/255).
+    // (4) laser_map replaces the view (agent.cpp:437): it starts at 200, beams write in index order and
+    //     later beams win, so a cell takes the value of the HIGHEST beam that writes it: 255 before that
+    //     beam's hit, 0 at the hit, 200 behind it unless the cell shares a row or column with the hit
+    //     cell, in which case that beam leaves the cell alone (agent.cpp:538-560) and the next lower beam
+    //     through the cell decides.  Then the own footprint is stamped 100 (agent.cpp:503) and the result
+    //     is stored as uint8 and as float16(v / 255).
     uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
     uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;
     for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
-        uint32_t packed = 0;
-        uint32_t h[4];
+        uint32_t vals[4];
+        if (laser) {
+            uint32_t top[4];
+            if (c4 + 4 <= NC) {
+                const uint4 t4 = *(const uint4*)(k.top_ent + c4);
+                top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
+            } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = c4 + q;
-            uint32_t val = 200;
-            if (c < NC) {
-                if (w.use_laser) {
-                    const uint32_t e0 = k.inv_off[c], e1 = k.inv_off[c + 1];
-                    for (uint32_t e = e0; e < e1; e++) {
-                        const uint32_t ent = k.inv_ent[e];
-                        const uint32_t b = ent >> 16, kk = ent & 0xFFFF;
-                        const uint32_t hk = hitk[b];
-                        if (hk == 0xFFFF || kk < hk) {
+                for (int q = 0; q < 4; q++) top[q] = c4 + q < NC ? k.top_ent[c4 + q] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t val = 200;
+                uint32_t ent = top[q];
+                if (ent != 0xFFFFFFFFu) {
+                    const int c = c4 + q;
+                    uint32_t e = 0, e1 = 0;
+                    bool have_range = false;
+                    while (true) {
+                        const uint32_t b = ent >> 16, kk = ent & 0xFFFFu;
+                        const uint32_t hk = hit[b];
+                        if (hk == 0xFFFFu || kk < hk) {
                             val = 255;
                             break;
                         }
@@ -541,18 +567,32 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                             break;
                         }
                         const uint32_t hc = k.ray_cells[(size_t)hk * k.ray_stride + b];
-                        const int hx = hc / Wv, hy = hc - hx * Wv;
-                        const int cx = c / Wv, cy = c - cx * Wv;
-                        if (cx != hx && cy != hy) break;  // writes 200
-                        // same row / column as the hit: this beam leaves the cell alone
+                        const int hx = (int)__umulhi(hc, wv_magic), hy = (int)hc - hx * Wv;
+                        const int cx = (int)__umulhi((uint32_t)c, wv_magic), cy = c - cx * Wv;
+                        if (cx != hx && cy != hy) break;  // this beam writes 200
+                        if (!have_range) {  // rare: fall back to the full ray list of this cell
+                            e = k.inv_off[c];
+                            e1 = k.inv_off[c + 1];
+                            have_range = true;
+                        }
+                        if (++e >= e1) break;  // no lower beam: the cell keeps 200
+                        ent = k.inv_ent[e];
                     }
-                } else {
-                    val = src[c];
                 }
-                if (((k.stamp_bits[c >> 5] >> (c & 31)) & 1u) && val > 2) val = 100;
+                vals[q] = val;
             }
-            packed |= val << (8 * q);
-            h[q] = w.f16_lut[val];
+        } else {
+            const uint32_t p = *(const uint32_t*)(src + c4);
+#pragma unroll
+            for (int q = 0; q < 4; q++) vals[q] = (p >> (8 * q)) & 0xFFu;
+        }
+        const uint32_t stamp = (k.stamp_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;
+        uint32_t packed = 0, h[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (((stamp >> q) & 1u) && vals[q] > 2) vals[q] = 100;
+            packed |= vals[q] << (8 * q);
+            h[q] = w.f16_lut[vals[q]];
         }
         if (c4 + 4 <= NC) {
             *(uint32_t*)(out_u8 + c4) = packed;
@@ -602,7 +642,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
     uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)NP * 4);
 
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    const Tf2 bw = tf_from_pose(r[0], r[1], r[2]);
+    const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
     // Agent::get_state (agent.cpp:156-184)
     const Tf2 t = tf_mul(w.world_target[l], bw);
     const Tf2 target_base = tf_inverse(t);

@@ -42,6 +42,15 @@ TFM_HD Tf2 tf_from_pose(double x, double y, double yaw) {
     return t;
 }
 
+// same, from the cached sin(yaw/2), cos(yaw/2) of a robot record
+TFM_HD Tf2 tf_from_pose_sc(double x, double y, double sh, double ch) {
+    Tf2 t;
+    tf_set_rotation_zw(t, sh, ch);
+    t.ox = x;
+    t.oy = y;
+    return t;
+}
+
 // Transform::operator()(Vector3)
 TFM_HD void tf_apply(const Tf2& t, double x, double y, double& rx, double& ry) {
     rx = (t.m00 * x + t.m01 * y) + t.ox;
@@ -101,3 +110,9 @@ TFM_HD double tf_yaw_from_quaternion_zw(double qz, double qw) {
 
 // GridMap::world2map (grid_map.cpp:40-44): C round(), half away from zero
 TFM_HD int w2m(double v, double res) { return (int)round(v / res); }
+// When the resolution is a power of two, v * (1/res) and v / res are the same exact scaling, so the
+// (much cheaper) multiply is bit-identical to the reference's division.
+template <bool POW2>
+TFM_HD int w2m_t(double v, double res, double inv_res) {
+    return (int)round(POW2 ? v * inv_res : v / res);
+}

@@ -32,6 +32,7 @@ struct RobotClassDev {
     const float* ray_dist;       // [ray_maxlen][ray_stride] float32(hit distance) if the hit is at step k
     const uint32_t* inv_off;     // [Hv*Wv+1] CSR offsets: rays through a view cell ...
     const uint32_t* inv_ent;     // ... as (beam << 16 | k), beam descending
+    const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or 0xFFFFFFFF
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
 };
 
@@ -58,7 +59,8 @@ struct DevWorld {
     int R, RL, r0, P, NA;  // world robots, local robots, first local robot, peds, RVO agents
     int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;
     int scene, relation, ktype, use_laser, laser_norm, time_max;
-    double res, step_hz, laser_max, ped_safety_space, ped_image_r, ped_image_r2, ped_res;
+    double res, inv_res, step_hz, laser_max, ped_safety_space, ped_image_r, ped_image_r2, ped_res;
+    uint32_t wv_magic;  // ceil(2^32 / Wv): c / Wv == __umulhi(c, wv_magic) for c < 65536
     Tf2 view_base, base_view;
     // limiter (speed_limit.cpp)
     int lv_has_v, lv_has_a, lv_has_j, lw_has_v, lw_has_a, lw_has_j;

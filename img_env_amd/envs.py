@@ -220,7 +220,10 @@ class VelActionWrapper(Wrapper):
         return out
 
     def step(self, action):
+        import torch
         a = self.action(action)
+        if not isinstance(a, torch.Tensor):
+            a = torch.as_tensor(np.ascontiguousarray(a, np.float32), device=self.world.device)
         state, reward, done, info = self.env.step(a)
         info["speeds"] = a[:, :2]
         return state, reward, done, info

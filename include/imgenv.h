@@ -223,8 +223,10 @@ int imgenv_step(imgenv_t* h, const float* actions, void* stream);
  * imgenv_step == step_begin; step_end when the handle owns the whole world. */
 int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream);
 int imgenv_step_end(imgenv_t* h, void* stream);
-/* records: DEVICE double[n_robots][IMGENV_RECORD_DOUBLES] = x, y, theta, vx, vy, (pad) */
-#define IMGENV_RECORD_DOUBLES 6
+/* records: DEVICE double[n_robots][IMGENV_RECORD_DOUBLES] = x, y, theta, vx, vy, sin(theta/2), cos(theta/2), pad
+ * (64 bytes per robot; the half-angle sine / cosine are cached so that the raster / view / observation kernels of
+ * every rank build the robot's tf::Transform without re-evaluating them) */
+#define IMGENV_RECORD_DOUBLES 8
 int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_robot);
 /* reset counterpart of the exchange (robots' initial records are known to every rank from the
  * batch, so reset needs no collective). */

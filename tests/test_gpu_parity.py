@@ -21,6 +21,7 @@ CASES = {
     "dense_collisions": dict(n_robots=96, n_peds=30, seed=5, grid_size=100, clearance=0.5, n_obstacles=2),
     "state5_norel": dict(n_robots=6, n_peds=5, seed=6, state_dim=5, relation_ped_robo=0),
     "res025": dict(n_robots=32, n_peds=12, seed=7, res=0.25, grid_size=120),
+    "res010_not_pow2": dict(n_robots=24, n_peds=8, seed=13, res=0.1, grid_size=200),
     "no_laser": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "time_limit": dict(n_robots=4, n_peds=2, seed=9, time_max=6),
 }
