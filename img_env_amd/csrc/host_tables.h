@@ -88,10 +88,11 @@ struct RobotClassHost {
     double sizes[4], sx, sy;
     Pts fp;
     std::vector<uint32_t> fov_bits, stamp_bits;
-    int ray_maxlen = 0, ray_stride = 0, box_rad = 0;
-    std::vector<uint16_t> ray_cells, ray_len;
+    int ray_maxlen = 0, ray_stride = 0, ray_kpad = 8, box_rad = 0;
+    bool ok = true;  // false: a table field overflowed its packing
+    std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
-    std::vector<uint32_t> inv_off, inv_ent, top_ent;
+    std::vector<uint32_t> inv_pack, inv_ent, top_ent;
 };
 
 static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
@@ -177,21 +178,25 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
         }
     }
     if (k.ray_maxlen == 0) k.ray_maxlen = 1;
-    k.ray_cells.assign((size_t)k.ray_maxlen * k.ray_stride, 0xFFFF);
+    k.ray_kpad = ((k.ray_maxlen + 7) / 8) * 8;
+    k.ray_rows.assign((size_t)(B > 0 ? B : 1) * k.ray_kpad + 8, 0xFFFF);
     k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
     std::vector<std::vector<uint32_t>> inv(NC);
     for (int b = 0; b < B; b++)
         for (size_t q = 0; q < cells[b].size(); q++) {
-            k.ray_cells[q * k.ray_stride + b] = cells[b][q];
+            k.ray_rows[(size_t)b * k.ray_kpad + q] = cells[b][q];
             k.ray_dist[q * k.ray_stride + b] = dists[b][q];
             inv[cells[b][q]].push_back(((uint32_t)b << 16) | (uint32_t)q);
         }
-    k.inv_off.assign(NC + 1, 0);
+    k.inv_pack.assign(NC, 0);
+    uint32_t off = 0;
     for (int c = 0; c < NC; c++) {
         std::sort(inv[c].begin(), inv[c].end(), [](uint32_t a, uint32_t b) { return a > b; });  // beam descending
-        k.inv_off[c + 1] = k.inv_off[c] + (uint32_t)inv[c].size();
+        if (off >= (1u << 20) || inv[c].size() >= (1u << 12)) k.ok = false;
+        k.inv_pack[c] = off | ((uint32_t)inv[c].size() << 20);
+        off += (uint32_t)inv[c].size();
     }
-    k.inv_ent.reserve(k.inv_off[NC] + 1);
+    k.inv_ent.reserve(off + 1);
     for (int c = 0; c < NC; c++) k.inv_ent.insert(k.inv_ent.end(), inv[c].begin(), inv[c].end());
     k.top_ent.assign(NC, 0xFFFFFFFFu);
     for (int c = 0; c < NC; c++)

@@ -245,6 +245,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (cfg->n_peds > cfg->max_ped)
         FAIL(IMGENV_EINVAL, "n_peds %d > max_ped %d (IndexError in yaml_env.py:401)", cfg->n_peds, cfg->max_ped);
     if (cfg->n_peds > 65000) FAIL(IMGENV_EINVAL, "n_peds > 65000 unsupported");
+    if (cfg->n_robots >= (int)OWNER_MULTI) FAIL(IMGENV_EINVAL, "more than 2^24 - 3 robots unsupported");
     if (cfg->global_resolution != cfg->view_resolution)
         FAIL(IMGENV_EINVAL, "global_resolution != view_resolution: load-time cv::resize not supported");
     if (cfg->state_dim < 3 || cfg->state_dim > 5) FAIL(IMGENV_EINVAL, "state_dim must be 3, 4 or 5");
@@ -367,8 +368,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     TRY(dev_alloc(h, &d.ped_layer, Gp));
     TRY(dev_alloc(h, &d.own_lo, Gp, 0xFF));
     TRY(dev_alloc(h, &d.own_hi, Gp));
-    TRY(dev_alloc(h, &d.cls, Gp));
-    TRY(dev_alloc(h, &d.owner, Gp));
+    TRY(dev_alloc(h, &d.cell, Gp));
 
     // class tables
     size_t max_stride = WAVE;
@@ -378,22 +378,34 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             const RobotClassHost& k = h->rcls[c];
             RobotClassDev& o = rc[c];
             o.n_fp = k.fp.n();
-            TRY(dev_upload(h, &o.fp_x, k.fp.x));
-            TRY(dev_upload(h, &o.fp_y, k.fp.y));
+            {
+                std::vector<double2> fp(k.fp.n());
+                for (int q = 0; q < k.fp.n(); q++) fp[q] = make_double2(k.fp.x[q], k.fp.y[q]);
+                TRY(dev_upload(h, &o.fp, fp));
+            }
             TRY(dev_upload(h, &o.fov_bits, k.fov_bits));
             TRY(dev_upload(h, &o.stamp_bits, k.stamp_bits));
             o.ray_maxlen = k.ray_maxlen;
             o.ray_stride = k.ray_stride;
-            TRY(dev_upload(h, &o.ray_cells, k.ray_cells));
+            o.ray_kpad = k.ray_kpad;
+            if (!k.ok) {
+                imgenv_destroy(h);
+                FAIL(IMGENV_EINVAL, "laser ray tables overflow their packing (too many beams x view cells)");
+            }
+            TRY(dev_upload(h, &o.ray_rows, k.ray_rows));
             TRY(dev_upload(h, &o.ray_len, k.ray_len));
             TRY(dev_upload(h, &o.ray_dist, k.ray_dist));
-            TRY(dev_upload(h, &o.inv_off, k.inv_off));
+            TRY(dev_upload(h, &o.inv_pack, k.inv_pack));
             TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
             TRY(dev_upload(h, &o.top_ent, k.top_ent));
             o.box_rad = k.box_rad;
             max_stride = std::max(max_stride, (size_t)k.ray_stride);
         }
-        TRY(dev_upload(h, &d.rclass, rc));
+        if (rc.size() > RC_INLINE || h->pcls.size() > PC_INLINE) {
+            imgenv_destroy(h);
+            FAIL(IMGENV_EINVAL, "more than %d robot or %d pedestrian classes (shape, size, sensor) in one world", RC_INLINE, PC_INLINE);
+        }
+        for (size_t c = 0; c < rc.size(); c++) d.rc[c] = rc[c];
         std::vector<PedClassDev> pc(h->pcls.size());
         for (size_t c = 0; c < h->pcls.size(); c++) {
             const PedClassHost& k = h->pcls[c];
@@ -411,8 +423,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.ry, k.right.y));
             memcpy(o.sizes, k.sizes, sizeof(o.sizes));
         }
-        if (pc.empty()) pc.resize(1);
-        TRY(dev_upload(h, &d.pclass, pc));
+        for (size_t c = 0; c < pc.size(); c++) d.pc[c] = pc[c];
     }
     TRY(dev_upload(h, &d.robot_cls, h->robot_cls));
     TRY(dev_upload(h, &d.ped_cls, h->ped_cls));
@@ -448,6 +459,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_upload(h, &d.amax_speed, ms));
     }
     TRY(dev_alloc(h, &d.err, 4));
+    TRY(dev_alloc(h, &d.prof, 16));
 
     // output arena
     ArenaPlan plan;
@@ -510,7 +522,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->PP = 2;
     while (h->PP < P) h->PP <<= 1;
     const size_t NC = (size_t)g.Hv * g.Wv;
-    h->lds_view = 4 * max_stride + (cfg->use_laser ? 0 : ((NC + 15) & ~(size_t)15)) + 16;
+    h->lds_view = 4 * max_stride + ((NC + 15) & ~(size_t)15) + 2 * (NC / 7 + 1) + 16;
     h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)d.Hp * d.Wp * 4 + (size_t)h->PP * 2 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);
@@ -743,3 +755,12 @@ extern "C" int imgenv_outputs(imgenv_t* h, imgenv_out* out) {
 }
 
 extern "C" int imgenv_step_launches(imgenv_t* h) { return h ? h->launches : 0; }
+
+// debug: read (and clear) the per-phase cycle counters of IMGENV_PHASE_PROFILE builds
+extern "C" int imgenv_debug_phases(imgenv_t* h, unsigned long long* out16) {
+    if (!h || !out16) FAIL(IMGENV_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out16, h->d.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d.prof, 0, 16 * sizeof(unsigned long long)));
+    return IMGENV_OK;
+}

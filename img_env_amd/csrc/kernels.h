@@ -20,6 +20,26 @@
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// robot class record: by value from the kernel arguments when possible (wave-uniform index)
+__device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls) {
+    return w.rc[cls];
+}
+
+// Optional per-phase cycle accounting (build with -DIMGENV_PHASE_PROFILE): lane 0 of every wave adds
+// the shader-clock cycles of each phase to w.prof[slot]; tools/phase_profile.py prints the split.
+#ifdef IMGENV_PHASE_PROFILE
+#define PHASE_BEGIN() long long ph_t_ = clock64()
+#define PHASE_MARK(slot)                                                                  \
+    do {                                                                                  \
+        const long long now_ = clock64();                                                 \
+        if (lane_id() == 0) atomicAdd((unsigned long long*)&w.prof[slot], (unsigned long long)(now_ - ph_t_)); \
+        ph_t_ = now_;                                                                     \
+    } while (0)
+#else
+#define PHASE_BEGIN() (void)0
+#define PHASE_MARK(slot) (void)0
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Pedestrian advance (ORCA)
 
@@ -106,7 +126,7 @@ __global__ void k_ped_update(DevWorld w) {
     w.ped_state[4 * j + 1] = y;
     w.ped_state[4 * j + 2] = (double)vx;
     w.ped_state[4 * j + 3] = (double)vy;
-    const PedClassDev& k = w.pclass[w.ped_cls[j]];
+    const PedClassDev k = w.pc[w.ped_cls[j]];
     if (k.shape == IMGENV_SHAPE_LEG) {
         const double step_len = 0.3;
         const double move = sqrt((x - ox) * (x - ox) + (y - oy) * (y - oy));
@@ -265,7 +285,7 @@ __global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
 template <bool POW2>
 __device__ void raster_ped(const DevWorld& w, int j) {
-    const PedClassDev& k = w.pclass[w.ped_cls[j]];
+    const PedClassDev k = w.pc[w.ped_cls[j]];
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id();
     const double res = w.res, inv = w.inv_res;
@@ -311,7 +331,7 @@ __device__ void raster_ped(const DevWorld& w, int j) {
 // cells, so they are de-duplicated in an LDS bitmap first: ~10-20 global atomics per robot.
 template <bool POW2>
 __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel) {
-    const RobotClassDev& k = w.rclass[w.robot_cls[i]];
+    const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id();
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
@@ -326,7 +346,8 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
     }
     for (int q = lane; q < k.n_fp; q += WAVE) {
         double wx, wy;
-        tf_apply(bw, k.fp_x[q], k.fp_y[q], wx, wy);
+        const double2 fp = k.fp[q];
+        tf_apply(bw, fp.x, fp.y, wx, wy);
         const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
             const int dm = m - cm + rad, dn = n - cn + rad;
@@ -388,7 +409,7 @@ __global__ void k_compose(DevWorld w) {
         const uint4 lo = *(const uint4*)(w.own_lo + c0);
         const uint4 hi = *(const uint4*)(w.own_hi + c0);
         const uint32_t los[4] = {lo.x, lo.y, lo.z, lo.w}, his[4] = {hi.x, hi.y, hi.z, hi.w};
-        uint32_t out = 0, any_robot = 0;
+        uint32_t out = 0;
         uint32_t own[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -399,12 +420,11 @@ __global__ void k_compose(DevWorld w) {
             if (b >= CLS_LOW && his[q] != 0) {
                 b |= CLS_ROBOT;
                 own[q] = (los[q] == his[q]) ? los[q] - 1 : OWNER_MULTI;
-                any_robot = 1;
             }
             out |= b << (8 * q);
         }
-        *(uint32_t*)(w.cls + c0) = out;
-        if (any_robot) *(uint4*)(w.owner + c0) = make_uint4(own[0], own[1], own[2], own[3]);
+        *(uint4*)(w.cell + c0) = make_uint4(((out >> 0) & 0xFFu) | (own[0] << 8), ((out >> 8) & 0xFFu) | (own[1] << 8),
+                                             ((out >> 16) & 0xFFu) | (own[2] << 8), ((out >> 24) & 0xFFu) | (own[3] << 8));
         if (ped) *(uint32_t*)(w.ped_layer + c0) = 0;
         if (his[0] | his[1] | his[2] | his[3]) {
             *(uint4*)(w.own_lo + c0) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -414,11 +434,12 @@ __global__ void k_compose(DevWorld w) {
         for (size_t c = c0; c < G; c++) {
             const uint32_t base = w.ped_layer[c] ? 1u : w.obs_map[c];
             uint32_t b = base <= 2 ? base : (base < 250 ? CLS_LOW : CLS_HIGH);
+            uint32_t own = 0;
             if (b >= CLS_LOW && w.own_hi[c] != 0) {
                 b |= CLS_ROBOT;
-                w.owner[c] = (w.own_lo[c] == w.own_hi[c]) ? w.own_lo[c] - 1 : OWNER_MULTI;
+                own = (w.own_lo[c] == w.own_hi[c]) ? w.own_lo[c] - 1 : OWNER_MULTI;
             }
-            w.cls[c] = (uint8_t)b;
+            w.cell[c] = b | (own << 8);
             w.ped_layer[c] = 0;
             w.own_lo[c] = 0xFFFFFFFFu;
             w.own_hi[c] = 0;
@@ -426,27 +447,28 @@ __global__ void k_compose(DevWorld w) {
     }
 }
 
-// value of cell c in robots_[i].global_map_ (img_env.cpp:623-628), as a small class code
+// value of cell c in robots_[i].global_map_ (img_env.cpp:623-628), as a small class code: one dword gather
 __device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, size_t c) {
-    const uint32_t b = w.cls[c];
-    if (b & CLS_ROBOT) {
-        const uint32_t o = w.owner[c];
-        if (o != i) return CLS_TWO;  // another robot (or several): value 2
-        return b & 7;
-    }
-    return b;
+    const uint32_t v = w.cell[c];
+    if ((v & CLS_ROBOT) && (v >> 8) != i) return CLS_TWO;  // another robot (or several): value 2
+    return v & 7u;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Agent::view (agent.cpp:356-509) for local robot l = blockIdx.x, one wavefront.
-//   LDS: hit[ray_stride] u32 = first-hit step of each beam (0xFFFF = none);
-//        src[Hv*Wv] u8 cropped view, only materialised when the laser is off.
+//   LDS: hit[ray_stride] u32 = (first-hit step << 16 | hit cell) of each beam, 0xFFFFFFFF = no hit;
+//        src[Hv*Wv] u8 cropped view; occ[] u16 list of occupied crop cells (sparse windows only).
 //
 // With the laser on, the reference overwrites the cropped view with laser_map (agent.cpp:437), so the
 // crop only matters through the first occupied cell on each beam.  Beam paths are static, hence
 //   hit[b] = min { k : crop(cell_k(b)) == 0 }
-// is computed from the OCCUPIED cells (usually a few per cent of the window): each occupied crop cell
-// pushes its step index to every ray through it with an LDS atomicMin.  Nothing walks rays.
+// and there are two ways to get it, chosen per robot from the number of occupied crop cells:
+//   sparse window : every occupied cell (compacted into an LDS list) pushes (k, cell) to each ray
+//                   through it with one LDS atomicMin -- cost ~ occupied cells, nothing walks rays;
+//   dense window  : one lane per beam walks its precomputed Bresenham path (8 cells per 16-byte load)
+//                   in LDS until the first occupied cell -- rays are short exactly when the window is dense.
+#define VIEW_OCC_CAP(NC) ((NC) / 7)
+
 template <bool POW2>
 __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -457,24 +479,28 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
         return;
     }
     const int i = w.r0 + l;
-    const RobotClassDev& k = w.rclass[w.robot_cls[i]];
+    const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
     const int Hv = w.Hv, Wv = w.Wv, NC = Hv * Wv;
     const double res = w.res, inv = w.inv_res;
     const uint32_t wv_magic = w.wv_magic;
     const bool laser = w.use_laser != 0;
+    const int occ_cap = VIEW_OCC_CAP(NC);
     uint32_t* hit = (uint32_t*)smem;
     uint8_t* src = smem + (size_t)k.ray_stride * 4;
+    uint16_t* occ = (uint16_t*)(src + ((NC + 15) & ~15));
+    PHASE_BEGIN();
     if (laser)
-        for (int b = lane; b < k.ray_stride; b += WAVE) hit[b] = 0xFFFFu;
+        for (int b = lane; b < k.ray_stride; b += WAVE) hit[b] = 0xFFFFFFFFu;
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits
     //     decides the code (agent.cpp:294-326) -> max over (sample index, code)
     uint32_t best = 0;
     for (int q = lane; q < k.n_fp; q += WAVE) {
         double wx, wy;
-        tf_apply(bw, k.fp_x[q], k.fp_y[q], wx, wy);
+        const double2 fp = k.fp[q];
+        tf_apply(bw, fp.x, fp.y, wx, wy);
         const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
             const uint32_t v = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n);
@@ -484,49 +510,96 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
     const int code = (int)(best & 3);
-    __syncthreads();  // hit[] initialised
+    PHASE_MARK(0);
 
-    // (2) egocentric crop (agent.cpp:373-404), 4 view cells per lane per round
+    // (2) egocentric crop (agent.cpp:373-404), 4 view cells per lane per round; occupied cells are
+    //     appended to occ[] (ballot + prefix count, no atomics) while the window still counts as sparse
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
-    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
-        const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds all 4 bits
+    int n_occ = 0;
+    for (int base = 0; base < NC; base += WAVE * 4) {  // wave-uniform trip count (ballots inside)
+        const int c4 = base + lane * 4;
+        const uint32_t fov = c4 < NC ? (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu : 0u;  // c4 % 4 == 0
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
-        if (fov) {
+        if (__ballot(fov != 0) == 0ull) {
+            if (c4 < NC) *(uint32_t*)(src + c4) = packed;
+            continue;
+        }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int c = c4 + q;
-                if (c < NC && ((fov >> q) & 1u)) {
-                    const int a = (int)__umulhi((uint32_t)c, wv_magic), b = c - a * Wv;
-                    double wx, wy;
-                    tf_apply(vw, a * res, b * res, wx, wy);
-                    const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
-                    if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-                        const bool free_cell = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n) == CLS_HIGH;
-                        packed = (packed & ~(0xFFu << (8 * q))) | ((free_cell ? 255u : 0u) << (8 * q));
-                        if (!free_cell && laser) {  // occupied: first-hit candidate of every ray through this cell
-                            const uint32_t e1 = k.inv_off[c + 1];
-                            for (uint32_t e = k.inv_off[c]; e < e1; e++) {
-                                const uint32_t ent = k.inv_ent[e];
-                                atomicMin(&hit[ent >> 16], ent & 0xFFFFu);
-                            }
-                        }
-                    }
+        for (int q = 0; q < 4; q++) {
+            const int c = c4 + q;
+            bool occupied = false;
+            if (c < NC && ((fov >> q) & 1u)) {
+                const int a = (int)__umulhi((uint32_t)c, wv_magic), b = c - a * Wv;
+                double wx, wy;
+                tf_apply(vw, a * res, b * res, wx, wy);
+                const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
+                if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+                    occupied = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n) != CLS_HIGH;
+                    packed = (packed & ~(0xFFu << (8 * q))) | ((occupied ? 0u : 255u) << (8 * q));
                 }
             }
+            if (laser) {
+                const unsigned long long mask = __ballot(occupied);
+                const int pos = n_occ + __popcll(mask & ((1ull << lane) - 1ull));
+                if (occupied && pos < occ_cap) occ[pos] = (uint16_t)c;
+                n_occ += __popcll(mask);
+            }
         }
-        if (!laser) *(uint32_t*)(src + c4) = packed;
+        if (c4 < NC) *(uint32_t*)(src + c4) = packed;
     }
     __syncthreads();
+    PHASE_MARK(1);
+
+    if (laser) {
+        if (n_occ <= occ_cap) {
+            // sparse: occupied cells push (k, cell) to the rays through them
+            for (int t = lane; t < n_occ; t += WAVE) {
+                const uint32_t c = occ[t];
+                const uint32_t pk = k.inv_pack[c];
+                const uint32_t e0 = pk & 0xFFFFFu, cnt = pk >> 20;
+                for (uint32_t e = 0; e < cnt; e++) {
+                    const uint32_t ent = k.inv_ent[e0 + e];
+                    atomicMin(&hit[ent >> 16], ((ent & 0xFFFFu) << 16) | c);
+                }
+            }
+        } else {
+            // dense: bresenhamLine (agent.cpp:511-624) replayed from the per-beam path rows
+            for (int b = lane; b < w.B; b += WAVE) {
+                const int len = k.ray_len[b];
+                const uint16_t* row = k.ray_rows + (size_t)b * k.ray_kpad;
+                uint32_t found = 0xFFFFFFFFu;
+                for (int q0 = 0; q0 < len && found == 0xFFFFFFFFu; q0 += 8) {
+                    const uint4 ch = *(const uint4*)(row + q0);
+                    const uint32_t wds[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t c = (wds[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                        if (found == 0xFFFFFFFFu && q0 + j < len && src[c] == 0) found = ((uint32_t)(q0 + j) << 16) | c;
+                    }
+                }
+                hit[b] = found;
+            }
+        }
+        __syncthreads();
+    }
+    PHASE_MARK(2);
+#ifdef IMGENV_PHASE_PROFILE
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)&w.prof[6], (unsigned long long)n_occ);
+        atomicAdd((unsigned long long*)&w.prof[7], 1ull);
+    }
+#endif
 
     // (3) laser ranges (agent.cpp:405-438): distance between the sensor cell and the hit cell, 6.0 if none
     if (laser) {
         for (int b = lane; b < w.B; b += WAVE) {
-            const uint32_t hk = hit[b];
-            const float h = hk != 0xFFFFu ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
+            const uint32_t hp = hit[b];
+            const float h = hp != 0xFFFFFFFFu ? k.ray_dist[(size_t)(hp >> 16) * k.ray_stride + b] : 6.0f;  // agent.cpp:513
             w.lasers_raw[(size_t)l * w.B + b] = h;
             w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)h / w.laser_max : (double)h;
         }
     }
+    PHASE_MARK(3);
 
     // (4) laser_map replaces the view (agent.cpp:437): it starts at 200, beams write in index order and
     //     later beams win, so a cell takes the value of the HIGHEST beam that writes it: 255 before that
@@ -536,6 +609,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     //     is stored as uint8 and as float16(v / 255).
     uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
     uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;
+    const uint32_t h0 = w.f16_lut[0], h100 = w.f16_lut[100], h200 = w.f16_lut[200], h255 = w.f16_lut[255];
     for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
         uint32_t vals[4];
         if (laser) {
@@ -556,9 +630,10 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                     uint32_t e = 0, e1 = 0;
                     bool have_range = false;
                     while (true) {
-                        const uint32_t b = ent >> 16, kk = ent & 0xFFFFu;
-                        const uint32_t hk = hit[b];
-                        if (hk == 0xFFFFu || kk < hk) {
+                        const uint32_t kk = ent & 0xFFFFu;
+                        const uint32_t hp = hit[ent >> 16];
+                        const uint32_t hk = hp >> 16;
+                        if (kk < hk) {  // also the "no hit" case: hk = 0xFFFF
                             val = 255;
                             break;
                         }
@@ -566,13 +641,14 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                             val = 0;
                             break;
                         }
-                        const uint32_t hc = k.ray_cells[(size_t)hk * k.ray_stride + b];
+                        const uint32_t hc = hp & 0xFFFFu;
                         const int hx = (int)__umulhi(hc, wv_magic), hy = (int)hc - hx * Wv;
                         const int cx = (int)__umulhi((uint32_t)c, wv_magic), cy = c - cx * Wv;
                         if (cx != hx && cy != hy) break;  // this beam writes 200
                         if (!have_range) {  // rare: fall back to the full ray list of this cell
-                            e = k.inv_off[c];
-                            e1 = k.inv_off[c + 1];
+                            const uint32_t pk = k.inv_pack[c];
+                            e = pk & 0xFFFFFu;
+                            e1 = e + (pk >> 20);
                             have_range = true;
                         }
                         if (++e >= e1) break;  // no lower beam: the cell keeps 200
@@ -592,7 +668,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
         for (int q = 0; q < 4; q++) {
             if (((stamp >> q) & 1u) && vals[q] > 2) vals[q] = 100;
             packed |= vals[q] << (8 * q);
-            h[q] = w.f16_lut[vals[q]];
+            h[q] = vals[q] == 255 ? h255 : (vals[q] == 0 ? h0 : (vals[q] == 200 ? h200 : (vals[q] == 100 ? h100 : w.f16_lut[vals[q]])));
         }
         if (c4 + 4 <= NC) {
             *(uint32_t*)(out_u8 + c4) = packed;
@@ -605,6 +681,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
         }
     }
     if (lane == 0) w.is_coll[l] = code;
+    PHASE_MARK(4);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,7 +6,9 @@
 #include "tfm.h"
 
 #define WAVE 64
-#define OWNER_MULTI 0xFFFFFFFEu
+#define OWNER_MULTI 0xFFFFFEu  // 24-bit owner field of the composed layer: several robots cover the cell
+#define RC_INLINE 6           // distinct robot classes (shape, size, sensor) per world, carried in the kernel arguments
+#define PC_INLINE 4           // distinct pedestrian classes per world
 
 // composed class layer byte (k_compose): low 3 bits = base class, bit 3 = "some robot covers it"
 #define CLS_STATIC 0   // occupancy value 0: static map / obstacle      (collision code 1)
@@ -21,17 +23,17 @@
 // the laser (agent.cpp:405-438, 511-624) and the own-footprint stamp (agent.cpp:503).
 struct RobotClassDev {
     int n_fp;
-    const double* fp_x;
-    const double* fp_y;
+    const double2* fp;           // [n_fp] footprint samples (x, y) in the base frame
     const uint32_t* fov_bits;    // [ceil(Hv*Wv/32)] bit = cell passes the angle / distance gate
     const uint32_t* stamp_bits;  // [ceil(Hv*Wv/32)] bit = own footprint covers the view cell
     int ray_maxlen;              // longest ray in cells
     int ray_stride;              // beams padded to a multiple of 64
-    const uint16_t* ray_cells;   // [ray_maxlen][ray_stride] view cell index of step k of beam b
+    int ray_kpad;                // ray_maxlen padded to a multiple of 8
+    const uint16_t* ray_rows;    // [beams][ray_kpad] view cell index of step k of beam b (16-byte chunks per lane)
     const uint16_t* ray_len;     // [ray_stride] number of in-map steps before the ray leaves / ends
     const float* ray_dist;       // [ray_maxlen][ray_stride] float32(hit distance) if the hit is at step k
-    const uint32_t* inv_off;     // [Hv*Wv+1] CSR offsets: rays through a view cell ...
-    const uint32_t* inv_ent;     // ... as (beam << 16 | k), beam descending
+    const uint32_t* inv_pack;    // [Hv*Wv] rays through a view cell: first entry | count << 20 ...
+    const uint32_t* inv_ent;     // ... entries (beam << 16 | k), beam descending
     const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or 0xFFFFFFFF
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
 };
@@ -71,11 +73,11 @@ struct DevWorld {
     uint8_t* ped_layer;      // 1 where view_ped() would have written a 1 this step
     uint32_t* own_lo;        // min (robot index + 1) covering the cell, 0xFFFFFFFF = none
     uint32_t* own_hi;        // max (robot index + 1) covering the cell, 0 = none
-    uint8_t* cls;            // composed class layer
-    uint32_t* owner;         // robot index | OWNER_MULTI where cls has CLS_ROBOT
-    // classes
-    const RobotClassDev* rclass;
-    const PedClassDev* pclass;
+    uint32_t* cell;          // composed layer: class byte | (owning robot or OWNER_MULTI) << 8, one gather per lookup
+    // class records travel by value in the kernel arguments: scalar loads, and their table pointers are known
+    // to be global (no flat loads, no reloads after stores)
+    RobotClassDev rc[RC_INLINE];
+    PedClassDev pc[PC_INLINE];
     const int* robot_cls;  // [R]
     const int* ped_cls;    // [P]
     const double* robot_size_last;  // [R]
@@ -102,6 +104,7 @@ struct DevWorld {
     const RvoNodeDev* onodes;
     int n_obst, n_onodes, oroot;
     int* err;  // [4] device-side overflow flags
+    unsigned long long* prof;  // [16] per-phase cycle counters (IMGENV_PHASE_PROFILE builds)
     // outputs (imgenv_out)
     float* vector_states;
     uint8_t* view_maps;
