@@ -179,7 +179,7 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
     }
     if (k.ray_maxlen == 0) k.ray_maxlen = 1;
     k.ray_kpad = ((k.ray_maxlen + 7) / 8) * 8;
-    k.ray_rows.assign((size_t)(B > 0 ? B : 1) * k.ray_kpad + 8, 0xFFFF);
+    k.ray_rows.assign((size_t)(B > 0 ? B : 1) * k.ray_kpad + 8, (uint16_t)NC);  // padding = a free dummy cell behind the view
     k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
     std::vector<std::vector<uint32_t>> inv(NC);
     for (int b = 0; b < B; b++)
@@ -200,7 +200,10 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
     for (int c = 0; c < NC; c++) k.inv_ent.insert(k.inv_ent.end(), inv[c].begin(), inv[c].end());
     k.top_ent.assign(NC, 0xFFFFFFFFu);
     for (int c = 0; c < NC; c++)
-        if (!inv[c].empty()) k.top_ent[c] = inv[c][0];
+        if (!inv[c].empty()) {
+            k.top_ent[c] = inv[c][0];
+        }
+    if (NC + 16 > 0xFFFF) k.ok = false;
     if (k.inv_ent.empty()) k.inv_ent.push_back(0);
 }
 

@@ -258,7 +258,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (cfg->image_size[0] != g.Wv || cfg->image_size[1] != g.Hv)
         FAIL(IMGENV_EINVAL, "image_size (%d,%d) != native view (%d,%d): cv2.resize INTER_CUBIC not supported",
              cfg->image_size[0], cfg->image_size[1], g.Wv, g.Hv);
-    if ((size_t)g.Hv * g.Wv > 65535) FAIL(IMGENV_EINVAL, "view larger than 65535 cells unsupported");
+    if ((size_t)g.Hv * g.Wv > 32767) FAIL(IMGENV_EINVAL, "view larger than 32767 cells unsupported");
     if (g.B > 65535) FAIL(IMGENV_EINVAL, "more than 65535 beams unsupported");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(IMGENV_EDEVICE, "no HIP device available");
@@ -522,7 +522,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->PP = 2;
     while (h->PP < P) h->PP <<= 1;
     const size_t NC = (size_t)g.Hv * g.Wv;
-    h->lds_view = 4 * max_stride + ((NC + 15) & ~(size_t)15) + 2 * (NC / 7 + 1) + 16;
+    h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 2 * NC + 16;  // src u8 (+ dummy cells) + hit u32 + skip list u16
     h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)d.Hp * d.Wp * 4 + (size_t)h->PP * 2 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);

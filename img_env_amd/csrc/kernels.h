@@ -456,18 +456,20 @@ __device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, si
 
 // ------------------------------------------------------------------------------------------------
 // Agent::view (agent.cpp:356-509) for local robot l = blockIdx.x, one wavefront.
-//   LDS: hit[ray_stride] u32 = (first-hit step << 16 | hit cell) of each beam, 0xFFFFFFFF = no hit;
-//        src[Hv*Wv] u8 cropped view; occ[] u16 list of occupied crop cells (sparse windows only).
+//   LDS: src[Hv*Wv + pad] u8  the cropped view (0 / 255 / 200); src[Hv*Wv] is a free dummy cell
+//        hit[B] u32           (first-hit step << 16 | hit cell) per beam, 0xFFFFFFFF = none
 //
-// With the laser on, the reference overwrites the cropped view with laser_map (agent.cpp:437), so the
-// crop only matters through the first occupied cell on each beam.  Beam paths are static, hence
-//   hit[b] = min { k : crop(cell_k(b)) == 0 }
-// and there are two ways to get it, chosen per robot from the number of occupied crop cells:
-//   sparse window : every occupied cell (compacted into an LDS list) pushes (k, cell) to each ray
-//                   through it with one LDS atomicMin -- cost ~ occupied cells, nothing walks rays;
-//   dense window  : one lane per beam walks its precomputed Bresenham path (8 cells per 16-byte load)
-//                   in LDS until the first occupied cell -- rays are short exactly when the window is dense.
-#define VIEW_OCC_CAP(NC) ((NC) / 7)
+// bresenhamLine (agent.cpp:511-624) writes laser_map beam after beam, later beams overwriting earlier
+// ones, so a cell ends with the value of the HIGHEST beam that writes it.  Beam paths are static, so
+//   (a) hit[b]: every lane walks the precomputed path of its beams in LDS until the first occupied cell
+//       (8 steps per 16-byte load, the wave leaves the loop as soon as all its beams have hit);
+//   (b) every view cell looks at the highest beam through it (static table `top_ent`): 255 before that
+//       beam's hit, 0 at the hit, 200 behind it -- unless the cell shares a row or column with the hit
+//       cell, where that beam leaves the cell alone (agent.cpp:555-560) and the next lower beam through
+//       the cell decides (rare slow path over the static per-cell ray list).
+// The kernel is written branch-free inside its loops (selects instead of divergent ifs): with one
+// wavefront per robot the scalar unit, not the vector ALUs, was the bottleneck of the branchy version.
+#define VIEW_SKIP 1u  // "left alone by the top beam": not a laser_map value (those are 0 / 200 / 255)
 
 template <bool POW2>
 __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
@@ -482,29 +484,41 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
-    const int Hv = w.Hv, Wv = w.Wv, NC = Hv * Wv;
+    const int Hv = w.Hv, Wv = w.Wv, NC = Hv * Wv, NCp = (NC + 16) & ~15;
+    const int Hg = w.Hg, Wg = w.Wg;
     const double res = w.res, inv = w.inv_res;
     const uint32_t wv_magic = w.wv_magic;
     const bool laser = w.use_laser != 0;
-    const int occ_cap = VIEW_OCC_CAP(NC);
-    uint32_t* hit = (uint32_t*)smem;
-    uint8_t* src = smem + (size_t)k.ray_stride * 4;
-    uint16_t* occ = (uint16_t*)(src + ((NC + 15) & ~15));
+    const uint32_t self = (uint32_t)i;
+    uint8_t* src = smem;
+    uint32_t* hit = (uint32_t*)(smem + NCp);
     PHASE_BEGIN();
-    if (laser)
-        for (int b = lane; b < k.ray_stride; b += WAVE) hit[b] = 0xFFFFFFFFu;
 
-    // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits
-    //     decides the code (agent.cpp:294-326) -> max over (sample index, code)
+    // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
+    //     the code (agent.cpp:294-326) -> max over (sample index, code); 4 independent gathers in flight
     uint32_t best = 0;
-    for (int q = lane; q < k.n_fp; q += WAVE) {
-        double wx, wy;
-        const double2 fp = k.fp[q];
-        tf_apply(bw, fp.x, fp.y, wx, wy);
-        const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
-        if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            const uint32_t v = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n);
-            if (v <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (v + 1));
+    for (int q0 = lane; q0 < k.n_fp; q0 += WAVE * 4) {
+        uint32_t idx[4], okm[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u * WAVE;
+            const double2 fp = k.fp[min(q, k.n_fp - 1)];
+            double wx, wy;
+            tf_apply(bw, fp.x, fp.y, wx, wy);
+            const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
+            const bool ok = (q < k.n_fp) & (m >= 0) & (m < Hg) & (n >= 0) & (n < Wg);
+            okm[u] = ok ? 0xFFFFFFFFu : 0u;
+            idx[u] = ok ? (uint32_t)(m * Wg + n) : 0u;
+        }
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = w.cell[idx[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool other = ((v[u] & CLS_ROBOT) != 0) & ((v[u] >> 8) != self);
+            const uint32_t cc = other ? (uint32_t)CLS_TWO : (v[u] & 7u);
+            const uint32_t cand = (((uint32_t)(q0 + u * WAVE + 1) << 2) | (cc + 1)) & okm[u];
+            best = max(best, cc <= 2 ? cand : 0u);
         }
     }
 #pragma unroll
@@ -512,163 +526,150 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const int code = (int)(best & 3);
     PHASE_MARK(0);
 
-    // (2) egocentric crop (agent.cpp:373-404), 4 view cells per lane per round; occupied cells are
-    //     appended to occ[] (ballot + prefix count, no atomics) while the window still counts as sparse
+    // (2) egocentric crop (agent.cpp:373-404): 4 view cells per lane per round -> one LDS dword
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
-    int n_occ = 0;
-    for (int base = 0; base < NC; base += WAVE * 4) {  // wave-uniform trip count (ballots inside)
-        const int c4 = base + lane * 4;
-        const uint32_t fov = c4 < NC ? (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu : 0u;  // c4 % 4 == 0
+    if (lane < 16) src[NC + lane] = 255;     // dummy free cells behind the view (padded path entries)
+    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
+        const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds the 4 bits
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
-        if (__ballot(fov != 0) == 0ull) {
-            if (c4 < NC) *(uint32_t*)(src + c4) = packed;
-            continue;
-        }
+        if (fov) {
+            uint32_t idx[4], okm[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = c4 + q;
-            bool occupied = false;
-            if (c < NC && ((fov >> q) & 1u)) {
+            for (int q = 0; q < 4; q++) {
+                const int c = c4 + q;
                 const int a = (int)__umulhi((uint32_t)c, wv_magic), b = c - a * Wv;
                 double wx, wy;
                 tf_apply(vw, a * res, b * res, wx, wy);
                 const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
-                if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-                    occupied = cell_class(w, (uint32_t)i, (size_t)m * w.Wg + n) != CLS_HIGH;
-                    packed = (packed & ~(0xFFu << (8 * q))) | ((occupied ? 0u : 255u) << (8 * q));
-                }
+                const bool ok = (c < NC) & (((fov >> q) & 1u) != 0) & (m >= 0) & (m < Hg) & (n >= 0) & (n < Wg);
+                okm[q] = ok ? 0xFFu : 0u;
+                idx[q] = ok ? (uint32_t)(m * Wg + n) : 0u;
             }
-            if (laser) {
-                const unsigned long long mask = __ballot(occupied);
-                const int pos = n_occ + __popcll(mask & ((1ull << lane) - 1ull));
-                if (occupied && pos < occ_cap) occ[pos] = (uint16_t)c;
-                n_occ += __popcll(mask);
+            uint32_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = w.cell[idx[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool other = ((v[q] & CLS_ROBOT) != 0) & ((v[q] >> 8) != self);
+                const bool free_cell = ((v[q] & 7u) == CLS_HIGH) & !other;
+                const uint32_t val = free_cell ? 255u : 0u;
+                packed = (packed & ~(okm[q] << (8 * q))) | ((val & okm[q]) << (8 * q));
             }
         }
-        if (c4 < NC) *(uint32_t*)(src + c4) = packed;
+        *(uint32_t*)(src + c4) = packed;
     }
     __syncthreads();
     PHASE_MARK(1);
 
+    // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
     if (laser) {
-        if (n_occ <= occ_cap) {
-            // sparse: occupied cells push (k, cell) to the rays through them
-            for (int t = lane; t < n_occ; t += WAVE) {
-                const uint32_t c = occ[t];
-                const uint32_t pk = k.inv_pack[c];
-                const uint32_t e0 = pk & 0xFFFFFu, cnt = pk >> 20;
-                for (uint32_t e = 0; e < cnt; e++) {
-                    const uint32_t ent = k.inv_ent[e0 + e];
-                    atomicMin(&hit[ent >> 16], ((ent & 0xFFFFu) << 16) | c);
-                }
-            }
-        } else {
-            // dense: bresenhamLine (agent.cpp:511-624) replayed from the per-beam path rows
-            for (int b = lane; b < w.B; b += WAVE) {
-                const int len = k.ray_len[b];
-                const uint16_t* row = k.ray_rows + (size_t)b * k.ray_kpad;
-                uint32_t found = 0xFFFFFFFFu;
-                for (int q0 = 0; q0 < len && found == 0xFFFFFFFFu; q0 += 8) {
-                    const uint4 ch = *(const uint4*)(row + q0);
-                    const uint32_t wds[4] = {ch.x, ch.y, ch.z, ch.w};
+        for (int b0 = 0; b0 < w.B; b0 += WAVE) {
+            const int b = b0 + lane;
+            const int bb = min(b, w.B - 1);
+            const int len = b < w.B ? (int)k.ray_len[bb] : 0;
+            const uint16_t* row = k.ray_rows + (size_t)bb * k.ray_kpad;
+            uint32_t found = 0xFFFFFFFFu;
+            for (int q0 = 0; q0 < k.ray_kpad; q0 += 8) {
+                const uint4 ch = *(const uint4*)(row + q0);
+                const uint32_t wds[4] = {ch.x, ch.y, ch.z, ch.w};
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const uint32_t c = (wds[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                        if (found == 0xFFFFFFFFu && q0 + j < len && src[c] == 0) found = ((uint32_t)(q0 + j) << 16) | c;
-                    }
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t c = (wds[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;  // padded entries point at a free dummy cell
+                    const bool h = (found == 0xFFFFFFFFu) & (q0 + j < len) & (src[c] == 0);
+                    found = h ? (((uint32_t)(q0 + j) << 16) | c) : found;
                 }
+                if (__all((found != 0xFFFFFFFFu) | (q0 + 8 >= len))) break;
+            }
+            if (b < w.B) {
                 hit[b] = found;
+                const float hd = found != 0xFFFFFFFFu ? k.ray_dist[(size_t)(found >> 16) * k.ray_stride + b] : 6.0f;  // agent.cpp:513
+                w.lasers_raw[(size_t)l * w.B + b] = hd;
+                w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
             }
         }
         __syncthreads();
     }
     PHASE_MARK(2);
-#ifdef IMGENV_PHASE_PROFILE
-    if (lane == 0) {
-        atomicAdd((unsigned long long*)&w.prof[6], (unsigned long long)n_occ);
-        atomicAdd((unsigned long long*)&w.prof[7], 1ull);
-    }
-#endif
 
-    // (3) laser ranges (agent.cpp:405-438): distance between the sensor cell and the hit cell, 6.0 if none
+    // (4) laser_map (agent.cpp:437) per cell from its top beam; cells that beam leaves alone are tagged
+    //     VIEW_SKIP and collected (ballot compaction) for (5).  The result overwrites src in LDS.
+    uint16_t* skip = (uint16_t*)(hit + k.ray_stride);
+    int n_skip = 0;
     if (laser) {
-        for (int b = lane; b < w.B; b += WAVE) {
-            const uint32_t hp = hit[b];
-            const float h = hp != 0xFFFFFFFFu ? k.ray_dist[(size_t)(hp >> 16) * k.ray_stride + b] : 6.0f;  // agent.cpp:513
-            w.lasers_raw[(size_t)l * w.B + b] = h;
-            w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)h / w.laser_max : (double)h;
-        }
-    }
-    PHASE_MARK(3);
-
-    // (4) laser_map replaces the view (agent.cpp:437): it starts at 200, beams write in index order and
-    //     later beams win, so a cell takes the value of the HIGHEST beam that writes it: 255 before that
-    //     beam's hit, 0 at the hit, 200 behind it unless the cell shares a row or column with the hit
-    //     cell, in which case that beam leaves the cell alone (agent.cpp:538-560) and the next lower beam
-    //     through the cell decides.  Then the own footprint is stamped 100 (agent.cpp:503) and the result
-    //     is stored as uint8 and as float16(v / 255).
-    uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
-    uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;
-    const uint32_t h0 = w.f16_lut[0], h100 = w.f16_lut[100], h200 = w.f16_lut[200], h255 = w.f16_lut[255];
-    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
-        uint32_t vals[4];
-        if (laser) {
-            uint32_t top[4];
+        for (int base = 0; base < NC; base += WAVE * 4) {  // wave-uniform trip count (ballots inside)
+            const int c4 = base + lane * 4;
+            uint32_t top[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (c4 + 4 <= NC) {
                 const uint4 t4 = *(const uint4*)(k.top_ent + c4);
                 top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) top[q] = c4 + q < NC ? k.top_ent[c4 + q] : 0xFFFFFFFFu;
+                for (int q = 0; q < 4; q++)
+                    if (c4 + q < NC) top[q] = k.top_ent[c4 + q];
             }
+            uint32_t packed = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                uint32_t val = 200;
-                uint32_t ent = top[q];
-                if (ent != 0xFFFFFFFFu) {
-                    const int c = c4 + q;
-                    uint32_t e = 0, e1 = 0;
-                    bool have_range = false;
-                    while (true) {
-                        const uint32_t kk = ent & 0xFFFFu;
-                        const uint32_t hp = hit[ent >> 16];
-                        const uint32_t hk = hp >> 16;
-                        if (kk < hk) {  // also the "no hit" case: hk = 0xFFFF
-                            val = 255;
-                            break;
-                        }
-                        if (kk == hk) {
-                            val = 0;
-                            break;
-                        }
-                        const uint32_t hc = hp & 0xFFFFu;
-                        const int hx = (int)__umulhi(hc, wv_magic), hy = (int)hc - hx * Wv;
-                        const int cx = (int)__umulhi((uint32_t)c, wv_magic), cy = c - cx * Wv;
-                        if (cx != hx && cy != hy) break;  // this beam writes 200
-                        if (!have_range) {  // rare: fall back to the full ray list of this cell
-                            const uint32_t pk = k.inv_pack[c];
-                            e = pk & 0xFFFFFu;
-                            e1 = e + (pk >> 20);
-                            have_range = true;
-                        }
-                        if (++e >= e1) break;  // no lower beam: the cell keeps 200
-                        ent = k.inv_ent[e];
-                    }
-                }
-                vals[q] = val;
+                const uint32_t c = (uint32_t)(c4 + q);
+                const bool has = top[q] != 0xFFFFFFFFu;
+                const uint32_t bq = has ? (top[q] >> 16) : 0u, kk = top[q] & 0xFFFFu;
+                const uint32_t hp = hit[bq], hk = hp >> 16, hc = hp & 0xFFFFu;
+                const uint32_t hx = __umulhi(hc, wv_magic), hy = hc - hx * (uint32_t)Wv;
+                const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
+                const uint32_t behind = ((cx != hx) & (cy != hy)) ? 200u : VIEW_SKIP;
+                uint32_t val = kk < hk ? 255u : (kk == hk ? 0u : behind);  // hk = 0xFFFF when the beam never hits
+                val = has ? val : 200u;
+                packed |= val << (8 * q);
+                const bool sk = val == VIEW_SKIP;
+                const unsigned long long mask = __ballot(sk);
+                if (sk) skip[n_skip + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)c;
+                n_skip += __popcll(mask);
             }
-        } else {
-            const uint32_t p = *(const uint32_t*)(src + c4);
-#pragma unroll
-            for (int q = 0; q < 4; q++) vals[q] = (p >> (8 * q)) & 0xFFu;
+            if (c4 < NC) *(uint32_t*)(src + c4) = packed;
         }
+        __syncthreads();
+        // (5) resolve the skipped cells: the next lower beam through the cell that writes decides (agent.cpp:555-560)
+        for (int t = lane; t < n_skip; t += WAVE) {
+            const uint32_t c = skip[t];
+            const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
+            const uint32_t pk = k.inv_pack[c];
+            const uint32_t e0 = pk & 0xFFFFFu, cnt = pk >> 20;
+            uint32_t val = 200;
+            for (uint32_t e = 1; e < cnt; e++) {  // entry 0 is the top beam
+                const uint32_t ent = k.inv_ent[e0 + e];
+                const uint32_t kk = ent & 0xFFFFu, hp = hit[ent >> 16], hk = hp >> 16;
+                if (kk < hk) {
+                    val = 255;
+                    break;
+                }
+                if (kk == hk) {
+                    val = 0;
+                    break;
+                }
+                const uint32_t hc = hp & 0xFFFFu;
+                const uint32_t hx = __umulhi(hc, wv_magic), hy = hc - hx * (uint32_t)Wv;
+                if (cx != hx && cy != hy) break;  // this beam writes 200
+            }
+            src[c] = (uint8_t)val;
+        }
+        __syncthreads();
+    }
+    PHASE_MARK(3);
+
+    // (6) own footprint stamped 100 (agent.cpp:503); stored as uint8 and as float16(v / 255) (yaml_env.py:431-438)
+    uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
+    uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;
+    const uint32_t h0 = w.f16_lut[0], h100 = w.f16_lut[100], h200 = w.f16_lut[200], h255 = w.f16_lut[255];
+    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
+        const uint32_t p = *(const uint32_t*)(src + c4);
         const uint32_t stamp = (k.stamp_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;
         uint32_t packed = 0, h[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if (((stamp >> q) & 1u) && vals[q] > 2) vals[q] = 100;
-            packed |= vals[q] << (8 * q);
-            h[q] = vals[q] == 255 ? h255 : (vals[q] == 0 ? h0 : (vals[q] == 200 ? h200 : (vals[q] == 100 ? h100 : w.f16_lut[vals[q]])));
+            uint32_t v = (p >> (8 * q)) & 0xFFu;
+            v = (((stamp >> q) & 1u) != 0) & (v > 2) ? 100u : v;
+            packed |= v << (8 * q);
+            h[q] = v == 255 ? h255 : (v == 0 ? h0 : (v == 200 ? h200 : h100));
         }
         if (c4 + 4 <= NC) {
             *(uint32_t*)(out_u8 + c4) = packed;
@@ -720,6 +721,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
 
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
+    PHASE_BEGIN();
     // Agent::get_state (agent.cpp:156-184)
     const Tf2 t = tf_mul(w.world_target[l], bw);
     const Tf2 target_base = tf_inverse(t);
@@ -763,6 +765,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
         }
         for (int c = lane; c < NP; c += WAVE) rank[c] = 0;
         __syncthreads();
+        PHASE_MARK(8);
         // stable sort by (key, index): bitonic network over PP = 2^k entries in LDS
         for (int kk = 2; kk <= PP; kk <<= 1) {
             for (int jj = kk >> 1; jj > 0; jj >>= 1) {
@@ -783,6 +786,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
                 __syncthreads();
             }
         }
+        PHASE_MARK(9);
         // ped_tmp vector + disc raster (yaml_env.py:392-429): rank r overwrites ranks < r
         float* pt = w.ped_vector_states + (size_t)l * w.PV;
         if (lane == 0) pt[0] = (float)P;
@@ -815,6 +819,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
                 }
         }
         __syncthreads();
+        PHASE_MARK(10);
         min_dist = __shfl(min_dist, 0);
         float* pm = w.ped_maps + (size_t)l * 3 * NP;
         for (int c4 = lane * 4; c4 < NP; c4 += WAVE * 4) {
@@ -844,6 +849,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
             }
         }
     }
+    PHASE_MARK(11);
     if (lane != 0) return;
     // ---- scalar tail on lane 0: _get_states distances, ImageEnv.step, wrapper stack ----
     w.ped_min_dists[l] = min_dist;

@@ -36,10 +36,14 @@ for s in range(N):
     w.step(a)
 w.lib.imgenv_debug_phases(w.h, buf)
 v = list(buf)
-names = ["view: collision", "view: crop", "view: hits", "view: lasers", "view: compose+store"]
-waves = max(v[7], 1)
-print("waves", waves, "avg occupied crop cells / robot %.1f" % (v[6] / waves))
+names = ["view: collision", "view: crop", "view: hits", "view: compose+skip", "view: store"]
+waves = N * R
 tot = sum(v[:5]) or 1
 for n, c in zip(names, v[:5]):
     print("  %-22s %9.0f cycles/wave  %5.1f %%" % (n, c / waves, 100.0 * c / tot))
 print("  total %.0f cycles/wave" % (tot / waves))
+names2 = ["obs: state + ped transform", "obs: bitonic sort", "obs: ped vector + raster", "obs: ped_map store"]
+tot2 = sum(v[8:12]) or 1
+for n, c in zip(names2, v[8:12]):
+    print("  %-28s %9.0f cycles/wave  %5.1f %%" % (n, c / waves, 100.0 * c / tot2))
+print("  total %.0f cycles/wave" % (tot2 / waves))
