@@ -177,9 +177,28 @@ def main():
         frozen = int(world.out["counters"][3].item()) - frozen0 + int(world.out["counters"][2].item())
         return dt, tm, frozen / float(steps * RL)
 
-    # pass 1 (untimed for the headline): per-kernel breakdown with events around every kernel
-    _, breakdown, _ = run("active", min(args.steps, 50), min(args.warmup, 5), timing_mode=1)
-    per_kernel_us = {k: (1e3 * ms / n if n else 0.0) for k, (ms, n) in breakdown.items()}
+    # pass 1 (not the headline): per-kernel breakdown, HIP events around every kernel, one sync per step;
+    # the median over steps is robust against first-launch and host-submission hiccups
+    def kernel_breakdown(steps=40):
+        acts = make_actions("active")
+        state["episode"] = 0
+        do_reset()
+        for s in range(5):
+            do_step(acts[s % n_act])
+        world.timing(1)
+        prev = {k: (0.0, 0) for k in world.timing_read()}
+        samples = {k: [] for k in prev}
+        for s in range(steps):
+            do_step(acts[s % n_act])
+            cur = world.timing_read()
+            for k, (ms, n) in cur.items():
+                if n > prev[k][1]:
+                    samples[k].append(1e3 * (ms - prev[k][0]) / (n - prev[k][1]))
+            prev = cur
+        world.timing(0)
+        return {k: (float(np.median(v)) if v else 0.0) for k, v in samples.items()}
+
+    per_kernel_us = kernel_breakdown()
     dominant = max(per_kernel_us, key=per_kernel_us.get)
     dom_id = list(per_kernel_us).index(dominant)
     # pass 2: THE timed region; HIP events only around the dominant kernel

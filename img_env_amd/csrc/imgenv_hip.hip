@@ -54,6 +54,11 @@ struct imgenv {
     int launches = 0;
     size_t lds_view = 0, lds_obs = 0;
     bool pow2 = false;
+    // the ORCA solve of step t+1 only needs what exists after the rasters of step t, so it runs on a side
+    // stream underneath the view / observation kernels of step t (200 waves alone cannot fill the chip)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool orca_pending = false;
     RvoObstacles rvo;
     // live timing (imgenv_timing)
     int t_mode = 0, t_which = -1;
@@ -230,6 +235,12 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
     if (!h) return;
     for (void* p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->t_ev) (void)hipEventDestroy(e);
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        (void)hipStreamDestroy(h->side);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
     delete h;
 }
@@ -443,6 +454,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     TRY(dev_alloc(h, &d.is_coll, RL)); TRY(dev_alloc(h, &d.is_arr, RL)); TRY(dev_alloc(h, &d.py_done, RL));
     TRY(dev_alloc(h, &d.clean_state, RL, 1));
     TRY(dev_alloc(h, &d.tmp_dist, RL));
+    TRY(dev_alloc(h, &d.pm_cells, (size_t)RL * PM_CAP));
+    TRY(dev_alloc(h, &d.pm_n, RL));  // 0: the arena starts zeroed, nothing to clear
     TRY(dev_alloc(h, &d.ppx, P)); TRY(dev_alloc(h, &d.ppy, P)); TRY(dev_alloc(h, &d.pyaw, P));
     TRY(dev_alloc(h, &d.plx, P)); TRY(dev_alloc(h, &d.ply, P)); TRY(dev_alloc(h, &d.pvx, P)); TRY(dev_alloc(h, &d.pvy, P));
     TRY(dev_alloc(h, &d.prem, P)); TRY(dev_alloc(h, &d.llx, P)); TRY(dev_alloc(h, &d.lly, P));
@@ -523,7 +536,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     while (h->PP < P) h->PP <<= 1;
     const size_t NC = (size_t)g.Hv * g.Wv;
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 2 * NC + 16;  // src u8 (+ dummy cells) + hit u32 + skip list u16
-    h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)d.Hp * d.Wp * 4 + (size_t)h->PP * 2 + 16;
+    h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)h->PP * 4 + WAVE * 7 * 4 + PM_CAP * 2 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);
         FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
@@ -534,6 +547,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     }
     if (h->lds_obs > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)k_obs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+    HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipDeviceSynchronize());
     *out = h;
     return IMGENV_OK;
@@ -590,6 +606,14 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
     else
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
+    if (h->P > 0 && h->NA > 0) {  // next step's _step_ped_normal solve (img_env.cpp:304-343), overlapped
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        TIMED(h, IMGENV_K_ORCA, h->side, (k_orca<<<dim3(h->P), dim3(WAVE), 0, h->side>>>(d)));
+        HIPCHK(hipEventRecord(h->ev_join, h->side));
+        h->orca_pending = true;
+        h->launches += 1;
+    }
     TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
     if (h->pow2)
         TIMED(h, IMGENV_K_VIEW, st, (k_view<true><<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d)));
@@ -607,6 +631,10 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     if (b->n_obstacles < 0 || (h->P > 0 && b->ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->orca_pending) {  // a solve of the abandoned episode may still be in flight
+        HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+        h->orca_pending = false;
+    }
     DevWorld& d = h->d;
     const int R = h->R, P = h->P, RL = h->RL;
     const double res = h->geom.res;
@@ -717,10 +745,13 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     hipStream_t st = (hipStream_t)stream;
     DevWorld& d = h->d;
     h->launches = 0;
-    if (h->P > 0 && h->NA > 0) {  // _step_ped_normal (img_env.cpp:304-359)
-        TIMED(h, IMGENV_K_ORCA, st, (k_orca<<<dim3(h->P), dim3(WAVE), 0, st>>>(d)));
+    if (h->P > 0 && h->NA > 0) {  // _step_ped_normal (img_env.cpp:304-359): the solve was launched after the last rasters
+        if (h->orca_pending) {
+            HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+            h->orca_pending = false;
+        }
         TIMED(h, IMGENV_K_PED_UPDATE, st, (k_ped_update<<<dim3((h->P + 63) / 64), dim3(64), 0, st>>>(d)));
-        h->launches += 2;
+        h->launches += 1;
     }
     // _step_robot (img_env.cpp:388-410)
     TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, actions)));

@@ -709,15 +709,22 @@ __device__ double py_floordiv(double vx, double wx) {
     return floordiv;
 }
 
+#define PM_CAP 512  // cells of a robot's ped_map that may be non-zero before it falls back to dense clears
+
+// LDS: key[PP] f64 sort keys | info[P] float4 (px,py,vx,vy) | ord[PP] u16 sorted ped index |
+//      inbox[PP] u16 ranks of the pedestrians inside the +-3 m box | stage[64*7] f32 | touched[PM_CAP] u16
 __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elapsed, int PP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = blockIdx.x, lane = lane_id();
     const int i = w.r0 + l;
     const int P = w.P, Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
+    const int Pa = P > 0 ? P : 1;
     double* key = (double*)smem;
     float4* info = (float4*)(smem + (size_t)PP * 8);
-    uint32_t* rank = (uint32_t*)(smem + (size_t)PP * 8 + (size_t)(P > 0 ? P : 1) * 16);
-    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)NP * 4);
+    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)Pa * 16);
+    uint16_t* inbox = ord + PP;
+    float* stage = (float*)(inbox + PP);
+    uint16_t* touched = (uint16_t*)(stage + WAVE * 7);
 
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
@@ -763,7 +770,6 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
                 ord[j] = 0xFFFF;
             }
         }
-        for (int c = lane; c < NP; c += WAVE) rank[c] = 0;
         __syncthreads();
         PHASE_MARK(8);
         // stable sort by (key, index): bitonic network over PP = 2^k entries in LDS
@@ -787,66 +793,103 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
             }
         }
         PHASE_MARK(9);
-        // ped_tmp vector + disc raster (yaml_env.py:392-429): rank r overwrites ranks < r
+        // ped_tmp vector (yaml_env.py:397-408): 7 floats per pedestrian in rank order, staged through LDS so
+        // that the global stores are contiguous; pedestrians inside the +-3 m box are collected in rank order
         float* pt = w.ped_vector_states + (size_t)l * w.PV;
         if (lane == 0) pt[0] = (float)P;
         const double rsl = w.robot_size_last[i];
+        int n_in = 0;
+        for (int q0 = 0; q0 < P; q0 += WAVE) {
+            const int q = q0 + lane;
+            bool in_box = false;
+            if (q < P) {
+                const int j = ord[q];
+                const float4 f = info[j];
+                const double dpx = f.x, dpy = f.y;
+                const double ped_r = w.ped_r_round[j];
+                const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
+                float* o = stage + lane * 7;
+                o[0] = f.x;
+                o[1] = f.y;
+                o[2] = f.z;
+                o[3] = f.w;
+                o[4] = (float)ped_r;
+                o[5] = (float)(ped_r + rsl);
+                o[6] = dist;
+                if (q == 0) min_dist = (double)(float)(dist - (float)(ped_r + rsl));  // yaml_env.py:455-456
+                in_box = !(dpx > 3 || dpx < -3 || dpy > 3 || dpy < -3);          // yaml_env.py:409-410
+            }
+            const unsigned long long mask = __ballot(in_box);
+            if (in_box) inbox[n_in + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)q;
+            n_in += __popcll(mask);
+            __syncthreads();
+            const int nf = min(WAVE, P - q0) * 7;
+            for (int e = lane; e < nf; e += WAVE) pt[1 + 7 * q0 + e] = stage[e];
+            __syncthreads();
+        }
+        min_dist = __shfl(min_dist, 0);
+        PHASE_MARK(10);
+
+        // ped_map (yaml_env.py:409-427), sparse update: the map is zero except under a few discs, so instead of
+        // rewriting 3 x Hp x Wp floats per robot per step, the cells written last step are cleared and the discs
+        // of the pedestrians inside the box are stamped in rank order (farther ones overwrite nearer ones).
+        float* pm = w.ped_maps + (size_t)l * 3 * NP;
+        uint16_t* prev = w.pm_cells + (size_t)l * PM_CAP;
+        const int n_prev = w.pm_n[l];
+        if (n_prev >= 0) {
+            for (int e = lane; e < n_prev; e += WAVE) {
+                const int c = prev[e];
+                pm[c] = 0.0f;
+                pm[NP + c] = 0.0f;
+                pm[2 * NP + c] = 0.0f;
+            }
+        } else {  // unknown contents (first use or overflow): dense clear
+            for (int c4 = lane * 4; c4 < 3 * NP; c4 += WAVE * 4) {
+                if (c4 + 4 <= 3 * NP) {
+                    *(float4*)(pm + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    for (int q = c4; q < 3 * NP; q++) pm[q] = 0.0f;
+                }
+            }
+        }
+        int n_new = 0;
         const double pres = w.ped_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
-        for (int q = lane; q < P; q += WAVE) {
-            const int j = ord[q];
-            const float4 f = info[j];
-            const double dpx = f.x, dpy = f.y;
-            const double ped_r = w.ped_r_round[j];
-            float* o = pt + 1 + 7 * q;
-            o[0] = f.x;
-            o[1] = f.y;
-            o[2] = f.z;
-            o[3] = f.w;
-            o[4] = (float)ped_r;
-            o[5] = (float)(ped_r + rsl);
-            const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
-            o[6] = dist;
-            if (q == 0) min_dist = (double)(float)(dist - (float)(ped_r + rsl));  // yaml_env.py:455-456
-            if (dpx > 3 || dpx < -3 || dpy > 3 || dpy < -3) continue;
-            const double tmx = -dpx + 3, tmy = -dpy + 3;
+        for (int e = 0; e < n_in; e++) {
+            __syncthreads();  // drains this wave's earlier stores: later discs overwrite earlier ones
+            const float4 f = info[ord[inbox[e]]];
+            const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
             const int ax = (int)py_floordiv(tmx - pr, pres), bx = (int)py_floordiv(tmx + pr, pres);
             const int ay = (int)py_floordiv(tmy - pr, pres), by = (int)py_floordiv(tmy + pr, pres);
-            for (int jj = ax; jj < bx; jj++)
-                for (int kq = ay; kq < by; kq++) {
-                    if (jj < 0 || jj >= Hp || kq < 0 || kq >= Wp) continue;
-                    const double ddx = (jj + 0.5) * pres - tmx, ddy = (kq + 0.5) * pres - tmy;
-                    if (ddx * ddx + ddy * ddy < pr2) atomicMax(&rank[jj * Wp + kq], (uint32_t)q + 1);
+            const int wy = by - ay, cnt = (bx - ax) * wy;
+            for (int t0 = 0; t0 < cnt; t0 += WAVE) {
+                const int tt = t0 + lane;
+                bool hitc = false;
+                int c = 0;
+                if (tt < cnt) {
+                    const int jj = ax + tt / wy, kq = ay + tt % wy;
+                    if (jj >= 0 && jj < Hp && kq >= 0 && kq < Wp) {
+                        const double ddx = (jj + 0.5) * pres - tmx, ddy = (kq + 0.5) * pres - tmy;
+                        hitc = ddx * ddx + ddy * ddy < pr2;
+                        c = jj * Wp + kq;
+                    }
                 }
+                if (hitc) {
+                    pm[c] = 1.0f;
+                    pm[NP + c] = f.z;
+                    pm[2 * NP + c] = f.w;
+                }
+                const unsigned long long mask = __ballot(hitc);
+                const int pos = n_new + __popcll(mask & ((1ull << lane) - 1ull));
+                if (hitc && pos < PM_CAP) touched[pos] = (uint16_t)c;
+                n_new += __popcll(mask);
+            }
         }
         __syncthreads();
-        PHASE_MARK(10);
-        min_dist = __shfl(min_dist, 0);
-        float* pm = w.ped_maps + (size_t)l * 3 * NP;
-        for (int c4 = lane * 4; c4 < NP; c4 += WAVE * 4) {
-            float a[4], b[4], c[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t rk = (c4 + q < NP) ? rank[c4 + q] : 0;
-                if (rk) {
-                    const float4 f = info[ord[rk - 1]];
-                    a[q] = 1.0f;
-                    b[q] = f.z;
-                    c[q] = f.w;
-                } else {
-                    a[q] = b[q] = c[q] = 0.0f;
-                }
-            }
-            if (c4 + 4 <= NP) {
-                *(float4*)(pm + c4) = make_float4(a[0], a[1], a[2], a[3]);
-                *(float4*)(pm + NP + c4) = make_float4(b[0], b[1], b[2], b[3]);
-                *(float4*)(pm + 2 * NP + c4) = make_float4(c[0], c[1], c[2], c[3]);
-            } else {
-                for (int q = 0; q < 4 && c4 + q < NP; q++) {
-                    pm[c4 + q] = a[q];
-                    pm[NP + c4 + q] = b[q];
-                    pm[2 * NP + c4 + q] = c[q];
-                }
-            }
+        if (n_new <= PM_CAP) {
+            for (int e = lane; e < n_new; e += WAVE) prev[e] = touched[e];
+            if (lane == 0) w.pm_n[l] = n_new;
+        } else if (lane == 0) {
+            w.pm_n[l] = -1;
         }
     }
     PHASE_MARK(11);

@@ -91,6 +91,8 @@ struct DevWorld {
     int* is_coll;                             // [RL]
     uint8_t *is_arr, *py_done, *clean_state;  // [RL]
     double* tmp_dist;                         // [RL]
+    uint16_t* pm_cells;                       // [RL][PM_CAP] ped_map cells written by the last step
+    int* pm_n;                                // [RL] their count, -1 = unknown (dense clear needed)
     // pedestrians
     double *ppx, *ppy, *pyaw, *plx, *ply, *pvx, *pvy, *prem, *llx, *lly, *rlx, *rly;  // [P]
     int *pstate, *ptraj_idx;                                                       // [P]
