@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--peds", type=int, default=N_PEDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
+                    "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -105,9 +107,11 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world_size))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    use_dist = world_size > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     RL = args.robots_per_gpu
     R = RL * world_size
@@ -121,6 +125,17 @@ def main():
                                   robot_begin=rank * RL, robot_end=(rank + 1) * RL)
     world = World(params, grid, device=local_rank)
     r0, r1 = rank * RL, (rank + 1) * RL
+    native = False
+    if use_dist:
+        try:  # preferred: the library runs ncclAllGather itself, on the step's stream
+            world.init_comm(rank, world_size)
+            native = True
+        except Exception as e:  # fall back to torch.distributed's collective between step_begin / step_end
+            if rank == 0:
+                print("bench.py: native RCCL exchange unavailable (%s); using torch.distributed.all_gather" % e, file=sys.stderr)
+        flags = [None] * world_size
+        dist.all_gather_object(flags, native)
+        native = all(flags)
 
     g = torch.Generator(device="cpu").manual_seed(1 + rank)
     n_act = 16
@@ -140,7 +155,7 @@ def main():
         state["elapsed"] = 0
 
     def do_step(a):
-        if world_size > 1:
+        if use_dist and not native:
             world.step_begin(a)
             dist.all_gather_into_tensor(world.records, world.records[r0:r1])
             world.step_end()
@@ -158,19 +173,19 @@ def main():
             do_step(acts[s % n_act])
         frozen0 = int(world.out["counters"][3].item())
         world.timing(timing_mode, which)
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(steps):
             do_step(acts[s % n_act])
         torch.cuda.synchronize()
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
         tm = world.timing_read()
         world.timing(0)
-        if world_size > 1:
+        if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -232,8 +247,9 @@ def main():
                                    % (RL, world_size, P, side, side, res, TIME_MAX),
                        "robots": R, "peds": P, "grid": side, "resolution": res, "view": 48, "beams": 360,
                        "policy": "active: v=0, w~U(-0.9,0.9): every robot-step runs the full view path",
-                       "parallelism": "robot-sharded x%d, RCCL all-gather of robot records" % world_size if world_size > 1
-                                      else "single GPU"},
+                       "parallelism": ("robot-sharded x%d, RCCL all-gather of robot records (%s)" % (
+                           world_size, "ncclAllGather inside imgenv_step" if native else "torch.distributed between step_begin/step_end"))
+                       if use_dist else "single GPU"},
             "frozen_fraction": frozen_active,
             "episode_policy": episode,
             "kernel_us": per_kernel_us,
@@ -248,7 +264,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(p1, grid, layouts[0])
         print(json.dumps(out))
     world.close()
-    if world_size > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

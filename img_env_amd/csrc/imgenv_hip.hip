@@ -3,7 +3,9 @@
 // sequence of HIP kernels on one stream; all simulator state lives in HBM for the life of the handle.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off (see __graft_entry__.py)
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <stdio.h>
 
 #include <string>
@@ -56,6 +58,8 @@ struct imgenv {
     bool pow2 = false;
     // the ORCA solve of step t+1 only needs what exists after the rasters of step t, so it runs on a side
     // stream underneath the view / observation kernels of step t (200 waves alone cannot fill the chip)
+    ncclComm_t comm = nullptr;  // optional: native RCCL exchange inside imgenv_step
+    int comm_ranks = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool orca_pending = false;
@@ -68,6 +72,36 @@ struct imgenv {
     double t_ms[IMGENV_K_COUNT] = {0};
     int64_t t_cnt[IMGENV_K_COUNT] = {0};
 };
+
+// RCCL is resolved at run time so that single-GPU users do not need it: prefer the copy the process already
+// loaded (torch ships one), then the ROCm one
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_id = nullptr;
+    decltype(&ncclCommInitRank) init_rank = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclCommDestroy) destroy = nullptr;
+    decltype(&ncclGetErrorString) err = nullptr;
+};
+static RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        void* lib = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);
+        for (int q = 0; !lib && q < 3; q++) lib = dlopen(names[q], RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            api.get_id = (decltype(api.get_id))dlsym(lib, "ncclGetUniqueId");
+            api.init_rank = (decltype(api.init_rank))dlsym(lib, "ncclCommInitRank");
+            api.all_gather = (decltype(api.all_gather))dlsym(lib, "ncclAllGather");
+            api.destroy = (decltype(api.destroy))dlsym(lib, "ncclCommDestroy");
+            api.err = (decltype(api.err))dlsym(lib, "ncclGetErrorString");
+            if (api.get_id && api.init_rank && api.all_gather && api.destroy && api.err) api.lib = lib;
+        }
+    }
+    return api.lib ? &api : nullptr;
+}
 
 static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster",
                                                          "k_compose", "k_view", "k_obs"};
@@ -234,6 +268,7 @@ static int dev_upload(imgenv* h, const T** out, const std::vector<T>& v) {
 extern "C" void imgenv_destroy(imgenv_t* h) {
     if (!h) return;
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->comm && rccl_api()) (void)rccl_api()->destroy(h->comm);
     for (hipEvent_t e : h->t_ev) (void)hipEventDestroy(e);
     if (h->side) {
         (void)hipStreamSynchronize(h->side);
@@ -769,7 +804,42 @@ extern "C" int imgenv_step_end(imgenv_t* h, void* stream) {
 
 extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) {
     if (int rc = imgenv_step_begin(h, actions, stream)) return rc;
+    if (h->comm) {  // the one exchange of a robot-sharded world: records of all robots, in place
+        const size_t count = (size_t)h->RL * IMGENV_RECORD_DOUBLES;
+        const ncclResult_t e = rccl_api()->all_gather(h->d.rec + (size_t)h->r0 * IMGENV_RECORD_DOUBLES, h->d.rec, count,
+                                                      ncclDouble, h->comm, (hipStream_t)stream);
+        if (e != ncclSuccess) FAIL(IMGENV_EDEVICE, "ncclAllGather: %s", rccl_api()->err(e));
+    }
     return imgenv_step_end(h, stream);
+}
+
+extern "C" int imgenv_comm_unique_id(void* id128) {
+    if (!id128) FAIL(IMGENV_EINVAL, "null argument");
+    RcclApi* a = rccl_api();
+    if (!a) FAIL(IMGENV_EDEVICE, "RCCL (librccl.so) is not available");
+    static_assert(sizeof(ncclUniqueId) == IMGENV_COMM_ID_BYTES, "ncclUniqueId size");
+    const ncclResult_t e = a->get_id((ncclUniqueId*)id128);
+    if (e != ncclSuccess) FAIL(IMGENV_EDEVICE, "ncclGetUniqueId: %s", a->err(e));
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_comm_init(imgenv_t* h, const void* id128, int32_t rank, int32_t n_ranks) {
+    if (!h || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) FAIL(IMGENV_EINVAL, "bad argument");
+    RcclApi* a = rccl_api();
+    if (!a) FAIL(IMGENV_EDEVICE, "RCCL (librccl.so) is not available");
+    if (h->RL * n_ranks != h->R || h->r0 != rank * h->RL)
+        FAIL(IMGENV_EINVAL, "native exchange needs equal contiguous shards: rank %d of %d owns [%d,%d) of %d robots", rank,
+             n_ranks, h->r0, h->r1, h->R);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    const ncclResult_t e = a->init_rank(&h->comm, n_ranks, id, rank);
+    if (e != ncclSuccess) {
+        h->comm = nullptr;
+        FAIL(IMGENV_EDEVICE, "ncclCommInitRank: %s", a->err(e));
+    }
+    h->comm_ranks = n_ranks;
+    return IMGENV_OK;
 }
 
 extern "C" int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_robot) {

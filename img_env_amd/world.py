@@ -105,6 +105,25 @@ class World:
         self._check(self.lib.imgenv_step_end(self.h, self._stream()), "imgenv_step_end")
         return self.out
 
+    def init_comm(self, rank=None, n_ranks=None):
+        """Give the library its own RCCL communicator so that ``step()`` runs the all-gather of a
+        robot-sharded world itself.  The 128-byte id is created on rank 0 and broadcast through the
+        already-initialised ``torch.distributed`` group (plumbing only)."""
+        import torch
+        import torch.distributed as dist
+        rank = dist.get_rank() if rank is None else rank
+        n_ranks = dist.get_world_size() if n_ranks is None else n_ranks
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            self._check(self.lib.imgenv_comm_unique_id(buf), "imgenv_comm_unique_id")
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=self.device)
+        if n_ranks > 1:
+            dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        buf2 = (C.c_ubyte * 128).from_buffer_copy(raw)
+        self._check(self.lib.imgenv_comm_init(self.h, buf2, rank, n_ranks), "imgenv_comm_init")
+        self.native_comm = True
+
     def launches(self):
         return self.lib.imgenv_step_launches(self.h)
 

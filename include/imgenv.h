@@ -231,6 +231,16 @@ int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_robot);
 /* reset counterpart of the exchange (robots' initial records are known to every rank from the
  * batch, so reset needs no collective). */
 
+/* Optional: let the library run the exchange itself.  After imgenv_comm_init() on every rank,
+ * imgenv_step() = step_begin; ncclAllGather (RCCL, in place, on the caller's stream); step_end -- no host
+ * synchronisation and no framework collective per step.  Needs equal contiguous shards
+ * (robot_begin == rank * n_local).  The 128-byte id comes from imgenv_comm_unique_id() on rank 0 and must be
+ * broadcast to the other ranks by the caller (any side channel, e.g. torch.distributed).  RCCL is loaded at
+ * run time (dlopen); IMGENV_EDEVICE if it is unavailable. */
+#define IMGENV_COMM_ID_BYTES 128
+int imgenv_comm_unique_id(void* id128);
+int imgenv_comm_init(imgenv_t* h, const void* id128, int32_t rank, int32_t n_ranks);
+
 int imgenv_outputs(imgenv_t* h, imgenv_out* out);
 
 /* number of kernels launched by the last step (bench / profiling aid) */
