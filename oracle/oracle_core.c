@@ -485,6 +485,7 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
             for (int i = 0; i < w->R; i++) /* rvoscene.h:60-66 */
                 rvo_add_agent(w->rvo, 0.f, 0.f, 0.5f, 10, 5.f, 5.f, 0.5f, 0.6f);
     } else if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM) {
+        sfm_reseed(); /* one handle = one fresh node process */
         w->sfm = sfm_create(P, cfg->relation_ped_robo == 1 ? w->R : 0, w->pmax_speed);
     }
 

@@ -23,6 +23,11 @@ void sfm_set_waypoints(sfm_scene* s, int j, double gx, double gy, const double* 
 void sfm_set_robot_pos(sfm_scene* s, int i, double x, double y);
 void sfm_move_agents(sfm_scene* s, double h);
 void sfm_get_ped(const sfm_scene* s, int j, double* x, double* y, double* vx, double* vy);
+/* agent idx (peds, then robots): p.x p.y p.z v.x v.y v.z */
+void sfm_get_agent(const sfm_scene* s, int idx, double* out6);
+double sfm_get_vmax(const sfm_scene* s, int idx);
+/* restart the two process-global random streams (minstd_rand0 for vmax, glibc rand() for the tree positions) */
+void sfm_reseed(void);
 
 #ifdef __cplusplus
 }

@@ -24,10 +24,12 @@ extern "C" {
 void* pedref_create(int n_peds, int n_robots, int robots_in_scene, const float* ped_max_speed) {
     PedRef* r = new PedRef();
     r->scene = new Ped::Tscene(0, 10, 10, 10); /* pedscene.h:18 */
-    for (int i = 0; i < n_peds; i++) {        /* addPed pedscene.h:57-69 (the rand() start position is
-                                                 overwritten by setPedPos before any step) */
+    for (int i = 0; i < n_peds; i++) {        /* addPed pedscene.h:57-69: rand() start positions (they decide the
+                                                 quadtree leaves; setPedPos overwrites them before any step) */
         Ped::Tagent* a = new Ped::Tagent();
-        a->setPosition(0, 0, 0);
+        double pxx = rand() / 2147483647.0 * 10.0;
+        double pyy = rand() / 2147483647.0 * 10.0;
+        a->setPosition(pxx, pyy, 0);
         a->setVmax((double)ped_max_speed[i]);
         r->scene->addAgent(a);
         r->peds.push_back(a);

@@ -1,0 +1,49 @@
+"""Oracle libpedsim (social force) restatement vs (a) the reference's own pedsimros sources compiled
+unmodified into oracle/_ref/libpedsim_ref.so and (b) a committed trace generated from that library.
+
+The restatement sums forces in agent order while the reference iterates a std::set ordered by heap
+address, so agreement is to summation-order rounding (1e-12), not bit-for-bit; the random vmax stream
+(libstdc++ minstd_rand0 + normal_distribution) and the quadtree bookkeeping must match exactly."""
+import os
+
+import numpy as np
+import pytest
+
+from sfm_harness import OracleSfm, RefSfm, run_scenario
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "sfm_ref_traces.npz")
+CASES = {
+    "peds_robots_obstacles": dict(),
+    "crowd_no_obstacles": dict(n_peds=20, n_robots=6, n_obs=0),
+    "obstacles_only": dict(n_peds=5, n_robots=0, n_obs=6, steps=150),
+    "map_16m_tree_band": dict(n_peds=12, n_robots=4, n_obs=2, world=16.0),
+}
+
+
+def _fresh_oracle():
+    import ctypes as C
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "liboracle.so"))
+    lib.sfm_reseed()
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_oracle_matches_committed_reference_trace(oracle_lib, case):
+    """the committed traces were generated in a fresh process, one scenario each (gen_sfm_golden.py)"""
+    z = np.load(GOLD)
+    _fresh_oracle()
+    trace, vmax = run_scenario(OracleSfm, 0, **CASES[case])
+    assert np.abs(trace - z[case]).max() < 1e-12
+    assert np.array_equal(vmax, z[case + "_vmax"])
+    assert np.abs(trace[-1, :, :2] - trace[0, :, :2]).max() > 0.5
+
+
+@pytest.mark.skipif(not os.path.exists(RefSfm.path()), reason="oracle/_ref not built (no reference tree)")
+def test_oracle_matches_reference_build(oracle_lib):
+    """same process, same creation order on both sides: the two global random streams advance in lock step"""
+    _fresh_oracle()
+    for seed in (1, 2, 3):
+        for case, kw in CASES.items():
+            got, vo = run_scenario(OracleSfm, seed, **kw)
+            ref, vr = run_scenario(RefSfm, seed, **kw)
+            assert np.abs(got - ref).max() < 1e-12, (seed, case)
+            assert np.array_equal(vo, vr), (seed, case)
