@@ -420,3 +420,60 @@ struct RvoObstacles {
         root = build(all);
     }
 };
+
+
+// ---------------------------------------------------------------------------------------------
+// libpedsim / PedScene construction on the host (pedscene.h:57-80, ped_agent.cpp:24-58): the per-agent
+// random vmax and the peds' rand() start positions that seed the quadtree.  Both generators are
+// third-party (libstdc++ <random>, glibc rand()), restated from their published algorithms; one handle is one
+// fresh node process, so both start from their default seeds.
+struct PedsimRng {
+    unsigned long lcg = 1u;  // std::default_random_engine = minstd_rand0, default seed 1
+    int32_t r[34 + 310 + 4096];
+    int rk = -1;
+    double lcg_next() {
+        lcg = (lcg * 16807ul) % 2147483647ul;
+        return (double)lcg;
+    }
+    double canonical() {  // std::generate_canonical<double, 53>: 2 draws of range 2147483646
+        const double R = 2147483646.0;
+        double sum = 0.0, tmp = 1.0;
+        for (int k = 0; k < 2; k++) {
+            sum += (lcg_next() - 1.0) * tmp;
+            tmp *= R;
+        }
+        double ret = sum / tmp;
+        if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+        return ret;
+    }
+    double normal_fresh(double mean, double stddev) {  // a new normal_distribution per Tagent: polar method, first value
+        double x, y, r2;
+        do {
+            x = 2.0 * canonical() - 1.0;
+            y = 2.0 * canonical() - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = sqrt(-2 * log(r2) / r2);
+        return (y * mult) * stddev + mean;
+    }
+    int glibc_rand() {  // TYPE_3 additive feedback generator, seed 1 (glibc stdlib/random_r.c)
+        if (rk < 0) {
+            r[0] = 1;
+            for (int i = 1; i < 31; i++) {
+                long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+                long word = 16807 * lo - 2836 * hi;
+                if (word < 0) word += 2147483647;
+                r[i] = (int32_t)word;
+            }
+            for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+            for (int i = 34; i < 344; i++) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+            rk = 344;
+        }
+        if (rk >= (int)(sizeof(r) / sizeof(r[0]))) {
+            memmove(r, r + rk - 34, sizeof(int32_t) * 34);
+            rk = 34;
+        }
+        r[rk] = (int32_t)((uint32_t)r[rk - 31] + (uint32_t)r[rk - 3]);
+        return (int)(((uint32_t)r[rk++]) >> 1);
+    }
+};

@@ -64,6 +64,7 @@ struct imgenv {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool orca_pending = false;
     RvoObstacles rvo;
+    int sfm_cap_obs = 0;
     // live timing (imgenv_timing)
     int t_mode = 0, t_which = -1;
     std::vector<hipEvent_t> t_ev;
@@ -296,8 +297,13 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         FAIL(IMGENV_EINVAL, "global_resolution != view_resolution: load-time cv::resize not supported");
     if (cfg->state_dim < 3 || cfg->state_dim > 5) FAIL(IMGENV_EINVAL, "state_dim must be 3, 4 or 5");
     if (cfg->ped_vec_dim != 7) FAIL(IMGENV_EINVAL, "ped_vec_dim must be 7");
-    if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM && cfg->n_peds > 0)
-        FAIL(IMGENV_EINVAL, "pedscene (social force) is not implemented in the HIP path yet");
+    if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM) {
+        const int n_sfm = cfg->n_peds + (cfg->relation_ped_robo == 1 ? cfg->n_robots : 0);
+        if (cfg->relation_ped_robo == 1 && cfg->n_robots > 8)
+            FAIL(IMGENV_EINVAL, "pedscene with relation_ped_robo=1 and more than 8 robots: the reference node recurses forever in "
+                                "Ttree::addAgent (all robot Tagents start at (0,0,0), ped_tree.cpp:65-96)");
+        if (n_sfm > SFM_MAX_AGENTS) FAIL(IMGENV_EINVAL, "pedscene crowds larger than %d agents are not supported", SFM_MAX_AGENTS);
+    }
     int r0, r1;
     if (shard_of(*cfg, r0, r1)) FAIL(IMGENV_EINVAL, "bad robot shard [%d,%d)", cfg->robot_begin, cfg->robot_end);
     const ViewGeom g = make_view_geom(*cfg);
@@ -507,6 +513,44 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_upload(h, &d.amax_speed, ms));
     }
     TRY(dev_alloc(h, &d.err, 4));
+    if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene(): Tscene(0,10,10,10), addPed, addRobot (pedscene.h:17-80)
+        SfmDev& f = d.sfm;
+        const int n = P + (cfg->relation_ped_robo == 1 ? R : 0);
+        f.n = n; f.n_peds = P; f.n_obs = 0; f.cap_nodes = 16384;
+        PedsimRng rng;
+        std::vector<double> p0((size_t)(n ? n : 1) * 3, 0.0), vmax(n ? n : 1, 0.0);
+        std::vector<SfmNode> nodes(f.cap_nodes);
+        std::vector<int> treehash(n ? n : 1, 0);
+        int n_nodes = 0, err = 0;
+        sfm_q_new(nodes.data(), &n_nodes, f.cap_nodes, 0, 10, 10, 10);
+        // every Tagent() draws its vmax (peds then robots, also robots that stay outside the scene)
+        for (int a = 0; a < n; a++) {
+            vmax[a] = rng.normal_fresh(1.2, 0.2);
+            if (a < P) {
+                p0[3 * a] = rng.glibc_rand() / 2147483647.0 * 10.0;
+                p0[3 * a + 1] = rng.glibc_rand() / 2147483647.0 * 10.0;
+                vmax[a] = (double)h->pmax[a];
+            }
+            sfm_add_agent(nodes.data(), &n_nodes, f.cap_nodes, treehash.data(), p0.data(), a, &err);
+        }
+        if (err) {
+            imgenv_destroy(h);
+            FAIL(IMGENV_EINVAL, "pedscene quadtree construction overflowed (%d)", err);
+        }
+        TRY(dev_alloc(h, &f.p, (size_t)(n ? n : 1) * 3));
+        TRY(dev_alloc(h, &f.v, (size_t)(n ? n : 1) * 3));
+        TRY(dev_alloc(h, &f.vmax, n)); TRY(dev_alloc(h, &f.wpx, (size_t)(n ? n : 1) * SFM_MAX_WP));
+        TRY(dev_alloc(h, &f.wpy, (size_t)(n ? n : 1) * SFM_MAX_WP)); TRY(dev_alloc(h, &f.wpr, (size_t)(n ? n : 1) * SFM_MAX_WP));
+        TRY(dev_alloc(h, &f.dq, (size_t)(n ? n : 1) * SFM_MAX_WP)); TRY(dev_alloc(h, &f.dq_n, n));
+        TRY(dev_alloc(h, &f.dest, n, 0xFF)); TRY(dev_alloc(h, &f.last, n, 0xFF));  // -1
+        TRY(dev_alloc(h, &f.nodes, f.cap_nodes)); TRY(dev_alloc(h, &f.n_nodes, 1)); TRY(dev_alloc(h, &f.treehash, n));
+        TRY(dev_alloc(h, &f.err, 1));
+        HIPCHK(hipMemcpy(f.p, p0.data(), sizeof(double) * 3 * (n ? n : 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(f.vmax, vmax.data(), sizeof(double) * (n ? n : 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(f.nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(f.n_nodes, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
+    }
     TRY(dev_alloc(h, &d.prof, 16));
 
     // output arena
@@ -628,6 +672,11 @@ __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
         w.apx[j] = (float)pose3[3 * j];
         w.apy[j] = (float)pose3[3 * j + 1];
     }
+    if (w.scene == IMGENV_SCENE_PEDSIM) {  // setPosition(x, y, 0) (pedscene.h:34-36); velocity persists
+        w.sfm.p[3 * j] = pose3[3 * j];
+        w.sfm.p[3 * j + 1] = pose3[3 * j + 1];
+        w.sfm.p[3 * j + 2] = 0.0;
+    }
     w.ped_state[4 * j] = pose3[3 * j];
     w.ped_state[4 * j + 1] = pose3[3 * j + 1];
     w.ped_state[4 * j + 2] = w.pvx[j];
@@ -675,6 +724,7 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     const double res = h->geom.res;
     // obstacles -> obs_map_ and the pedestrian simulator (img_env.cpp:166-193)
     std::vector<uint8_t> obs(h->static_map);
+    std::vector<double> sfm_obs;
     h->rvo.clear();
     for (int q = 0; q < b->n_obstacles; q++) {
         double sizes[4];
@@ -685,6 +735,9 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         draw_obstacle(obs.data(), h->Hg, h->Wg, res, bw, bb);
         double pax, pay, pbx, pby;
         get_corners(b->obs_shape[q], sizes, bw, pax, pay, pbx, pby);
+        if (!b->ignore_obstacle && h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::addObs: the segment pa -> pb (pedscene.h:22-26)
+            sfm_obs.push_back(pax); sfm_obs.push_back(pay); sfm_obs.push_back(pbx); sfm_obs.push_back(pby);
+        }
         if (!b->ignore_obstacle && h->NA > 0) {  // RVOScene::addObs (rvoscene.h:19-26)
             const float v[8] = {(float)pax, (float)pay, (float)pax, (float)pby, (float)pbx, (float)pby, (float)pbx, (float)pay};
             h->rvo.add(v, 4);
@@ -710,6 +763,15 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     d.n_obst = (int)h->rvo.ob.size();
     d.n_onodes = (int)h->rvo.nodes.size();
     d.oroot = h->rvo.root;
+    if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {
+        const int nob = (int)sfm_obs.size() / 4;
+        if (nob > h->sfm_cap_obs) {
+            h->sfm_cap_obs = nob * 2;
+            if (int rc = dev_alloc(h, &d.sfm.obs, (size_t)h->sfm_cap_obs * 4)) return rc;
+        }
+        if (nob) HIPCHK(hipMemcpyAsync(d.sfm.obs, sfm_obs.data(), sizeof(double) * sfm_obs.size(), hipMemcpyHostToDevice, st));
+        d.sfm.n_obs = nob;
+    }
     // pedestrians (img_env.cpp:220-250)
     std::vector<double> ped3((size_t)(P > 0 ? P : 1) * 3);
     std::vector<int> tlen(P > 0 ? P : 1);
@@ -731,6 +793,35 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         }
         HIPCHK(hipMemcpyAsync(h->d_traj, traj.data(), traj.size() * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(h->d_traj_len, tlen.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
+        if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::setWayPoint (pedscene.h:38-46): [goal r=1, trajectory r=z]
+            std::vector<double> wx((size_t)P * SFM_MAX_WP, 0.0), wy(wx), wr(wx);
+            std::vector<int> dq((size_t)P * SFM_MAX_WP, 0), dqn(P, 0), dest(P, 0), last(P, -1);
+            for (int j = 0; j < P; j++) {
+                int nw = 0;
+                wx[(size_t)j * SFM_MAX_WP] = b->ped_goal[2 * j];
+                wy[(size_t)j * SFM_MAX_WP] = b->ped_goal[2 * j + 1];
+                wr[(size_t)j * SFM_MAX_WP] = 1.0;
+                nw = 1;
+                for (int q = 0; q < tlen[j] && nw < SFM_MAX_WP; q++, nw++) {
+                    const double* tp = b->ped_traj + ((size_t)j * b->ped_traj_cap + q) * 3;
+                    wx[(size_t)j * SFM_MAX_WP + nw] = tp[0];
+                    wy[(size_t)j * SFM_MAX_WP + nw] = tp[1];
+                    wr[(size_t)j * SFM_MAX_WP + nw] = tp[2];
+                }
+                for (int q = 0; q < nw; q++) dq[(size_t)j * SFM_MAX_WP + q] = q;
+                dqn[j] = nw;
+                dest[j] = 0;  // addWaypoint leaves destination = waypoints.front() without popping it (ped_agent.cpp:97-100)
+            }
+            const SfmDev& f = d.sfm;
+            HIPCHK(hipMemcpyAsync(f.wpx, wx.data(), wx.size() * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(f.wpy, wy.data(), wy.size() * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(f.wpr, wr.data(), wr.size() * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(f.dq, dq.data(), dq.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(f.dq_n, dqn.data(), dqn.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(f.dest, dest.data(), dest.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(f.last, last.data(), last.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));  // the staging vectors above die with this block
+        }
         d.ptraj = h->d_traj;
         d.traj_cap = h->traj_cap;
     }
@@ -786,6 +877,10 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
             h->orca_pending = false;
         }
         TIMED(h, IMGENV_K_PED_UPDATE, st, (k_ped_update<<<dim3((h->P + 63) / 64), dim3(64), 0, st>>>(d)));
+        h->launches += 1;
+    }
+    if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
+        TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), 0, st>>>(d)));
         h->launches += 1;
     }
     // _step_robot (img_env.cpp:388-410)

@@ -101,6 +101,37 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
     }
 }
 
+// PedAgent::update_bbox (agent.cpp:696-735); step_len_ = 0.3 (2-arg constructor, agent.cpp:659-664)
+__device__ void ped_leg_gait(const DevWorld& w, int j, double x, double y, double ox, double oy) {
+    const PedClassDev k = w.pc[w.ped_cls[j]];
+    if (k.shape != IMGENV_SHAPE_LEG) return;
+    const double step_len = 0.3;
+    const double move = sqrt((x - ox) * (x - ox) + (y - oy) * (y - oy));
+    const int last = w.pstate[j];
+    int st = (int)((move + w.prem[j]) / step_len + last);
+    w.prem[j] = move + w.prem[j] - (st - last) * step_len;
+    st %= 7;
+    w.pstate[j] = st;
+    if (st == 0 || st == 4) {
+        w.llx[j] = k.sizes[0];
+        w.lly[j] = k.sizes[1];
+        w.rlx[j] = k.sizes[3];
+        w.rly[j] = k.sizes[4];
+    } else if (st == 1 || st == 3) {
+        w.llx[j] = -step_len / 2;
+        w.rlx[j] = step_len / 2;
+    } else if (st == 2) {
+        w.llx[j] = -step_len;
+        w.rlx[j] = step_len;
+    } else if (st == 5) {
+        w.llx[j] = step_len / 2;
+        w.rlx[j] = -step_len / 2;
+    } else if (st == 6) {
+        w.llx[j] = step_len;
+        w.rlx[j] = -step_len;
+    }
+}
+
 // Agent::update (Agent.cpp:840-843), getNewPosAndVel (rvoscene.h:72-82), set_position + update_bbox
 // (agent.cpp:691-735)
 __global__ void k_ped_update(DevWorld w) {
@@ -126,34 +157,31 @@ __global__ void k_ped_update(DevWorld w) {
     w.ped_state[4 * j + 1] = y;
     w.ped_state[4 * j + 2] = (double)vx;
     w.ped_state[4 * j + 3] = (double)vy;
-    const PedClassDev k = w.pc[w.ped_cls[j]];
-    if (k.shape == IMGENV_SHAPE_LEG) {
-        const double step_len = 0.3;
-        const double move = sqrt((x - ox) * (x - ox) + (y - oy) * (y - oy));
-        const int last = w.pstate[j];
-        int st = (int)((move + w.prem[j]) / step_len + last);
-        w.prem[j] = move + w.prem[j] - (st - last) * step_len;
-        st %= 7;
-        w.pstate[j] = st;
-        if (st == 0 || st == 4) {
-            w.llx[j] = k.sizes[0];
-            w.lly[j] = k.sizes[1];
-            w.rlx[j] = k.sizes[3];
-            w.rly[j] = k.sizes[4];
-        } else if (st == 1 || st == 3) {
-            w.llx[j] = -step_len / 2;
-            w.rlx[j] = step_len / 2;
-        } else if (st == 2) {
-            w.llx[j] = -step_len;
-            w.rlx[j] = step_len;
-        } else if (st == 5) {
-            w.llx[j] = step_len / 2;
-            w.rlx[j] = -step_len / 2;
-        } else if (st == 6) {
-            w.llx[j] = step_len;
-            w.rlx[j] = -step_len;
-        }
-    }
+    ped_leg_gait(w, j, x, y, ox, oy);
+}
+
+// PedScene::step (pedscene.h:48-50) = Tscene::moveAgents(step_hz) for the whole social-force crowd, then the
+// write-back of img_env.cpp:344-358 (getNewPosAndVel pedscene.h:82-91, set_position, update_bbox)
+__global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w) {
+    __shared__ uint32_t nb_bits[SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32)];
+    sfm_step(w.sfm, w.step_hz, nb_bits);
+    const int j = threadIdx.x;
+    if (j >= w.P) return;
+    const double ox = w.ppx[j], oy = w.ppy[j];
+    const double x = w.sfm.p[3 * j], y = w.sfm.p[3 * j + 1];
+    const double vx = w.sfm.v[3 * j], vy = w.sfm.v[3 * j + 1];
+    w.plx[j] = ox;
+    w.ply[j] = oy;
+    w.ppx[j] = x;
+    w.ppy[j] = y;
+    w.pyaw[j] = 0.0;  // uninitialised local `yaw` in the reference (img_env.cpp:346-349)
+    w.pvx[j] = vx;
+    w.pvy[j] = vy;
+    w.ped_state[4 * j] = x;
+    w.ped_state[4 * j + 1] = y;
+    w.ped_state[4 * j + 2] = vx;
+    w.ped_state[4 * j + 3] = vy;
+    ped_leg_gait(w, j, x, y, ox, oy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,6 +407,12 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
         w.apy[a] = (float)r[1];
         w.avx[a] = zero_vel ? 0.0f : (float)r[3];
         w.avy[a] = zero_vel ? 0.0f : (float)r[4];
+    }
+    if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
+        double* p = w.sfm.p + 3 * (size_t)(w.P + i);
+        p[0] = r[0];
+        p[1] = r[1];
+        p[2] = 1.0;
     }
 }
 

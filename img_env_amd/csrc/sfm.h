@@ -1,0 +1,359 @@
+// sfm.h -- libpedsim social-force pedestrians (PedScene, src/img_env/src/pedscene.h:17-91) for the HIP path.
+//
+// Reference: src/3rdparty/pedsimros  Tagent::desiredForce / socialForce / obstacleForce / lookaheadForce /
+// computeForces / move (src/ped_agent.cpp:236-571), Twaypoint::getForce (src/ped_waypoint.cpp:81-134),
+// Tobstacle::closestPoint (src/ped_obstacle.cpp:90-113), Tvector (src/ped_vector.cpp, 3-D: z matters because
+// robots sit at z = 1, pedscene.h:54), Tscene::moveAgents / getNeighbors (src/ped_scene.cpp:167-252) and the
+// quadtree Ttree (src/ped_tree.cpp).
+//
+// The quadtree is part of the behaviour, not an accelerator: PedScene builds it over x in [0,10], y in [10,20]
+// (pedscene.h:18), Ttree::moveAgent re-inserts an agent that left its leaf from the root and THEN erases it
+// from the old leaf (ped_tree.cpp:131-137) -- which removes it altogether when both are the same leaf -- and
+// the force loops only see agents that are still in the tree.  So the tree, its treehash and its split rule
+// are carried in HBM and updated exactly as the reference does (sequentially, in agent order).
+//
+// The reference can only run small crowds here (more than 8 agents at one position -- e.g. 9 robots, which all
+// start at (0,0,0) -- recurse forever in Ttree::addAgent), so one 256-thread workgroup handles the whole
+// crowd: thread i owns agent i.  float64 throughout, -ffp-contract=off; force sums run in agent order
+// (the reference iterates a std::set ordered by heap address = allocation order).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "cr_atan2.h"
+
+#if defined(__HIPCC__)
+#define SFM_HD __host__ __device__
+#else
+#define SFM_HD
+#endif
+
+#define SFM_MAX_AGENTS 256
+#define SFM_MAX_WP 8
+#define SFM_LEAF_CAP 12
+#define SFM_MAX_DEPTH 64
+
+struct SfmNode {  // Ped::Ttree
+    double x, y, w, h;
+    int isleaf, n_agents;
+    int child[4];
+    int agents[SFM_LEAF_CAP];  // std::set<const Tagent*>, kept sorted by agent index
+};
+
+struct SfmDev {
+    int n, n_peds, n_obs, cap_nodes;
+    double* p;     // [n][3]
+    double* v;     // [n][3]
+    double* vmax;  // [n]
+    double *wpx, *wpy, *wpr;  // [n][SFM_MAX_WP]
+    int *dq, *dq_n, *dest, *last;  // waypoint deque (indices), its length, destination, lastdestination
+    double* obs;  // [n_obs][4] ax ay bx by
+    SfmNode* nodes;
+    int* n_nodes;   // [1]
+    int* treehash;  // [n]
+    int* err;       // [1] overflow flag (node pool / leaf capacity / depth)
+};
+
+// ---- Ttree (ped_tree.cpp:18-137) on flat arrays, shared by the host (initial tree) and the device ----
+SFM_HD inline int sfm_q_new(SfmNode* nodes, int* n_nodes, int cap, double x, double y, double w, double h) {
+    if (*n_nodes >= cap) return -1;
+    SfmNode& q = nodes[*n_nodes];
+    q.x = x; q.y = y; q.w = w; q.h = h;
+    q.isleaf = 1;
+    q.n_agents = 0;
+    q.child[0] = q.child[1] = q.child[2] = q.child[3] = -1;
+    return (*n_nodes)++;
+}
+SFM_HD inline void sfm_set_insert(SfmNode& q, int a, int* err) {
+    int lo = 0;
+    while (lo < q.n_agents && q.agents[lo] < a) lo++;
+    if (lo < q.n_agents && q.agents[lo] == a) return;
+    if (q.n_agents >= SFM_LEAF_CAP) {
+        *err = 1;
+        return;
+    }
+    for (int k = q.n_agents; k > lo; k--) q.agents[k] = q.agents[k - 1];
+    q.agents[lo] = a;
+    q.n_agents++;
+}
+SFM_HD inline void sfm_set_erase(SfmNode& q, int a) {
+    for (int k = 0; k < q.n_agents; k++)
+        if (q.agents[k] == a) {
+            for (int j = k; j + 1 < q.n_agents; j++) q.agents[j] = q.agents[j + 1];
+            q.n_agents--;
+            return;
+        }
+}
+
+// Ttree::addAgent (ped_tree.cpp:65-96), recursion unrolled onto an explicit stack.  Work items are
+// (node, agent); an item whose node is a leaf inserts and may split the leaf, pushing the former members.
+SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err) {
+    int st_node[SFM_MAX_DEPTH * 8], st_agent[SFM_MAX_DEPTH * 8];
+    int sp = 0;
+    st_node[sp] = 0;
+    st_agent[sp++] = agent;
+    while (sp > 0) {
+        --sp;
+        const int node = st_node[sp], a = st_agent[sp];
+        SfmNode& q = nodes[node];
+        if (q.isleaf) {
+            sfm_set_insert(q, a, err);
+            treehash[a] = node;
+            if (q.n_agents > 8) {  // split: addChildren + redistribute in set order
+                const int c0 = sfm_q_new(nodes, n_nodes, cap, q.x, q.y, q.w / 2, q.h / 2);
+                const int c1 = sfm_q_new(nodes, n_nodes, cap, q.x + q.w / 2, q.y, q.w / 2, q.h / 2);
+                const int c2 = sfm_q_new(nodes, n_nodes, cap, q.x + q.w / 2, q.y + q.h / 2, q.w / 2, q.h / 2);
+                const int c3 = sfm_q_new(nodes, n_nodes, cap, q.x, q.y + q.h / 2, q.w / 2, q.h / 2);
+                if (c3 < 0) {
+                    *err = 2;
+                    return;
+                }
+                q.isleaf = 0;
+                q.child[0] = c0; q.child[1] = c1; q.child[2] = c2; q.child[3] = c3;
+                // the reference re-adds members in ascending set order, depth first; pushing them in
+                // descending order onto the LIFO stack reproduces that order
+                for (int k = q.n_agents - 1; k >= 0; k--) {
+                    if (sp >= SFM_MAX_DEPTH * 8) {
+                        *err = 3;
+                        return;
+                    }
+                    st_node[sp] = node;
+                    st_agent[sp++] = q.agents[k];
+                }
+                q.n_agents = 0;
+            }
+        } else {
+            const double px = p[3 * a], py = p[3 * a + 1];
+            const double cx = q.x + q.w / 2, cy = q.y + q.h / 2;
+            // order of the four non-exclusive tests: tree3, tree1, tree2, tree4 (LIFO: push reversed)
+            int tgt[4], nt = 0;
+            if ((px >= cx) && (py >= cy)) tgt[nt++] = q.child[2];
+            if ((px <= cx) && (py <= cy)) tgt[nt++] = q.child[0];
+            if ((px >= cx) && (py <= cy)) tgt[nt++] = q.child[1];
+            if ((px <= cx) && (py >= cy)) tgt[nt++] = q.child[3];
+            for (int k = nt - 1; k >= 0; k--) {
+                if (sp >= SFM_MAX_DEPTH * 8) {
+                    *err = 3;
+                    return;
+                }
+                st_node[sp] = tgt[k];
+                st_agent[sp++] = a;
+            }
+        }
+    }
+}
+
+// Tscene::moveAgent -> Ttree::moveAgent (ped_tree.cpp:131-137)
+SFM_HD inline void sfm_move_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int a, int* err) {
+    const int leaf = treehash[a];
+    const SfmNode& q = nodes[leaf];
+    const double px = p[3 * a], py = p[3 * a + 1];
+    if ((px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h))) {
+        sfm_add_agent(nodes, n_nodes, cap, treehash, p, a, err);  // scene->placeAgent(a): from the root
+        sfm_set_erase(nodes[leaf], a);                            // erased from the OLD leaf, even if it is the new one
+    }
+}
+
+#if defined(__HIPCC__)
+struct d3 {
+    double x, y, z;
+};
+__device__ __forceinline__ d3 D3(double x, double y, double z) {
+    d3 r;
+    r.x = x; r.y = y; r.z = z;
+    return r;
+}
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return D3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return D3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 scaled(d3 a, double f) { return D3(f * a.x, f * a.y, f * a.z); }  // Tvector::scaled
+__device__ __forceinline__ double len2(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ double len3(d3 a) {
+    if ((a.x == 0) && (a.y == 0) && (a.z == 0)) return 0;
+    return sqrt(len2(a));
+}
+__device__ __forceinline__ d3 normalized(d3 a) {
+    const double l = len3(a);
+    if (l == 0) return D3(0, 0, 0);
+    return D3(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return (a.x * b.x + a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ d3 ld3(const double* a, int i) { return D3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+
+__device__ double sfm_angle_to(d3 a, d3 b) {  // Tvector::angleTo
+    const double kPi = 3.14159265358979323846;
+    // cr_atan2: see cr_atan2.h -- the sign of this difference between two nearly parallel vectors switches a
+    // full-magnitude force term, so it must round like the reference's (glibc) atan2
+    double diff = cr_atan2(b.y, b.x) - cr_atan2(a.y, a.x);
+    if (diff > kPi)
+        diff -= 2 * kPi;
+    else if (diff <= -kPi)
+        diff += 2 * kPi;
+    return diff;
+}
+
+// one Tscene::moveAgents(h) for the whole crowd: thread i = agent i, one workgroup
+__device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SFM_MAX_AGENTS][SFM_MAX_AGENTS/32] */) {
+    const int i = threadIdx.x;
+    const int n = s.n;
+    d3 desiredforce = D3(0, 0, 0), socialforce = D3(0, 0, 0), obstacleforce = D3(0, 0, 0), lookaheadforce = D3(0, 0, 0);
+    d3 me_p = D3(0, 0, 0), me_v = D3(0, 0, 0);
+    uint32_t* mine = nb_bits + (size_t)i * (SFM_MAX_AGENTS / 32);
+    if (i < n) {
+        me_p = ld3(s.p, i);
+        me_v = ld3(s.v, i);
+        // Tscene::getNeighbors(p.x, p.y, 20) (ped_scene.cpp:217-252): agents of the leaves the square touches
+        for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) mine[k] = 0;
+        int stack[SFM_MAX_DEPTH * 3 + 4], sp = 0;
+        stack[sp++] = 0;
+        while (sp > 0) {
+            const SfmNode& t = s.nodes[stack[--sp]];
+            if (t.isleaf) {
+                for (int k = 0; k < t.n_agents; k++) mine[t.agents[k] >> 5] |= 1u << (t.agents[k] & 31);
+            } else {
+                for (int c = 0; c < 4; c++) {
+                    const SfmNode& ch = s.nodes[t.child[c]];
+                    if (((me_p.x + 20.0) > ch.x) && ((me_p.x - 20.0) < (ch.x + ch.w)) && ((me_p.y + 20.0) > ch.y) &&
+                        ((me_p.y - 20.0) < (ch.y + ch.h))) {
+                        if (sp < SFM_MAX_DEPTH * 3 + 4) stack[sp++] = t.child[c];
+                        else *s.err = 4;
+                    }
+                }
+            }
+        }
+        // Tagent::desiredForce (ped_agent.cpp:236-306)
+        int dest = s.dest[i], last = s.last[i];
+        const int dqn = s.dq_n[i];
+        int* dq = s.dq + (size_t)i * SFM_MAX_WP;
+        if ((dest == -1) && (dqn > 0)) {
+            dest = dq[0];
+            for (int k = 0; k + 1 < dqn; k++) dq[k] = dq[k + 1];
+            dq[dqn - 1] = dest;
+        }
+        d3 desired_direction = D3(0, 0, 0);
+        bool reached = false;
+        if (dest != -1) {
+            const d3 diff = D3(s.wpx[(size_t)i * SFM_MAX_WP + dest] - me_p.x, s.wpy[(size_t)i * SFM_MAX_WP + dest] - me_p.y, 0);
+            reached = len3(diff) < s.wpr[(size_t)i * SFM_MAX_WP + dest];
+            desired_direction = normalized(diff);
+        }
+        if ((dest != -1) && reached) {
+            last = dest;
+            dest = -1;
+        }
+        s.dest[i] = dest;
+        s.last[i] = last;
+        desiredforce = scaled(normalized(desired_direction), s.vmax[i]);
+        // Tagent::lookaheadForce (ped_agent.cpp:439-480)
+        {
+            const double pi = 3.14159265;
+            int count = 0;
+            const d3 e = desired_direction;
+            for (int o = 0; o < n; o++) {
+                if (o == i || !((mine[o >> 5] >> (o & 31)) & 1u)) continue;
+                const double dx = s.p[3 * o] - me_p.x, dy = s.p[3 * o + 1] - me_p.y;
+                const double dist2 = (dx * dx + dy * dy);
+                if (dist2 < 400) {
+                    const double at2v = cr_atan2(-e.x, -e.y);
+                    const double at2d = cr_atan2(-dx, -dy);
+                    const double at2v2 = cr_atan2(-s.v[3 * o], -s.v[3 * o + 1]);
+                    double sd = at2d - at2v;
+                    if (sd > pi) sd -= 2 * pi;
+                    if (sd < -pi) sd += 2 * pi;
+                    double vv = at2v - at2v2;
+                    if (vv > pi) vv -= 2 * pi;
+                    if (vv < -pi) vv += 2 * pi;
+                    if (fabs(vv) > 2.5) {
+                        if ((sd < 0) && (sd > -0.3)) count--;
+                        if ((sd > 0) && (sd < 0.3)) count++;
+                    }
+                }
+            }
+            if (count < 0) {
+                lookaheadforce.x = 0.5f * e.y;
+                lookaheadforce.y = 0.5f * -e.x;
+            }
+            if (count > 0) {
+                lookaheadforce.x = 0.5f * -e.y;
+                lookaheadforce.y = 0.5f * e.x;
+            }
+        }
+        // Tagent::socialForce (ped_agent.cpp:316-404)
+        {
+            const double lambda_importance = 2.0, gamma = 0.35, nn = 2, n_prime = 3;
+            for (int o = 0; o < n; o++) {
+                if (o == i || !((mine[o >> 5] >> (o & 31)) & 1u)) continue;
+                const d3 diff = ld3(s.p, o) - me_p;
+                if (len2(diff) > 64.0) continue;
+                const d3 diff_direction = normalized(diff);
+                const d3 vel_diff = me_v - ld3(s.v, o);
+                const d3 interaction_vector = scaled(vel_diff, lambda_importance) + diff_direction;
+                const double interaction_length = len3(interaction_vector);
+                const d3 interaction_direction = scaled(interaction_vector, 1 / interaction_length);
+                const double theta = sfm_angle_to(interaction_direction, diff_direction);
+                const int theta_sign = (theta == 0) ? (0) : (int)(theta / fabs(theta));
+                const double B = gamma * interaction_length;
+                const double fva = -exp(-len3(diff) / B - (n_prime * B * theta) * (n_prime * B * theta));
+                const double faa = -theta_sign * exp(-len3(diff) / B - (nn * B * theta) * (nn * B * theta));
+                const d3 force_velocity = scaled(interaction_direction, fva);
+                const d3 force_angle = scaled(D3(-interaction_direction.y, interaction_direction.x, 0), faa);
+                socialforce = socialforce + (force_velocity + force_angle);
+            }
+        }
+        // Tagent::obstacleForce (ped_agent.cpp:411-429)
+        {
+            d3 min_diff = D3(0, 0, 0);
+            double min_d2 = __builtin_huge_val();
+            for (int q = 0; q < s.n_obs; q++) {
+                const double* o = s.obs + 4 * q;
+                const d3 start = D3(o[0], o[1], 0), end = D3(o[2], o[3], 0);
+                const d3 rel_end = end - start;
+                const d3 rel_p = me_p - start;
+                const double lambda = dot3(rel_p, rel_end) / len2(rel_end);
+                d3 closest;
+                if (lambda <= 0)
+                    closest = start;
+                else if (lambda >= 1)
+                    closest = end;
+                else
+                    closest = start + scaled(rel_end, lambda);
+                const d3 diff = me_p - closest;
+                const double d2 = len2(diff);
+                if (d2 < min_d2) {
+                    min_d2 = d2;
+                    min_diff = diff;
+                }
+            }
+            const double distance = sqrt(min_d2) - 0.2;
+            const double force_amount = exp(-distance / 0.8);
+            obstacleforce = scaled(normalized(min_diff), force_amount);
+        }
+    }
+    __syncthreads();  // all forces are computed from the t-1 state (ped_scene.cpp:170)
+    if (i < n) {
+        // Tagent::move (ped_agent.cpp:519-571)
+        d3 p_desired = me_p + scaled(me_v, h);
+        for (int q = 0; q < s.n_obs; q++) {
+            const double* o = s.obs + 4 * q;
+            const double s1x = p_desired.x - me_p.x, s1y = p_desired.y - me_p.y;
+            const double s2x = o[2] - o[0], s2y = o[3] - o[1];
+            const double ss = (-s1y * (me_p.x - o[0]) + s1x * (me_p.y - o[1])) / (-s2x * s1y + s1x * s2y);
+            const double tt = (s2x * (me_p.y - o[1]) - s2y * (me_p.x - o[0])) / (-s2x * s1y + s1x * s2y);
+            if (ss >= 0 && ss <= 1 && tt >= 0 && tt <= 1) {
+                const d3 inter = D3(me_p.x + (tt * s1x), me_p.y + (tt * s1y), 0);
+                p_desired = inter - scaled(normalized(scaled(me_v, h)), 0.1);
+            }
+        }
+        const d3 a = (((scaled(desiredforce, 1.0) + scaled(socialforce, 2.1)) + scaled(obstacleforce, 1.0)) +
+                      scaled(lookaheadforce, 1.0)) + D3(0, 0, 0);
+        d3 v = scaled(me_v, 0.5) + scaled(a, h);
+        if (len3(v) > s.vmax[i]) v = scaled(normalized(v), s.vmax[i]);
+        s.p[3 * i] = p_desired.x; s.p[3 * i + 1] = p_desired.y; s.p[3 * i + 2] = p_desired.z;
+        s.v[3 * i] = v.x; s.v[3 * i + 1] = v.y; s.v[3 * i + 2] = v.z;
+    }
+    __syncthreads();
+    if (i == 0) {  // scene->moveAgent(this), in agent order
+        for (int a = 0; a < n; a++) sfm_move_agent(s.nodes, s.n_nodes, s.cap_nodes, s.treehash, s.p, a, s.err);
+    }
+    __syncthreads();
+}
+#endif

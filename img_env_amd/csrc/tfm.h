@@ -8,6 +8,8 @@
 #pragma once
 #include <math.h>
 
+#include "cr_atan2.h"
+
 #if defined(__HIPCC__)
 #define TFM_HD __host__ __device__ __forceinline__
 #else
@@ -98,7 +100,11 @@ TFM_HD double tf_basis_yaw_via_quaternion(const Tf2& t) {
     }
     Tf2 r;
     tf_set_rotation_zw(r, qz, qw);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return cr_atan2(r.m10 / 1.0, r.m00 / 1.0);  // rounds like glibc's atan2 (cr_atan2.h); the host keeps libm
+#else
     return atan2(r.m10 / 1.0, r.m00 / 1.0);
+#endif
 }
 
 // tf::Matrix3x3(q).getRPY for a planar quaternion (img_env.cpp:180-183)

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 
+#include "sfm.h"
 #include "tfm.h"
 
 #define WAVE 64
@@ -105,6 +106,7 @@ struct DevWorld {
     const RvoObstDev* obst;
     const RvoNodeDev* onodes;
     int n_obst, n_onodes, oroot;
+    SfmDev sfm;  // social-force crowd (pedscene)
     int* err;  // [4] device-side overflow flags
     unsigned long long* prof;  // [16] per-phase cycle counters (IMGENV_PHASE_PROFILE builds)
     // outputs (imgenv_out)

@@ -533,3 +533,18 @@ void sfm_get_agent(const sfm_scene* s, int idx, double* out6) {
 }
 
 double sfm_get_vmax(const sfm_scene* s, int idx) { return s->ag[idx].vmax; }
+
+
+#include <stdio.h>
+void sfm_debug_dump(const sfm_scene* s) { /* test aid: tree leaves and treehash */
+    printf("oracle: n_nodes %d\n", s->n_nodes);
+    for (int k = 0; k < s->n_nodes; k++)
+        if (s->nodes[k].isleaf && s->nodes[k].n_agents) {
+            printf(" leaf %d [%.3f %.3f %.3f %.3f]:", k, s->nodes[k].x, s->nodes[k].y, s->nodes[k].w, s->nodes[k].h);
+            for (int q = 0; q < s->nodes[k].n_agents; q++) printf(" %d", s->nodes[k].agents[q]);
+            printf("\n");
+        }
+    printf(" treehash:");
+    for (int a = 0; a < s->n; a++) printf(" %d", s->treehash[a]);
+    printf("\n");
+}

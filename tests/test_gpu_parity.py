@@ -22,6 +22,11 @@ CASES = {
     "state5_norel": dict(n_robots=6, n_peds=5, seed=6, state_dim=5, relation_ped_robo=0),
     "res025": dict(n_robots=32, n_peds=12, seed=7, res=0.25, grid_size=120),
     "res010_not_pow2": dict(n_robots=24, n_peds=8, seed=13, res=0.1, grid_size=200),
+    "pedscene_sfm_11m": dict(n_robots=4, n_peds=7, seed=14, scene="pedscene", grid_size=88, n_obstacles=3),
+    "pedscene_sfm_16m_legs": dict(n_robots=6, n_peds=14, seed=15, scene="pedscene", grid_size=128, n_obstacles=2,
+                                  ped_shape="leg", clearance=0.8),
+    "pedscene_norel": dict(n_robots=12, n_peds=9, seed=16, scene="pedscene", grid_size=88, relation_ped_robo=0,
+                           clearance=0.7),
     "no_laser": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "time_limit": dict(n_robots=4, n_peds=2, seed=9, time_max=6),
 }

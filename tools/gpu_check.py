@@ -15,7 +15,11 @@ from scenarios import random_actions, small_world  # noqa: E402
 from test_gpu_parity import CASES  # noqa: E402
 
 print("device:", torch.cuda.get_device_name(0))
-only = sys.argv[1:]
+only = [a for a in sys.argv[1:] if not a.startswith("{")]
+import json  # noqa: E402
+for q, a in enumerate(x for x in sys.argv[1:] if x.startswith("{")):   # ad-hoc cases as JSON dicts
+    CASES["adhoc%d" % q] = json.loads(a)
+    only.append("adhoc%d" % q)
 for name, kw in CASES.items():
     if only and name not in only:
         continue
