@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--peds", type=int, default=N_PEDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true")
+    ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
                     "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
     args = ap.parse_args()
@@ -189,7 +190,7 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        frozen = int(world.out["counters"][3].item()) - frozen0 + int(world.out["counters"][2].item())
+        frozen = int(world.out["counters"][3].item()) - frozen0
         return dt, tm, frozen / float(steps * RL)
 
     # pass 1 (not the headline): per-kernel breakdown, HIP events around every kernel, one sync per step;
@@ -220,6 +221,13 @@ def main():
     dt, tm, frozen_active = run("active", args.steps, args.warmup, timing_mode=2, which=dom_id)
     dom_ms, dom_n = tm[dominant]
     value = R * args.steps / dt
+    for q in range(args.repeat):
+        for mode in (0, 2):
+            d2, _, _ = run("active", args.steps, args.warmup, timing_mode=mode, which=dom_id)
+            d3, _, _ = run("episode", args.steps, args.warmup, timing_mode=mode, which=dom_id)
+            if rank == 0:
+                print("repeat %d timing mode %d: active %.1f us/step, episode %.1f us/step"
+                      % (q, mode, 1e6 * d2 / args.steps, 1e6 * d3 / args.steps), file=sys.stderr)
     episode = None
     if not args.no_episode:
         dte, _, frozen_ep = run("episode", args.steps, args.warmup)

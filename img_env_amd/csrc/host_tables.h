@@ -179,12 +179,13 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
     }
     if (k.ray_maxlen == 0) k.ray_maxlen = 1;
     k.ray_kpad = ((k.ray_maxlen + 7) / 8) * 8;
-    k.ray_rows.assign((size_t)(B > 0 ? B : 1) * k.ray_kpad + 8, (uint16_t)NC);  // padding = a free dummy cell behind the view
+    // chunk-major: the 8 steps 8c..8c+7 of beam b sit at ((c * ray_stride) + b) * 8; padding = a free dummy cell behind the view
+    k.ray_rows.assign((size_t)(k.ray_kpad / 8) * k.ray_stride * 8, (uint16_t)NC);
     k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
     std::vector<std::vector<uint32_t>> inv(NC);
     for (int b = 0; b < B; b++)
         for (size_t q = 0; q < cells[b].size(); q++) {
-            k.ray_rows[(size_t)b * k.ray_kpad + q] = cells[b][q];
+            k.ray_rows[((q / 8) * (size_t)k.ray_stride + b) * 8 + (q % 8)] = cells[b][q];
             k.ray_dist[q * k.ray_stride + b] = dists[b][q];
             inv[cells[b][q]].push_back(((uint32_t)b << 16) | (uint32_t)q);
         }
@@ -204,6 +205,7 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
             k.top_ent[c] = inv[c][0];
         }
     if (NC + 16 > 0xFFFF) k.ok = false;
+    if (k.ray_maxlen > 255 || Hv > 256 || Wv > 256) k.ok = false;  // k_view packs (step, row, col) of a hit into 8 bits each
     if (k.inv_ent.empty()) k.inv_ent.push_back(0);
 }
 

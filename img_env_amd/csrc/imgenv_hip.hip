@@ -105,7 +105,7 @@ static RcclApi* rccl_api() {
 }
 
 static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster",
-                                                         "k_compose", "k_view", "k_obs"};
+                                                         "k_compose", "k_view", "k_obs", "k_tail"};
 extern "C" const char* imgenv_kernel_name(int id) { return (id >= 0 && id < IMGENV_K_COUNT) ? KERNEL_NAMES[id] : ""; }
 
 static int timing_flush(imgenv* h) {
@@ -154,6 +154,15 @@ static int timing_mark(imgenv* h, int id, hipStream_t st, int end) {
 extern "C" int imgenv_timing(imgenv_t* h, int mode, int which) {
     if (!h || mode < 0 || mode > 2) FAIL(IMGENV_EINVAL, "bad timing mode");
     if (int rc = timing_flush(h)) return rc;
+    if (mode != 0) {  // create the event pool up front: hipEventCreate inside a timed region would be measured
+        const size_t want = mode == 1 ? 2 * 64 * IMGENV_K_COUNT : 2 * 1024;
+        while (h->t_ev.size() < want) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            h->t_ev.push_back(e);
+            if (h->t_ev.size() % 2 == 0) h->t_id.push_back(0);
+        }
+    }
     h->t_mode = mode;
     h->t_which = which;
     for (int q = 0; q < IMGENV_K_COUNT; q++) {
@@ -497,6 +506,19 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     TRY(dev_alloc(h, &d.tmp_dist, RL));
     TRY(dev_alloc(h, &d.pm_cells, (size_t)RL * PM_CAP));
     TRY(dev_alloc(h, &d.pm_n, RL));  // 0: the arena starts zeroed, nothing to clear
+    {   // k_raster's LDS box and the per-robot footprint cell lists (classes with a huge footprint go without)
+        int box = 1, cap = 1;
+        for (const RobotClassHost& k : h->rcls) {
+            const int side = 2 * k.box_rad + 1;
+            if (side * side > RASTER_BOX_CELLS) continue;
+            box = std::max(box, side * side);
+            cap = std::max(cap, std::min(side * side, k.fp.n()));
+        }
+        d.box_cells = box;
+        d.fp_cap = cap;
+        TRY(dev_alloc(h, &d.fp_cells, (size_t)RL * cap));
+        TRY(dev_alloc(h, &d.fp_n, RL, 0xFF));  // -1 until the first raster
+    }
     TRY(dev_alloc(h, &d.ppx, P)); TRY(dev_alloc(h, &d.ppy, P)); TRY(dev_alloc(h, &d.pyaw, P));
     TRY(dev_alloc(h, &d.plx, P)); TRY(dev_alloc(h, &d.ply, P)); TRY(dev_alloc(h, &d.pvx, P)); TRY(dev_alloc(h, &d.pvy, P));
     TRY(dev_alloc(h, &d.prem, P)); TRY(dev_alloc(h, &d.llx, P)); TRY(dev_alloc(h, &d.lly, P));
@@ -551,7 +573,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK(hipMemcpy(f.n_nodes, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
     }
-    TRY(dev_alloc(h, &d.prof, 16));
+    TRY(dev_alloc(h, &d.prof, 16 + 8 * (size_t)RL));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
 
     // output arena
     ArenaPlan plan;
@@ -614,15 +636,18 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->PP = 2;
     while (h->PP < P) h->PP <<= 1;
     const size_t NC = (size_t)g.Hv * g.Wv;
-    h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 2 * NC + 16;  // src u8 (+ dummy cells) + hit u32 + skip list u16
+    d.hit_stride = (int)max_stride;
+    h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv;  // src u8 (+ dummy cells) | hit u32 | column terms
     h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)h->PP * 4 + WAVE * 7 * 4 + PM_CAP * 2 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);
         FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
     }
     if (h->lds_view > 64 * 1024) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_view<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
-        HIPCHK(hipFuncSetAttribute((const void*)k_view<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+        HIPCHK(hipFuncSetAttribute((const void*)k_view<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+        HIPCHK(hipFuncSetAttribute((const void*)k_view<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+        HIPCHK(hipFuncSetAttribute((const void*)k_view<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+        HIPCHK(hipFuncSetAttribute((const void*)k_view<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
     }
     if (h->lds_obs > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)k_obs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
@@ -659,6 +684,7 @@ __global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, con
         w.is_coll[l] = 0;
         w.is_arr[l] = 0;
     }
+    if (i == 0) w.counters[2] = 0;  // frozen robot-steps since this reset
 }
 
 __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
@@ -687,9 +713,9 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const size_t G = (size_t)h->Hg * h->Wg;
     if (h->pow2)
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     else
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P + h->R), dim3(WAVE), 0, st>>>(d, is_reset)));
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     if (h->P > 0 && h->NA > 0) {  // next step's _step_ped_normal solve (img_env.cpp:304-343), overlapped
         HIPCHK(hipEventRecord(h->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -699,11 +725,19 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         h->launches += 1;
     }
     TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
-    if (h->pow2)
-        TIMED(h, IMGENV_K_VIEW, st, (k_view<true><<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d)));
-    else
-        TIMED(h, IMGENV_K_VIEW, st, (k_view<false><<<dim3(h->RL), dim3(WAVE), h->lds_view, st>>>(d)));
-    TIMED(h, IMGENV_K_OBS, st, (k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, st>>>(d, is_reset, h->elapsed, h->PP)));
+    {
+        const dim3 gv(h->RL), bv(WAVE);
+        const int variant = (h->pow2 ? 2 : 0) | (h->geom.Wv % 4 == 0 ? 1 : 0);
+        if (variant == 3) TIMED(h, IMGENV_K_VIEW, st, (k_view<true, true><<<gv, bv, h->lds_view, st>>>(d)));
+        else if (variant == 2) TIMED(h, IMGENV_K_VIEW, st, (k_view<true, false><<<gv, bv, h->lds_view, st>>>(d)));
+        else if (variant == 1) TIMED(h, IMGENV_K_VIEW, st, (k_view<false, true><<<gv, bv, h->lds_view, st>>>(d)));
+        else TIMED(h, IMGENV_K_VIEW, st, (k_view<false, false><<<gv, bv, h->lds_view, st>>>(d)));
+    }
+    if (h->P > 0) {
+        TIMED(h, IMGENV_K_OBS, st, (k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, st>>>(d, h->PP)));
+        h->launches += 1;
+    }
+    TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed)));
     h->launches += 4;
     HIPCHK(hipGetLastError());
     return 0;
@@ -958,5 +992,12 @@ extern "C" int imgenv_debug_phases(imgenv_t* h, unsigned long long* out16) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out16, h->d.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d.prof, 0, 16 * sizeof(unsigned long long)));
+    return IMGENV_OK;
+}
+// debug: per-wave (start, end, hw id, 0) records of the last k_view [0, 4 RL) and k_obs [4 RL, 8 RL) launches
+extern "C" int imgenv_debug_waves(imgenv_t* h, unsigned long long* out) {
+    if (!h || !out) FAIL(IMGENV_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, h->d.prof + 16, 8 * (size_t)h->RL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return IMGENV_OK;
 }

@@ -27,8 +27,24 @@ __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls)
 
 // Optional per-phase cycle accounting (build with -DIMGENV_PHASE_PROFILE): lane 0 of every wave adds
 // the shader-clock cycles of each phase to w.prof[slot]; tools/phase_profile.py prints the split.
+#if defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE)
+#define WAVE_T0() const unsigned long long wave_t0_ = wall_clock64()
+#define WAVE_DONE(base)                                                                   \
+    do {                                                                                  \
+        if (lane_id() == 0) {                                                             \
+            unsigned long long* p_ = w.prof + 16 + (size_t)(base) * 4 * w.RL + 4 * (size_t)blockIdx.x; \
+            p_[0] = wave_t0_;                                                             \
+            p_[1] = wall_clock64();                                                       \
+            p_[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));          \
+            p_[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));         \
+        }                                                                                 \
+    } while (0)
+#else
+#define WAVE_T0() (void)0
+#define WAVE_DONE(base) (void)0
+#endif
 #ifdef IMGENV_PHASE_PROFILE
-#define PHASE_BEGIN() long long ph_t_ = clock64()
+#define PHASE_BEGIN() long long ph_t_ = clock64(); WAVE_T0()
 #define PHASE_MARK(slot)                                                                  \
     do {                                                                                  \
         const long long now_ = clock64();                                                 \
@@ -36,7 +52,7 @@ __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls)
         ph_t_ = now_;                                                                     \
     } while (0)
 #else
-#define PHASE_BEGIN() (void)0
+#define PHASE_BEGIN() WAVE_T0()
 #define PHASE_MARK(slot) (void)0
 #endif
 
@@ -228,10 +244,7 @@ __device__ void limiter_limit(bool has_v, bool has_a, bool has_j, double min_v, 
 }
 
 // _step_req (yaml_env.py:319-331) + Agent::cmd (agent.cpp:186-283)
-__global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= w.RL) return;
-    if (w.py_done[l]) return;  // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
+__device__ __forceinline__ void integrate_robot(const DevWorld& w, const float* __restrict__ actions, int l) {
     double* r = w.rec + (size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES;
     double v = (double)actions[3 * l], wv = (double)actions[3 * l + 1];
     const double v_y = (double)actions[3 * l + 2];
@@ -302,6 +315,21 @@ __global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
     w.is_arr[l] = is_arrive ? 1 : 0;
 }
 
+__global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = l < w.RL;
+    // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
+    if (valid && !w.py_done[l]) integrate_robot(w, actions, l);
+    // robots whose view is frozen this step (agent.cpp:358-360), one atomic per wavefront:
+    // counters[2] since the last reset, counters[3] since create
+    const bool frozen = valid && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
+    const unsigned long long mask = __ballot(frozen);
+    if (mask != 0 && lane_id() == 0) {
+        atomicAdd(&w.counters[2], __popcll(mask));
+        atomicAdd(&w.counters[3], __popcll(mask));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Rasters: blocks [0, P) draw pedestrians, blocks [P, P + R) draw robots.
 
@@ -321,7 +349,8 @@ __device__ void raster_ped(const DevWorld& w, int j) {
         for (int q = lane; q < k.n_bbox; q += WAVE) {
             double wx, wy;
             tf_apply(bw, k.bx[q], k.by[q], wx, wy);
-            const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
+            int m, n;
+            w2m_pair<POW2>(wx, wy, res, inv, m, n);
             if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
                 const size_t c = (size_t)m * w.Wg + n;
                 if (w.obs_map[c] > 2) w.ped_layer[c] = 1;
@@ -340,7 +369,8 @@ __device__ void raster_ped(const DevWorld& w, int j) {
                 double bx, by, wx, wy;
                 tf_apply(lb, sx[q], sy[q], bx, by);
                 tf_apply(bw, bx, by, wx, wy);
-                const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
+                int m, n;
+                w2m_pair<POW2>(wx, wy, res, inv, m, n);
                 if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
                     const size_t c = (size_t)m * w.Wg + n;
                     if (leg == 1 || w.obs_map[c] != 0) w.ped_layer[c] = 1;
@@ -350,13 +380,17 @@ __device__ void raster_ped(const DevWorld& w, int j) {
     }
 }
 
-#define RASTER_BOX_WORDS 64  // LDS bitmap: up to 2048 cells = 45 x 45 box
+#define RASTER_BOX_CELLS 2048  // LDS box of a robot raster: up to 45 x 45 cells
 
 // view_robot's inner loop (img_env.cpp:624-628) for ALL robots at once: instead of stamping every
 // other robot into a private copy of the grid per robot (O(R * Hg*Wg + R^2 * F)), each robot records
 // itself in two shared layers, own_lo = min id and own_hi = max id covering a cell.  Robot i then
 // sees "another robot" in a cell iff (lo != i or hi != i).  The 901 footprint samples fall on a few
-// cells, so they are de-duplicated in an LDS bitmap first: ~10-20 global atomics per robot.
+// cells, so they are de-duplicated in an LDS box around the robot first: ~10-20 global atomics per
+// robot.  The box keeps the LAST sample index that landed in each cell; for local robots the
+// (cell, last sample) pairs go to fp_cells so that the collision test of k_view (agent.cpp:294-326:
+// the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
+// second pass over the samples.
 template <bool POW2>
 __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel) {
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
@@ -365,40 +399,60 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
     const double res = w.res, inv = w.inv_res;
     const uint32_t id = (uint32_t)i + 1;
-    const int rad = k.box_rad, side = 2 * rad + 1;
-    const bool use_box = side * side <= RASTER_BOX_WORDS * 32;
+    const int rad = k.box_rad, side = 2 * rad + 1, ncell = side * side;
+    const bool use_box = ncell <= w.box_cells;
+    const int l = i - w.r0;
+    const bool local = l >= 0 && l < w.RL;
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
     if (use_box) {
-        for (int q = lane; q < RASTER_BOX_WORDS; q += WAVE) box[q] = 0;
+        for (int q = lane; q < ncell; q += WAVE) box[q] = 0;
         __syncthreads();
     }
+    bool stray = false;
     for (int q = lane; q < k.n_fp; q += WAVE) {
         double wx, wy;
         const double2 fp = k.fp[q];
         tf_apply(bw, fp.x, fp.y, wx, wy);
-        const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
+        int m, n;
+        w2m_pair<POW2>(wx, wy, res, inv, m, n);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
             const int dm = m - cm + rad, dn = n - cn + rad;
             if (use_box && dm >= 0 && dm < side && dn >= 0 && dn < side) {
-                const int b = dm * side + dn;
-                atomicOr(&box[b >> 5], 1u << (b & 31));
+                atomicMax(&box[dm * side + dn], (uint32_t)q + 1);
             } else {
                 const size_t c = (size_t)m * w.Wg + n;
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
+                stray = true;
             }
         }
     }
     if (use_box) {
         __syncthreads();
-        for (int b = lane; b < side * side; b += WAVE) {
-            if (box[b >> 5] & (1u << (b & 31))) {
-                const int m = cm - rad + b / side, n = cn - rad + b % side;
-                const size_t c = (size_t)m * w.Wg + n;
+        uint2* list = w.fp_cells + (size_t)(local ? l : 0) * w.fp_cap;
+        int n_out = 0;
+        for (int b0 = 0; b0 < ncell; b0 += WAVE) {  // wave-uniform trip count (ballot inside)
+            const int b = b0 + lane;
+            const uint32_t last = b < ncell ? box[b] : 0u;
+            uint32_t c = 0;
+            if (last) {
+                const int bm = b / side;
+                const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
+                c = (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
             }
+            if (local) {
+                const unsigned long long mask = __ballot(last != 0);
+                const int pos = n_out + __popcll(mask & ((1ull << lane) - 1ull));
+                if (last && pos < w.fp_cap) list[pos] = make_uint2(c, last);
+                n_out += __popcll(mask);
+            }
         }
+        const bool any_stray = __any(stray);
+        if (local && lane == 0) w.fp_n[l] = (n_out <= w.fp_cap && !any_stray) ? n_out : -1;
+    } else if (local && lane == 0) {
+        w.fp_n[l] = -1;
     }
     // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417, rvoscene.h:47-51)
     if (lane == 0 && w.relation == 1 && (w.scene == IMGENV_SCENE_RVO || w.scene == IMGENV_SCENE_ERVO)) {
@@ -418,12 +472,12 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
 
 template <bool POW2>
 __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
-    __shared__ uint32_t box[RASTER_BOX_WORDS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     if (b < w.P)
         raster_ped<POW2>(w, b);
     else
-        raster_robot<POW2>(w, b - w.P, box, zero_vel != 0);
+        raster_robot<POW2>(w, b - w.P, (uint32_t*)smem, zero_vel != 0);
 }
 
 // class layer: one byte per cell that a robot's view kernel can decode without touching the three
@@ -431,11 +485,7 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
 __global__ void k_compose(DevWorld w) {
     const size_t G = (size_t)w.Hg * w.Wg;
     const size_t c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        w.counters[3] += w.counters[2];  // cumulative frozen robot-steps since create (bench statistic)
-        w.counters[1] = 0;
-        w.counters[2] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_obs tallies this step's dones
     if (c0 >= G) return;
     if (c0 + 4 <= G) {
         const uint32_t obs = *(const uint32_t*)(w.obs_map + c0);
@@ -491,29 +541,66 @@ __device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, si
 // ------------------------------------------------------------------------------------------------
 // Agent::view (agent.cpp:356-509) for local robot l = blockIdx.x, one wavefront.
 //   LDS: src[Hv*Wv + pad] u8  the cropped view (0 / 255 / 200); src[Hv*Wv] is a free dummy cell
-//        hit[B] u32           (first-hit step << 16 | hit cell) per beam, 0xFFFFFFFF = none
+//        hit[B] u32           first hit of each beam: step << 16 | row << 8 | col, 0xFFFFFFFF = none
+//        colt[Wv] double2     the column terms of the view -> world transform
 //
 // bresenhamLine (agent.cpp:511-624) writes laser_map beam after beam, later beams overwriting earlier
 // ones, so a cell ends with the value of the HIGHEST beam that writes it.  Beam paths are static, so
-//   (a) hit[b]: every lane walks the precomputed path of its beams in LDS until the first occupied cell
-//       (8 steps per 16-byte load, the wave leaves the loop as soon as all its beams have hit);
+//   (a) hit[b]: every lane walks the precomputed path of its beams in LDS (8 steps per 16-byte load);
+//       a step contributes key = value << 24 | step << 16 | cell and the minimum key is the first
+//       occupied cell (value 0) -- no compares, no selects; the wave leaves the loop as soon as all
+//       its beams have hit or ended;
 //   (b) every view cell looks at the highest beam through it (static table `top_ent`): 255 before that
 //       beam's hit, 0 at the hit, 200 behind it -- unless the cell shares a row or column with the hit
 //       cell, where that beam leaves the cell alone (agent.cpp:555-560) and the next lower beam through
-//       the cell decides (rare slow path over the static per-cell ray list).
+//       the cell decides (rare slow path over the static per-cell ray list);
+//   (c) the same pass stamps the own footprint and writes both output planes straight from
+//       registers: cell values live as 2-bit class indices, v_perm_b32 turns four of them into four
+//       uint8 values / four float16 values.
 // The kernel is written branch-free inside its loops (selects instead of divergent ifs): with one
-// wavefront per robot the scalar unit, not the vector ALUs, was the bottleneck of the branchy version.
-#define VIEW_SKIP 1u  // "left alone by the top beam": not a laser_map value (those are 0 / 200 / 255)
+// wavefront per robot the instruction issue rate, not memory, bounds it.
 
+// collision code from the footprint samples themselves (classes whose box does not fit k_raster's LDS)
 template <bool POW2>
+__device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, const RobotClassDev& k, const Tf2& bw, uint32_t self) {
+    const int lane = lane_id();
+    const double res = w.res, inv = w.inv_res;
+    uint32_t best = 0;
+    for (int q = lane; q < k.n_fp; q += WAVE) {
+        const double2 fp = k.fp[q];
+        double wx, wy;
+        tf_apply(bw, fp.x, fp.y, wx, wy);
+        int m, n;
+        w2m_pair<POW2>(wx, wy, res, inv, m, n);
+        if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+            const uint32_t cc = cell_class(w, self, (size_t)m * w.Wg + n);
+            if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
+        }
+    }
+    return best;
+}
+
+// laser_map value of a cell its top beam leaves alone: the next lower beam through the cell that writes decides
+__device__ __forceinline__ uint32_t resolve_skipped_cell(const RobotClassDev& k, const uint32_t* hit, uint32_t c, uint32_t cx, uint32_t cy) {
+    const uint32_t pk = k.inv_pack[c];
+    const uint32_t e0 = pk & 0xFFFFFu, cnt = pk >> 20;
+    for (uint32_t e = 1; e < cnt; e++) {  // entry 0 is the top beam
+        const uint32_t ent = k.inv_ent[e0 + e];
+        const uint32_t kk = ent & 0xFFFFu, hp = hit[ent >> 16], hk = hp >> 16;
+        if (kk < hk) return 3u;   // 255
+        if (kk == hk) return 0u;  // 0
+        if (cx != ((hp >> 8) & 0xFFu) && cy != (hp & 0xFFu)) break;  // this beam writes 200
+    }
+    return 2u;
+}
+
+template <bool POW2, bool A4>
 __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
+    // A4: Wv % 4 == 0 (a lane's 4 consecutive cells share their row and nothing runs over the end of the view)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = blockIdx.x;
     const int lane = lane_id();
-    if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value
-        if (lane == 0) atomicAdd(&w.counters[2], 1);
-        return;
-    }
+    if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: every per-robot output keeps its last value (counted in k_integrate)
     const int i = w.r0 + l;
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
@@ -526,58 +613,81 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const uint32_t self = (uint32_t)i;
     uint8_t* src = smem;
     uint32_t* hit = (uint32_t*)(smem + NCp);
+    double2* colt = (double2*)(smem + NCp + 4 * (size_t)w.hit_stride);
     PHASE_BEGIN();
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
-    //     the code (agent.cpp:294-326) -> max over (sample index, code); 4 independent gathers in flight
+    //     the code (agent.cpp:294-326) -> max over (last sample index in the cell, code) of the covered cells
     uint32_t best = 0;
-    for (int q0 = lane; q0 < k.n_fp; q0 += WAVE * 4) {
-        uint32_t idx[4], okm[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int q = q0 + u * WAVE;
-            const double2 fp = k.fp[min(q, k.n_fp - 1)];
-            double wx, wy;
-            tf_apply(bw, fp.x, fp.y, wx, wy);
-            const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
-            const bool ok = (q < k.n_fp) & (m >= 0) & (m < Hg) & (n >= 0) & (n < Wg);
-            okm[u] = ok ? 0xFFFFFFFFu : 0u;
-            idx[u] = ok ? (uint32_t)(m * Wg + n) : 0u;
+    const int n_cov = w.fp_n[l];
+    if (n_cov >= 0) {
+        const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
+        for (int e = lane; e < n_cov; e += WAVE) {
+            const uint2 ce = list[e];
+            const uint32_t v = w.cell[ce.x];
+            const bool other = ((v & CLS_ROBOT) != 0) & ((v >> 8) != self);
+            const uint32_t cc = other ? (uint32_t)CLS_TWO : (v & 7u);
+            best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
         }
-        uint32_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = w.cell[idx[u]];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const bool other = ((v[u] & CLS_ROBOT) != 0) & ((v[u] >> 8) != self);
-            const uint32_t cc = other ? (uint32_t)CLS_TWO : (v[u] & 7u);
-            const uint32_t cand = (((uint32_t)(q0 + u * WAVE + 1) << 2) | (cc + 1)) & okm[u];
-            best = max(best, cc <= 2 ? cand : 0u);
-        }
+    } else {
+        best = collision_from_samples<POW2>(w, k, bw, self);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
     const int code = (int)(best & 3);
     PHASE_MARK(0);
 
-    // (2) egocentric crop (agent.cpp:373-404): 4 view cells per lane per round -> one LDS dword
+    // (2) egocentric crop (agent.cpp:373-404): 4 view cells per lane per round -> one LDS dword.
+    //     world = (m00 * (a res) + m01 * (b res)) + ox: the column products come from an LDS table, the row
+    //     products are shared by the 4 cells of a lane
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
-    if (lane < 16) src[NC + lane] = 255;     // dummy free cells behind the view (padded path entries)
+    for (int b = lane; b < Wv; b += WAVE) {
+        const double y = b * res;
+        colt[b] = make_double2(vw.m01 * y, vw.m11 * y);
+    }
+    if (lane < 16) src[NC + lane] = 255;  // dummy free cells behind the view (padded path entries)
+    __syncthreads();
     for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
         const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds the 4 bits
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
         if (fov) {
+            const int a0 = (int)__umulhi((uint32_t)c4, wv_magic), b0 = c4 - a0 * Wv;
+            const double x0 = a0 * res;
+            const double rx0 = vw.m00 * x0, ry0 = vw.m10 * x0;
+            double tx[4], ty[4];
+            int m[4], n[4];
+            bool tie = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                double rx = rx0, ry = ry0;
+                int b = b0 + q;
+                if (!A4) {  // the group may run over the end of its row (or of the view)
+                    const int c = min(c4 + q, NC - 1);
+                    const int a = (int)__umulhi((uint32_t)c, wv_magic);
+                    b = c - a * Wv;
+                    const double x = a * res;
+                    rx = vw.m00 * x;
+                    ry = vw.m10 * x;
+                }
+                const double2 cc = colt[b];
+                tx[q] = w2m_scale<POW2>((rx + cc.x) + vw.ox, res, inv);
+                ty[q] = w2m_scale<POW2>((ry + cc.y) + vw.oy, res, inv);
+                m[q] = round_even_i(tx[q], tie);
+                n[q] = round_even_i(ty[q], tie);
+            }
+            if (__builtin_expect(__any(tie), 0)) {  // an exact .5 somewhere in the wave: C round() goes away from zero
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    m[q] = round_tie_fix(tx[q]);
+                    n[q] = round_tie_fix(ty[q]);
+                }
+            }
             uint32_t idx[4], okm[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int c = c4 + q;
-                const int a = (int)__umulhi((uint32_t)c, wv_magic), b = c - a * Wv;
-                double wx, wy;
-                tf_apply(vw, a * res, b * res, wx, wy);
-                const int m = w2m_t<POW2>(wx, res, inv), n = w2m_t<POW2>(wy, res, inv);
-                const bool ok = (c < NC) & (((fov >> q) & 1u) != 0) & (m >= 0) & (m < Hg) & (n >= 0) & (n < Wg);
+                const bool ok = (A4 || c4 + q < NC) & (((fov >> q) & 1u) != 0) & (m[q] >= 0) & (m[q] < Hg) & (n[q] >= 0) & (n[q] < Wg);
                 okm[q] = ok ? 0xFFu : 0u;
-                idx[q] = ok ? (uint32_t)(m * Wg + n) : 0u;
+                idx[q] = ok ? (uint32_t)(m[q] * Wg + n[q]) : 0u;
             }
             uint32_t v[4];
 #pragma unroll
@@ -597,26 +707,32 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
 
     // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
     if (laser) {
+        const uint4* rows = (const uint4*)k.ray_rows;
+        const int n_chunks = k.ray_kpad >> 3;
         for (int b0 = 0; b0 < w.B; b0 += WAVE) {
             const int b = b0 + lane;
             const int bb = min(b, w.B - 1);
             const int len = b < w.B ? (int)k.ray_len[bb] : 0;
-            const uint16_t* row = k.ray_rows + (size_t)bb * k.ray_kpad;
             uint32_t found = 0xFFFFFFFFu;
-            for (int q0 = 0; q0 < k.ray_kpad; q0 += 8) {
-                const uint4 ch = *(const uint4*)(row + q0);
-                const uint32_t wds[4] = {ch.x, ch.y, ch.z, ch.w};
+            uint4 nxt = rows[bb];
+            for (int ch = 0; ch < n_chunks; ch++) {
+                const uint4 cur = nxt;
+                if (ch + 1 < n_chunks) nxt = rows[(size_t)(ch + 1) * k.ray_stride + bb];  // in flight while this chunk is walked
+                const uint32_t wds[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const uint32_t c = (wds[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;  // padded entries point at a free dummy cell
-                    const bool h = (found == 0xFFFFFFFFu) & (q0 + j < len) & (src[c] == 0);
-                    found = h ? (((uint32_t)(q0 + j) << 16) | c) : found;
+                    const uint32_t c = (wds[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;  // padded entries point at the free dummy cell
+                    const uint32_t key = ((uint32_t)src[c] << 24) | ((uint32_t)(8 * ch + j) << 16) | c;
+                    found = min(found, key);
                 }
-                if (__all((found != 0xFFFFFFFFu) | (q0 + 8 >= len))) break;
+                if (__all((found < 0x01000000u) | (8 * ch + 8 >= len))) break;
             }
             if (b < w.B) {
-                hit[b] = found;
-                const float hd = found != 0xFFFFFFFFu ? k.ray_dist[(size_t)(found >> 16) * k.ray_stride + b] : 6.0f;  // agent.cpp:513
+                const bool has = found < 0x01000000u;  // value 0 in the top byte
+                const uint32_t hk = (found >> 16) & 0xFFu, hc = found & 0xFFFFu;
+                const uint32_t hx = __umulhi(hc, wv_magic), hy = hc - hx * (uint32_t)Wv;
+                hit[b] = has ? ((hk << 16) | (hx << 8) | hy) : 0xFFFFFFFFu;
+                const float hd = has ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
                 w.lasers_raw[(size_t)l * w.B + b] = hd;
                 w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
             }
@@ -625,15 +741,19 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     }
     PHASE_MARK(2);
 
-    // (4) laser_map (agent.cpp:437) per cell from its top beam; cells that beam leaves alone are tagged
-    //     VIEW_SKIP and collected (ballot compaction) for (5).  The result overwrites src in LDS.
-    uint16_t* skip = (uint16_t*)(hit + k.ray_stride);
-    int n_skip = 0;
-    if (laser) {
-        for (int base = 0; base < NC; base += WAVE * 4) {  // wave-uniform trip count (ballots inside)
-            const int c4 = base + lane * 4;
+    // (4) laser_map (agent.cpp:437) per cell from its top beam, the own footprint stamped 100 (agent.cpp:503),
+    //     stored as uint8 and as float16(v / 255) (yaml_env.py:431-438).  Class index: 0 -> 0, 1 -> 100, 2 -> 200, 3 -> 255
+    uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
+    uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;
+    const uint32_t lut_u8 = 0u | (100u << 8) | (200u << 16) | (255u << 24);
+    const uint32_t h0 = w.f16_lut[0], h1 = w.f16_lut[100], h2 = w.f16_lut[200], h3 = w.f16_lut[255];
+    const uint32_t lut_lo = (h0 & 0xFFu) | ((h1 & 0xFFu) << 8) | ((h2 & 0xFFu) << 16) | ((h3 & 0xFFu) << 24);
+    const uint32_t lut_hi = (h0 >> 8) | ((h1 >> 8) << 8) | ((h2 >> 8) << 16) | ((h3 >> 8) << 24);
+    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
+        uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
+        if (laser) {
             uint32_t top[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (c4 + 4 <= NC) {
+            if (A4 || c4 + 4 <= NC) {
                 const uint4 t4 = *(const uint4*)(k.top_ent + c4);
                 top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
             } else {
@@ -641,82 +761,68 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                 for (int q = 0; q < 4; q++)
                     if (c4 + q < NC) top[q] = k.top_ent[c4 + q];
             }
-            uint32_t packed = 0;
+            if (__any((top[0] & top[1] & top[2] & top[3]) != 0xFFFFFFFFu)) {  // rows behind the sensor see no beam at all
+                const uint32_t cx0 = __umulhi((uint32_t)c4, wv_magic), cy0 = (uint32_t)c4 - cx0 * (uint32_t)Wv;
+                uint32_t skips = 0;
+                I = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t cx = cx0, cy = cy0 + q;
+                    if (!A4) {
+                        cx = __umulhi((uint32_t)(c4 + q), wv_magic);
+                        cy = (uint32_t)(c4 + q) - cx * (uint32_t)Wv;
+                    }
+                    const bool has = top[q] != 0xFFFFFFFFu;
+                    const uint32_t bq = has ? (top[q] >> 16) : 0u, kk = top[q] & 0xFFFFu;
+                    const uint32_t hp = hit[bq], hk = hp >> 16;  // hk = 0xFFFF when the beam never hits
+                    const bool alone = (cx == ((hp >> 8) & 0xFFu)) | (cy == (hp & 0xFFu));
+                    uint32_t v = kk < hk ? 3u : (kk == hk ? 0u : 2u);
+                    v = has ? v : 2u;
+                    skips |= (has & (kk > hk) & alone) ? (1u << q) : 0u;
+                    I |= v << (8 * q);
+                }
+                if (__any(skips != 0)) {
+#pragma unroll 1
+                    for (int q = 0; q < 4; q++)
+                        if ((skips >> q) & 1u) {
+                            const uint32_t c = (uint32_t)(c4 + q);
+                            const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
+                            const uint32_t v = resolve_skipped_cell(k, hit, c, cx, cy);
+                            I = (I & ~(0xFFu << (8 * q))) | (v << (8 * q));
+                        }
+                }
+            }
+        } else {
+            const uint32_t p = *(const uint32_t*)(src + c4);
+            I = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t c = (uint32_t)(c4 + q);
-                const bool has = top[q] != 0xFFFFFFFFu;
-                const uint32_t bq = has ? (top[q] >> 16) : 0u, kk = top[q] & 0xFFFFu;
-                const uint32_t hp = hit[bq], hk = hp >> 16, hc = hp & 0xFFFFu;
-                const uint32_t hx = __umulhi(hc, wv_magic), hy = hc - hx * (uint32_t)Wv;
-                const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
-                const uint32_t behind = ((cx != hx) & (cy != hy)) ? 200u : VIEW_SKIP;
-                uint32_t val = kk < hk ? 255u : (kk == hk ? 0u : behind);  // hk = 0xFFFF when the beam never hits
-                val = has ? val : 200u;
-                packed |= val << (8 * q);
-                const bool sk = val == VIEW_SKIP;
-                const unsigned long long mask = __ballot(sk);
-                if (sk) skip[n_skip + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)c;
-                n_skip += __popcll(mask);
+                const uint32_t v = (p >> (8 * q)) & 0xFFu;
+                I |= (v == 255u ? 3u : (v == 0u ? 0u : 2u)) << (8 * q);
             }
-            if (c4 < NC) *(uint32_t*)(src + c4) = packed;
         }
-        __syncthreads();
-        // (5) resolve the skipped cells: the next lower beam through the cell that writes decides (agent.cpp:555-560)
-        for (int t = lane; t < n_skip; t += WAVE) {
-            const uint32_t c = skip[t];
-            const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
-            const uint32_t pk = k.inv_pack[c];
-            const uint32_t e0 = pk & 0xFFFFFu, cnt = pk >> 20;
-            uint32_t val = 200;
-            for (uint32_t e = 1; e < cnt; e++) {  // entry 0 is the top beam
-                const uint32_t ent = k.inv_ent[e0 + e];
-                const uint32_t kk = ent & 0xFFFFu, hp = hit[ent >> 16], hk = hp >> 16;
-                if (kk < hk) {
-                    val = 255;
-                    break;
-                }
-                if (kk == hk) {
-                    val = 0;
-                    break;
-                }
-                const uint32_t hc = hp & 0xFFFFu;
-                const uint32_t hx = __umulhi(hc, wv_magic), hy = hc - hx * (uint32_t)Wv;
-                if (cx != hx && cy != hy) break;  // this beam writes 200
-            }
-            src[c] = (uint8_t)val;
-        }
-        __syncthreads();
-    }
-    PHASE_MARK(3);
-
-    // (6) own footprint stamped 100 (agent.cpp:503); stored as uint8 and as float16(v / 255) (yaml_env.py:431-438)
-    uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
-    uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;
-    const uint32_t h0 = w.f16_lut[0], h100 = w.f16_lut[100], h200 = w.f16_lut[200], h255 = w.f16_lut[255];
-    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
-        const uint32_t p = *(const uint32_t*)(src + c4);
+        // own footprint: class 1 wherever the stamp bit is set and the cell is not 0 (agent.cpp:307-312 skips 0 / 1 / 2)
         const uint32_t stamp = (k.stamp_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;
-        uint32_t packed = 0, h[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t v = (p >> (8 * q)) & 0xFFu;
-            v = (((stamp >> q) & 1u) != 0) & (v > 2) ? 100u : v;
-            packed |= v << (8 * q);
-            h[q] = v == 255 ? h255 : (v == 0 ? h0 : (v == 200 ? h200 : h100));
-        }
-        if (c4 + 4 <= NC) {
+        const uint32_t st = (stamp * 0x00204081u) & 0x01010101u;  // bit q -> bit 8q
+        const uint32_t sel = st & (I | (I >> 1));                   // ... and class != 0
+        I = (I & ~(sel | (sel << 1))) | sel;
+        const uint32_t packed = __builtin_amdgcn_perm(lut_u8, lut_u8, I);
+        const uint32_t s01 = __builtin_amdgcn_perm(I, I, 0x01010000u), s23 = __builtin_amdgcn_perm(I, I, 0x03030202u);
+        const uint32_t f01 = (__builtin_amdgcn_perm(lut_lo, lut_lo, s01) & 0x00FF00FFu) | (__builtin_amdgcn_perm(lut_hi, lut_hi, s01) & 0xFF00FF00u);
+        const uint32_t f23 = (__builtin_amdgcn_perm(lut_lo, lut_lo, s23) & 0x00FF00FFu) | (__builtin_amdgcn_perm(lut_hi, lut_hi, s23) & 0xFF00FF00u);
+        if (A4 || c4 + 4 <= NC) {
             *(uint32_t*)(out_u8 + c4) = packed;
-            *(uint2*)(out_f16 + c4) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *(uint2*)(out_f16 + c4) = make_uint2(f01, f23);
         } else {
             for (int q = 0; q < 4 && c4 + q < NC; q++) {
                 out_u8[c4 + q] = (uint8_t)(packed >> (8 * q));
-                out_f16[c4 + q] = (uint16_t)h[q];
+                out_f16[c4 + q] = (uint16_t)((q < 2 ? f01 : f23) >> (16 * (q & 1)));
             }
         }
     }
     if (lane == 0) w.is_coll[l] = code;
     PHASE_MARK(4);
+    WAVE_DONE(0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -743,31 +849,15 @@ __device__ double py_floordiv(double vx, double wx) {
     return floordiv;
 }
 
-#define PM_CAP 512  // cells of a robot's ped_map that may be non-zero before it falls back to dense clears
-
-// LDS: key[PP] f64 sort keys | info[P] float4 (px,py,vx,vy) | ord[PP] u16 sorted ped index |
-//      inbox[PP] u16 ranks of the pedestrians inside the +-3 m box | stage[64*7] f32 | touched[PM_CAP] u16
-__global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elapsed, int PP) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int l = blockIdx.x, lane = lane_id();
+__device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset, int elapsed) {
     const int i = w.r0 + l;
-    const int P = w.P, Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
-    const int Pa = P > 0 ? P : 1;
-    double* key = (double*)smem;
-    float4* info = (float4*)(smem + (size_t)PP * 8);
-    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)Pa * 16);
-    uint16_t* inbox = ord + PP;
-    float* stage = (float*)(inbox + PP);
-    uint16_t* touched = (uint16_t*)(stage + WAVE * 7);
-
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
-    PHASE_BEGIN();
     // Agent::get_state (agent.cpp:156-184)
     const Tf2 t = tf_mul(w.world_target[l], bw);
     const Tf2 target_base = tf_inverse(t);
     const float s0 = (float)target_base.ox, s1 = (float)target_base.oy;
-    if (lane == 0) {
+    {
         float* vs = w.vector_states + (size_t)l * w.SD;
         vs[0] = s0;
         vs[1] = s1;
@@ -785,6 +875,88 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
         w.robot_pose[3 * l + 1] = r[1];
         w.robot_pose[3 * l + 2] = r[2];
     }
+    const double min_dist = w.ped_min_dists[l];
+    const int coll = w.is_coll[l];
+    const int arr = w.is_arr[l];
+    w.is_collisions[l] = (int8_t)coll;
+    w.is_arrives[l] = (uint8_t)arr;
+    const double dist = sqrt((double)s0 * (double)s0 + (double)s1 * (double)s1);  // yaml_env.py:467
+    const double step_d = is_reset ? 0.0 : w.tmp_dist[l] - dist;
+    w.step_ds[l] = step_d;
+    w.tmp_dist[l] = dist;
+    if (is_reset) {
+        w.base_rewards[l] = 0;
+        w.base_dones[l] = 0;
+        w.py_done[l] = 0;  // self.dones = zeros (yaml_env.py:316)
+        w.rewards[l] = 0.0;
+        w.paper_rewards[l] = 0.0;
+        w.dones[l] = 0;
+        w.dones_info[l] = 0;
+        w.is_clean[l] = 1;
+        w.clean_state[l] = 1;
+        if (l == 0) w.counters[0] = 0;
+        return 0;
+    }
+    // ImageEnv.step (yaml_env.py:372-377)
+    w.base_rewards[l] = arr - coll;
+    int d = (coll > 1 ? 1 : coll) + arr;
+    d = d > 1 ? 1 : d;
+    w.base_dones[l] = (uint8_t)d;
+    w.py_done[l] = (uint8_t)d;
+    // TimeLimitWrapper (base.py:222-227)
+    const bool timeout = elapsed > w.time_max;
+    const int done = timeout ? 1 : d;
+    int dinfo = timeout ? 10 : 0;
+    // SensorsPaperRewardWrapper._each_r (base.py:164-188)
+    double collision_reward = 0, reach_reward = 0, step_reward = 0, distance_reward = 0;
+    if (min_dist <= w.ped_safety_space) collision_reward = -50 * (w.ped_safety_space - min_dist);
+    if (coll > 0) {
+        collision_reward = -500;
+    } else {
+        if (dist < 0.3 || arr) {
+            reach_reward = 500.0;
+        } else {
+            distance_reward = step_d * 200;
+            step_reward = -5;
+        }
+    }
+    double reward = collision_reward + reach_reward + step_reward + distance_reward + 0.0;
+    // InfoLogWrapper (base.py:241-254)
+    if (coll > 0) dinfo = coll;
+    if (arr == 1) dinfo = 5;
+    // MultiRobotCleanWrapper (base.py:79-88)
+    w.paper_rewards[l] = reward;
+    const uint8_t clean_before = w.clean_state[l];
+    if (!clean_before) reward = 0;
+    w.rewards[l] = reward;
+    w.dones[l] = (uint8_t)done;
+    w.dones_info[l] = dinfo;
+    w.is_clean[l] = clean_before;
+    w.clean_state[l] = done > 0 ? 0 : clean_before;
+    if (l == 0) w.counters[0] = elapsed;
+    return done;
+}
+
+#define PM_CAP 512  // cells of a robot's ped_map that may be non-zero before it falls back to dense clears
+
+// LDS: key[PP] f64 sort keys | info[P] float4 (px,py,vx,vy) | ord[PP] u16 sorted ped index |
+//      inbox[PP] u16 ranks of the pedestrians inside the +-3 m box | stage[64*7] f32 | touched[PM_CAP] u16
+__global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int l = blockIdx.x, lane = lane_id();
+    const int i = w.r0 + l;
+    const int P = w.P, Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
+    const int Pa = P > 0 ? P : 1;
+    double* key = (double*)smem;
+    float4* info = (float4*)(smem + (size_t)PP * 8);
+    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)Pa * 16);
+    uint16_t* inbox = ord + PP;
+    float* stage = (float*)(inbox + PP);
+    uint16_t* touched = (uint16_t*)(stage + WAVE * 7);
+
+    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
+    PHASE_BEGIN();
     double min_dist = w.ped_min_dists[l];
     if (P > 0) {
         // PedInfo in the robot base frame, float32 on the wire (img_env.cpp:568-584)
@@ -927,66 +1099,18 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int is_reset, int elap
         }
     }
     PHASE_MARK(11);
-    if (lane != 0) return;
-    // ---- scalar tail on lane 0: _get_states distances, ImageEnv.step, wrapper stack ----
-    w.ped_min_dists[l] = min_dist;
-    const int coll = w.is_coll[l];
-    const int arr = w.is_arr[l];
-    w.is_collisions[l] = (int8_t)coll;
-    w.is_arrives[l] = (uint8_t)arr;
-    const double dist = sqrt((double)s0 * (double)s0 + (double)s1 * (double)s1);  // yaml_env.py:467
-    const double step_d = is_reset ? 0.0 : w.tmp_dist[l] - dist;
-    w.step_ds[l] = step_d;
-    w.tmp_dist[l] = dist;
-    if (is_reset) {
-        w.base_rewards[l] = 0;
-        w.base_dones[l] = 0;
-        w.py_done[l] = 0;  // self.dones = zeros (yaml_env.py:316)
-        w.rewards[l] = 0.0;
-        w.paper_rewards[l] = 0.0;
-        w.dones[l] = 0;
-        w.dones_info[l] = 0;
-        w.is_clean[l] = 1;
-        w.clean_state[l] = 1;
-        if (l == 0) w.counters[0] = 0;
-        return;
-    }
-    // ImageEnv.step (yaml_env.py:372-377)
-    w.base_rewards[l] = arr - coll;
-    int d = (coll > 1 ? 1 : coll) + arr;
-    d = d > 1 ? 1 : d;
-    w.base_dones[l] = (uint8_t)d;
-    w.py_done[l] = (uint8_t)d;
-    // TimeLimitWrapper (base.py:222-227)
-    const bool timeout = elapsed > w.time_max;
-    const int done = timeout ? 1 : d;
-    int dinfo = timeout ? 10 : 0;
-    // SensorsPaperRewardWrapper._each_r (base.py:164-188)
-    double collision_reward = 0, reach_reward = 0, step_reward = 0, distance_reward = 0;
-    if (min_dist <= w.ped_safety_space) collision_reward = -50 * (w.ped_safety_space - min_dist);
-    if (coll > 0) {
-        collision_reward = -500;
-    } else {
-        if (dist < 0.3 || arr) {
-            reach_reward = 500.0;
-        } else {
-            distance_reward = step_d * 200;
-            step_reward = -5;
-        }
-    }
-    double reward = collision_reward + reach_reward + step_reward + distance_reward + 0.0;
-    // InfoLogWrapper (base.py:241-254)
-    if (coll > 0) dinfo = coll;
-    if (arr == 1) dinfo = 5;
-    // MultiRobotCleanWrapper (base.py:79-88)
-    w.paper_rewards[l] = reward;
-    const uint8_t clean_before = w.clean_state[l];
-    if (!clean_before) reward = 0;
-    w.rewards[l] = reward;
-    w.dones[l] = (uint8_t)done;
-    w.dones_info[l] = dinfo;
-    w.is_clean[l] = clean_before;
-    w.clean_state[l] = done > 0 ? 0 : clean_before;
-    if (done > 0) atomicAdd(&w.counters[1], 1);
-    if (l == 0) w.counters[0] = elapsed;
+    WAVE_DONE(1);
+    if (lane == 0) w.ped_min_dists[l] = min_dist;
 }
+
+// Per-robot scalars, one thread per robot: Agent::get_state (agent.cpp:156-184), the _get_states distances,
+// ImageEnv.step and the wrapper stack (reward / done).  Runs after k_view (collision code) and k_obs (ped distance).
+__global__ void k_tail(DevWorld w, int is_reset, int elapsed) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = l < w.RL;
+    int done = 0;
+    if (valid) done = tail_robot(w, l, is_reset, elapsed);
+    const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
+    if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
+}
+

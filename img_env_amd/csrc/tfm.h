@@ -114,11 +114,54 @@ TFM_HD double tf_yaw_from_quaternion_zw(double qz, double qw) {
     return atan2(r.m10 / 1.0, r.m00 / 1.0);
 }
 
+// C round() (half away from zero) as an int.  On the device: round-to-nearest-even (one instruction) is the
+// same integer except on exact .5 ties, which take the rare second branch.
+TFM_HD int round_away_i(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = rint(t);
+    if (__builtin_expect(fabs(t - r) == 0.5, 0)) r = t + copysign(0.5, t);  // t - r is exact
+    return (int)r;
+#else
+    return (int)round(t);
+#endif
+}
 // GridMap::world2map (grid_map.cpp:40-44): C round(), half away from zero
-TFM_HD int w2m(double v, double res) { return (int)round(v / res); }
+TFM_HD int w2m(double v, double res) { return round_away_i(v / res); }
+#if defined(__HIPCC__)
+// Device rounding in two steps: round-to-nearest-even now, and a flag that says whether any of the values was
+// an exact .5 tie (where C round() differs); callers test the flag once per group of cells and only then
+// redo the group with round_tie_fix.  Keeps the hot loops free of per-value branches.
+__device__ __forceinline__ int round_even_i(double t, bool& tie) {
+    const double r = rint(t);
+    tie |= fabs(t - r) == 0.5;  // t - r is exact
+    return (int)r;
+}
+__device__ __forceinline__ int round_tie_fix(double t) {
+    const double r = rint(t);
+    return (int)(fabs(t - r) == 0.5 ? t + copysign(0.5, t) : r);
+}
+#endif
 // When the resolution is a power of two, v * (1/res) and v / res are the same exact scaling, so the
 // (much cheaper) multiply is bit-identical to the reference's division.
 template <bool POW2>
-TFM_HD int w2m_t(double v, double res, double inv_res) {
-    return (int)round(POW2 ? v * inv_res : v / res);
+TFM_HD double w2m_scale(double v, double res, double inv_res) {
+    return POW2 ? v * inv_res : v / res;
 }
+template <bool POW2>
+TFM_HD int w2m_t(double v, double res, double inv_res) {
+    return round_away_i(w2m_scale<POW2>(v, res, inv_res));
+}
+#if defined(__HIPCC__)
+// both cell indices of a world point, one (rarely taken) branch for the pair
+template <bool POW2>
+__device__ __forceinline__ void w2m_pair(double wx, double wy, double res, double inv_res, int& m, int& n) {
+    const double tx = w2m_scale<POW2>(wx, res, inv_res), ty = w2m_scale<POW2>(wy, res, inv_res);
+    bool tie = false;
+    m = round_even_i(tx, tie);
+    n = round_even_i(ty, tie);
+    if (__builtin_expect(tie, 0)) {
+        m = round_tie_fix(tx);
+        n = round_tie_fix(ty);
+    }
+}
+#endif

@@ -30,7 +30,8 @@ struct RobotClassDev {
     int ray_maxlen;              // longest ray in cells
     int ray_stride;              // beams padded to a multiple of 64
     int ray_kpad;                // ray_maxlen padded to a multiple of 8
-    const uint16_t* ray_rows;    // [beams][ray_kpad] view cell index of step k of beam b (16-byte chunks per lane)
+    const uint16_t* ray_rows;    // [ray_kpad / 8][ray_stride][8] view cell index of steps 8c..8c+7 of beam b: one 16-byte
+                                 // chunk per lane, consecutive lanes contiguous; padding points at a free dummy cell
     const uint16_t* ray_len;     // [ray_stride] number of in-map steps before the ray leaves / ends
     const float* ray_dist;       // [ray_maxlen][ray_stride] float32(hit distance) if the hit is at step k
     const uint32_t* inv_pack;    // [Hv*Wv] rays through a view cell: first entry | count << 20 ...
@@ -94,6 +95,10 @@ struct DevWorld {
     double* tmp_dist;                         // [RL]
     uint16_t* pm_cells;                       // [RL][PM_CAP] ped_map cells written by the last step
     int* pm_n;                                // [RL] their count, -1 = unknown (dense clear needed)
+    uint2* fp_cells;                          // [RL][fp_cap] grid cells under the footprint (cell, last sample index + 1), from k_raster
+    int* fp_n;                                // [RL] their count, -1 = not available (k_view walks the samples itself)
+    int fp_cap, box_cells;                    // list capacity; LDS box cells of k_raster (max over classes)
+    int hit_stride;                           // max ray_stride over classes (LDS layout of k_view)
     // pedestrians
     double *ppx, *ppy, *pyaw, *plx, *ply, *pvx, *pvy, *prem, *llx, *lly, *rlx, *rly;  // [P]
     int *pstate, *ptraj_idx;                                                       // [P]

@@ -188,7 +188,7 @@ typedef struct imgenv_out {
     /* simulator state mirrors, handy for tests and GUIs */
     double* robot_pose;           /* [R][3] x, y, theta */
     double* ped_state;            /* [n_peds][4] x, y, vx, vy (world copy) */
-    int32_t* counters;            /* [4]: steps since reset, #done robots (local), #frozen views (local), reserved */
+    int32_t* counters;            /* [4]: steps since reset, #done robots of the last step (local), #frozen views since reset (local), #frozen views since create */
 } imgenv_out;
 
 typedef struct imgenv imgenv_t;
@@ -255,7 +255,8 @@ int imgenv_step_launches(imgenv_t* h);
 #define IMGENV_K_COMPOSE 4
 #define IMGENV_K_VIEW 5
 #define IMGENV_K_OBS 6
-#define IMGENV_K_COUNT 7
+#define IMGENV_K_TAIL 7
+#define IMGENV_K_COUNT 8
 int imgenv_timing(imgenv_t* h, int mode, int which);
 /* synchronises the recorded events and returns accumulated milliseconds / launch counts per kernel
  * id since the last imgenv_timing() call; arrays of IMGENV_K_COUNT entries */

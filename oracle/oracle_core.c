@@ -803,7 +803,6 @@ static void agent_view(oracle_world* w, int l, const gridview* g) {
 /* ImgEnv::view_agent (img_env.cpp:589-592) */
 static void view_agent(oracle_world* w) {
     view_ped(w);
-    w->out.counters[2] = 0;
     if (w->cfg.flags & IMGENV_FLAG_PRIVATE_GRIDS) {
         for (int l = 0; l < w->RL; l++) {
             build_private(w, w->r0 + l, w->priv);
@@ -1049,6 +1048,7 @@ int oracle_reset(oracle_world* w, const imgenv_reset_batch* b) {
     w->elapsed = 0;  /* TimeLimitWrapper.reset (base.py:229-231) */
     w->out.counters[0] = 0;
     w->out.counters[1] = 0;
+    w->out.counters[2] = 0; /* frozen views since this reset */
     w->has_reset = 1;
     view_agent(w);
     get_states(w);

@@ -1,0 +1,51 @@
+"""Per-wave timeline of k_view / k_obs (needs the -DIMGENV_PHASE_PROFILE build): how long each robot's wavefront
+lives, when it starts relative to the first one, and how many are resident at once.
+usage (on the GPU box): python tools/wave_timeline.py"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+so = os.path.join(g.CSRC, "libimgenv_hip_tl.so")
+subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + ["-DIMGENV_WAVE_TIMELINE", os.path.join(g.CSRC, "imgenv_hip.hip"), "-o", so])
+from img_env_amd import _cabi, worldgen  # noqa: E402
+_cabi.library_path = lambda: so
+import torch  # noqa: E402
+from img_env_amd.world import World  # noqa: E402
+
+R, P, res = 8192, 200, 0.25
+grid = worldgen.make_grid(400, 0)
+layout = worldgen.make_layout(grid, res, R, P, seed=100, clearance=0.7)
+w = World(worldgen.make_params(R, P, res=res, scene="rvoscene"), grid)
+w.lib.imgenv_debug_waves.argtypes = [C.c_void_p, C.c_void_p]
+w.reset(layout)
+a = torch.zeros(R, 3, device="cuda")
+a[:, 1] = torch.rand(R, device="cuda") * 1.8 - 0.9
+for s in range(12):
+    w.step(a)
+buf = np.zeros(8 * R, dtype=np.uint64)
+w.lib.imgenv_debug_waves(w.h, buf.ctypes.data_as(C.c_void_p))
+for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:].reshape(R, 4))):
+    t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
+    ok = (t1 > 0) & (t0 > t0.max() - 30000)  # this launch only: frozen robots keep the record of an older step
+    xc = (rec[:, 3] & 0xF).astype(np.int64)
+    print("   per-XCC first start (ticks): " + " ".join(str(int(t0[ok & (xc == x)].min() - t0[ok].min())) for x in sorted(set(xc[ok].tolist()))))
+    base = t0[ok].min()
+    s, e = (t0[ok] - base) / 100.0, (t1[ok] - base) / 100.0  # 100 MHz wall clock -> us
+    d = e - s
+    print("%s: %d waves, span %.1f us; wave life us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (
+        name, ok.sum(), e.max(), d.min(), *np.percentile(d, [10, 50, 90, 99]), d.max()))
+    print("   starts us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % (*np.percentile(s, [10, 50, 90]), s.max()))
+    ts = np.linspace(0, e.max(), 11)[1:-1]
+    print("   resident waves at " + " ".join("%.0fus:%d" % (t, ((s <= t) & (e > t)).sum()) for t in ts))
+    hw = rec[ok, 2]
+    cu = (hw >> 8) & 0xF
+    se = (hw >> 13) & 0x7
+    xcc = rec[ok, 3] & 0xF
+    print("   distinct (xcc,se,cu): %d" % len(set(zip(xcc.tolist(), se.tolist(), cu.tolist()))))
