@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--peds", type=int, default=N_PEDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true")
+    ap.add_argument("--spinup", type=int, default=2000, help="untimed steps before the warm-up (clock ramp)")
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
                     "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
@@ -217,6 +218,9 @@ def main():
     per_kernel_us = kernel_breakdown()
     dominant = max(per_kernel_us, key=per_kernel_us.get)
     dom_id = list(per_kernel_us).index(dominant)
+    # untimed spin-up: the first ~second of sustained work after start-up runs at lower clocks than steady state
+    if args.spinup > 0:
+        run("active", args.spinup, 0)
     # pass 2: THE timed region; HIP events only around the dominant kernel
     dt, tm, frozen_active = run("active", args.steps, args.warmup, timing_mode=2, which=dom_id)
     dom_ms, dom_n = tm[dominant]

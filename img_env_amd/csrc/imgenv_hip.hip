@@ -62,6 +62,8 @@ struct imgenv {
     int comm_ranks = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side2 = nullptr;  // pedestrian observation (k_obs) underneath raster / compose / view
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     bool orca_pending = false;
     RvoObstacles rvo;
     int sfm_cap_obs = 0;
@@ -284,6 +286,12 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamSynchronize(h->side);
         (void)hipStreamDestroy(h->side);
     }
+    if (h->side2) {
+        (void)hipStreamSynchronize(h->side2);
+        (void)hipStreamDestroy(h->side2);
+    }
+    if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
+    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
@@ -652,6 +660,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (h->lds_obs > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)k_obs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipDeviceSynchronize());
@@ -712,6 +723,13 @@ __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const size_t G = (size_t)h->Hg * h->Wg;
+    if (h->P > 0) {  // the pedestrian half of the observation needs poses only: it runs beside the rasters and the view
+        HIPCHK(hipEventRecord(h->ev_fork2, st));
+        HIPCHK(hipStreamWaitEvent(h->side2, h->ev_fork2, 0));
+        TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, h->side2>>>(d, h->PP)));
+        HIPCHK(hipEventRecord(h->ev_join2, h->side2));
+        h->launches += 1;
+    }
     if (h->pow2)
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     else
@@ -733,10 +751,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         else if (variant == 1) TIMED(h, IMGENV_K_VIEW, st, (k_view<false, true><<<gv, bv, h->lds_view, st>>>(d)));
         else TIMED(h, IMGENV_K_VIEW, st, (k_view<false, false><<<gv, bv, h->lds_view, st>>>(d)));
     }
-    if (h->P > 0) {
-        TIMED(h, IMGENV_K_OBS, st, (k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, st>>>(d, h->PP)));
-        h->launches += 1;
-    }
+    if (h->P > 0) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed)));
     h->launches += 4;
     HIPCHK(hipGetLastError());
