@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true")
     ap.add_argument("--spinup", type=int, default=2000, help="untimed steps before the warm-up (clock ramp)")
+    ap.add_argument("--timing-mode", type=int, default=2, help="diagnostic: 0 = no HIP events in the timed pass")
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
                     "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
@@ -222,7 +223,7 @@ def main():
     if args.spinup > 0:
         run("active", args.spinup, 0)
     # pass 2: THE timed region; HIP events only around the dominant kernel
-    dt, tm, frozen_active = run("active", args.steps, args.warmup, timing_mode=2, which=dom_id)
+    dt, tm, frozen_active = run("active", args.steps, args.warmup, timing_mode=args.timing_mode, which=dom_id)
     dom_ms, dom_n = tm[dominant]
     value = R * args.steps / dt
     for q in range(args.repeat):

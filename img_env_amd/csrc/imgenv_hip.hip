@@ -55,6 +55,7 @@ struct imgenv {
     bool has_reset = false;
     int launches = 0;
     size_t lds_view = 0, lds_obs = 0;
+    int obs_E = 0;  // sort slots per lane of k_obs (0: LDS sort)
     bool pow2 = false;
     // the ORCA solve of step t+1 only needs what exists after the rasters of step t, so it runs on a side
     // stream underneath the view / observation kernels of step t (200 waves alone cannot fill the chip)
@@ -69,6 +70,7 @@ struct imgenv {
     int sfm_cap_obs = 0;
     // live timing (imgenv_timing)
     int t_mode = 0, t_which = -1;
+    unsigned t_tick = 0;
     std::vector<hipEvent_t> t_ev;
     std::vector<int> t_id;  // kernel id of event pair q
     size_t t_used = 0;
@@ -121,7 +123,12 @@ static int timing_flush(imgenv* h) {
     h->t_used = 0;
     return 0;
 }
-static inline bool timing_on(const imgenv* h, int id) { return h->t_mode == 1 || (h->t_mode == 2 && h->t_which == id); }
+// mode 1: every launch of every kernel; mode 2: every 8th launch of one kernel (an event pair costs the stream a
+// dependency barrier, ~5 us of idle GPU, so the timed bench pass samples instead of bracketing every step)
+static inline bool timing_on(imgenv* h, int id) {
+    if (h->t_mode == 1) return true;
+    return h->t_mode == 2 && h->t_which == id && (h->t_tick++ & 7) == 0;
+}
 static int timing_mark(imgenv* h, int id, hipStream_t st, int end) {
     if (!end) {
         if (h->t_used * 2 + 2 > h->t_ev.size()) {
@@ -641,12 +648,13 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK(hipMemcpy(o.ped_min_dists, inf.data(), sizeof(double) * RL, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(o.is_clean, 1, RL));
     }
-    h->PP = 2;
+    h->PP = WAVE;  // sort slots of k_obs: a power of two, 64 * E of them in registers up to 1024 pedestrians
     while (h->PP < P) h->PP <<= 1;
+    h->obs_E = h->PP <= 1024 ? h->PP / WAVE : 0;
     const size_t NC = (size_t)g.Hv * g.Wv;
     d.hit_stride = (int)max_stride;
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv;  // src u8 (+ dummy cells) | hit u32 | column terms
-    h->lds_obs = (size_t)h->PP * 8 + (size_t)(P > 0 ? P : 1) * 16 + (size_t)h->PP * 4 + WAVE * 7 * 4 + PM_CAP * 2 + 16;
+    h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(P > 0 ? P : 1) * 16 + (size_t)h->PP * 4 + WAVE * 7 * 4 + PM_CAP * 2 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);
         FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
@@ -658,7 +666,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK(hipFuncSetAttribute((const void*)k_view<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
     }
     if (h->lds_obs > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)k_obs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+        HIPCHK(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
@@ -726,7 +734,15 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     if (h->P > 0) {  // the pedestrian half of the observation needs poses only: it runs beside the rasters and the view
         HIPCHK(hipEventRecord(h->ev_fork2, st));
         HIPCHK(hipStreamWaitEvent(h->side2, h->ev_fork2, 0));
-        TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<<<dim3(h->RL), dim3(WAVE), h->lds_obs, h->side2>>>(d, h->PP)));
+        const dim3 go(h->RL), bo(WAVE);
+        switch (h->obs_E) {
+            case 1: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<1><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
+            case 2: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<2><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
+            case 4: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<4><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
+            case 8: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<8><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
+            case 16: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<16><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
+            default: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<0><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
+        }
         HIPCHK(hipEventRecord(h->ev_join2, h->side2));
         h->launches += 1;
     }
@@ -925,15 +941,16 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
             HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
             h->orca_pending = false;
         }
-        TIMED(h, IMGENV_K_PED_UPDATE, st, (k_ped_update<<<dim3((h->P + 63) / 64), dim3(64), 0, st>>>(d)));
-        h->launches += 1;
     }
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
         TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), 0, st>>>(d)));
         h->launches += 1;
     }
     // _step_robot (img_env.cpp:388-410)
-    TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, actions)));
+    {   // ... and the pedestrians' move (img_env.cpp:343-358) in the same launch
+        const int nb_robot = (h->RL + 127) / 128, nb_ped = (h->P > 0 && h->NA > 0) ? (h->P + 127) / 128 : 0;
+        TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot)));
+    }
     h->launches += 1;
     HIPCHK(hipGetLastError());
     return IMGENV_OK;

@@ -150,9 +150,7 @@ __device__ void ped_leg_gait(const DevWorld& w, int j, double x, double y, doubl
 
 // Agent::update (Agent.cpp:840-843), getNewPosAndVel (rvoscene.h:72-82), set_position + update_bbox
 // (agent.cpp:691-735)
-__global__ void k_ped_update(DevWorld w) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= w.P) return;
+__device__ __forceinline__ void ped_update_one(const DevWorld& w, int j) {
     const float ts = (float)w.step_hz;
     const float vx = w.anvx[j], vy = w.anvy[j];
     w.avx[j] = vx;
@@ -315,7 +313,14 @@ __device__ __forceinline__ void integrate_robot(const DevWorld& w, const float* 
     w.is_arr[l] = is_arrive ? 1 : 0;
 }
 
-__global__ void k_integrate(DevWorld w, const float* __restrict__ actions) {
+// One launch for the two independent per-agent updates of a step: blocks [0, nb_robot) integrate the robots,
+// the blocks behind them (ped_blocks of them) move the ORCA pedestrians by the velocities k_orca solved for.
+__global__ void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot) {
+    if ((int)blockIdx.x >= nb_robot) {
+        const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
+        if (j < w.P) ped_update_one(w, j);
+        return;
+    }
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = l < w.RL;
     // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
@@ -941,15 +946,61 @@ __device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset
 
 // LDS: key[PP] f64 sort keys | info[P] float4 (px,py,vx,vy) | ord[PP] u16 sorted ped index |
 //      inbox[PP] u16 ranks of the pedestrians inside the +-3 m box | stage[64*7] f32 | touched[PM_CAP] u16
+// Stable sort of 64 * E (key, index) pairs by (key, index), E pairs per lane in registers: a bitonic network
+// whose compare-exchanges run on registers (partner in the same lane) or over lane shuffles (partner lane =
+// lane ^ m) -- no LDS traffic, no barriers.  Slot e = lane * E + r; afterwards slot e holds the e-th smallest.
+template <int E>
+__device__ __forceinline__ void sort_pairs_in_registers(double (&key)[E], uint32_t (&id)[E], int lane) {
+#pragma unroll
+    for (int size = 2; size <= WAVE * E; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= E) {
+                const int lm = stride / E;
+                const bool lower = (lane & lm) == 0;
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const bool up = ((lane * E + r) & size) == 0;
+                    const double pk = __shfl_xor(key[r], lm);
+                    const uint32_t pi = (uint32_t)__shfl_xor((int)id[r], lm);
+                    const bool self_gt = (key[r] > pk) | ((key[r] == pk) & (id[r] > pi));
+                    const bool take = (lower == up) ? self_gt : !self_gt;  // the lower slot keeps the smaller pair when ascending
+                    key[r] = take ? pk : key[r];
+                    id[r] = take ? pi : id[r];
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < E; a++) {
+                    const int b = a ^ stride;
+                    if (b > a) {
+                        const bool up = ((lane * E + a) & size) == 0;
+                        const bool gt = (key[a] > key[b]) | ((key[a] == key[b]) & (id[a] > id[b]));
+                        const bool sw = gt == up;
+                        const double ka = key[a], kb = key[b];
+                        const uint32_t ia = id[a], ib = id[b];
+                        key[a] = sw ? kb : ka;
+                        key[b] = sw ? ka : kb;
+                        id[a] = sw ? ib : ia;
+                        id[b] = sw ? ia : ib;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// E > 0: PP = 64 * E sort slots held in registers; E == 0: any PP = 2^k, sorted in LDS (more than 1024 pedestrians)
+template <int E>
 __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = blockIdx.x, lane = lane_id();
     const int i = w.r0 + l;
     const int P = w.P, Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
     const int Pa = P > 0 ? P : 1;
+    const size_t key_bytes = E == 0 ? (size_t)PP * 8 : 0;
     double* key = (double*)smem;
-    float4* info = (float4*)(smem + (size_t)PP * 8);
-    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)Pa * 16);
+    float4* info = (float4*)(smem + key_bytes);
+    uint16_t* ord = (uint16_t*)(smem + key_bytes + (size_t)Pa * 16);
     uint16_t* inbox = ord + PP;
     float* stage = (float*)(inbox + PP);
     uint16_t* touched = (uint16_t*)(stage + WAVE * 7);
@@ -959,43 +1010,69 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
     PHASE_BEGIN();
     double min_dist = w.ped_min_dists[l];
     if (P > 0) {
-        // PedInfo in the robot base frame, float32 on the wire (img_env.cpp:568-584)
+        // PedInfo in the robot base frame, float32 on the wire (img_env.cpp:568-584); sort key yaml_env.py:451
         const Tf2 wb = tf_inverse(bw);
-        for (int j = lane; j < PP; j += WAVE) {
-            if (j < P) {
-                double px, py;
-                tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
-                const double vx = (wb.m00 * w.pvx[j] + wb.m01 * w.pvy[j]) + 0.0;
-                const double vy = (wb.m10 * w.pvx[j] + wb.m11 * w.pvy[j]) + 0.0;
-                const float fx = (float)px, fy = (float)py;
-                info[j] = make_float4(fx, fy, (float)vx, (float)vy);
-                key[j] = (double)fx * (double)fx + (double)fy * (double)fy;  // yaml_env.py:451
-                ord[j] = (uint16_t)j;
-            } else {
-                key[j] = __builtin_huge_val();
-                ord[j] = 0xFFFF;
-            }
-        }
-        __syncthreads();
-        PHASE_MARK(8);
-        // stable sort by (key, index): bitonic network over PP = 2^k entries in LDS
-        for (int kk = 2; kk <= PP; kk <<= 1) {
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                for (int t2 = lane; t2 < PP / 2; t2 += WAVE) {
-                    const int a = ((t2 / jj) * 2 * jj) + (t2 % jj);
-                    const int b = a + jj;
-                    const bool up = ((a & kk) == 0);
-                    const double ka = key[a], kb = key[b];
-                    const uint16_t oa = ord[a], ob = ord[b];
-                    const bool a_gt_b = (ka > kb) || (ka == kb && oa > ob);
-                    if (a_gt_b == up) {
-                        key[a] = kb;
-                        key[b] = ka;
-                        ord[a] = ob;
-                        ord[b] = oa;
-                    }
+        if (E > 0) {
+            double skey[E > 0 ? E : 1];
+            uint32_t sid[E > 0 ? E : 1];
+#pragma unroll
+            for (int q = 0; q < (E > 0 ? E : 1); q++) {
+                const int j = lane + WAVE * q;
+                skey[q] = __builtin_huge_val();
+                sid[q] = 0xFFFFu;
+                if (j < P) {
+                    double px, py;
+                    tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
+                    const double vx = (wb.m00 * w.pvx[j] + wb.m01 * w.pvy[j]) + 0.0;
+                    const double vy = (wb.m10 * w.pvx[j] + wb.m11 * w.pvy[j]) + 0.0;
+                    const float fx = (float)px, fy = (float)py;
+                    info[j] = make_float4(fx, fy, (float)vx, (float)vy);
+                    skey[q] = (double)fx * (double)fx + (double)fy * (double)fy;
+                    sid[q] = (uint32_t)j;
                 }
-                __syncthreads();
+            }
+            PHASE_MARK(8);
+            sort_pairs_in_registers<(E > 0 ? E : 1)>(skey, sid, lane);
+#pragma unroll
+            for (int q = 0; q < (E > 0 ? E : 1); q++) ord[lane * (E > 0 ? E : 1) + q] = (uint16_t)sid[q];
+            __syncthreads();
+        } else {
+            for (int j = lane; j < PP; j += WAVE) {
+                if (j < P) {
+                    double px, py;
+                    tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
+                    const double vx = (wb.m00 * w.pvx[j] + wb.m01 * w.pvy[j]) + 0.0;
+                    const double vy = (wb.m10 * w.pvx[j] + wb.m11 * w.pvy[j]) + 0.0;
+                    const float fx = (float)px, fy = (float)py;
+                    info[j] = make_float4(fx, fy, (float)vx, (float)vy);
+                    key[j] = (double)fx * (double)fx + (double)fy * (double)fy;
+                    ord[j] = (uint16_t)j;
+                } else {
+                    key[j] = __builtin_huge_val();
+                    ord[j] = 0xFFFF;
+                }
+            }
+            __syncthreads();
+            PHASE_MARK(8);
+            // stable sort by (key, index): bitonic network over PP = 2^k entries in LDS
+            for (int kk = 2; kk <= PP; kk <<= 1) {
+                for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                    for (int t2 = lane; t2 < PP / 2; t2 += WAVE) {
+                        const int a = ((t2 / jj) * 2 * jj) + (t2 % jj);
+                        const int b = a + jj;
+                        const bool up = ((a & kk) == 0);
+                        const double ka = key[a], kb = key[b];
+                        const uint16_t oa = ord[a], ob = ord[b];
+                        const bool a_gt_b = (ka > kb) || (ka == kb && oa > ob);
+                        if (a_gt_b == up) {
+                            key[a] = kb;
+                            key[b] = ka;
+                            ord[a] = ob;
+                            ord[b] = oa;
+                        }
+                    }
+                    __syncthreads();
+                }
             }
         }
         PHASE_MARK(9);

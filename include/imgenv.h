@@ -247,7 +247,8 @@ int imgenv_outputs(imgenv_t* h, imgenv_out* out);
 int imgenv_step_launches(imgenv_t* h);
 
 /* Live per-kernel timing with HIP events recorded on the stream the kernels are launched on.
- * mode 0: off; 1: every kernel; 2: only kernel `which`.  Kernel ids: */
+ * mode 0: off; 1: every launch of every kernel; 2: every 8th launch of kernel `which` only (sampling keeps the
+ * event barriers out of most steps).  Kernel ids (K_PED_UPDATE is part of the K_INTEGRATE launch): */
 #define IMGENV_K_ORCA 0
 #define IMGENV_K_PED_UPDATE 1
 #define IMGENV_K_INTEGRATE 2

@@ -27,6 +27,16 @@ CASES = {
                                   ped_shape="leg", clearance=0.8),
     "pedscene_norel": dict(n_robots=12, n_peds=9, seed=16, scene="pedscene", grid_size=88, relation_ped_robo=0,
                            clearance=0.7),
+    # pedestrian sort variants of k_obs: 64 * E register slots (E = 2, 4, 8, 16) and the LDS sort beyond 1024
+    "peds_100_sort2": dict(n_robots=6, n_peds=100, seed=20, grid_size=240, clearance=0.6),
+    "peds_200_sort4": dict(n_robots=6, n_peds=200, seed=21, grid_size=320, clearance=0.6),
+    "peds_300_sort8": dict(n_robots=5, n_peds=300, seed=22, grid_size=400, clearance=0.6),
+    "peds_600_sort16": dict(n_robots=4, n_peds=600, seed=23, grid_size=400, clearance=0.5),
+    "peds_1100_lds_sort": dict(n_robots=3, n_peds=1100, seed=24, grid_size=480, clearance=0.5),
+    # view widths that are not a multiple of 4 (generic k_view variants), power-of-two resolution and not
+    "view_50_not_a4": dict(n_robots=16, n_peds=6, seed=25, view_cells=50),
+    "view_37_odd_res010": dict(n_robots=16, n_peds=6, seed=26, view_cells=37, res=0.1, grid_size=200,
+                               view_width=3.75, view_height=3.75),  # int(3.75 / 0.1) = 37 cells
     "no_laser": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "time_limit": dict(n_robots=4, n_peds=2, seed=9, time_max=6),
 }
