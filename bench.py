@@ -51,11 +51,12 @@ def grid_cells(n_gpus):
 
 
 def algorithmic_bytes(P, hv=48, wv=48, beams=360, max_ped=N_PEDS):
-    """SURVEY 8(d) per robot-step, split by the kernel that moves them"""
-    view = hv * wv + hv * wv + 4 * beams          # grid window gather + sensor_map u8 + lasers f32
+    """SURVEY 8(d) per robot-step (the variant that materialises the f16 copy of the sensor map, as this build
+    does), split by the kernel that moves them"""
+    view = hv * wv + hv * wv + 2 * hv * wv + 4 * beams   # grid window gather + sensor_map u8 + f16 copy + lasers f32
     obs = (20 * P + 3 * 48 * 48 * 4 + 4 * (1 + 7 * max_ped)) if P > 0 else 0
     state = 128
-    return dict(k_view=view, k_obs=obs + state, total=view + obs + state)
+    return dict(k_view=view, k_obs=obs, k_tail=state, total=view + obs + state)
 
 
 def cpu_baseline(params, grid, layout, seconds=12.0):
