@@ -669,10 +669,10 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK(hipDeviceSynchronize());
     *out = h;
     return IMGENV_OK;
@@ -743,7 +743,6 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             case 16: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<16><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
             default: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<0><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
         }
-        HIPCHK(hipEventRecord(h->ev_join2, h->side2));
         h->launches += 1;
     }
     if (h->pow2)
@@ -755,8 +754,11 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         TIMED(h, IMGENV_K_ORCA, h->side, (k_orca<<<dim3(h->P), dim3(WAVE), 0, h->side>>>(d)));
         HIPCHK(hipEventRecord(h->ev_join, h->side));
-        h->orca_pending = true;
         h->launches += 1;
+    }
+    if (h->P > 0) {  // the observation stream's join event also covers the solve: one wait on the caller's stream
+        if (h->NA > 0) HIPCHK(hipStreamWaitEvent(h->side2, h->ev_join, 0));
+        HIPCHK(hipEventRecord(h->ev_join2, h->side2));
     }
     TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
     {
