@@ -731,9 +731,13 @@ __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const size_t G = (size_t)h->Hg * h->Wg;
-    if (h->P > 0) {  // the pedestrian half of the observation needs poses only: it runs beside the rasters and the view
-        HIPCHK(hipEventRecord(h->ev_fork2, st));
-        HIPCHK(hipStreamWaitEvent(h->side2, h->ev_fork2, 0));
+    if (h->P > 0) {
+        // One fork and one join per step on the caller's stream (every event operation costs it a ~6 us dependency
+        // bubble).  Beside the rasters, compose and view run, on two side streams, the pedestrian half of the
+        // observation and the next step's _step_ped_normal solve (img_env.cpp:304-343); both need poses only.  The
+        // observation stream finally waits for the solve, so its join event covers both.
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
         const dim3 go(h->RL), bo(WAVE);
         switch (h->obs_E) {
             case 1: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<1><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
@@ -744,22 +748,20 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             default: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<0><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
         }
         h->launches += 1;
+        if (h->NA > 0) {
+            HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            if (d.relation == 1) k_robot_agents<<<dim3((h->R + 255) / 256), dim3(256), 0, h->side>>>(d, is_reset);
+            TIMED(h, IMGENV_K_ORCA, h->side, (k_orca<<<dim3(h->P), dim3(WAVE), 0, h->side>>>(d)));
+            HIPCHK(hipEventRecord(h->ev_join, h->side));
+            HIPCHK(hipStreamWaitEvent(h->side2, h->ev_join, 0));
+            h->launches += 2;
+        }
+        HIPCHK(hipEventRecord(h->ev_join2, h->side2));
     }
     if (h->pow2)
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     else
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
-    if (h->P > 0 && h->NA > 0) {  // next step's _step_ped_normal solve (img_env.cpp:304-343), overlapped
-        HIPCHK(hipEventRecord(h->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        TIMED(h, IMGENV_K_ORCA, h->side, (k_orca<<<dim3(h->P), dim3(WAVE), 0, h->side>>>(d)));
-        HIPCHK(hipEventRecord(h->ev_join, h->side));
-        h->launches += 1;
-    }
-    if (h->P > 0) {  // the observation stream's join event also covers the solve: one wait on the caller's stream
-        if (h->NA > 0) HIPCHK(hipStreamWaitEvent(h->side2, h->ev_join, 0));
-        HIPCHK(hipEventRecord(h->ev_join2, h->side2));
-    }
     TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
     {
         const dim3 gv(h->RL), bv(WAVE);

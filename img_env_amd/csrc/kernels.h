@@ -459,20 +459,26 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
     } else if (local && lane == 0) {
         w.fp_n[l] = -1;
     }
-    // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417, rvoscene.h:47-51)
-    if (lane == 0 && w.relation == 1 && (w.scene == IMGENV_SCENE_RVO || w.scene == IMGENV_SCENE_ERVO)) {
-        const int a = w.P + i;
-        w.apx[a] = (float)r[0];
-        w.apy[a] = (float)r[1];
-        w.avx[a] = zero_vel ? 0.0f : (float)r[3];
-        w.avy[a] = zero_vel ? 0.0f : (float)r[4];
-    }
+    // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_robot_agents
     if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
         double* p = w.sfm.p + 3 * (size_t)(w.P + i);
         p[0] = r[0];
         p[1] = r[1];
         p[2] = 1.0;
     }
+}
+
+// _step_robot tail for the RVO scenes: setRobotPos for every robot (img_env.cpp:411-417, rvoscene.h:47-51).  Runs on the
+// solve's side stream straight from the gathered robot records, so that the solve does not have to wait for the raster.
+__global__ void k_robot_agents(DevWorld w, int zero_vel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.R) return;
+    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    const int a = w.P + i;
+    w.apx[a] = (float)r[0];
+    w.apy[a] = (float)r[1];
+    w.avx[a] = zero_vel ? 0.0f : (float)r[3];
+    w.avy[a] = zero_vel ? 0.0f : (float)r[4];
 }
 
 template <bool POW2>
