@@ -414,22 +414,34 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
         __syncthreads();
     }
     bool stray = false;
-    for (int q = lane; q < k.n_fp; q += WAVE) {
-        double wx, wy;
-        const double2 fp = k.fp[q];
-        tf_apply(bw, fp.x, fp.y, wx, wy);
-        int m, n;
-        w2m_pair<POW2>(wx, wy, res, inv, m, n);
-        if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            const int dm = m - cm + rad, dn = n - cn + rad;
-            if (use_box && dm >= 0 && dm < side && dn >= 0 && dn < side) {
-                atomicMax(&box[dm * side + dn], (uint32_t)q + 1);
-            } else {
-                const size_t c = (size_t)m * w.Wg + n;
-                atomicMin(&w.own_lo[c], id);
-                atomicMax(&w.own_hi[c], id);
-                stray = true;
+    for (int q0 = 0; q0 < k.n_fp; q0 += WAVE * 4) {  // wave-uniform trip count (lane shuffles inside), 4 loads in flight
+        double2 fp[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) fp[u] = k.fp[min(q0 + u * WAVE + lane, k.n_fp - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u * WAVE + lane;
+            double wx, wy;
+            tf_apply(bw, fp[u].x, fp[u].y, wx, wy);
+            int m, n;
+            w2m_pair<POW2>(wx, wy, res, inv, m, n);
+            int b = -1;  // box cell of this sample
+            if (q < k.n_fp && m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+                const int dm = m - cm + rad, dn = n - cn + rad;
+                if (use_box && dm >= 0 && dm < side && dn >= 0 && dn < side) {
+                    b = dm * side + dn;
+                } else {
+                    const size_t c = (size_t)m * w.Wg + n;
+                    atomicMin(&w.own_lo[c], id);
+                    atomicMax(&w.own_hi[c], id);
+                    stray = true;
+                }
             }
+            // consecutive samples are lattice neighbours and mostly share their cell: only the last lane of each run of
+            // equal cells (it holds the run's highest sample index) touches the LDS box -- a handful of atomics
+            // instead of 64 on a few addresses
+            const int b_next = __shfl_down(b, 1);
+            if (b >= 0 && (lane == WAVE - 1 || b_next != b)) atomicMax(&box[b], (uint32_t)q + 1);
         }
     }
     if (use_box) {
@@ -444,8 +456,10 @@ __device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_
                 const int bm = b / side;
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c = (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
+#ifndef IMGENV_EXPERIMENT_NO_OWNER_ATOMICS
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
+#endif
             }
             if (local) {
                 const unsigned long long mask = __ballot(last != 0);
