@@ -66,6 +66,7 @@ struct imgenv {
     hipStream_t side2 = nullptr;  // pedestrian observation (k_obs) underneath raster / compose / view
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     bool orca_pending = false;
+    bool serial = false;  // IMGENV_SERIAL=1: no side streams (profiling aid)
     RvoObstacles rvo;
     int sfm_cap_obs = 0;
     // live timing (imgenv_timing)
@@ -667,6 +668,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     }
     if (h->lds_obs > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+    h->serial = getenv("IMGENV_SERIAL") && getenv("IMGENV_SERIAL")[0] == '1';
     HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -736,27 +738,34 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // bubble).  Beside the rasters, compose and view run, on two side streams, the pedestrian half of the
         // observation and the next step's _step_ped_normal solve (img_env.cpp:304-343); both need poses only.  The
         // observation stream finally waits for the solve, so its join event covers both.
-        HIPCHK(hipEventRecord(h->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
+        // (IMGENV_SERIAL=1 in the environment keeps everything on the caller's stream: clean per-kernel timings.)
+        const bool overlap = !h->serial;
+        hipStream_t s_obs = overlap ? h->side2 : st, s_orca = overlap ? h->side : st;
+        if (overlap) {
+            HIPCHK(hipEventRecord(h->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(s_obs, h->ev_fork, 0));
+        }
         const dim3 go(h->RL), bo(WAVE);
         switch (h->obs_E) {
-            case 1: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<1><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
-            case 2: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<2><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
-            case 4: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<4><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
-            case 8: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<8><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
-            case 16: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<16><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
-            default: TIMED(h, IMGENV_K_OBS, h->side2, (k_obs<0><<<go, bo, h->lds_obs, h->side2>>>(d, h->PP))); break;
+            case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+            case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+            case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+            case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+            case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+            default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
         }
         h->launches += 1;
         if (h->NA > 0) {
-            HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            if (d.relation == 1) k_robot_agents<<<dim3((h->R + 255) / 256), dim3(256), 0, h->side>>>(d, is_reset);
-            TIMED(h, IMGENV_K_ORCA, h->side, (k_orca<<<dim3(h->P), dim3(WAVE), 0, h->side>>>(d)));
-            HIPCHK(hipEventRecord(h->ev_join, h->side));
-            HIPCHK(hipStreamWaitEvent(h->side2, h->ev_join, 0));
+            if (overlap) HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
+            if (d.relation == 1) k_robot_agents<<<dim3((h->R + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset);
+            TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(h->P), dim3(WAVE), 0, s_orca>>>(d)));
+            if (overlap) {
+                HIPCHK(hipEventRecord(h->ev_join, s_orca));
+                HIPCHK(hipStreamWaitEvent(s_obs, h->ev_join, 0));
+            }
             h->launches += 2;
         }
-        HIPCHK(hipEventRecord(h->ev_join2, h->side2));
+        if (overlap) HIPCHK(hipEventRecord(h->ev_join2, s_obs));
     }
     if (h->pow2)
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
@@ -771,7 +780,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         else if (variant == 1) TIMED(h, IMGENV_K_VIEW, st, (k_view<false, true><<<gv, bv, h->lds_view, st>>>(d)));
         else TIMED(h, IMGENV_K_VIEW, st, (k_view<false, false><<<gv, bv, h->lds_view, st>>>(d)));
     }
-    if (h->P > 0) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
+    if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed)));
     h->launches += 4;
     HIPCHK(hipGetLastError());

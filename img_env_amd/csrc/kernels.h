@@ -672,6 +672,10 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     }
     if (lane < 16) src[NC + lane] = 255;  // dummy free cells behind the view (padded path entries)
     __syncthreads();
+#ifdef IMGENV_EXP_SKIP_CROP
+    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) *(uint32_t*)(src + c4) = 0xFFFFFFFFu;
+    if (false)
+#endif
     for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
         const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds the 4 bits
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
@@ -731,7 +735,13 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     PHASE_MARK(1);
 
     // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
+#ifdef IMGENV_EXP_SKIP_HITS
+    for (int b = lane; b < w.B; b += WAVE) hit[b] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (false) {
+#else
     if (laser) {
+#endif
         const uint4* rows = (const uint4*)k.ray_rows;
         const int n_chunks = k.ray_kpad >> 3;
         for (int b0 = 0; b0 < w.B; b0 += WAVE) {
@@ -750,6 +760,15 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                     const uint32_t key = ((uint32_t)src[c] << 24) | ((uint32_t)(8 * ch + j) << 16) | c;
                     found = min(found, key);
                 }
+#ifdef IMGENV_PHASE_PROFILE
+                {   // how many of the 64 beams of this chunk iteration were still looking for a hit
+                    const unsigned long long act_ = __ballot(!((found < 0x01000000u) | (8 * ch >= len)) || false);
+                    if (lane == 0) {
+                        atomicAdd((unsigned long long*)&w.prof[12], (unsigned long long)__popcll(act_));
+                        atomicAdd((unsigned long long*)&w.prof[13], 64ull);
+                    }
+                }
+#endif
                 if (__all((found < 0x01000000u) | (8 * ch + 8 >= len))) break;
             }
             if (b < w.B) {
@@ -774,6 +793,12 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const uint32_t h0 = w.f16_lut[0], h1 = w.f16_lut[100], h2 = w.f16_lut[200], h3 = w.f16_lut[255];
     const uint32_t lut_lo = (h0 & 0xFFu) | ((h1 & 0xFFu) << 8) | ((h2 & 0xFFu) << 16) | ((h3 & 0xFFu) << 24);
     const uint32_t lut_hi = (h0 >> 8) | ((h1 >> 8) << 8) | ((h2 >> 8) << 16) | ((h3 >> 8) << 24);
+#ifdef IMGENV_EXP_SKIP_FINAL
+    if (false)
+#endif
+    uint16_t* skip_list = (uint16_t*)src;  // the crop is dead once the beams have their hits
+    const int skip_cap = laser ? NC / 2 : 0;
+    int n_skip = 0;
     for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
         uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
         if (laser) {
@@ -806,15 +831,24 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                     skips |= (has & (kk > hk) & alone) ? (1u << q) : 0u;
                     I |= v << (8 * q);
                 }
-                if (__any(skips != 0)) {
-#pragma unroll 1
-                    for (int q = 0; q < 4; q++)
-                        if ((skips >> q) & 1u) {
-                            const uint32_t c = (uint32_t)(c4 + q);
-                            const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
-                            const uint32_t v = resolve_skipped_cell(k, hit, c, cx, cy);
-                            I = (I & ~(0xFFu << (8 * q))) | (v << (8 * q));
+                if (__any(skips != 0)) {  // left alone by their top beam: provisional 200 now, resolved after the pass
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const bool sk = ((skips >> q) & 1u) != 0;
+                        const unsigned long long mask = __ballot(sk);
+                        const int pos = n_skip + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (sk) {
+                            if (pos < skip_cap) {
+                                skip_list[pos] = (uint16_t)(c4 + q);
+                            } else {  // list full (never seen): resolve in place
+                                const uint32_t c = (uint32_t)(c4 + q);
+                                const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
+                                const uint32_t v = resolve_skipped_cell(k, hit, c, cx, cy);
+                                I = (I & ~(0xFFu << (8 * q))) | (v << (8 * q));
+                            }
                         }
+                        n_skip += __popcll(mask);
+                    }
                 }
             }
         } else {
@@ -842,6 +876,24 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
             for (int q = 0; q < 4 && c4 + q < NC; q++) {
                 out_u8[c4 + q] = (uint8_t)(packed >> (8 * q));
                 out_f16[c4 + q] = (uint16_t)((q < 2 ? f01 : f23) >> (16 * (q & 1)));
+            }
+        }
+    }
+    // (5) the cells a top beam left alone, one per lane: the next lower beam through the cell that writes decides
+    //     (agent.cpp:555-560); only values other than the provisional 200 are patched into the two output planes
+    n_skip = min(__builtin_amdgcn_readfirstlane(n_skip), skip_cap);  // lane 0 ran every round of the loop above
+    if (n_skip > 0) {
+        __builtin_amdgcn_s_waitcnt(0);  // the provisional stores of this wave have landed
+        __syncthreads();
+        for (int t = lane; t < n_skip; t += WAVE) {
+            const uint32_t c = skip_list[t];
+            const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
+            uint32_t v = resolve_skipped_cell(k, hit, c, cx, cy);
+            if (v != 2u) {
+                const bool st = ((k.stamp_bits[c >> 5] >> (c & 31)) & 1u) != 0;
+                v = (st && v != 0u) ? 1u : v;
+                out_u8[c] = (uint8_t)(lut_u8 >> (8 * v));
+                out_f16[c] = (uint16_t)(v == 0u ? h0 : (v == 1u ? h1 : h3));
             }
         }
     }

@@ -10,8 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
-so = os.path.join(g.CSRC, "libimgenv_hip_exp.so")
-subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + sys.argv[1:] + [os.path.join(g.CSRC, "imgenv_hip.hip"), "-o", so])
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+out = [a for a in sys.argv[1:] if a.startswith("--out=")]
+so = out[0][6:] if out else os.path.join(g.CSRC, "libimgenv_hip_exp.so")
+subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + args + [os.path.join(g.CSRC, "imgenv_hip.hip"), "-o", so])
+if "--build-only" in sys.argv:
+    sys.exit(0)
 from img_env_amd import _cabi, worldgen  # noqa: E402
 _cabi.library_path = lambda: so
 import torch  # noqa: E402
