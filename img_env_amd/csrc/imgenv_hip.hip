@@ -589,7 +589,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK(hipMemcpy(f.n_nodes, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
     }
-    TRY(dev_alloc(h, &d.prof, 16 + 8 * (size_t)RL));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
+    TRY(dev_alloc(h, &d.prof, 16 + 12 * (size_t)RL));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
 
     // output arena
     ArenaPlan plan;
@@ -768,9 +768,9 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         if (overlap) HIPCHK(hipEventRecord(h->ev_join2, s_obs));
     }
     if (h->pow2)
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P > h->R ? h->P : h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     else
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P + h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P > h->R ? h->P : h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
     {
         const dim3 gv(h->RL), bv(WAVE);
@@ -1043,6 +1043,6 @@ extern "C" int imgenv_debug_phases(imgenv_t* h, unsigned long long* out16) {
 extern "C" int imgenv_debug_waves(imgenv_t* h, unsigned long long* out) {
     if (!h || !out) FAIL(IMGENV_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, h->d.prof + 16, 8 * (size_t)h->RL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, h->d.prof + 16, 12 * (size_t)h->RL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return IMGENV_OK;
 }

@@ -498,11 +498,13 @@ __global__ void k_robot_agents(DevWorld w, int zero_vel) {
 template <bool POW2>
 __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
+    // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
     const int b = blockIdx.x;
-    if (b < w.P)
-        raster_ped<POW2>(w, b);
-    else
-        raster_robot<POW2>(w, b - w.P, (uint32_t*)smem, zero_vel != 0);
+    WAVE_T0();
+    if (b < w.R) raster_robot<POW2>(w, b, (uint32_t*)smem, zero_vel != 0);
+    if (b < w.P) raster_ped<POW2>(w, b);
+    if (b < w.RL) WAVE_DONE(2);
 }
 
 // class layer: one byte per cell that a robot's view kernel can decode without touching the three

@@ -29,9 +29,9 @@ a = torch.zeros(R, 3, device="cuda")
 a[:, 1] = torch.rand(R, device="cuda") * 1.8 - 0.9
 for s in range(12):
     w.step(a)
-buf = np.zeros(8 * R, dtype=np.uint64)
+buf = np.zeros(12 * R, dtype=np.uint64)
 w.lib.imgenv_debug_waves(w.h, buf.ctypes.data_as(C.c_void_p))
-for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:].reshape(R, 4))):
+for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 * R].reshape(R, 4)), ("k_raster", buf[8 * R:].reshape(R, 4))):
     t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
     ok = (t1 > 0) & (t0 > t0.max() - 30000)  # this launch only: frozen robots keep the record of an older step
     xc = (rec[:, 3] & 0xF).astype(np.int64)
