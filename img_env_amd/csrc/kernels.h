@@ -21,6 +21,14 @@
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 // robot class record: by value from the kernel arguments when possible (wave-uniform index)
+// a double that is known to be the same in every lane, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls) {
     return w.rc[cls];
 }
@@ -906,7 +914,6 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
 
 // ------------------------------------------------------------------------------------------------
 // Observation + reward / done for local robot l = blockIdx.x, one wavefront.
-//   LDS: key[PP] f64 sort keys, ord[PP] pedestrian index, info[P] float4 (px,py,vx,vy), rank[Hp*Wp]
 
 // Python float floor division (CPython float_floor_div / _float_div_mod)
 __device__ double py_floordiv(double vx, double wx) {
@@ -1018,8 +1025,8 @@ __device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset
 
 #define PM_CAP 512  // cells of a robot's ped_map that may be non-zero before it falls back to dense clears
 
-// LDS: key[PP] f64 sort keys | info[P] float4 (px,py,vx,vy) | ord[PP] u16 sorted ped index |
-//      inbox[PP] u16 ranks of the pedestrians inside the +-3 m box | stage[64*7] f32 | touched[PM_CAP] u16
+// LDS: (key[PP] f64 sort keys, LDS sort only) | info[P] float2 (px,py) | ord[PP] u16 sorted ped index |
+//      inbox[PP] u16 ranks of the pedestrians inside the +-3 m box | stage[64*7] f32, later touched[PM_CAP] u16
 // Stable sort of 64 * E (key, index) pairs by (key, index), E pairs per lane in registers: a bitonic network
 // whose compare-exchanges run on registers (partner in the same lane) or over lane shuffles (partner lane =
 // lane ^ m) -- no LDS traffic, no barriers.  Slot e = lane * E + r; afterwards slot e holds the e-th smallest.
@@ -1065,7 +1072,7 @@ __device__ __forceinline__ void sort_pairs_in_registers(double (&key)[E], uint32
 
 // E > 0: PP = 64 * E sort slots held in registers; E == 0: any PP = 2^k, sorted in LDS (more than 1024 pedestrians)
 template <int E>
-__global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8 : 4, 8))) void k_obs(DevWorld w, int PP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = blockIdx.x, lane = lane_id();
     const int i = w.r0 + l;
@@ -1073,11 +1080,11 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
     const int Pa = P > 0 ? P : 1;
     const size_t key_bytes = E == 0 ? (size_t)PP * 8 : 0;
     double* key = (double*)smem;
-    float4* info = (float4*)(smem + key_bytes);
-    uint16_t* ord = (uint16_t*)(smem + key_bytes + (size_t)Pa * 16);
+    float2* info = (float2*)(smem + key_bytes);  // position in the robot frame; the velocity is recomputed where needed
+    uint16_t* ord = (uint16_t*)(smem + key_bytes + (size_t)Pa * 8);
     uint16_t* inbox = ord + PP;
     float* stage = (float*)(inbox + PP);
-    uint16_t* touched = (uint16_t*)(stage + WAVE * 7);
+    uint16_t* touched = (uint16_t*)stage;  // the staging buffer is dead by the time discs are stamped
 
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
@@ -1085,7 +1092,13 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
     double min_dist = w.ped_min_dists[l];
     if (P > 0) {
         // PedInfo in the robot base frame, float32 on the wire (img_env.cpp:568-584); sort key yaml_env.py:451
-        const Tf2 wb = tf_inverse(bw);
+        Tf2 wb = tf_inverse(bw);
+        wb.m00 = uniform_f64(wb.m00);  // the same in every lane: scalar registers
+        wb.m01 = uniform_f64(wb.m01);
+        wb.m10 = uniform_f64(wb.m10);
+        wb.m11 = uniform_f64(wb.m11);
+        wb.ox = uniform_f64(wb.ox);
+        wb.oy = uniform_f64(wb.oy);
         if (E > 0) {
             double skey[E > 0 ? E : 1];
             uint32_t sid[E > 0 ? E : 1];
@@ -1097,10 +1110,8 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
                 if (j < P) {
                     double px, py;
                     tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
-                    const double vx = (wb.m00 * w.pvx[j] + wb.m01 * w.pvy[j]) + 0.0;
-                    const double vy = (wb.m10 * w.pvx[j] + wb.m11 * w.pvy[j]) + 0.0;
                     const float fx = (float)px, fy = (float)py;
-                    info[j] = make_float4(fx, fy, (float)vx, (float)vy);
+                    info[j] = make_float2(fx, fy);
                     skey[q] = (double)fx * (double)fx + (double)fy * (double)fy;
                     sid[q] = (uint32_t)j;
                 }
@@ -1115,10 +1126,8 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
                 if (j < P) {
                     double px, py;
                     tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
-                    const double vx = (wb.m00 * w.pvx[j] + wb.m01 * w.pvy[j]) + 0.0;
-                    const double vy = (wb.m10 * w.pvx[j] + wb.m11 * w.pvy[j]) + 0.0;
                     const float fx = (float)px, fy = (float)py;
-                    info[j] = make_float4(fx, fy, (float)vx, (float)vy);
+                    info[j] = make_float2(fx, fy);
                     key[j] = (double)fx * (double)fx + (double)fy * (double)fy;
                     ord[j] = (uint16_t)j;
                 } else {
@@ -1161,15 +1170,17 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
             bool in_box = false;
             if (q < P) {
                 const int j = ord[q];
-                const float4 f = info[j];
+                const float2 f = info[j];
+                const double pvx = w.pvx[j], pvy = w.pvy[j];  // PedInfo velocity in the robot frame (img_env.cpp:576-580)
+                const float fvx = (float)((wb.m00 * pvx + wb.m01 * pvy) + 0.0), fvy = (float)((wb.m10 * pvx + wb.m11 * pvy) + 0.0);
                 const double dpx = f.x, dpy = f.y;
                 const double ped_r = w.ped_r_round[j];
                 const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
                 float* o = stage + lane * 7;
                 o[0] = f.x;
                 o[1] = f.y;
-                o[2] = f.z;
-                o[3] = f.w;
+                o[2] = fvx;
+                o[3] = fvy;
                 o[4] = (float)ped_r;
                 o[5] = (float)(ped_r + rsl);
                 o[6] = dist;
@@ -1213,7 +1224,10 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
         const double pres = w.ped_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
         for (int e = 0; e < n_in; e++) {
             __syncthreads();  // drains this wave's earlier stores: later discs overwrite earlier ones
-            const float4 f = info[ord[inbox[e]]];
+            const int je = ord[inbox[e]];
+            const float2 f = info[je];
+            const double evx = w.pvx[je], evy = w.pvy[je];
+            const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
             const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
             const int ax = (int)py_floordiv(tmx - pr, pres), bx = (int)py_floordiv(tmx + pr, pres);
             const int ay = (int)py_floordiv(tmy - pr, pres), by = (int)py_floordiv(tmy + pr, pres);
@@ -1232,8 +1246,8 @@ __global__ __launch_bounds__(WAVE) void k_obs(DevWorld w, int PP) {
                 }
                 if (hitc) {
                     pm[c] = 1.0f;
-                    pm[NP + c] = f.z;
-                    pm[2 * NP + c] = f.w;
+                    pm[NP + c] = fvx;
+                    pm[2 * NP + c] = fvy;
                 }
                 const unsigned long long mask = __ballot(hitc);
                 const int pos = n_new + __popcll(mask & ((1ull << lane) - 1ull));
