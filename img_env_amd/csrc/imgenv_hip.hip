@@ -56,6 +56,7 @@ struct imgenv {
     int launches = 0;
     size_t lds_view = 0, lds_obs = 0;
     int obs_E = 0;  // sort slots per lane of k_obs (0: LDS sort)
+    int n_sub = 0;  // 0.05 s sub-steps of Agent::cmd per step (agent.cpp:221-236)
     bool pow2 = false;
     // the ORCA solve of step t+1 only needs what exists after the rasters of step t, so it runs on a side
     // stream underneath the view / observation kernels of step t (200 waves alone cannot fill the chip)
@@ -425,7 +426,19 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     d.step_hz = (double)cfg->step_hz; d.laser_max = cfg->laser_max;
     d.ped_safety_space = cfg->ped_safety_space; d.ped_image_r = cfg->ped_image_r;
     d.ped_image_r2 = pow(cfg->ped_image_r, 2.0);        // self.ped_image_r ** 2 (yaml_env.py:425)
+    {   // while (cur_control <= step_hz) { ...; cur_control += 0.05; } with the loop's own fp64 accumulation
+        double cur = 0;
+        h->n_sub = 0;
+        while (cur <= d.step_hz && h->n_sub < (1 << 20)) {
+            h->n_sub++;
+            cur += 0.05;
+        }
+    }
     d.ped_res = 6.0 / cfg->ped_image_size[0];            // yaml_env.py:164
+    {
+        int e = 0;
+        d.ped_inv_res = frexp(d.ped_res, &e) == 0.5 ? 1.0 / d.ped_res : 0.0;
+    }
     d.view_base = g.view_base; d.base_view = g.base_view;
     {   // SpeedLimiter(msg) (speed_limit.cpp:56-65): max_jerk <- msg.min_jerk, min_jerk uninitialised (0 here)
         const imgenv_limiter& v = cfg->limiter_v; const imgenv_limiter& ww = cfg->limiter_w;
@@ -501,6 +514,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             memcpy(o.sizes, k.sizes, sizeof(o.sizes));
         }
         for (size_t c = 0; c < pc.size(); c++) d.pc[c] = pc[c];
+        if (pc.empty()) pc.resize(1);
+        TRY(dev_upload(h, &d.pc_mem, pc));
     }
     TRY(dev_upload(h, &d.robot_cls, h->robot_cls));
     TRY(dev_upload(h, &d.ped_cls, h->ped_cls));
@@ -962,8 +977,14 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     }
     // _step_robot (img_env.cpp:388-410)
     {   // ... and the pedestrians' move (img_env.cpp:343-358) in the same launch
-        const int nb_robot = (h->RL + 127) / 128, nb_ped = (h->P > 0 && h->NA > 0) ? (h->P + 127) / 128 : 0;
-        TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot)));
+        const bool peds = h->P > 0 && h->NA > 0;
+        if (h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS) {
+            const int nb_robot = (h->RL + INT_ROBOTS - 1) / INT_ROBOTS, nb_ped = peds ? (h->P + INT_G * INT_ROBOTS - 1) / (INT_G * INT_ROBOTS) : 0;
+            TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3(nb_robot + nb_ped), dim3(INT_G * INT_ROBOTS), 0, st>>>(d, actions, nb_robot, h->n_sub)));
+        } else {
+            const int nb_robot = (h->RL + 127) / 128, nb_ped = peds ? (h->P + 127) / 128 : 0;
+            TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate_serial<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot)));
+        }
     }
     h->launches += 1;
     HIPCHK(hipGetLastError());

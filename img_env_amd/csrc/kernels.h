@@ -126,8 +126,10 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
 }
 
 // PedAgent::update_bbox (agent.cpp:696-735); step_len_ = 0.3 (2-arg constructor, agent.cpp:659-664)
-__device__ void ped_leg_gait(const DevWorld& w, int j, double x, double y, double ox, double oy) {
-    const PedClassDev k = w.pc[w.ped_cls[j]];
+__device__ __forceinline__ void ped_leg_gait(const DevWorld& w, int j, double x, double y, double ox, double oy) {
+    // the class differs from lane to lane: read it from the copy of the class records in HBM -- a per-lane index into
+    // the by-value kernel argument would make the compiler spill the whole DevWorld to scratch
+    const PedClassDev& k = w.pc_mem[w.ped_cls[j]];
     if (k.shape != IMGENV_SHAPE_LEG) return;
     const double step_len = 0.3;
     const double move = sqrt((x - ox) * (x - ox) + (y - oy) * (y - oy));
@@ -321,9 +323,8 @@ __device__ __forceinline__ void integrate_robot(const DevWorld& w, const float* 
     w.is_arr[l] = is_arrive ? 1 : 0;
 }
 
-// One launch for the two independent per-agent updates of a step: blocks [0, nb_robot) integrate the robots,
-// the blocks behind them (ped_blocks of them) move the ORCA pedestrians by the velocities k_orca solved for.
-__global__ void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot) {
+// Serial fallback of the robot update (more sub-steps than INT_ITEMS - 2): one thread per robot.
+__global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions, int nb_robot) {
     if ((int)blockIdx.x >= nb_robot) {
         const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
         if (j < w.P) ped_update_one(w, j);
@@ -331,11 +332,126 @@ __global__ void k_integrate(DevWorld w, const float* __restrict__ actions, int n
     }
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = l < w.RL;
-    // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
     if (valid && !w.py_done[l]) integrate_robot(w, actions, l);
+    const bool frozen = valid && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
+    const unsigned long long mask = __ballot(frozen);
+    if (mask != 0 && lane_id() == 0) {
+        atomicAdd(&w.counters[2], __popcll(mask));
+        atomicAdd(&w.counters[3], __popcll(mask));
+    }
+}
+
+#define INT_G 8        // lanes per robot in k_integrate
+#define INT_ITEMS 32   // sin / cos pairs per robot: the sub-step headings, the new heading and its half
+#define INT_ROBOTS 32  // robots per 256-thread block
+
+// One launch for the two independent per-agent updates of a step: blocks [0, nb_robot) integrate the robots,
+// the blocks behind them move the ORCA pedestrians by the velocities k_orca solved for.
+//
+// Agent::cmd is a chain of ~20 dependent fp64 sin / cos calls per robot (one heading per 0.05 s sub-step, agent.cpp:
+// 221-236, then the exact arc).  The headings do not depend on the positions, so 8 lanes per robot evaluate them side by
+// side -- each lane re-accumulates `oz += w * 0.05` up to its own sub-step, which keeps the reference's rounding -- and
+// lane 0 then runs the (cheap) position recurrence and the arrive tests over the table in LDS.
+__global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot, int n_sub) {
+    __shared__ double2 trig[INT_ROBOTS][INT_ITEMS];  // (cos, sin)
+    if ((int)blockIdx.x >= nb_robot) {
+        const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
+        if (j < w.P) ped_update_one(w, j);
+        return;
+    }
+    const int g = threadIdx.x & (INT_G - 1), rb = threadIdx.x / INT_G;
+    const int l = blockIdx.x * INT_ROBOTS + rb;
+    const bool valid = l < w.RL;
+    const bool alive = valid && !w.py_done[l];  // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
+    double* r = w.rec + (size_t)(w.r0 + (valid ? l : 0)) * IMGENV_RECORD_DOUBLES;
+    const double step_hz = w.step_hz, control_hz = 0.05;
+    double v = 0, wv = 0, v_y = 0, theta = 0;
+    if (alive) {
+        v = (double)actions[3 * l];
+        wv = (double)actions[3 * l + 1];
+        v_y = (double)actions[3 * l + 2];
+        limiter_limit(w.lv_has_v, w.lv_has_a, w.lv_has_j, w.lv_min_v, w.lv_max_v, w.lv_min_a, w.lv_max_a, w.lv_min_j,
+                      w.lv_max_j, v, w.l0v[l], w.l1v[l], step_hz);
+        limiter_limit(w.lw_has_v, w.lw_has_a, w.lw_has_j, w.lw_min_v, w.lw_max_v, w.lw_min_a, w.lw_max_a, w.lw_min_j,
+                      w.lw_max_j, wv, w.l0w[l], w.l1w[l], step_hz);
+        theta = r[2];
+        for (int it = g; it < n_sub + 2; it += INT_G) {
+            double a;
+            if (it < n_sub) {
+                a = theta;
+                for (int q = 0; q < it; q++) a += wv * control_hz;  // odom.z of sub-step `it`, rounded as the loop rounds it
+            } else {
+                a = theta + wv * step_hz;
+                if (it == n_sub + 1) a = a * 0.5;
+            }
+            trig[rb][it] = make_double2(cos(a), sin(a));
+        }
+    }
+    __syncthreads();
+    if (alive && g == 0) {
+        w.l1v[l] = w.l0v[l];
+        w.l1w[l] = w.l0w[l];
+        w.l0v[l] = v;
+        w.l0w[l] = wv;
+        bool is_arrive = false;
+        const double gx = w.gx[l], gy = w.gy[l];
+        double ox = r[0], oy = r[1];
+        double vx = r[3], vy = r[4];
+        const bool omni = w.ktype == IMGENV_KTYPE_OMNI;
+        for (int q = 0; q < n_sub; q++) {
+            const double c = trig[rb][q].x, s = trig[rb][q].y;
+            if (!omni) {
+                ox += v * control_hz * c;
+                oy += v * control_hz * s;
+                vx = v * c;
+                vy = v * s;
+            } else {
+                ox += v * control_hz * c - v_y * control_hz * s;
+                oy += v * control_hz * s + v_y * control_hz * c;
+            }
+            const double cur_dist = sqrt((ox - gx) * (ox - gx) + (oy - gy) * (oy - gy));
+            if (cur_dist <= 0.3) {
+                is_arrive = true;
+                break;
+            }
+        }
+        const double dt = step_hz;
+        const double c0 = trig[rb][0].x, s0 = trig[rb][0].y;          // cos / sin(theta): sub-step 0's heading is theta
+        const double c1 = trig[rb][n_sub].x, s1 = trig[rb][n_sub].y;  // cos / sin(theta + w dt)
+        double x = r[0], y = r[1];
+        if (wv == 0) {
+            if (!omni) {
+                x += v * dt * c0;
+                y += v * dt * s0;
+            } else {
+                x += v * dt * c0 - v_y * dt * s0;
+                y += v * dt * s0 + v_y * dt * c0;
+            }
+        } else {
+            const double vw = v / wv;
+            x += -vw * s0 + vw * s1;
+            y += vw * c0 - vw * c1;
+            if (omni) {
+                const double v_yw = v_y / wv;
+                x += -v_yw * c0 + v_yw * c1;
+                y += -v_yw * s0 + v_yw * s1;
+            }
+        }
+        const double th = theta + wv * dt;
+        const double cur_dist = sqrt((x - gx) * (x - gx) + (y - gy) * (y - gy));
+        if (cur_dist <= 0.3) is_arrive = true;
+        r[0] = x;
+        r[1] = y;
+        r[2] = th;
+        r[3] = vx;
+        r[4] = vy;
+        r[5] = trig[rb][n_sub + 1].y;  // Quaternion::setRPY(0,0,theta) of the new pose, shared by the next kernels
+        r[6] = trig[rb][n_sub + 1].x;
+        w.is_arr[l] = is_arrive ? 1 : 0;
+    }
     // robots whose view is frozen this step (agent.cpp:358-360), one atomic per wavefront:
     // counters[2] since the last reset, counters[3] since create
-    const bool frozen = valid && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
+    const bool frozen = valid && g == 0 && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
     const unsigned long long mask = __ballot(frozen);
     if (mask != 0 && lane_id() == 0) {
         atomicAdd(&w.counters[2], __popcll(mask));
@@ -353,7 +469,7 @@ __global__ void k_integrate(DevWorld w, const float* __restrict__ actions, int n
 //   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
 template <bool POW2>
-__device__ void raster_ped(const DevWorld& w, int j) {
+__device__ __forceinline__ void raster_ped(const DevWorld& w, int j) {
     const PedClassDev k = w.pc[w.ped_cls[j]];
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id();
@@ -405,7 +521,7 @@ __device__ void raster_ped(const DevWorld& w, int j) {
 // the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
 // second pass over the samples.
 template <bool POW2>
-__device__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel) {
+__device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel) {
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id();
@@ -1221,7 +1337,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             }
         }
         int n_new = 0;
-        const double pres = w.ped_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
+        const double pres = w.ped_res, pinv = w.ped_inv_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
         for (int e = 0; e < n_in; e++) {
             __syncthreads();  // drains this wave's earlier stores: later discs overwrite earlier ones
             const int je = ord[inbox[e]];
@@ -1229,8 +1345,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             const double evx = w.pvx[je], evy = w.pvy[je];
             const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
             const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
-            const int ax = (int)py_floordiv(tmx - pr, pres), bx = (int)py_floordiv(tmx + pr, pres);
-            const int ay = (int)py_floordiv(tmy - pr, pres), by = (int)py_floordiv(tmy + pr, pres);
+            int ax, bx, ay, by;
+            if (pinv != 0.0) {  // power-of-two cell: Python's v // res is floor(v * (1 / res)) exactly, without the fmod
+                ax = (int)floor((tmx - pr) * pinv);
+                bx = (int)floor((tmx + pr) * pinv);
+                ay = (int)floor((tmy - pr) * pinv);
+                by = (int)floor((tmy + pr) * pinv);
+            } else {
+                ax = (int)py_floordiv(tmx - pr, pres);
+                bx = (int)py_floordiv(tmx + pr, pres);
+                ay = (int)py_floordiv(tmy - pr, pres);
+                by = (int)py_floordiv(tmy + pr, pres);
+            }
             const int wy = by - ay, cnt = (bx - ax) * wy;
             for (int t0 = 0; t0 < cnt; t0 += WAVE) {
                 const int tt = t0 + lane;

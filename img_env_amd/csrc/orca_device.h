@@ -102,7 +102,7 @@ __device__ void insert_agent_neighbor(OrcaScratch& s, float dist_sq, int other, 
 }
 
 // Agent::insertObstacleNeighbor (lane 0)
-__device__ void insert_obstacle_neighbor(const DevWorld& w, OrcaScratch& s, f2 pos, int ob, float range_sq) {
+__device__ __forceinline__ void insert_obstacle_neighbor(const DevWorld& w, OrcaScratch& s, f2 pos, int ob, float range_sq) {
     const int nx = w.obst[ob].next;
     const float dist_sq = dist_sq_point_segment(opoint(w, ob), opoint(w, nx), pos);
     if (dist_sq < range_sq) {
@@ -125,7 +125,7 @@ __device__ void insert_obstacle_neighbor(const DevWorld& w, OrcaScratch& s, f2 p
 }
 
 // KdTree::queryObstacleTreeRecursive, iteratively, same visiting order (lane 0)
-__device__ void query_obstacle_tree(const DevWorld& w, OrcaScratch& s, f2 pos, float range_sq) {
+__device__ __forceinline__ void query_obstacle_tree(const DevWorld& w, OrcaScratch& s, f2 pos, float range_sq) {
     int sp = 0;
     if (w.oroot < 0) return;
     s.stack[sp++] = w.oroot << 1;  // (node << 1) | stage
@@ -256,7 +256,7 @@ __device__ void linear_program3(OrcaScratch& s, int n, int num_obst_lines, int b
 }
 
 // Agent::computeNewVelocity for agent `self` given its neighbour lists in the scratch (lane 0)
-__device__ f2 compute_new_velocity(const DevWorld& w, OrcaScratch& s, int self, f2 pref) {
+__device__ __forceinline__ f2 compute_new_velocity(const DevWorld& w, OrcaScratch& s, int self, f2 pref) {
     const f2 pos = F2(w.apx[self], w.apy[self]);
     const f2 vel = F2(w.avx[self], w.avy[self]);
     const float radius = 0.5f, time_horizon = 5.0f, time_horizon_obst = 5.0f;  // rvoscene.h:57,63

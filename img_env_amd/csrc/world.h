@@ -64,6 +64,7 @@ struct DevWorld {
     int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;
     int scene, relation, ktype, use_laser, laser_norm, time_max;
     double res, inv_res, step_hz, laser_max, ped_safety_space, ped_image_r, ped_image_r2, ped_res;
+    double ped_inv_res;  // 1 / ped_res when ped_res is a power of two (v // ped_res == floor(v * ped_inv_res) exactly), else 0
     uint32_t wv_magic;  // ceil(2^32 / Wv): c / Wv == __umulhi(c, wv_magic) for c < 65536
     Tf2 view_base, base_view;
     // limiter (speed_limit.cpp)
@@ -80,6 +81,7 @@ struct DevWorld {
     // to be global (no flat loads, no reloads after stores)
     RobotClassDev rc[RC_INLINE];
     PedClassDev pc[PC_INLINE];
+    const PedClassDev* pc_mem;  // the same records in HBM, for per-lane (divergent) class lookups
     const int* robot_cls;  // [R]
     const int* ped_cls;    // [P]
     const double* robot_size_last;  // [R]
