@@ -9,6 +9,7 @@
 #include <stdio.h>
 
 #include <string>
+#include <chrono>
 #include <vector>
 
 #define WAVE_SZ 64
@@ -49,6 +50,13 @@ struct imgenv {
     RvoNodeDev* d_nodes = nullptr;
     int cap_obst = 0, cap_nodes = 0;
     double* d_traj = nullptr;
+    double *d_rob3 = nullptr, *d_ped3 = nullptr;  // reset staging (persistent: no pool traffic per reset)
+    // pinned host staging of imgenv_reset: copies are truly asynchronous and reset never waits for the stream
+    struct Chunk { unsigned char* p; size_t cap, used; };
+    std::vector<Chunk> stage;
+    hipEvent_t ev_stage = nullptr;
+    bool stage_pending = false;
+    void* d_rr = nullptr;
     int* d_traj_len = nullptr;
     int traj_cap = 0;
     int elapsed = 0;
@@ -299,6 +307,8 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamSynchronize(h->side2);
         (void)hipStreamDestroy(h->side2);
     }
+    for (auto& c : h->stage) (void)hipHostFree(c.p);
+    if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -803,6 +813,58 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     return 0;
 }
 
+// ---- pinned staging for reset: H2D copies out of page-locked chunks owned by the handle ----
+__global__ void k_stage_copy(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, size_t bytes) {
+    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t q = t; q < n16; q += stride) ((uint4*)dst)[q] = ((const uint4*)src)[q];
+    for (size_t q = n16 * 16 + t; q < bytes; q += stride) dst[q] = src[q];
+}
+static int stage_begin(imgenv* h) {
+    if (!h->ev_stage) HIPCHK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+    if (h->stage_pending) {  // the previous reset's copies (long finished in practice) still own the chunks
+        HIPCHK(hipEventSynchronize(h->ev_stage));
+        h->stage_pending = false;
+    }
+    for (auto& c : h->stage) c.used = 0;
+    return 0;
+}
+static int stage_put(imgenv* h, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    imgenv::Chunk* use = nullptr;
+    for (auto& c : h->stage)
+        if (c.cap - c.used >= bytes) {
+            use = &c;
+            break;
+        }
+    if (!use) {
+        imgenv::Chunk c{nullptr, std::max(bytes, (size_t)1 << 20), 0};
+        HIPCHK(hipHostMalloc((void**)&c.p, c.cap, hipHostMallocDefault));
+        h->stage.push_back(c);
+        use = &h->stage.back();
+    }
+    unsigned char* p = use->p + use->used;
+    use->used += (bytes + 255) & ~(size_t)255;
+    if (use->used > use->cap) use->used = use->cap;
+    memcpy(p, src, bytes);
+    // a kernel pulls the bytes out of the page-locked chunk: unlike hipMemcpyAsync (which was seen to block the host for
+    // several milliseconds on a busy stream once a copy exceeds a few hundred KB) a launch never waits
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>((std::max<size_t>(n16, 1) + 255) / 256, 1024);
+    k_stage_copy<<<dim3(blocks), dim3(256), 0, st>>>((unsigned char*)dst, (const unsigned char*)p, bytes);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int stage_end(imgenv* h, hipStream_t st) {
+    HIPCHK(hipEventRecord(h->ev_stage, st));
+    h->stage_pending = true;
+    return 0;
+}
+
+// (errors inside reset leave the handle alive)
+#define RTRY(expr)                   \
+    do {                             \
+        if (int rc_ = (expr)) return rc_; \
+    } while (0)
 extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stream) {
     if (!h || !b) FAIL(IMGENV_EINVAL, "null argument");
     if (b->struct_size != (int32_t)sizeof(imgenv_reset_batch)) FAIL(IMGENV_EINVAL, "reset batch ABI mismatch");
@@ -813,6 +875,11 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
         h->orca_pending = false;
     }
+    const bool trace_ = getenv("IMGENV_TRACE_RESET") != nullptr;
+    std::chrono::steady_clock::time_point tp_[8];
+    tp_[0] = std::chrono::steady_clock::now();
+    RTRY(stage_begin(h));
+    tp_[1] = std::chrono::steady_clock::now();
     DevWorld& d = h->d;
     const int R = h->R, P = h->P, RL = h->RL;
     const double res = h->geom.res;
@@ -838,7 +905,8 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         }
     }
     h->rvo.process();  // processObs (img_env.cpp:283)
-    HIPCHK(hipMemcpyAsync(h->d_obs_map, obs.data(), obs.size(), hipMemcpyHostToDevice, st));
+    tp_[2] = std::chrono::steady_clock::now();
+    RTRY(stage_put(h, h->d_obs_map, obs.data(), obs.size(), st));
     if ((int)h->rvo.ob.size() > h->cap_obst) {
         h->cap_obst = (int)h->rvo.ob.size() * 2;
         if (int rc = dev_alloc(h, &h->d_obst, h->cap_obst)) return rc;
@@ -849,9 +917,9 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     }
     static_assert(sizeof(RvoObstHost) == sizeof(RvoObstDev) && sizeof(RvoNodeHost) == sizeof(RvoNodeDev), "layout");
     if (!h->rvo.ob.empty())
-        HIPCHK(hipMemcpyAsync(h->d_obst, h->rvo.ob.data(), sizeof(RvoObstDev) * h->rvo.ob.size(), hipMemcpyHostToDevice, st));
+        RTRY(stage_put(h, h->d_obst, h->rvo.ob.data(), sizeof(RvoObstDev) * h->rvo.ob.size(), st));
     if (!h->rvo.nodes.empty())
-        HIPCHK(hipMemcpyAsync(h->d_nodes, h->rvo.nodes.data(), sizeof(RvoNodeDev) * h->rvo.nodes.size(), hipMemcpyHostToDevice, st));
+        RTRY(stage_put(h, h->d_nodes, h->rvo.nodes.data(), sizeof(RvoNodeDev) * h->rvo.nodes.size(), st));
     d.obst = h->d_obst;
     d.onodes = h->d_nodes;
     d.n_obst = (int)h->rvo.ob.size();
@@ -863,9 +931,10 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
             h->sfm_cap_obs = nob * 2;
             if (int rc = dev_alloc(h, &d.sfm.obs, (size_t)h->sfm_cap_obs * 4)) return rc;
         }
-        if (nob) HIPCHK(hipMemcpyAsync(d.sfm.obs, sfm_obs.data(), sizeof(double) * sfm_obs.size(), hipMemcpyHostToDevice, st));
+        if (nob) RTRY(stage_put(h, d.sfm.obs, sfm_obs.data(), sizeof(double) * sfm_obs.size(), st));
         d.sfm.n_obs = nob;
     }
+    tp_[3] = std::chrono::steady_clock::now();
     // pedestrians (img_env.cpp:220-250)
     std::vector<double> ped3((size_t)(P > 0 ? P : 1) * 3);
     std::vector<int> tlen(P > 0 ? P : 1);
@@ -885,8 +954,8 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
             for (int q = 0; q < tlen[j]; q++)
                 memcpy(&traj[((size_t)j * h->traj_cap + q) * 3], b->ped_traj + ((size_t)j * b->ped_traj_cap + q) * 3, 24);
         }
-        HIPCHK(hipMemcpyAsync(h->d_traj, traj.data(), traj.size() * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(h->d_traj_len, tlen.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
+        RTRY(stage_put(h, h->d_traj, traj.data(), traj.size() * 8, st));
+        RTRY(stage_put(h, h->d_traj_len, tlen.data(), sizeof(int) * P, st));
         if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::setWayPoint (pedscene.h:38-46): [goal r=1, trajectory r=z]
             std::vector<double> wx((size_t)P * SFM_MAX_WP, 0.0), wy(wx), wr(wx);
             std::vector<int> dq((size_t)P * SFM_MAX_WP, 0), dqn(P, 0), dest(P, 0), last(P, -1);
@@ -907,18 +976,18 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
                 dest[j] = 0;  // addWaypoint leaves destination = waypoints.front() without popping it (ped_agent.cpp:97-100)
             }
             const SfmDev& f = d.sfm;
-            HIPCHK(hipMemcpyAsync(f.wpx, wx.data(), wx.size() * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(f.wpy, wy.data(), wy.size() * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(f.wpr, wr.data(), wr.size() * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(f.dq, dq.data(), dq.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(f.dq_n, dqn.data(), dqn.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(f.dest, dest.data(), dest.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(f.last, last.data(), last.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));  // the staging vectors above die with this block
+            RTRY(stage_put(h, f.wpx, wx.data(), wx.size() * 8, st));
+            RTRY(stage_put(h, f.wpy, wy.data(), wy.size() * 8, st));
+            RTRY(stage_put(h, f.wpr, wr.data(), wr.size() * 8, st));
+            RTRY(stage_put(h, f.dq, dq.data(), dq.size() * 4, st));
+            RTRY(stage_put(h, f.dq_n, dqn.data(), dqn.size() * 4, st));
+            RTRY(stage_put(h, f.dest, dest.data(), dest.size() * 4, st));
+            RTRY(stage_put(h, f.last, last.data(), last.size() * 4, st));
         }
         d.ptraj = h->d_traj;
         d.traj_cap = h->traj_cap;
     }
+    tp_[4] = std::chrono::steady_clock::now();
     // robots (img_env.cpp:252-282)
     std::vector<double> rob3((size_t)R * 5);
     std::vector<ResetRobot> rr(RL);
@@ -937,23 +1006,33 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
             q.world_target = tf_inverse(tf_from_pose(q.gx, q.gy, yaw));
         }
     }
-    double *d_rob3 = nullptr, *d_ped3 = nullptr;
-    ResetRobot* d_rr = nullptr;
-    HIPCHK(hipMallocAsync((void**)&d_rob3, rob3.size() * 8, st));
-    HIPCHK(hipMallocAsync((void**)&d_ped3, ped3.size() * 8, st));
-    HIPCHK(hipMallocAsync((void**)&d_rr, rr.size() * sizeof(ResetRobot), st));
-    HIPCHK(hipMemcpyAsync(d_rob3, rob3.data(), rob3.size() * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_ped3, ped3.data(), ped3.size() * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_rr, rr.data(), rr.size() * sizeof(ResetRobot), hipMemcpyHostToDevice, st));
+    if (!h->d_rob3) {
+        RTRY(dev_alloc(h, &h->d_rob3, rob3.size()));
+        RTRY(dev_alloc(h, &h->d_ped3, ped3.size()));
+        ResetRobot* q = nullptr;
+        RTRY(dev_alloc(h, &q, rr.size()));
+        h->d_rr = q;
+    }
+    double *d_rob3 = h->d_rob3, *d_ped3 = h->d_ped3;
+    ResetRobot* d_rr = (ResetRobot*)h->d_rr;
+    RTRY(stage_put(h, d_rob3, rob3.data(), rob3.size() * 8, st));
+    RTRY(stage_put(h, d_ped3, ped3.data(), ped3.size() * 8, st));
+    RTRY(stage_put(h, d_rr, rr.data(), rr.size() * sizeof(ResetRobot), st));
+    tp_[5] = std::chrono::steady_clock::now();
     k_reset_robots<<<dim3((R + 255) / 256), dim3(256), 0, st>>>(d, d_rob3, d_rr);
     if (P > 0) k_reset_peds<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(d, d_ped3);
     h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
     h->launches = 2;
     if (int rc = launch_views(h, st, 1)) return rc;  // view_agent + get_states (img_env.cpp:285-286)
-    HIPCHK(hipFreeAsync(d_rob3, st));
-    HIPCHK(hipFreeAsync(d_ped3, st));
-    HIPCHK(hipFreeAsync(d_rr, st));
-    HIPCHK(hipStreamSynchronize(st));  // host staging buffers die with this frame
+    tp_[6] = std::chrono::steady_clock::now();
+    RTRY(stage_end(h, st));
+    tp_[7] = std::chrono::steady_clock::now();
+    if (trace_) {
+        auto us = [&](int a_, int b_) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(tp_[b_] - tp_[a_]).count(); };
+        if (us(0, 7) > 2000)
+            fprintf(stderr, "[imgenv_reset] stage_begin %ld us, obstacles %ld, map+rvo copies %ld, peds %ld, robots(host+copies) %ld, kernels+views %ld, stage_end %ld\n",
+                    us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
+    }  // no host wait: the copies above read the handle's pinned chunks
     h->has_reset = true;
     return IMGENV_OK;
 }
