@@ -141,15 +141,17 @@ def main():
         dist.all_gather_object(flags, native)
         native = all(flags)
 
-    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
     n_act = 16
 
     def make_actions(policy):
-        a = torch.zeros(n_act, RL, 3)
+        # generated on the device: a pageable host-to-device copy here leaves a deferred un-pin behind in the HIP runtime
+        # that was seen to stall kernel submission for ~30 ms a few dozen steps later
+        a = torch.zeros(n_act, RL, 3, device=dev)
         if policy == "episode":
-            a[:, :, 0] = torch.rand(n_act, RL, generator=g) * 0.6
-        a[:, :, 1] = torch.rand(n_act, RL, generator=g) * 1.8 - 0.9
-        return a.to(dev)
+            a[:, :, 0] = torch.rand(n_act, RL, generator=g, device=dev) * 0.6
+        a[:, :, 1] = torch.rand(n_act, RL, generator=g, device=dev) * 1.8 - 0.9
+        return a
 
     state = dict(elapsed=0, episode=0)
 
@@ -181,8 +183,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for s in range(steps):
-            do_step(acts[s % n_act])
+        if os.environ.get("BENCH_TRACE"):  # diagnostic: where inside a pass does the time go (adds a sync every 20 steps)
+            tw, marks = t0, []
+            if os.environ.get("BENCH_TRACE") == "2":
+                world.timing(1)
+                prevk = world.timing_read()
+            for s in range(steps):
+                e0 = state["episode"]
+                do_step(acts[s % n_act])
+                if state["episode"] != e0:
+                    marks.append(s)
+                if s % 20 == 19:
+                    torch.cuda.synchronize()
+                    now = time.perf_counter()
+                    print("  trace %s steps %d-%d: %.1f us/step%s" % (policy, s - 19, s, 1e6 * (now - tw) / 20,
+                                                                  " reset@%s" % marks if marks else ""), file=sys.stderr)
+                    if os.environ.get("BENCH_TRACE") == "2":
+                        curk = world.timing_read()
+                        print("      kernels: " + " ".join("%s %.0f" % (k[2:], 1e3 * (curk[k][0] - prevk[k][0]) / max(curk[k][1] - prevk[k][1], 1))
+                                                         for k in curk), file=sys.stderr)
+                        prevk = curk
+                        now = time.perf_counter()
+                    tw, marks = now, []
+        else:
+            for s in range(steps):
+                do_step(acts[s % n_act])
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()

@@ -781,15 +781,16 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
         }
         h->launches += 1;
+        if (overlap) HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
+        k_side_robots<<<dim3((h->R + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
+        h->launches += 1;
         if (h->NA > 0) {
-            if (overlap) HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
-            if (d.relation == 1) k_robot_agents<<<dim3((h->R + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset);
             TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(h->P), dim3(WAVE), 0, s_orca>>>(d)));
-            if (overlap) {
-                HIPCHK(hipEventRecord(h->ev_join, s_orca));
-                HIPCHK(hipStreamWaitEvent(s_obs, h->ev_join, 0));
-            }
-            h->launches += 2;
+            h->launches += 1;
+        }
+        if (overlap) {
+            HIPCHK(hipEventRecord(h->ev_join, s_orca));
+            HIPCHK(hipStreamWaitEvent(s_obs, h->ev_join, 0));
         }
         if (overlap) HIPCHK(hipEventRecord(h->ev_join2, s_obs));
     }
@@ -807,7 +808,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         else TIMED(h, IMGENV_K_VIEW, st, (k_view<false, false><<<gv, bv, h->lds_view, st>>>(d)));
     }
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
-    TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed)));
+    TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed, h->P > 0 ? 0 : 1)));
     h->launches += 4;
     HIPCHK(hipGetLastError());
     return 0;

@@ -597,26 +597,13 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
     } else if (local && lane == 0) {
         w.fp_n[l] = -1;
     }
-    // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_robot_agents
+    // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
     if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
         double* p = w.sfm.p + 3 * (size_t)(w.P + i);
         p[0] = r[0];
         p[1] = r[1];
         p[2] = 1.0;
     }
-}
-
-// _step_robot tail for the RVO scenes: setRobotPos for every robot (img_env.cpp:411-417, rvoscene.h:47-51).  Runs on the
-// solve's side stream straight from the gathered robot records, so that the solve does not have to wait for the raster.
-__global__ void k_robot_agents(DevWorld w, int zero_vel) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.R) return;
-    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    const int a = w.P + i;
-    w.apx[a] = (float)r[0];
-    w.apy[a] = (float)r[1];
-    w.avx[a] = zero_vel ? 0.0f : (float)r[3];
-    w.avy[a] = zero_vel ? 0.0f : (float)r[4];
 }
 
 template <bool POW2>
@@ -1051,32 +1038,34 @@ __device__ double py_floordiv(double vx, double wx) {
     return floordiv;
 }
 
-__device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset, int elapsed) {
-    const int i = w.r0 + l;
-    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+// Agent::get_state (agent.cpp:156-184) of local robot l: the goal in the robot frame (+ heading / speeds)
+__device__ __forceinline__ void state_robot(const DevWorld& w, int l) {
+    const double* r = w.rec + (size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
-    // Agent::get_state (agent.cpp:156-184)
     const Tf2 t = tf_mul(w.world_target[l], bw);
     const Tf2 target_base = tf_inverse(t);
-    const float s0 = (float)target_base.ox, s1 = (float)target_base.oy;
-    {
-        float* vs = w.vector_states + (size_t)l * w.SD;
-        vs[0] = s0;
-        vs[1] = s1;
-        if (w.SD == 3) {
-            vs[2] = (float)tf_basis_yaw_via_quaternion(target_base);
-        } else if (w.SD == 4) {
-            vs[2] = (float)w.l0v[l];
-            vs[3] = (float)w.l0w[l];
-        } else {
-            vs[2] = (float)tf_basis_yaw_via_quaternion(target_base);
-            vs[3] = (float)w.l0v[l];
-            vs[4] = (float)w.l0w[l];
-        }
-        w.robot_pose[3 * l] = r[0];
-        w.robot_pose[3 * l + 1] = r[1];
-        w.robot_pose[3 * l + 2] = r[2];
+    float* vs = w.vector_states + (size_t)l * w.SD;
+    vs[0] = (float)target_base.ox;
+    vs[1] = (float)target_base.oy;
+    if (w.SD == 3) {
+        vs[2] = (float)tf_basis_yaw_via_quaternion(target_base);
+    } else if (w.SD == 4) {
+        vs[2] = (float)w.l0v[l];
+        vs[3] = (float)w.l0w[l];
+    } else {
+        vs[2] = (float)tf_basis_yaw_via_quaternion(target_base);
+        vs[3] = (float)w.l0v[l];
+        vs[4] = (float)w.l0w[l];
     }
+    w.robot_pose[3 * l] = r[0];
+    w.robot_pose[3 * l + 1] = r[1];
+    w.robot_pose[3 * l + 2] = r[2];
+}
+
+__device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset, int elapsed, int do_state) {
+    if (do_state) state_robot(w, l);  // otherwise k_side_robots has written it on the side stream
+    const float* vs01 = w.vector_states + (size_t)l * w.SD;
+    const float s0 = vs01[0], s1 = vs01[1];
     const double min_dist = w.ped_min_dists[l];
     const int coll = w.is_coll[l];
     const int arr = w.is_arr[l];
@@ -1394,13 +1383,33 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     if (lane == 0) w.ped_min_dists[l] = min_dist;
 }
 
+// Per-robot work that needs the new poses only, on the side stream beside the rasters and the view:
+//  * _step_robot tail for the RVO scenes: setRobotPos for every robot (img_env.cpp:411-417, rvoscene.h:47-51), straight
+//    from the gathered robot records, so that the solve does not have to wait for the raster;
+//  * Agent::get_state of the local robots (its correctly rounded atan2 is a long serial chain that k_tail, on the
+//    critical path, would otherwise run).
+__global__ void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.R) return;
+    if (rvo_agents) {
+        const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+        const int a = w.P + i;
+        w.apx[a] = (float)r[0];
+        w.apy[a] = (float)r[1];
+        w.avx[a] = zero_vel ? 0.0f : (float)r[3];
+        w.avy[a] = zero_vel ? 0.0f : (float)r[4];
+    }
+    const int l = i - w.r0;
+    if (l >= 0 && l < w.RL) state_robot(w, l);
+}
+
 // Per-robot scalars, one thread per robot: Agent::get_state (agent.cpp:156-184), the _get_states distances,
 // ImageEnv.step and the wrapper stack (reward / done).  Runs after k_view (collision code) and k_obs (ped distance).
-__global__ void k_tail(DevWorld w, int is_reset, int elapsed) {
+__global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = l < w.RL;
     int done = 0;
-    if (valid) done = tail_robot(w, l, is_reset, elapsed);
+    if (valid) done = tail_robot(w, l, is_reset, elapsed, do_state);
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
 }
