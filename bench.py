@@ -125,6 +125,13 @@ def main():
     grid = worldgen.make_grid(side, 0)
     n_layouts = 2 + (args.steps + args.warmup) // (TIME_MAX + 1)
     layouts = [worldgen.make_layout(grid, res, R, P, seed=100 + s, clearance=clearance) for s in range(min(n_layouts, 4))]
+    if world_size > 1:
+        # robots are numbered along x, so that a rank's contiguous shard is a vertical strip of the map: each rank then
+        # rasterises only the robots its own strip can see (the library clips to the shard's bounding box + view reach)
+        for lay in layouts:
+            order = np.argsort(lay.robot_pose[:, 0], kind="stable")
+            lay.robot_pose = lay.robot_pose[order].copy()
+            lay.robot_goal = lay.robot_goal[order].copy()
     params = worldgen.make_params(R, P, res=res, view_cells=48, beams=360, scene="rvoscene", time_max=TIME_MAX,
                                   robot_begin=rank * RL, robot_end=(rank + 1) * RL)
     world = World(params, grid, device=local_rank)

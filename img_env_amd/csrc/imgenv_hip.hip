@@ -76,6 +76,7 @@ struct imgenv {
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     bool orca_pending = false;
     bool serial = false;  // IMGENV_SERIAL=1: no side streams (profiling aid)
+    bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
     RvoObstacles rvo;
     int sfm_cap_obs = 0;
     // live timing (imgenv_timing)
@@ -557,6 +558,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         }
         d.box_cells = box;
         d.fp_cap = cap;
+        TRY(dev_alloc(h, &d.bbox, 4));
+        d.sharded = RL != R;
+        int max_rad = 0;
+        for (const RobotClassHost& k : h->rcls) max_rad = std::max(max_rad, k.box_rad);
+        d.region_margin = (int)ceil(0.5 * sqrt((double)g.Hv * g.Hv + (double)g.Wv * g.Wv)) + max_rad + 3;
         TRY(dev_alloc(h, &d.fp_cells, (size_t)RL * cap));
         TRY(dev_alloc(h, &d.fp_n, RL, 0xFF));  // -1 until the first raster
     }
@@ -734,6 +740,14 @@ __global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, con
     if (i == 0) w.counters[2] = 0;  // frozen robot-steps since this reset
 }
 
+// reset of a robot-sharded world: bounding box of the local robots' new positions (k_tail re-arms it every step)
+__global__ void k_reset_bbox(DevWorld w, const double* __restrict__ pose3) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = l < w.RL;
+    const double* p = pose3 + 5 * (size_t)(w.r0 + (valid ? l : 0));
+    bbox_accumulate(w, valid, p[0], p[1]);
+}
+
 __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= w.P) return;
@@ -756,6 +770,30 @@ __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
     w.ped_state[4 * j + 3] = w.pvy[j];
 }
 
+// fork: the pedestrian half of the observation needs the local robots' new poses only, so it starts right behind
+// k_integrate (in a sharded world: underneath the record exchange) on its own stream
+static int launch_obs(imgenv* h, hipStream_t st) {
+    DevWorld& d = h->d;
+    const bool overlap = !h->serial;
+    hipStream_t s_obs = overlap ? h->side2 : st;
+    if (overlap) {
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(s_obs, h->ev_fork, 0));
+    }
+    const dim3 go(h->RL), bo(WAVE);
+    switch (h->obs_E) {
+        case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+        case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+        case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+        case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+        case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+        default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
+    }
+    h->launches += 1;
+    h->obs_forked = true;
+    return 0;
+}
+
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const size_t G = (size_t)h->Hg * h->Wg;
@@ -766,22 +804,19 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // observation stream finally waits for the solve, so its join event covers both.
         // (IMGENV_SERIAL=1 in the environment keeps everything on the caller's stream: clean per-kernel timings.)
         const bool overlap = !h->serial;
-        hipStream_t s_obs = overlap ? h->side2 : st, s_orca = overlap ? h->side : st;
+        hipStream_t s_orca = overlap ? h->side : st;
+        if (!h->obs_forked)
+            if (int rc = launch_obs(h, st)) return rc;
+        h->obs_forked = false;
+        hipStream_t s_obs = overlap ? h->side2 : st;
         if (overlap) {
-            HIPCHK(hipEventRecord(h->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(s_obs, h->ev_fork, 0));
+            if (d.sharded) {  // the solve needs every rank's robots: a second fork behind the exchange
+                HIPCHK(hipEventRecord(h->ev_fork2, st));
+                HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork2, 0));
+            } else {
+                HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
+            }
         }
-        const dim3 go(h->RL), bo(WAVE);
-        switch (h->obs_E) {
-            case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-            case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-            case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-            case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-            case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-            default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-        }
-        h->launches += 1;
-        if (overlap) HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
         k_side_robots<<<dim3((h->R + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
         h->launches += 1;
         if (h->NA > 0) {
@@ -791,8 +826,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         if (overlap) {
             HIPCHK(hipEventRecord(h->ev_join, s_orca));
             HIPCHK(hipStreamWaitEvent(s_obs, h->ev_join, 0));
+            HIPCHK(hipEventRecord(h->ev_join2, s_obs));
         }
-        if (overlap) HIPCHK(hipEventRecord(h->ev_join2, s_obs));
     }
     if (h->pow2)
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P > h->R ? h->P : h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
@@ -1021,6 +1056,11 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     RTRY(stage_put(h, d_rr, rr.data(), rr.size() * sizeof(ResetRobot), st));
     tp_[5] = std::chrono::steady_clock::now();
     k_reset_robots<<<dim3((R + 255) / 256), dim3(256), 0, st>>>(d, d_rob3, d_rr);
+    if (d.sharded) {
+        const uint32_t init[4] = {BBOX_INIT_MIN, BBOX_INIT_MIN, BBOX_INIT_MAX, BBOX_INIT_MAX};
+        RTRY(stage_put(h, d.bbox, init, sizeof(init), st));
+        k_reset_bbox<<<dim3((RL + 255) / 256), dim3(256), 0, st>>>(d, d_rob3);
+    }
     if (P > 0) k_reset_peds<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(d, d_ped3);
     h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
     h->launches = 2;
@@ -1067,6 +1107,8 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         }
     }
     h->launches += 1;
+    if (h->P > 0)
+        if (int rc = launch_obs(h, st)) return rc;
     HIPCHK(hipGetLastError());
     return IMGENV_OK;
 }

@@ -19,6 +19,7 @@
 #include "world.h"
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int lane_id_raw() { return threadIdx.x & (WAVE - 1); }
 
 // robot class record: by value from the kernel arguments when possible (wave-uniform index)
 // a double that is known to be the same in every lane, moved to scalar registers
@@ -27,6 +28,52 @@ __device__ __forceinline__ double uniform_f64(double v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// ---- region of the grid a robot-sharded rank keeps up to date: bounding box of its robots +- view reach ----
+__device__ __forceinline__ uint32_t ordered_u32(float f) {  // monotonic float -> uint32
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_f32(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+#define BBOX_INIT_MIN 0xFFFFFFFFu
+#define BBOX_INIT_MAX 0u
+struct Region {
+    int m0, m1, n0, n1;  // cells [m0, m1) x [n0, n1)
+};
+__device__ __forceinline__ Region grid_region(const DevWorld& w) {
+    Region g = {0, w.Hg, 0, w.Wg};
+    if (w.sharded) {
+        const uint32_t u0 = w.bbox[0], u1 = w.bbox[1], u2 = w.bbox[2], u3 = w.bbox[3];
+        if (u0 == BBOX_INIT_MIN) {  // no local robot
+            g.m1 = g.n1 = 0;
+        } else {
+            const double inv = 1.0 / w.res;
+            g.m0 = max(0, (int)floor((double)ordered_f32(u0) * inv) - w.region_margin);
+            g.n0 = max(0, (int)floor((double)ordered_f32(u1) * inv) - w.region_margin);
+            g.m1 = min(w.Hg, (int)ceil((double)ordered_f32(u2) * inv) + w.region_margin + 1);
+            g.n1 = min(w.Wg, (int)ceil((double)ordered_f32(u3) * inv) + w.region_margin + 1);
+        }
+    }
+    return g;
+}
+// one lane per robot contributes (valid = false: nothing); one atomic quadruple per wavefront
+__device__ __forceinline__ void bbox_accumulate(const DevWorld& w, bool valid, double x, double y) {
+    uint32_t lo_x = valid ? ordered_u32((float)x) : BBOX_INIT_MIN, lo_y = valid ? ordered_u32((float)y) : BBOX_INIT_MIN;
+    uint32_t hi_x = valid ? ordered_u32((float)x) : BBOX_INIT_MAX, hi_y = valid ? ordered_u32((float)y) : BBOX_INIT_MAX;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo_x = min(lo_x, (uint32_t)__shfl_xor((int)lo_x, off));
+        lo_y = min(lo_y, (uint32_t)__shfl_xor((int)lo_y, off));
+        hi_x = max(hi_x, (uint32_t)__shfl_xor((int)hi_x, off));
+        hi_y = max(hi_y, (uint32_t)__shfl_xor((int)hi_y, off));
+    }
+    if (lane_id_raw() == 0 && lo_x != BBOX_INIT_MIN) {
+        atomicMin(&w.bbox[0], lo_x);
+        atomicMin(&w.bbox[1], lo_y);
+        atomicMax(&w.bbox[2], hi_x);
+        atomicMax(&w.bbox[3], hi_y);
+    }
 }
 
 __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls) {
@@ -333,6 +380,10 @@ __global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = l < w.RL;
     if (valid && !w.py_done[l]) integrate_robot(w, actions, l);
+    if (w.sharded) {
+        const double* r = w.rec + (size_t)(w.r0 + (valid ? l : 0)) * IMGENV_RECORD_DOUBLES;
+        bbox_accumulate(w, valid, r[0], r[1]);
+    }
     const bool frozen = valid && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
     const unsigned long long mask = __ballot(frozen);
     if (mask != 0 && lane_id() == 0) {
@@ -449,6 +500,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
         r[6] = trig[rb][n_sub + 1].x;
         w.is_arr[l] = is_arrive ? 1 : 0;
     }
+    if (w.sharded) bbox_accumulate(w, valid && g == 0, r[0], r[1]);
     // robots whose view is frozen this step (agent.cpp:358-360), one atomic per wavefront:
     // counters[2] since the last reset, counters[3] since create
     const bool frozen = valid && g == 0 && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
@@ -469,7 +521,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 //   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
 template <bool POW2>
-__device__ __forceinline__ void raster_ped(const DevWorld& w, int j) {
+__device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Region& g) {
     const PedClassDev k = w.pc[w.ped_cls[j]];
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id();
@@ -480,7 +532,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j) {
             tf_apply(bw, k.bx[q], k.by[q], wx, wy);
             int m, n;
             w2m_pair<POW2>(wx, wy, res, inv, m, n);
-            if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+            if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
                 const size_t c = (size_t)m * w.Wg + n;
                 if (w.obs_map[c] > 2) w.ped_layer[c] = 1;
             }
@@ -500,7 +552,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j) {
                 tf_apply(bw, bx, by, wx, wy);
                 int m, n;
                 w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+                if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
                     const size_t c = (size_t)m * w.Wg + n;
                     if (leg == 1 || w.obs_map[c] != 0) w.ped_layer[c] = 1;
                 }
@@ -521,7 +573,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j) {
 // the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
 // second pass over the samples.
 template <bool POW2>
-__device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel) {
+__device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel, const Region& g) {
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id();
@@ -533,6 +585,10 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
     const int l = i - w.r0;
     const bool local = l >= 0 && l < w.RL;
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
+    // another rank's robot only matters where this rank's robots can see it (a local robot's footprint is inside the
+    // region by construction, so the clip never changes its own cells)
+    const int lo_m = local ? 0 : g.m0, hi_m = local ? w.Hg : g.m1, lo_n = local ? 0 : g.n0, hi_n = local ? w.Wg : g.n1;
+    if (!local && (cm + rad < lo_m || cm - rad >= hi_m || cn + rad < lo_n || cn - rad >= hi_n)) return;
     if (use_box) {
         for (int q = lane; q < ncell; q += WAVE) box[q] = 0;
         __syncthreads();
@@ -550,7 +606,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
             int m, n;
             w2m_pair<POW2>(wx, wy, res, inv, m, n);
             int b = -1;  // box cell of this sample
-            if (q < k.n_fp && m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+            if (q < k.n_fp && m >= lo_m && m < hi_m && n >= lo_n && n < hi_n) {
                 const int dm = m - cm + rad, dn = n - cn + rad;
                 if (use_box && dm >= 0 && dm < side && dn >= 0 && dn < side) {
                     b = dm * side + dn;
@@ -613,8 +669,9 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
     const int b = blockIdx.x;
     WAVE_T0();
-    if (b < w.R) raster_robot<POW2>(w, b, (uint32_t*)smem, zero_vel != 0);
-    if (b < w.P) raster_ped<POW2>(w, b);
+    const Region g = grid_region(w);
+    if (b < w.R) raster_robot<POW2>(w, b, (uint32_t*)smem, zero_vel != 0, g);
+    if (b < w.P) raster_ped<POW2>(w, b, g);
     if (b < w.RL) WAVE_DONE(2);
 }
 
@@ -625,6 +682,20 @@ __global__ void k_compose(DevWorld w) {
     const size_t c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_obs tallies this step's dones
     if (c0 >= G) return;
+    if (w.sharded) {  // only the region this rank's rasters were clipped to (everything else is clean and unread)
+        const Region g = grid_region(w);
+        int m = (int)(c0 / (size_t)w.Wg), n = (int)(c0 - (size_t)m * w.Wg);
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            any |= m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+            if (++n == w.Wg) {
+                n = 0;
+                m++;
+            }
+        }
+        if (!any) return;
+    }
     if (c0 + 4 <= G) {
         const uint32_t obs = *(const uint32_t*)(w.obs_map + c0);
         const uint32_t ped = *(const uint32_t*)(w.ped_layer + c0);
@@ -1410,6 +1481,8 @@ __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
     const bool valid = l < w.RL;
     int done = 0;
     if (valid) done = tail_robot(w, l, is_reset, elapsed, do_state);
+    if (w.sharded && blockIdx.x == 0 && threadIdx.x < 4)  // the rasters of this step are done with the box: re-arm it
+        w.bbox[threadIdx.x] = threadIdx.x < 2 ? BBOX_INIT_MIN : BBOX_INIT_MAX;
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
 }

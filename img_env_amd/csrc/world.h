@@ -114,6 +114,10 @@ struct DevWorld {
     const RvoNodeDev* onodes;
     int n_obst, n_onodes, oroot;
     SfmDev sfm;  // social-force crowd (pedscene)
+    // robot-sharded worlds: this rank only needs the rasters under its own robots' views.  bbox = ordered-uint32 encoded
+    // float min x, min y, max x, max y of the local robots' centres, accumulated by k_integrate / k_reset_robots
+    int sharded, region_margin;
+    uint32_t* bbox;
     int* err;  // [4] device-side overflow flags
     unsigned long long* prof;  // [16] per-phase cycle counters (IMGENV_PHASE_PROFILE builds)
     // outputs (imgenv_out)

@@ -131,3 +131,48 @@ def test_step_before_reset_is_an_error(worlds):
             gpu.step(torch.zeros(2, 3, device="cuda"))
     finally:
         gpu.close()
+
+
+@pytest.mark.parametrize("by_x", [False, True], ids=["interleaved", "spatial_shards"])
+def test_two_sharded_handles_match_single_world(worlds, by_x):
+    """Two handles on one GPU play ranks 0 / 1 of a robot-sharded world (caller-owned exchange between step_begin and
+    step_end).  Every shard must equal the same robots of the unsharded world bit for bit -- in particular with
+    spatially separated shards, where each rank rasterises only what its own robots can see."""
+    import torch
+    World, _ = worlds
+    n, n_peds, steps = 24, 10, 30
+    grid, params, layout = small_world(n, n_peds, seed=31, grid_size=320, clearance=0.8)
+    if by_x:  # contiguous index ranges = vertical strips of the map
+        order = np.argsort(layout.robot_pose[:, 0], kind="stable")
+        layout.robot_pose = layout.robot_pose[order].copy()
+        layout.robot_goal = layout.robot_goal[order].copy()
+    full = World(params, grid)
+    ranks = [World(dict(params, robot_begin=r * n // 2, robot_end=(r + 1) * n // 2), grid) for r in range(2)]
+    try:
+        full.reset(layout)
+        for w in ranks:
+            w.reset(layout)
+        rng = np.random.default_rng(5)
+        for s in range(steps):
+            a = random_actions(rng, n)
+            full.step(a)
+            for r, w in enumerate(ranks):
+                w.step_begin(a[r * n // 2:(r + 1) * n // 2])
+            torch.cuda.synchronize()
+            for r, w in enumerate(ranks):  # the all-gather, by hand
+                for q, o in enumerate(ranks):
+                    if q != r:
+                        w.records[q * n // 2:(q + 1) * n // 2].copy_(o.records[q * n // 2:(q + 1) * n // 2])
+            for w in ranks:
+                w.step_end()
+            want = full.snapshot()
+            for r, w in enumerate(ranks):
+                got = w.snapshot()
+                sl = slice(r * n // 2, (r + 1) * n // 2)
+                for k in ("vector_states", "view_maps", "sensor_maps", "lasers", "ped_vector_states", "ped_maps", "is_collisions",
+                          "is_arrives", "rewards", "dones", "dones_info", "step_ds", "ped_min_dists"):
+                    assert np.array_equal(got[k], want[k][sl]), (s, r, k)
+    finally:
+        full.close()
+        for w in ranks:
+            w.close()
