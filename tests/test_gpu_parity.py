@@ -176,3 +176,69 @@ def test_two_sharded_handles_match_single_world(worlds, by_x):
         full.close()
         for w in ranks:
             w.close()
+
+
+def _rect(params, n):
+    from img_env_amd import _cabi
+    params["robot_shape"] = np.full(n, _cabi.SHAPE_RECTANGLE, np.int32)
+    params["robot_size"] = np.tile(np.array([-0.25, 0.15, -0.12, 0.12], np.float32), (n, 1))  # x_min, x_max, y_min, y_max
+    params["robot_size_last"] = np.full(n, 0.12)
+
+
+def _mixed(params, n):
+    from img_env_amd import _cabi
+    shape = np.full(n, _cabi.SHAPE_CIRCLE, np.int32)
+    size = np.tile(np.array([0, 0, 0.17, 0], np.float32), (n, 1))
+    size[1::3] = (0.02, -0.01, 0.24, 0)                     # a larger, off-centre disc
+    shape[2::3] = _cabi.SHAPE_RECTANGLE
+    size[2::3] = (-0.2, 0.2, -0.1, 0.1)
+    sensor = np.zeros((n, 2), np.float32)
+    sensor[::2] = (0.08, -0.03)                             # laser not at the base origin
+    params.update(robot_shape=shape, robot_size=size, robot_sensor_cfg=sensor,
+                  robot_size_last=np.where(shape == _cabi.SHAPE_CIRCLE, size[:, 2], 0.1).astype(np.float64))
+
+
+def _limiter(params, n):
+    params["limiter_v"] = dict(has_velocity_limits=True, has_acceleration_limits=True, has_jerk_limits=True,
+                               min_velocity=-0.1, max_velocity=0.5, min_acceleration=-0.8, max_acceleration=0.6,
+                               min_jerk=-2.0, max_jerk=2.0)
+    params["limiter_w"] = dict(has_velocity_limits=True, has_acceleration_limits=True, min_velocity=-0.7, max_velocity=0.7,
+                               min_acceleration=-1.5, max_acceleration=1.5)
+
+
+VARIANTS = {
+    "omni_with_lateral_speed": (dict(robot_ktype="omni"), None, True),
+    "rectangle_robots": ({}, _rect, False),
+    "mixed_classes_sensor_offset": ({}, _mixed, False),
+    "speed_limiters": ({}, _limiter, False),
+    "state4_raw_laser": (dict(state_dim=4, laser_norm=False), None, False),
+    "narrow_fov_min_dist": (dict(view_angle_begin=-0.9, view_angle_end=0.6, view_min_dist=0.4, view_max_dist=2.5), None, False),
+    "dt_040_nine_substeps": (dict(dt=0.4), None, False),
+    "dt_100_many_substeps": (dict(dt=1.0), None, False),
+    "dt_200_serial_integrate": (dict(dt=2.0), None, False),
+}
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_hip_matches_oracle_variants(worlds, name):
+    """feature variants of the same path: kinematics, footprint classes, limiter, state layout, FOV gate, step length"""
+    World, OracleWorld = worlds
+    kw, mutate, lateral = VARIANTS[name]
+    n = 12
+    grid, params, layout = small_world(n, 5, seed=40 + len(name), n_obstacles=3, **kw)
+    if mutate:
+        mutate(params, n)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(len(name))
+        acts = []
+        for _ in range(30):
+            a = random_actions(rng, n)
+            if lateral:
+                a[:, 2] = rng.uniform(-0.3, 0.3, n).astype(np.float32)
+            acts.append(a)
+        fails = run_pair(gpu, cpu, layout, acts)
+        assert not fails, fails[:3]
+    finally:
+        gpu.close()
+        cpu.close()
