@@ -12,13 +12,13 @@ ABI_VERSION = 1
 RECORD_DOUBLES = 8
 
 SHAPE_CIRCLE, SHAPE_RECTANGLE, SHAPE_LEG = 0, 1, 2
-SCENE_EMPTY, SCENE_RVO, SCENE_ERVO, SCENE_PEDSIM = 0, 1, 2, 3
+SCENE_EMPTY, SCENE_RVO, SCENE_ERVO, SCENE_PEDSIM, SCENE_DATASET = 0, 1, 2, 3, 4
 KTYPE_DIFF, KTYPE_OMNI = 0, 1
 FLAG_PRIVATE_GRIDS = 1
 
 SHAPES = {"circle": SHAPE_CIRCLE, "rectangle": SHAPE_RECTANGLE, "leg": SHAPE_LEG}
 # Env.msg ped_scene_type strings (scenefactory.h:8-24): anything else is the EmptyScene
-SCENES = {"rvoscene": SCENE_RVO, "ervoscene": SCENE_ERVO, "pedscene": SCENE_PEDSIM}
+SCENES = {"rvoscene": SCENE_RVO, "ervoscene": SCENE_ERVO, "pedscene": SCENE_PEDSIM, "dataset": SCENE_DATASET}
 KTYPES = {"diff": KTYPE_DIFF, "omni": KTYPE_OMNI}
 
 _i32, _f32, _f64, _i64 = C.c_int32, C.c_float, C.c_double, C.c_int64
@@ -60,6 +60,7 @@ class ResetBatch(C.Structure):
         ("robot_pose", _pf64), ("robot_goal", _pf64),
         ("ped_pose", _pf64), ("ped_goal", _pf64), ("ped_traj_len", _pi32), ("ped_traj", _pf64),
         ("ped_traj_cap", _i32), ("ignore_obstacle", _i32),
+        ("ped_traj_v", _pf64),
     ]
 
 
@@ -200,6 +201,9 @@ def make_reset_batch(b, n_robots, n_peds):
     r.ped_traj = _ptr(keep["ped_traj"], C.c_double)
     r.ped_traj_cap = cap
     r.ignore_obstacle = int(bool(b.get("ignore_obstacle", False)))
+    if b.get("ped_traj_v") is not None:  # dataset scene: recorded velocities beside the recorded positions
+        keep["ped_traj_v"] = _keep(b["ped_traj_v"], np.float64).reshape(P, cap, 2)
+        r.ped_traj_v = _ptr(keep["ped_traj_v"], C.c_double)
     return r, keep
 
 

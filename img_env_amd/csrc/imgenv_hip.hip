@@ -50,6 +50,7 @@ struct imgenv {
     RvoNodeDev* d_nodes = nullptr;
     int cap_obst = 0, cap_nodes = 0;
     double* d_traj = nullptr;
+    double* d_traj_v = nullptr;  // dataset scene
     double *d_rob3 = nullptr, *d_ped3 = nullptr;  // reset staging (persistent: no pool traffic per reset)
     // pinned host staging of imgenv_reset: copies are truly asynchronous and reset never waits for the stream
     struct Chunk { unsigned char* p; size_t cap, used; };
@@ -975,9 +976,13 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     std::vector<double> ped3((size_t)(P > 0 ? P : 1) * 3);
     std::vector<int> tlen(P > 0 ? P : 1);
     if (P > 0) {
+        const bool dataset = h->cfg.ped_scene_type == IMGENV_SCENE_DATASET;
+        if (dataset && !b->ped_traj_v) FAIL(IMGENV_EINVAL, "dataset scene: ped_traj_v is missing from the reset batch");
         if (b->ped_traj_cap > h->traj_cap) {
             h->traj_cap = b->ped_traj_cap;
             if (int rc = dev_alloc(h, &h->d_traj, (size_t)P * h->traj_cap * 3)) return rc;
+            if (dataset)
+                if (int rc = dev_alloc(h, &h->d_traj_v, (size_t)P * h->traj_cap * 3)) return rc;
         }
         std::vector<double> traj((size_t)P * h->traj_cap * 3, 0.0);
         for (int j = 0; j < P; j++) {
@@ -992,6 +997,19 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         }
         RTRY(stage_put(h, h->d_traj, traj.data(), traj.size() * 8, st));
         RTRY(stage_put(h, h->d_traj_len, tlen.data(), sizeof(int) * P, st));
+        if (dataset) {  // trajectory_v (img_env.cpp:246-247) + the yaw _step_ped_dataset derives from it, with the host's libm
+            std::vector<double> tv((size_t)P * h->traj_cap * 3, 0.0);
+            for (int j = 0; j < P; j++)
+                for (int q = 0; q < tlen[j]; q++) {
+                    const double* v = b->ped_traj_v + ((size_t)j * b->ped_traj_cap + q) * 2;
+                    double* o = &tv[((size_t)j * h->traj_cap + q) * 3];
+                    o[0] = v[0];
+                    o[1] = v[1];
+                    o[2] = atan2(v[1], v[0]);
+                }
+            RTRY(stage_put(h, h->d_traj_v, tv.data(), tv.size() * 8, st));
+            d.ptraj_v = h->d_traj_v;
+        }
         if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::setWayPoint (pedscene.h:38-46): [goal r=1, trajectory r=z]
             std::vector<double> wx((size_t)P * SFM_MAX_WP, 0.0), wy(wx), wr(wx);
             std::vector<int> dq((size_t)P * SFM_MAX_WP, 0), dqn(P, 0), dest(P, 0), last(P, -1);
@@ -1097,13 +1115,13 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     }
     // _step_robot (img_env.cpp:388-410)
     {   // ... and the pedestrians' move (img_env.cpp:343-358) in the same launch
-        const bool peds = h->P > 0 && h->NA > 0;
+        const bool peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET);
         if (h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS) {
             const int nb_robot = (h->RL + INT_ROBOTS - 1) / INT_ROBOTS, nb_ped = peds ? (h->P + INT_G * INT_ROBOTS - 1) / (INT_G * INT_ROBOTS) : 0;
-            TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3(nb_robot + nb_ped), dim3(INT_G * INT_ROBOTS), 0, st>>>(d, actions, nb_robot, h->n_sub)));
+            TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3(nb_robot + nb_ped), dim3(INT_G * INT_ROBOTS), 0, st>>>(d, actions, nb_robot, h->n_sub, h->elapsed)));
         } else {
             const int nb_robot = (h->RL + 127) / 128, nb_ped = peds ? (h->P + 127) / 128 : 0;
-            TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate_serial<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot)));
+            TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate_serial<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot, h->elapsed)));
         }
     }
     h->launches += 1;

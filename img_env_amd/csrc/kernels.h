@@ -370,11 +370,36 @@ __device__ __forceinline__ void integrate_robot(const DevWorld& w, const float* 
     w.is_arr[l] = is_arrive ? 1 : 0;
 }
 
+// ImgEnv::_step_ped_dataset (img_env.cpp:361-386): pedestrian j replays record min(step, len - 1) of its trajectory
+__device__ __forceinline__ void ped_dataset_one(const DevWorld& w, int j, int step) {
+    const int len = w.ptraj_len[j];
+    const int idx = step >= len ? len - 1 : step;
+    const double* tp = w.ptraj + ((size_t)j * w.traj_cap + idx) * 3;
+    const double* tv = w.ptraj_v + ((size_t)j * w.traj_cap + idx) * 3;
+    const double ox = w.ppx[j], oy = w.ppy[j];
+    const double x = tp[0], y = tp[1], vx = tv[0], vy = tv[1];
+    w.plx[j] = ox;  // set_position (agent.cpp:691-694)
+    w.ply[j] = oy;
+    w.ppx[j] = x;
+    w.ppy[j] = y;
+    w.pyaw[j] = tv[2];  // atan2(vy, vx), evaluated by the host's libm at reset
+    w.pvx[j] = vx;
+    w.pvy[j] = vy;
+    w.ped_state[4 * j] = x;
+    w.ped_state[4 * j + 1] = y;
+    w.ped_state[4 * j + 2] = vx;
+    w.ped_state[4 * j + 3] = vy;
+    ped_leg_gait(w, j, x, y, ox, oy);
+}
+
 // Serial fallback of the robot update (more sub-steps than INT_ITEMS - 2): one thread per robot.
-__global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions, int nb_robot) {
+__global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions, int nb_robot, int step) {
     if ((int)blockIdx.x >= nb_robot) {
         const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
-        if (j < w.P) ped_update_one(w, j);
+        if (j < w.P) {
+            if (w.scene == IMGENV_SCENE_DATASET) ped_dataset_one(w, j, step);
+            else ped_update_one(w, j);
+        }
         return;
     }
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,11 +428,14 @@ __global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions
 // 221-236, then the exact arc).  The headings do not depend on the positions, so 8 lanes per robot evaluate them side by
 // side -- each lane re-accumulates `oz += w * 0.05` up to its own sub-step, which keeps the reference's rounding -- and
 // lane 0 then runs the (cheap) position recurrence and the arrive tests over the table in LDS.
-__global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot, int n_sub) {
+__global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot, int n_sub, int step) {
     __shared__ double2 trig[INT_ROBOTS][INT_ITEMS];  // (cos, sin)
     if ((int)blockIdx.x >= nb_robot) {
         const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
-        if (j < w.P) ped_update_one(w, j);
+        if (j < w.P) {
+            if (w.scene == IMGENV_SCENE_DATASET) ped_dataset_one(w, j, step);
+            else ped_update_one(w, j);
+        }
         return;
     }
     const int g = threadIdx.x & (INT_G - 1), rb = threadIdx.x / INT_G;

@@ -106,6 +106,7 @@ struct DevWorld {
     int *pstate, *ptraj_idx;                                                       // [P]
     const int* ptraj_len;
     const double* ptraj;  // [P][traj_cap][3]
+    const double* ptraj_v;  // [P][traj_cap][3] dataset scene: recorded (vx, vy) and the host's atan2(vy, vx)
     int traj_cap;
     // RVO (float32)
     float *apx, *apy, *avx, *avy, *anvx, *anvy;  // [NA]

@@ -159,6 +159,9 @@ class ImageEnv(Env):
         """yaml_env.py:296-317.  ``layout`` (a worldgen.ResetLayout) overrides the random spawn."""
         if layout is None:
             layout = self.env_pose.reset(self._extent)
+        data = kwargs.get("cur_ped_pos_v_datas")
+        if data is not None:  # EnvPos.init_ped_dataset (reset_helper.py:417-432, yaml_env.py:246-247)
+            spawn.init_ped_dataset(layout, np.asarray(data, np.float64))
         self.world.reset(layout)
         self.dones = self.world.out["base_dones"]
         return self._state()

@@ -159,3 +159,19 @@ class EnvPos:
                            ped_goal=target[nr:, :2], ped_traj=traj, ped_traj_len=tlen, obs_shape=oshape, obs_size=osize,
                            obs_pose=yaw_to_pose(opose[:, :2], opose[:, 2]) if len(opose) else np.zeros((0, 4)),
                            ignore_obstacle=bool(cfg["ped_sim"].get("ignore_obstacle", False)))
+
+
+def init_ped_dataset(layout, ped_pos_v_datas):
+    """EnvPos.init_ped_dataset (reset_helper.py:417-432): ``ped_pos_v_datas[i]`` holds one row (x, y, yaw, vx, vy) per
+    step for pedestrian i; the trajectory becomes the recorded poses, ``trajectory_v`` the recorded velocities and the
+    initial pose the first row.  Used with ``ped_sim.type: dataset`` (img_env.cpp:294-296)."""
+    d = np.asarray(ped_pos_v_datas, np.float64)
+    P, T = d.shape[0], d.shape[1]
+    layout.ped_traj = np.ascontiguousarray(d[:, :, :3])
+    layout.ped_traj_v = np.ascontiguousarray(d[:, :, 3:5])
+    layout.ped_traj_len = np.full(P, T, np.int32)
+    pose = np.zeros((P, 4))
+    pose[:, 0], pose[:, 1] = d[:, 0, 0], d[:, 0, 1]
+    pose[:, 2], pose[:, 3] = np.sin(d[:, 0, 2] / 2.0), np.cos(d[:, 0, 2] / 2.0)
+    layout.ped_pose = pose
+    return layout

@@ -118,9 +118,10 @@ class ResetLayout:
     obs_size: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float32))
     obs_pose: np.ndarray = field(default_factory=lambda: np.zeros((0, 4)))
     ignore_obstacle: bool = False
+    ped_traj_v: np.ndarray = None  # [P, cap, 2] recorded (vx, vy) beside ped_traj: the "dataset" pedestrian scene
 
     def as_batch(self):
-        return dict(robot_pose=self.robot_pose, robot_goal=self.robot_goal, ped_pose=self.ped_pose,
+        return dict(ped_traj_v=self.ped_traj_v, robot_pose=self.robot_pose, robot_goal=self.robot_goal, ped_pose=self.ped_pose,
                     ped_goal=self.ped_goal, ped_traj=self.ped_traj, ped_traj_len=self.ped_traj_len,
                     ped_traj_cap=self.ped_traj.shape[1] if self.ped_traj.ndim == 3 else 2,
                     obs_shape=self.obs_shape, obs_size=self.obs_size, obs_pose=self.obs_pose,

@@ -59,6 +59,7 @@ extern "C" {
 #define IMGENV_SCENE_RVO 1     /* "rvoscene"  rvoscene.h  */
 #define IMGENV_SCENE_ERVO 2    /* "ervoscene" ervoscene.h */
 #define IMGENV_SCENE_PEDSIM 3  /* "pedscene"  pedscene.h  */
+#define IMGENV_SCENE_DATASET 4 /* "dataset": pedestrians replay recorded trajectories (img_env.cpp:295-296, 361-386) */
 
 /* Agent.msg `ktype` of robots (agent.cpp:198, 238) */
 #define IMGENV_KTYPE_DIFF 0
@@ -153,6 +154,7 @@ typedef struct imgenv_reset_batch {
     const double* ped_traj;       /* [n_peds][ped_traj_cap][3]  Agent.msg trajectory (x, y, z) */
     int32_t ped_traj_cap;
     int32_t ignore_obstacle;
+    const double* ped_traj_v;     /* [n_peds][ped_traj_cap][2]  Agent.msg trajectory_v (vx, vy): IMGENV_SCENE_DATASET only, else NULL */
 } imgenv_reset_batch;
 
 /* Device pointers of the per-robot outputs, R = robot_end - robot_begin local robots.

@@ -96,6 +96,7 @@ struct oracle_world {
     double *ppx, *ppy, *pyaw, *plx, *ply, *pvx, *pvy, *prem, *llx, *lly, *rlx, *rly, *pr_round;
     int *pstate, *ptraj_idx, *ptraj_len;
     double* ptraj;
+    double* ptraj_v; /* [P][traj_cap][2] Agent.msg trajectory_v, dataset scene */
     int traj_cap;
     float* pmax_speed;
     rvo_sim* rvo;
@@ -536,7 +537,7 @@ void oracle_destroy(oracle_world* w) {
     free(w->world_target); free(w->is_coll); free(w->is_arr); free(w->py_done); free(w->clean_state); free(w->view); free(w->hits);
     free(w->ppx); free(w->ppy); free(w->pyaw); free(w->plx); free(w->ply); free(w->pvx); free(w->pvy);
     free(w->prem); free(w->llx); free(w->lly); free(w->rlx); free(w->rly); free(w->pr_round);
-    free(w->pstate); free(w->ptraj_idx); free(w->ptraj_len); free(w->ptraj); free(w->pmax_speed);
+    free(w->pstate); free(w->ptraj_idx); free(w->ptraj_len); free(w->ptraj); free(w->ptraj_v); free(w->pmax_speed);
     free(w->tmp_dist);
     free(w->pedinfo);
     rvo_destroy(w->rvo);
@@ -980,7 +981,9 @@ int oracle_reset(oracle_world* w, const imgenv_reset_batch* b) {
     if (b->ped_traj_cap > w->traj_cap) {
         w->traj_cap = b->ped_traj_cap;
         w->ptraj = (double*)realloc(w->ptraj, sizeof(double) * 3 * (size_t)w->traj_cap * (size_t)(w->P > 0 ? w->P : 1));
+        w->ptraj_v = (double*)realloc(w->ptraj_v, sizeof(double) * 2 * (size_t)w->traj_cap * (size_t)(w->P > 0 ? w->P : 1));
     }
+    if (w->cfg.ped_scene_type == IMGENV_SCENE_DATASET && w->P > 0 && !b->ped_traj_v) return IMGENV_EINVAL;
     for (int j = 0; j < w->P; j++) {
         const double* p = b->ped_pose + 4 * j;
         double yaw = tf_yaw_from_quaternion_zw(p[2], p[3]);
@@ -993,6 +996,10 @@ int oracle_reset(oracle_world* w, const imgenv_reset_batch* b) {
         for (int q = 0; q < len; q++)
             memcpy(w->ptraj + ((size_t)j * w->traj_cap + q) * 3, b->ped_traj + ((size_t)j * b->ped_traj_cap + q) * 3,
                    sizeof(double) * 3);
+        if (w->cfg.ped_scene_type == IMGENV_SCENE_DATASET) /* trajectory_v (img_env.cpp:246-247) */
+            for (int q = 0; q < len; q++)
+                memcpy(w->ptraj_v + ((size_t)j * w->traj_cap + q) * 2, b->ped_traj_v + ((size_t)j * b->ped_traj_cap + q) * 2,
+                       sizeof(double) * 2);
         w->ptraj_idx[j] = 0;
         if (w->rvo) { /* setPedPos (rvoscene.h:32-34) */
             w->rvo->px[j] = (float)p[0];
@@ -1089,9 +1096,33 @@ static void ped_update_bbox(oracle_world* w, int j) {
     }
 }
 
+/* ImgEnv::_step_ped_dataset (img_env.cpp:361-386): pedestrians replay recorded positions / velocities, one record
+ * per step since the reset (step_ is reset at img_env.cpp:164 and incremented at the end of _step, :518) */
+static void step_ped_dataset(oracle_world* w) {
+    for (int j = 0; j < w->P; j++) {
+        const int len = w->ptraj_len[j];
+        const int idx = w->elapsed >= len ? len - 1 : w->elapsed;
+        const double* tp = w->ptraj + ((size_t)j * w->traj_cap + idx) * 3;
+        const double* tv = w->ptraj_v + ((size_t)j * w->traj_cap + idx) * 2;
+        const double vx = tv[0], vy = tv[1];
+        w->plx[j] = w->ppx[j]; /* set_position (agent.cpp:691-694) */
+        w->ply[j] = w->ppy[j];
+        w->ppx[j] = tp[0];
+        w->ppy[j] = tp[1];
+        w->pyaw[j] = atan2(vy, vx);
+        w->pvx[j] = vx;
+        w->pvy[j] = vy;
+        ped_update_bbox(w, j);
+    }
+}
+
 /* ImgEnv::_step_ped_normal (img_env.cpp:304-359) */
 static void step_ped(oracle_world* w) {
     const int P = w->P;
+    if (w->cfg.ped_scene_type == IMGENV_SCENE_DATASET) { /* ImgEnv::_step_ped (img_env.cpp:294-302) */
+        step_ped_dataset(w);
+        return;
+    }
     if (P == 0 && !w->rvo && !w->sfm) return;
     if (w->rvo) {
         for (int j = 0; j < P; j++) {

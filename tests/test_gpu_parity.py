@@ -242,3 +242,41 @@ def test_hip_matches_oracle_variants(worlds, name):
     finally:
         gpu.close()
         cpu.close()
+
+
+def _dataset_world(n_robots, n_peds, steps, seed, ped_shape="circle"):
+    """pedestrians replay a recorded random walk: rows (x, y, yaw, vx, vy) per step (reset_helper.py:417-432)"""
+    from img_env_amd import spawn
+    grid, params, layout = small_world(n_robots, n_peds, seed=seed, n_obstacles=2, scene="dataset", ped_shape=ped_shape)
+    rng = np.random.default_rng(seed)
+    T = steps - 7  # shorter than the episode: the last record is held (img_env.cpp:365-368)
+    data = np.zeros((n_peds, T, 5))
+    pos = layout.ped_pose[:, :2].copy()
+    for t in range(T):
+        v = rng.uniform(-0.5, 0.5, (n_peds, 2))
+        if t % 5 == 0:
+            v[0] = 0.0  # atan2(0, 0) and a standing pedestrian
+        data[:, t, :2] = pos
+        data[:, t, 2] = rng.uniform(-3, 3, n_peds)
+        data[:, t, 3:] = v
+        pos = pos + 0.25 * v
+    spawn.init_ped_dataset(layout, data)
+    return grid, params, layout
+
+
+@pytest.mark.parametrize("ped_shape", ["circle", "leg"])
+def test_dataset_pedestrians_match_oracle(worlds, ped_shape):
+    """ped_sim type "dataset" (img_env.cpp:294-296, 361-386)"""
+    World, OracleWorld = worlds
+    n, steps = 10, 30
+    grid, params, layout = _dataset_world(n, 7, steps, seed=77, ped_shape=ped_shape)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(3)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(steps)])
+        assert not fails, fails[:3]
+        moved = np.abs(cpu.snapshot()["ped_state"][:, :2] - layout.ped_pose[:, :2]).max()
+        assert moved > 0.5  # the crowd really followed the record
+    finally:
+        gpu.close()
+        cpu.close()
