@@ -1,0 +1,109 @@
+"""Host-side logic that needs neither the GPU nor the HIP library: synthetic worlds, the EnvPos spawn
+rules, the YAML -> InitEnv parameter mapping and the float32 wire rounding of the C ABI structs."""
+import numpy as np
+import pytest
+
+from img_env_amd import _cabi, config, spawn, worldgen
+
+
+def _pairwise_min(xy):
+    d = np.linalg.norm(xy[:, None, :] - xy[None, :, :], axis=-1)
+    d[np.diag_indices(len(xy))] = np.inf
+    return d.min()
+
+
+def test_grid_is_deterministic_and_walled():
+    a, b = worldgen.make_grid(200, 3), worldgen.make_grid(200, 3)
+    assert a.dtype == np.uint8 and a.shape == (200, 200) and np.array_equal(a, b)
+    assert not np.array_equal(a, worldgen.make_grid(200, 4))
+    assert set(np.unique(a)) <= {0, 255}
+    assert (a[:8] == 0).all() and (a[-8:] == 0).all() and (a[:, :8] == 0).all() and (a[:, -8:] == 0).all()
+    assert (a[100] == 255).any()
+
+
+def test_layout_respects_clearances():
+    res, clearance = 0.125, 1.0
+    grid = worldgen.make_grid(320, 1)
+    lay = worldgen.make_layout(grid, res, 40, 12, seed=5, clearance=clearance, n_obstacles=4)
+    starts = np.vstack([lay.robot_pose[:, :2], lay.ped_pose[:, :2]])
+    assert _pairwise_min(starts) >= clearance - 1e-9
+    cells = np.rint(starts / res).astype(int)
+    assert (grid[cells[:, 0], cells[:, 1]] == 255).all()               # every start on a free cell
+    d_goal = np.linalg.norm(lay.robot_goal - lay.robot_pose[:, :2], axis=1)
+    assert (d_goal >= 1.0 - 1e-9).all() and (np.abs(lay.robot_goal - lay.robot_pose[:, :2]).max(1) <= 4.0 + 1e-9).all()
+    q = lay.robot_pose[:, 2:]
+    assert np.allclose((q ** 2).sum(1), 1.0)                           # (qz, qw) is a unit quaternion
+    assert lay.ped_traj.shape == (12, 2, 3) and (lay.ped_traj_len == 2).all()  # go_back: [goal, start]
+    assert np.allclose(lay.ped_traj[:, 1, :2], lay.ped_pose[:, :2])
+    b = lay.as_batch()
+    assert b["ped_traj_cap"] == 2 and len(b["obs_shape"]) == 4 and b["ped_traj_v"] is None
+    again = worldgen.make_layout(grid, res, 40, 12, seed=5, clearance=clearance, n_obstacles=4)
+    assert np.array_equal(again.robot_pose, lay.robot_pose) and np.array_equal(again.ped_traj, lay.ped_traj)
+
+
+def test_yaml_cfg_maps_to_the_same_parameters_as_make_params():
+    grid = worldgen.make_grid(200, 0)
+    cfg = worldgen.make_yaml_cfg(6, 3, grid, time_max=40, ped_shape="leg", state_dim=5, n_obstacles=2)
+    p = config.params_from_cfg(cfg)
+    q = worldgen.make_params(6, 3, ped_shape="leg", state_dim=5, time_max=40)
+    for k in ("view_resolution", "view_width", "view_height", "step_hz", "state_dim", "range_total", "view_angle_begin",
+              "view_angle_end", "relation_ped_robo", "ped_scene_type", "n_robots", "n_peds", "time_max", "laser_max",
+              "ped_image_r", "max_ped"):
+        assert p[k] == q[k], k
+    assert np.array_equal(np.asarray(p["ped_size"], np.float32), np.asarray(q["ped_size"], np.float32))
+    assert np.array_equal(np.asarray(p["robot_size"], np.float32), np.asarray(q["robot_size"], np.float32))
+    assert tuple(p["image_size"]) == (48, 48)
+
+
+def test_cfg_struct_rounds_to_the_float32_wire():
+    p = worldgen.make_params(2, 0, res=0.1)                            # 0.1 is not a float32
+    c, keep = _cabi.make_cfg(p)
+    assert c.view_resolution == np.float32(0.1) and c.view_resolution != 0.1
+    assert c.struct_size == _cabi.C.sizeof(_cabi.Cfg) and c.abi_version == _cabi.ABI_VERSION
+    assert c.robot_end == 2 and c.robot_begin == 0 and c.n_robots == 2
+    assert keep["robot_size"].dtype == np.float32 and keep["robot_size_last"].dtype == np.float64
+
+
+def test_reset_batch_keeps_its_buffers_alive_and_typed():
+    grid = worldgen.make_grid(200, 0)
+    lay = worldgen.make_layout(grid, 0.125, 3, 2, seed=1)
+    b, keep = _cabi.make_reset_batch(lay.as_batch(), 3, 2)
+    assert b.struct_size == _cabi.C.sizeof(_cabi.ResetBatch) and b.ped_traj_cap == 2 and not b.ped_traj_v
+    assert keep["robot_pose"].shape == (3, 4) and keep["ped_traj"].shape == (2, 2, 3)
+    assert b.robot_pose[0] == lay.robot_pose[0, 0]
+
+
+def test_envpos_spawn_rules():
+    grid = worldgen.make_grid(320, 0)
+    cfg = worldgen.make_yaml_cfg(16, 6, grid, n_obstacles=2)
+    ep = spawn.EnvPos(cfg, seed=11)
+    extent = 320 * 0.125
+    lay = ep.reset(extent)
+    starts = np.vstack([lay.robot_pose[:, :2], lay.ped_pose[:, :2]])
+    assert _pairwise_min(starts) > 1.0 - 1e-9                          # free_check_robo_ped d = 1.0 (reset_helper.py:35-43)
+    assert (np.linalg.norm(lay.robot_goal - lay.robot_pose[:, :2], axis=1) > float(cfg["target_min_dist"]) - 1e-9).all()
+    for p in ep.obs_range:                                             # starts clear of the obstacles (reset_helper.py:46-55)
+        assert (np.linalg.norm(starts - np.array(p[:2]), axis=1) > p[-1]).all()
+    same = spawn.EnvPos(cfg, seed=11).reset(extent)
+    assert np.array_equal(same.robot_pose, lay.robot_pose)
+    assert not np.array_equal(spawn.EnvPos(cfg, seed=12).reset(extent).robot_pose, lay.robot_pose)
+
+
+def test_init_ped_dataset_shapes():
+    grid = worldgen.make_grid(200, 0)
+    lay = worldgen.make_layout(grid, 0.125, 2, 3, seed=1)
+    data = np.arange(3 * 5 * 5, dtype=np.float64).reshape(3, 5, 5)
+    spawn.init_ped_dataset(lay, data)
+    assert lay.ped_traj.shape == (3, 5, 3) and lay.ped_traj_v.shape == (3, 5, 2) and (lay.ped_traj_len == 5).all()
+    assert np.array_equal(lay.ped_pose[:, :2], data[:, 0, :2])
+    assert np.allclose(lay.ped_pose[:, 2], np.sin(data[:, 0, 2] / 2)) and np.allclose(lay.ped_pose[:, 3], np.cos(data[:, 0, 2] / 2))
+    b, keep = _cabi.make_reset_batch(lay.as_batch(), 2, 3)
+    assert b.ped_traj_cap == 5 and bool(b.ped_traj_v) and keep["ped_traj_v"].shape == (3, 5, 2)
+
+
+def test_unsupported_spawn_layouts_fail_loudly():
+    grid = worldgen.make_grid(200, 0)
+    cfg = worldgen.make_yaml_cfg(2, 0, grid)
+    cfg["robot"]["begin_poses_type"] = ["circle", "circle"]
+    with pytest.raises(NotImplementedError):
+        spawn.EnvPos(cfg, seed=0).reset(25.0)
