@@ -40,10 +40,14 @@ def test_oracle_matches_committed_reference_trace(oracle_lib, case):
 @pytest.mark.skipif(not os.path.exists(RefSfm.path()), reason="oracle/_ref not built (no reference tree)")
 def test_oracle_matches_reference_build(oracle_lib):
     """same process, same creation order on both sides: the two global random streams advance in lock step"""
+    import ctypes as C
     _fresh_oracle()
+    C.CDLL(None).srand(1)  # the reference draws from libc's rand(): back to a fresh process' state (other tests may have drawn)
     for seed in (1, 2, 3):
         for case, kw in CASES.items():
             got, vo = run_scenario(OracleSfm, seed, **kw)
             ref, vr = run_scenario(RefSfm, seed, **kw)
-            assert np.abs(got - ref).max() < 1e-12, (seed, case)
+            # the reference sums forces in the order of a std::set<Tagent*>, i.e. of heap addresses: its own result moves by
+            # up to ~2e-12 over 150 steps from one process layout to the next (measured), so 1e-10 is the honest bar here
+            assert np.abs(got - ref).max() < 1e-10, (seed, case)
             assert np.array_equal(vo, vr), (seed, case)
