@@ -37,6 +37,8 @@ CASES = {
     "view_50_not_a4": dict(n_robots=16, n_peds=6, seed=25, view_cells=50),
     "view_37_odd_res010": dict(n_robots=16, n_peds=6, seed=26, view_cells=37, res=0.1, grid_size=200,
                                view_width=3.75, view_height=3.75),  # int(3.75 / 0.1) = 37 cells
+    # BASELINE cfg-5 geometry: 96 x 96 view, 720 beams
+    "view96_720beams": dict(n_robots=10, n_peds=6, seed=27, view_cells=96, beams=720, grid_size=240),
     "no_laser": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "time_limit": dict(n_robots=4, n_peds=2, seed=9, time_max=6),
 }
@@ -277,6 +279,23 @@ def test_dataset_pedestrians_match_oracle(worlds, ped_shape):
         assert not fails, fails[:3]
         moved = np.abs(cpu.snapshot()["ped_state"][:, :2] - layout.ped_pose[:, :2]).max()
         assert moved > 0.5  # the crowd really followed the record
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_two_thousand_robots_match_oracle(worlds):
+    """a crowd at the density of the benchmark world (0.25 m cells, 0.7 m clearance): every wavefront slot of a few
+    dozen CUs is busy, robots see dozens of each other, collisions and arrivals happen"""
+    World, OracleWorld = worlds
+    n = 2048
+    grid, params, layout = small_world(n, 60, seed=51, grid_size=200, res=0.25, clearance=0.7, n_obstacles=0)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(9)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(6)])
+        assert not fails, fails[:3]
+        assert (cpu.snapshot()["is_collisions"] != 0).any()
     finally:
         gpu.close()
         cpu.close()
