@@ -77,6 +77,7 @@ struct imgenv {
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     bool orca_pending = false;
     bool serial = false;  // IMGENV_SERIAL=1: no side streams (profiling aid)
+    volatile int* err_host = nullptr;  // [8] page-locked flags the kernels raise on overflow; checked at every API call
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
     RvoObstacles rvo;
     int sfm_cap_obs = 0;
@@ -309,6 +310,7 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamSynchronize(h->side2);
         (void)hipStreamDestroy(h->side2);
     }
+    if (h->err_host) (void)hipHostFree((void*)h->err_host);
     for (auto& c : h->stage) (void)hipHostFree(c.p);
     if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
@@ -582,7 +584,16 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         for (int j = 0; j < P && j < NA; j++) ms[j] = (float)(double)h->pmax[j];
         TRY(dev_upload(h, &d.amax_speed, ms));
     }
-    TRY(dev_alloc(h, &d.err, 4));
+    {   // overflow flags live in page-locked host memory the device writes through: no copy, no sync to read them
+        int* e = nullptr;
+        HIPCHK(hipHostMalloc((void**)&e, 8 * sizeof(int), hipHostMallocMapped));
+        memset(e, 0, 8 * sizeof(int));
+        h->err_host = e;
+        int* dev = nullptr;
+        HIPCHK(hipHostGetDevicePointer((void**)&dev, e, 0));
+        d.err = dev;
+        d.sfm.err = dev + 4;
+    }
     if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene(): Tscene(0,10,10,10), addPed, addRobot (pedscene.h:17-80)
         SfmDev& f = d.sfm;
         const int n = P + (cfg->relation_ped_robo == 1 ? R : 0);
@@ -614,7 +625,6 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_alloc(h, &f.dq, (size_t)(n ? n : 1) * SFM_MAX_WP)); TRY(dev_alloc(h, &f.dq_n, n));
         TRY(dev_alloc(h, &f.dest, n, 0xFF)); TRY(dev_alloc(h, &f.last, n, 0xFF));  // -1
         TRY(dev_alloc(h, &f.nodes, f.cap_nodes)); TRY(dev_alloc(h, &f.n_nodes, 1)); TRY(dev_alloc(h, &f.treehash, n));
-        TRY(dev_alloc(h, &f.err, 1));
         HIPCHK(hipMemcpy(f.p, p0.data(), sizeof(double) * 3 * (n ? n : 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.vmax, vmax.data(), sizeof(double) * (n ? n : 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
@@ -771,6 +781,19 @@ __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
     w.ped_state[4 * j + 3] = w.pvy[j];
 }
 
+// device-side overflow flags (raised by kernels, see world.h / sfm.h): turn them into an error at the next API call
+static int check_device_flags(imgenv* h) {
+    const volatile int* e = h->err_host;
+    if (!e) return 0;
+    if (e[0]) FAIL(IMGENV_EDEVICE, "ORCA: a pedestrian sees more obstacle segments than the neighbour scratch holds");
+    if (e[1]) FAIL(IMGENV_EDEVICE, "ORCA: obstacle BSP walk overflowed its stack");
+    if (e[4])
+        FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth) -- more than "
+                             "8 agents piled up outside the tree's 10 m x 10 m root square, where the reference recurses forever "
+                             "(ped_tree.cpp:65-96)", e[4]);
+    return 0;
+}
+
 // fork: the pedestrian half of the observation needs the local robots' new poses only, so it starts right behind
 // k_integrate (in a sharded world: underneath the record exchange) on its own stream
 static int launch_obs(imgenv* h, hipStream_t st) {
@@ -915,6 +938,10 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     const bool trace_ = getenv("IMGENV_TRACE_RESET") != nullptr;
     std::chrono::steady_clock::time_point tp_[8];
     tp_[0] = std::chrono::steady_clock::now();
+    if (int rc = check_device_flags(h)) {  // report what the abandoned episode raised, then start clean
+        for (int q = 0; q < 8; q++) h->err_host[q] = 0;
+        return rc;
+    }
     RTRY(stage_begin(h));
     tp_[1] = std::chrono::steady_clock::now();
     DevWorld& d = h->d;
@@ -1100,6 +1127,7 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
 extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream) {
     if (!h || !actions) FAIL(IMGENV_EINVAL, "null argument");
     if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
+    if (int rc = check_device_flags(h)) return rc;
     hipStream_t st = (hipStream_t)stream;
     DevWorld& d = h->d;
     h->launches = 0;

@@ -235,7 +235,11 @@ __device__ __forceinline__ void ped_update_one(const DevWorld& w, int j) {
 // write-back of img_env.cpp:344-358 (getNewPosAndVel pedscene.h:82-91, set_position, update_bbox)
 __global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w) {
     __shared__ uint32_t nb_bits[SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32)];
+#ifdef IMGENV_PHASE_PROFILE
+    sfm_step(w.sfm, w.step_hz, nb_bits, w.prof);
+#else
     sfm_step(w.sfm, w.step_hz, nb_bits);
+#endif
     const int j = threadIdx.x;
     if (j >= w.P) return;
     const double ox = w.ppx[j], oy = w.ppy[j];

@@ -192,7 +192,10 @@ __device__ double sfm_angle_to(d3 a, d3 b) {  // Tvector::angleTo
 }
 
 // one Tscene::moveAgents(h) for the whole crowd: thread i = agent i, one workgroup
-__device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SFM_MAX_AGENTS][SFM_MAX_AGENTS/32] */) {
+__device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SFM_MAX_AGENTS][SFM_MAX_AGENTS/32] */,
+                         unsigned long long* stamp = nullptr /* debug: wall-clock marks of thread 0 */) {
+#define SFM_STAMP(q) do { if (stamp && threadIdx.x == 0) stamp[q] = wall_clock64(); } while (0)
+    SFM_STAMP(0);
     const int i = threadIdx.x;
     const int n = s.n;
     d3 desiredforce = D3(0, 0, 0), socialforce = D3(0, 0, 0), obstacleforce = D3(0, 0, 0), lookaheadforce = D3(0, 0, 0);
@@ -220,6 +223,7 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
                 }
             }
         }
+        SFM_STAMP(1);
         // Tagent::desiredForce (ped_agent.cpp:236-306)
         int dest = s.dest[i], last = s.last[i];
         const int dqn = s.dq_n[i];
@@ -277,6 +281,7 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
                 lookaheadforce.y = 0.5f * e.x;
             }
         }
+        SFM_STAMP(2);
         // Tagent::socialForce (ped_agent.cpp:316-404)
         {
             const double lambda_importance = 2.0, gamma = 0.35, nn = 2, n_prime = 3;
@@ -299,6 +304,7 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
                 socialforce = socialforce + (force_velocity + force_angle);
             }
         }
+        SFM_STAMP(3);
         // Tagent::obstacleForce (ped_agent.cpp:411-429)
         {
             d3 min_diff = D3(0, 0, 0);
@@ -329,6 +335,7 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         }
     }
     __syncthreads();  // all forces are computed from the t-1 state (ped_scene.cpp:170)
+    SFM_STAMP(4);
     if (i < n) {
         // Tagent::move (ped_agent.cpp:519-571)
         d3 p_desired = me_p + scaled(me_v, h);
@@ -351,9 +358,14 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         s.v[3 * i] = v.x; s.v[3 * i + 1] = v.y; s.v[3 * i + 2] = v.z;
     }
     __syncthreads();
+    SFM_STAMP(5);
     if (i == 0) {  // scene->moveAgent(this), in agent order
-        for (int a = 0; a < n; a++) sfm_move_agent(s.nodes, s.n_nodes, s.cap_nodes, s.treehash, s.p, a, s.err);
+        int lerr = 0;  // s.err is page-locked host memory: touched only to report
+        for (int a = 0; a < n && lerr == 0; a++) sfm_move_agent(s.nodes, s.n_nodes, s.cap_nodes, s.treehash, s.p, a, &lerr);
+        if (lerr) *s.err = lerr;
     }
     __syncthreads();
+    SFM_STAMP(6);
+#undef SFM_STAMP
 }
 #endif

@@ -299,3 +299,21 @@ def test_two_thousand_robots_match_oracle(worlds):
     finally:
         gpu.close()
         cpu.close()
+
+
+def test_quadtree_overflow_is_reported(worlds):
+    """more than 8 social-force agents outside the 10 m x 10 m root square of libpedsim's quadtree: the reference recurses
+    forever (ped_tree.cpp:65-96); the library raises the device flag and the next call fails loudly"""
+    import torch
+    World, _ = worlds
+    grid, params, layout = small_world(4, 40, seed=61, grid_size=400, scene="pedscene", relation_ped_robo=0, clearance=0.8)
+    w = World(params, grid)
+    try:
+        w.reset(layout)
+        a = np.zeros((4, 3), np.float32)
+        with pytest.raises(RuntimeError, match="quadtree overflowed"):
+            for s in range(6):
+                w.step(a)
+                torch.cuda.synchronize()
+    finally:
+        w.close()
