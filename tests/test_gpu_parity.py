@@ -317,3 +317,29 @@ def test_quadtree_overflow_is_reported(worlds):
                 torch.cuda.synchronize()
     finally:
         w.close()
+
+
+def test_ragged_trajectories_and_padded_ped_vector(worlds):
+    """pedestrian waypoint lists of different lengths (1..4, img_env.cpp:306-319 cycles through them) and a ped vector
+    padded to max_ped > n_peds (yaml_env.py:397-408)"""
+    World, OracleWorld = worlds
+    n, P = 8, 9
+    grid, params, layout = small_world(n, P, seed=71, n_obstacles=2, max_ped=14)
+    rng = np.random.default_rng(71)
+    cap = 4
+    traj = np.zeros((P, cap, 3))
+    lens = rng.integers(1, cap + 1, P).astype(np.int32)
+    for j in range(P):
+        for q in range(lens[j]):
+            traj[j, q, :2] = layout.ped_pose[j, :2] + rng.uniform(-2.0, 2.0, 2)
+    layout.ped_traj, layout.ped_traj_len = traj, lens
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        acts = [random_actions(rng, n) for _ in range(60)]
+        fails = run_pair(gpu, cpu, layout, acts)
+        assert not fails, fails[:3]
+        pv = cpu.snapshot()["ped_vector_states"]
+        assert pv.shape[1] == 1 + 7 * 14 and (pv[:, 1 + 7 * P:] == 0).all() and (pv[:, 0] == P).all()
+    finally:
+        gpu.close()
+        cpu.close()
