@@ -75,7 +75,6 @@ struct imgenv {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t side2 = nullptr;  // pedestrian observation (k_obs) underneath raster / compose / view
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
-    bool orca_pending = false;
     bool serial = false;  // IMGENV_SERIAL=1: no side streams (profiling aid)
     volatile int* err_host = nullptr;  // [8] page-locked flags the kernels raise on overflow; checked at every API call
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
@@ -931,10 +930,6 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     if (b->n_obstacles < 0 || (h->P > 0 && b->ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->orca_pending) {  // a solve of the abandoned episode may still be in flight
-        HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
-        h->orca_pending = false;
-    }
     const bool trace_ = getenv("IMGENV_TRACE_RESET") != nullptr;
     std::chrono::steady_clock::time_point tp_[8];
     tp_[0] = std::chrono::steady_clock::now();
@@ -1131,12 +1126,8 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     hipStream_t st = (hipStream_t)stream;
     DevWorld& d = h->d;
     h->launches = 0;
-    if (h->P > 0 && h->NA > 0) {  // _step_ped_normal (img_env.cpp:304-359): the solve was launched after the last rasters
-        if (h->orca_pending) {
-            HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
-            h->orca_pending = false;
-        }
-    }
+    // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
+    // step's views and was joined before that step's k_tail; its velocities are applied by k_integrate's pedestrian blocks
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
         TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), 0, st>>>(d)));
         h->launches += 1;

@@ -1,17 +1,19 @@
 // kernels.h -- the HIP kernels of one img_env step, one kernel per stage, gfx950 (wave64).
 //
-//   k_orca        1 wave / pedestrian   waypoint logic + ORCA half-planes + LP   (img_env.cpp:304-343)
-//   k_ped_update  1 thread / pedestrian Agent::update + write-back + leg gait    (img_env.cpp:344-358)
-//   k_integrate   1 thread / robot      Agent::cmd                               (agent.cpp:186-283)
-//   k_raster      1 wave / ped | robot  view_ped + the shared robot-owner layer  (img_env.cpp:594-629)
-//   k_compose     1 thread / 4 cells    class layer = obstacles + peds + robots
-//   k_view        1 wave / robot        Agent::view: collision, crop, laser, stamp (agent.cpp:356-509)
-//   k_obs         1 wave / robot        get_state, PedInfo, ped_map, reward/done (img_env.cpp:547-587,
-//                                       yaml_env.py:392-481, base.py:153-254)
+//   k_integrate    8 lanes / robot       Agent::cmd (agent.cpp:186-283); + 1 thread / pedestrian: Agent::update,
+//                                        write-back, leg gait (img_env.cpp:344-358) or the recorded trajectory (361-386)
+//   k_sfm          1 workgroup / world   libpedsim crowd step (pedscene only)
+//   k_raster       1 wave / ped + robot  view_ped + the shared robot-owner layers (img_env.cpp:594-629)
+//   k_compose      1 thread / 4 cells    composed layer = obstacles + peds + robot owners
+//   k_view         1 wave / robot        Agent::view: collision, crop, laser, stamp (agent.cpp:356-509)
+//   k_obs<E>       1 wave / robot        PedInfo, sorted ped vector, ped_map (img_env.cpp:568-584, yaml_env.py:392-456)
+//   k_side_robots  1 thread / robot      RVO robot records + Agent::get_state (agent.cpp:156-184), on a side stream
+//   k_orca         1 wave / pedestrian   waypoint logic + ORCA half-planes + LP (img_env.cpp:304-343), on a side stream
+//   k_tail         1 thread / robot      step_ds, reward / done wrappers (yaml_env.py:446-481, base.py:153-254)
 //
 // This is gather / raster / scan work on bytes and small integers: no MFMA.  What matters is
 // wave-per-robot decomposition, LDS staging of the 48x48 windows and pedestrian lists, coalesced
-// dword stores of the outputs, and no atomics on the hot per-robot path.
+// dword stores of the outputs, no contended atomics, and all 8192 wavefronts of a launch resident at once.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -19,7 +21,6 @@
 #include "world.h"
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
-__device__ __forceinline__ int lane_id_raw() { return threadIdx.x & (WAVE - 1); }
 
 // robot class record: by value from the kernel arguments when possible (wave-uniform index)
 // a double that is known to be the same in every lane, moved to scalar registers
@@ -68,7 +69,7 @@ __device__ __forceinline__ void bbox_accumulate(const DevWorld& w, bool valid, d
         hi_x = max(hi_x, (uint32_t)__shfl_xor((int)hi_x, off));
         hi_y = max(hi_y, (uint32_t)__shfl_xor((int)hi_y, off));
     }
-    if (lane_id_raw() == 0 && lo_x != BBOX_INIT_MIN) {
+    if (lane_id() == 0 && lo_x != BBOX_INIT_MIN) {
         atomicMin(&w.bbox[0], lo_x);
         atomicMin(&w.bbox[1], lo_y);
         atomicMax(&w.bbox[2], hi_x);
