@@ -624,13 +624,15 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_alloc(h, &f.dq, (size_t)(n ? n : 1) * SFM_MAX_WP)); TRY(dev_alloc(h, &f.dq_n, n));
         TRY(dev_alloc(h, &f.dest, n, 0xFF)); TRY(dev_alloc(h, &f.last, n, 0xFF));  // -1
         TRY(dev_alloc(h, &f.nodes, f.cap_nodes)); TRY(dev_alloc(h, &f.n_nodes, 1)); TRY(dev_alloc(h, &f.treehash, n));
+        TRY(dev_alloc(h, &f.pair_f, (size_t)(n ? n : 1) * (n ? n : 1) * 3)); TRY(dev_alloc(h, &f.pair_code, (size_t)(n ? n : 1) * (n ? n : 1)));
         HIPCHK(hipMemcpy(f.p, p0.data(), sizeof(double) * 3 * (n ? n : 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.vmax, vmax.data(), sizeof(double) * (n ? n : 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.n_nodes, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
     }
-    TRY(dev_alloc(h, &d.prof, 16 + 12 * (size_t)RL));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
+    TRY(dev_alloc(h, &d.prof, 16 + 12 * (size_t)RL));
+    TRY(dev_alloc(h, &d.dbg, 32));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
 
     // output arena
     ArenaPlan plan;
@@ -1218,6 +1220,13 @@ extern "C" int imgenv_debug_phases(imgenv_t* h, unsigned long long* out16) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out16, h->d.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d.prof, 0, 16 * sizeof(unsigned long long)));
+    return IMGENV_OK;
+}
+// debug: the 32 free-form marks of profile builds
+extern "C" int imgenv_debug_marks(imgenv_t* h, unsigned long long* out32) {
+    if (!h || !out32) FAIL(IMGENV_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out32, h->d.dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return IMGENV_OK;
 }
 // debug: per-wave (start, end, hw id, 0) records of the last k_view [0, 4 RL) and k_obs [4 RL, 8 RL) launches

@@ -236,10 +236,15 @@ __device__ __forceinline__ void ped_update_one(const DevWorld& w, int j) {
 // write-back of img_env.cpp:344-358 (getNewPosAndVel pedscene.h:82-91, set_position, update_bbox)
 __global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w) {
     __shared__ uint32_t nb_bits[SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32)];
+    __shared__ double sfm_sh[4 * SFM_MAX_AGENTS];
+    __shared__ unsigned short sfm_stk[SFM_WALK_CAP * SFM_MAX_AGENTS];
+    __shared__ SfmNode sfm_nodes[SFM_LDS_NODES];
+    __shared__ int sfm_hash[SFM_MAX_AGENTS];
+    __shared__ int sfm_nn;
 #ifdef IMGENV_PHASE_PROFILE
-    sfm_step(w.sfm, w.step_hz, nb_bits, w.prof);
+    sfm_step(w.sfm, w.step_hz, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn, w.dbg);
 #else
-    sfm_step(w.sfm, w.step_hz, nb_bits);
+    sfm_step(w.sfm, w.step_hz, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn);
 #endif
     const int j = threadIdx.x;
     if (j >= w.P) return;

@@ -32,6 +32,8 @@
 #define SFM_MAX_WP 8
 #define SFM_LEAF_CAP 12
 #define SFM_MAX_DEPTH 64
+#define SFM_WALK_CAP 24  // LDS stack entries per agent of the neighbour walk
+#define SFM_LDS_NODES 192  // quadtree nodes mirrored in LDS for a step (larger trees are walked in HBM)
 
 struct SfmNode {  // Ped::Ttree
     double x, y, w, h;
@@ -52,6 +54,8 @@ struct SfmDev {
     int* n_nodes;   // [1]
     int* treehash;  // [n]
     int* err;       // [1] overflow flag (node pool / leaf capacity / depth)
+    double* pair_f;            // [n][n][3] social-force term of (agent, neighbour)
+    unsigned char* pair_code;  // [n][n] lookahead vote + 1 | has-term << 2
 };
 
 // ---- Ttree (ped_tree.cpp:18-137) on flat arrays, shared by the host (initial tree) and the device ----
@@ -87,8 +91,13 @@ SFM_HD inline void sfm_set_erase(SfmNode& q, int a) {
 
 // Ttree::addAgent (ped_tree.cpp:65-96), recursion unrolled onto an explicit stack.  Work items are
 // (node, agent); an item whose node is a leaf inserts and may split the leaf, pushing the former members.
-SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err) {
-    int st_node[SFM_MAX_DEPTH * 8], st_agent[SFM_MAX_DEPTH * 8];
+// `work`: 2 * SFM_MAX_DEPTH * 8 ints for the explicit stack (the device passes LDS: a dynamically indexed private array
+// would sit in scratch memory, ~1 us per push / pop); nullptr = a local array (host)
+SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err,
+                                 int* work = nullptr) {
+    int local_stack[2 * SFM_MAX_DEPTH * 8];
+    int* st_node = work ? work : local_stack;
+    int* st_agent = st_node + SFM_MAX_DEPTH * 8;
     int sp = 0;
     st_node[sp] = 0;
     st_agent[sp++] = agent;
@@ -144,12 +153,13 @@ SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* tre
 }
 
 // Tscene::moveAgent -> Ttree::moveAgent (ped_tree.cpp:131-137)
-SFM_HD inline void sfm_move_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int a, int* err) {
+SFM_HD inline void sfm_move_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int a, int* err,
+                                  int* work = nullptr) {
     const int leaf = treehash[a];
     const SfmNode& q = nodes[leaf];
     const double px = p[3 * a], py = p[3 * a + 1];
     if ((px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h))) {
-        sfm_add_agent(nodes, n_nodes, cap, treehash, p, a, err);  // scene->placeAgent(a): from the root
+        sfm_add_agent(nodes, n_nodes, cap, treehash, p, a, err, work);  // scene->placeAgent(a): from the root
         sfm_set_erase(nodes[leaf], a);                            // erased from the OLD leaf, even if it is the new one
     }
 }
@@ -193,11 +203,31 @@ __device__ double sfm_angle_to(d3 a, d3 b) {  // Tvector::angleTo
 
 // one Tscene::moveAgents(h) for the whole crowd: thread i = agent i, one workgroup
 __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SFM_MAX_AGENTS][SFM_MAX_AGENTS/32] */,
+                         double* sh /* LDS [4][SFM_MAX_AGENTS]: desired direction x / y and two angles per agent */,
+                         unsigned short* stk /* LDS [SFM_WALK_CAP][blockDim.x]: walk stacks; later one "left its leaf" flag per agent */,
+                         SfmNode* lnodes /* LDS [SFM_LDS_NODES] */, int* lhash /* LDS [SFM_MAX_AGENTS] */, int* ln_nodes /* LDS [1] */,
                          unsigned long long* stamp = nullptr /* debug: wall-clock marks of thread 0 */) {
 #define SFM_STAMP(q) do { if (stamp && threadIdx.x == 0) stamp[q] = wall_clock64(); } while (0)
     SFM_STAMP(0);
     const int i = threadIdx.x;
     const int n = s.n;
+    const int n_cap = SFM_MAX_AGENTS;
+    // The tree is pointer-chased many times per step and then edited agent by agent: for the step it lives in LDS (when it
+    // fits with room for a few splits), so a dependent access costs ~100 ns instead of ~1 us.
+    double* lp = (double*)nb_bits;  // [n][3] new positions; the neighbour bit sets (8 KB) are dead once the pair terms exist
+    const int n_nodes0 = *s.n_nodes;
+    const bool in_lds = n_nodes0 + 32 <= SFM_LDS_NODES;
+    SfmNode* nodes = in_lds ? lnodes : s.nodes;
+    int* treehash = in_lds ? lhash : s.treehash;
+    int* n_nodes = in_lds ? ln_nodes : s.n_nodes;
+    const int cap_nodes = in_lds ? SFM_LDS_NODES : s.cap_nodes;
+    if (in_lds) {
+        const int words = n_nodes0 * (int)(sizeof(SfmNode) / 4);
+        for (int q = threadIdx.x; q < words; q += blockDim.x) ((uint32_t*)lnodes)[q] = ((const uint32_t*)s.nodes)[q];
+        if (i < n) lhash[i] = s.treehash[i];
+        if (i == 0) *ln_nodes = n_nodes0;
+        __syncthreads();
+    }
     d3 desiredforce = D3(0, 0, 0), socialforce = D3(0, 0, 0), obstacleforce = D3(0, 0, 0), lookaheadforce = D3(0, 0, 0);
     d3 me_p = D3(0, 0, 0), me_v = D3(0, 0, 0);
     uint32_t* mine = nb_bits + (size_t)i * (SFM_MAX_AGENTS / 32);
@@ -206,18 +236,20 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         me_v = ld3(s.v, i);
         // Tscene::getNeighbors(p.x, p.y, 20) (ped_scene.cpp:217-252): agents of the leaves the square touches
         for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) mine[k] = 0;
-        int stack[SFM_MAX_DEPTH * 3 + 4], sp = 0;
-        stack[sp++] = 0;
+        // depth-first walk with the stack in LDS (a dynamically indexed private array would live in scratch memory):
+        // entry k of thread i sits at stk[k * blockDim.x + i]
+        int sp = 0;
+        stk[(sp++) * blockDim.x + i] = 0;
         while (sp > 0) {
-            const SfmNode& t = s.nodes[stack[--sp]];
+            const SfmNode& t = nodes[stk[(--sp) * blockDim.x + i]];
             if (t.isleaf) {
                 for (int k = 0; k < t.n_agents; k++) mine[t.agents[k] >> 5] |= 1u << (t.agents[k] & 31);
             } else {
                 for (int c = 0; c < 4; c++) {
-                    const SfmNode& ch = s.nodes[t.child[c]];
+                    const SfmNode& ch = nodes[t.child[c]];
                     if (((me_p.x + 20.0) > ch.x) && ((me_p.x - 20.0) < (ch.x + ch.w)) && ((me_p.y + 20.0) > ch.y) &&
                         ((me_p.y - 20.0) < (ch.y + ch.h))) {
-                        if (sp < SFM_MAX_DEPTH * 3 + 4) stack[sp++] = t.child[c];
+                        if (sp < SFM_WALK_CAP) stk[(sp++) * blockDim.x + i] = (unsigned short)t.child[c];
                         else *s.err = 4;
                     }
                 }
@@ -247,30 +279,89 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         s.dest[i] = dest;
         s.last[i] = last;
         desiredforce = scaled(normalized(desired_direction), s.vmax[i]);
-        // Tagent::lookaheadForce (ped_agent.cpp:439-480)
-        {
-            const double pi = 3.14159265;
-            int count = 0;
-            const d3 e = desired_direction;
-            for (int o = 0; o < n; o++) {
-                if (o == i || !((mine[o >> 5] >> (o & 31)) & 1u)) continue;
-                const double dx = s.p[3 * o] - me_p.x, dy = s.p[3 * o + 1] - me_p.y;
+        SFM_STAMP(2);
+        // loop-invariant angles of Tagent::lookaheadForce (ped_agent.cpp:439-480): of my desired direction and of my
+        // velocity as somebody else's neighbour
+        sh[i] = desired_direction.x;
+        sh[n_cap + i] = desired_direction.y;
+        sh[2 * n_cap + i] = cr_atan2(-desired_direction.x, -desired_direction.y);
+        sh[3 * n_cap + i] = cr_atan2(-me_v.x, -me_v.y);
+    }
+    __syncthreads();
+    // Pair terms of lookaheadForce and socialForce (ped_agent.cpp:316-404, 439-480), one (agent, neighbour) pair per
+    // thread and round: the three correctly rounded atan2 of a pair are ~1500 serial instructions, and an agent has up to
+    // n - 1 neighbours.  Each term is evaluated exactly as the reference does and parked in HBM; the agents then add
+    // their terms in neighbour order, so the sums round as the sequential loops do.
+    for (int pq = threadIdx.x; pq < n * n; pq += blockDim.x) {
+        const int pi = pq / n, o = pq - pi * n;
+        unsigned char code = 0;  // bits 0-1: lookahead vote + 1, bit 2: has a social term
+        d3 term = D3(0, 0, 0);
+        const uint32_t* bits = nb_bits + (size_t)pi * (SFM_MAX_AGENTS / 32);
+        if (o != pi && ((bits[o >> 5] >> (o & 31)) & 1u)) {
+            const d3 pp = ld3(s.p, pi), po = ld3(s.p, o);
+            {
+                const double pi_c = 3.14159265;
+                int vote = 0;
+                const double dx = po.x - pp.x, dy = po.y - pp.y;
                 const double dist2 = (dx * dx + dy * dy);
                 if (dist2 < 400) {
-                    const double at2v = cr_atan2(-e.x, -e.y);
+                    const double at2v = sh[2 * n_cap + pi];
                     const double at2d = cr_atan2(-dx, -dy);
-                    const double at2v2 = cr_atan2(-s.v[3 * o], -s.v[3 * o + 1]);
+                    const double at2v2 = sh[3 * n_cap + o];
                     double sd = at2d - at2v;
-                    if (sd > pi) sd -= 2 * pi;
-                    if (sd < -pi) sd += 2 * pi;
+                    if (sd > pi_c) sd -= 2 * pi_c;
+                    if (sd < -pi_c) sd += 2 * pi_c;
                     double vv = at2v - at2v2;
-                    if (vv > pi) vv -= 2 * pi;
-                    if (vv < -pi) vv += 2 * pi;
+                    if (vv > pi_c) vv -= 2 * pi_c;
+                    if (vv < -pi_c) vv += 2 * pi_c;
                     if (fabs(vv) > 2.5) {
-                        if ((sd < 0) && (sd > -0.3)) count--;
-                        if ((sd > 0) && (sd < 0.3)) count++;
+                        if ((sd < 0) && (sd > -0.3)) vote--;
+                        if ((sd > 0) && (sd < 0.3)) vote++;
                     }
                 }
+                code = (unsigned char)(vote + 1);
+            }
+            {
+                const double lambda_importance = 2.0, gamma = 0.35, nn = 2, n_prime = 3;
+                const d3 diff = po - pp;
+                if (!(len2(diff) > 64.0)) {
+                    const d3 diff_direction = normalized(diff);
+                    const d3 vel_diff = ld3(s.v, pi) - ld3(s.v, o);
+                    const d3 interaction_vector = scaled(vel_diff, lambda_importance) + diff_direction;
+                    const double interaction_length = len3(interaction_vector);
+                    const d3 interaction_direction = scaled(interaction_vector, 1 / interaction_length);
+                    const double theta = sfm_angle_to(interaction_direction, diff_direction);
+                    const int theta_sign = (theta == 0) ? (0) : (int)(theta / fabs(theta));
+                    const double B = gamma * interaction_length;
+                    const double fva = -exp(-len3(diff) / B - (n_prime * B * theta) * (n_prime * B * theta));
+                    const double faa = -theta_sign * exp(-len3(diff) / B - (nn * B * theta) * (nn * B * theta));
+                    const d3 force_velocity = scaled(interaction_direction, fva);
+                    const d3 force_angle = scaled(D3(-interaction_direction.y, interaction_direction.x, 0), faa);
+                    term = force_velocity + force_angle;
+                    code |= 4;
+                }
+            }
+        } else {
+            code = 1;
+        }
+        s.pair_code[pq] = code;
+        if (code & 4) {
+            s.pair_f[3 * (size_t)pq] = term.x;
+            s.pair_f[3 * (size_t)pq + 1] = term.y;
+            s.pair_f[3 * (size_t)pq + 2] = term.z;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    SFM_STAMP(3);
+    if (i < n) {
+        {
+            int count = 0;
+            const d3 e = D3(sh[i], sh[n_cap + i], 0);
+            for (int o = 0; o < n; o++) {
+                const unsigned char code = s.pair_code[(size_t)i * n + o];
+                count += (int)(code & 3) - 1;
+                if (code & 4) socialforce = socialforce + ld3(s.pair_f, i * n + o);
             }
             if (count < 0) {
                 lookaheadforce.x = 0.5f * e.y;
@@ -281,30 +372,6 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
                 lookaheadforce.y = 0.5f * e.x;
             }
         }
-        SFM_STAMP(2);
-        // Tagent::socialForce (ped_agent.cpp:316-404)
-        {
-            const double lambda_importance = 2.0, gamma = 0.35, nn = 2, n_prime = 3;
-            for (int o = 0; o < n; o++) {
-                if (o == i || !((mine[o >> 5] >> (o & 31)) & 1u)) continue;
-                const d3 diff = ld3(s.p, o) - me_p;
-                if (len2(diff) > 64.0) continue;
-                const d3 diff_direction = normalized(diff);
-                const d3 vel_diff = me_v - ld3(s.v, o);
-                const d3 interaction_vector = scaled(vel_diff, lambda_importance) + diff_direction;
-                const double interaction_length = len3(interaction_vector);
-                const d3 interaction_direction = scaled(interaction_vector, 1 / interaction_length);
-                const double theta = sfm_angle_to(interaction_direction, diff_direction);
-                const int theta_sign = (theta == 0) ? (0) : (int)(theta / fabs(theta));
-                const double B = gamma * interaction_length;
-                const double fva = -exp(-len3(diff) / B - (n_prime * B * theta) * (n_prime * B * theta));
-                const double faa = -theta_sign * exp(-len3(diff) / B - (nn * B * theta) * (nn * B * theta));
-                const d3 force_velocity = scaled(interaction_direction, fva);
-                const d3 force_angle = scaled(D3(-interaction_direction.y, interaction_direction.x, 0), faa);
-                socialforce = socialforce + (force_velocity + force_angle);
-            }
-        }
-        SFM_STAMP(3);
         // Tagent::obstacleForce (ped_agent.cpp:411-429)
         {
             d3 min_diff = D3(0, 0, 0);
@@ -355,16 +422,39 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         d3 v = scaled(me_v, 0.5) + scaled(a, h);
         if (len3(v) > s.vmax[i]) v = scaled(normalized(v), s.vmax[i]);
         s.p[3 * i] = p_desired.x; s.p[3 * i + 1] = p_desired.y; s.p[3 * i + 2] = p_desired.z;
+        lp[3 * i] = p_desired.x;  // the serial tree surgery below reads positions from LDS
+        lp[3 * i + 1] = p_desired.y;
         s.v[3 * i] = v.x; s.v[3 * i + 1] = v.y; s.v[3 * i + 2] = v.z;
     }
     __syncthreads();
     SFM_STAMP(5);
-    if (i == 0) {  // scene->moveAgent(this), in agent order
+    // scene->moveAgent(this) in agent order (ped_tree.cpp:131-137).  Whether an agent left its leaf is tested by all agents
+    // at once; the tree surgery itself stays serial.  The parallel verdicts hold as long as no leaf has been split in this
+    // round (a split re-homes the leaf's members); after a split the remaining agents are re-tested one by one.
+    if (i < n) {
+        const SfmNode& q = nodes[treehash[i]];
+        const double px = lp[3 * i], py = lp[3 * i + 1];
+        stk[i] = ((px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h))) ? 1 : 0;
+    }
+    __syncthreads();
+    if (i == 0) {
         int lerr = 0;  // s.err is page-locked host memory: touched only to report
-        for (int a = 0; a < n && lerr == 0; a++) sfm_move_agent(s.nodes, s.n_nodes, s.cap_nodes, s.treehash, s.p, a, &lerr);
+        const int nodes_before = *n_nodes;
+        bool split = false;
+        for (int a = 0; a < n && lerr == 0; a++) {
+            if (!split && !stk[a]) continue;
+            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh);  // sh (8 KB) is free by now
+            split = *n_nodes != nodes_before;
+        }
         if (lerr) *s.err = lerr;
     }
     __syncthreads();
+    if (in_lds) {  // back to HBM for the next step (and for imgenv_reset, which rebuilds the tree there)
+        const int words = *ln_nodes * (int)(sizeof(SfmNode) / 4);
+        for (int q = threadIdx.x; q < words; q += blockDim.x) ((uint32_t*)s.nodes)[q] = ((const uint32_t*)lnodes)[q];
+        if (i < n) s.treehash[i] = lhash[i];
+        if (i == 0) *s.n_nodes = *ln_nodes;
+    }
     SFM_STAMP(6);
 #undef SFM_STAMP
 }

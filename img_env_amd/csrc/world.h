@@ -121,6 +121,7 @@ struct DevWorld {
     uint32_t* bbox;
     int* err;  // [4] device-side overflow flags
     unsigned long long* prof;  // [16] per-phase cycle counters (IMGENV_PHASE_PROFILE builds)
+    unsigned long long* dbg;   // [32] free-form debug marks (profile builds)
     // outputs (imgenv_out)
     float* vector_states;
     uint8_t* view_maps;
