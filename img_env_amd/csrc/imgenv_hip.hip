@@ -578,6 +578,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     const int NA = h->NA;
     TRY(dev_alloc(h, &d.apx, NA)); TRY(dev_alloc(h, &d.apy, NA)); TRY(dev_alloc(h, &d.avx, NA)); TRY(dev_alloc(h, &d.avy, NA));
     TRY(dev_alloc(h, &d.anvx, NA)); TRY(dev_alloc(h, &d.anvy, NA));
+    TRY(dev_alloc(h, &d.near_n, P)); TRY(dev_alloc(h, &d.near_list, (size_t)(P > 0 ? P : 1) * ORCA_NEAR_CAP));
     {
         std::vector<float> ms(NA > 0 ? NA : 1, 0.6f);  // robots: maxSpeed 0.6 (rvoscene.h:63)
         for (int j = 0; j < P && j < NA; j++) ms[j] = (float)(double)h->pmax[j];

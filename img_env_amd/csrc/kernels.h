@@ -139,13 +139,27 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
         s.n_on = 0;
     }
     __syncthreads();
-    // agent neighbours: brute-force scan in index order, 64 agents per round
+    // agent neighbours (Agent::computeNeighbors over the kd-tree = the maxNeighbors nearest within neighborDist): scan in
+    // agent index order, 64 agents per round -- every pedestrian, then the robots k_side_robots found near this one
+    // (sorted by index; the full robot range if that list overflowed)
+    __shared__ int near_sorted[ORCA_NEAR_CAP];
     float range_sq = sqr(0.5f);  // neighborDist (rvoscene.h:57)
-    for (int base = 0; base < w.NA; base += WAVE) {
-        const int a = base + lane;
+    const int n_near = w.NA > w.P ? w.near_n[j] : 0;
+    const bool listed = n_near <= ORCA_NEAR_CAP;
+    if (listed && n_near > 0) {
+        const int mine = lane < n_near ? w.near_list[(size_t)j * ORCA_NEAR_CAP + lane] : 0x7FFFFFFF;
+        int rank = 0;
+        for (int q = 0; q < n_near; q++) rank += __shfl(mine, q) < mine ? 1 : 0;
+        if (lane < n_near) near_sorted[rank] = mine;
+    }
+    __syncthreads();
+    const int n_scan = listed ? w.P + n_near : w.NA;
+    for (int base = 0; base < n_scan; base += WAVE) {
+        const int t = base + lane;
+        const int a = (listed && t >= w.P && t < n_scan) ? near_sorted[t - w.P] : t;
         float dist_sq = 0.0f;
         bool cand = false;
-        if (a < w.NA && a != j) {
+        if (t < n_scan && a != j) {
             dist_sq = abs_sq(pos - F2(w.apx[a], w.apy[a]));
             cand = dist_sq < range_sq;
         }
@@ -155,11 +169,13 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const float d = __shfl(dist_sq, src);
-                if (lane == 0) insert_agent_neighbor(s, d, base + src, range_sq);
+                const int who = __shfl(a, src);
+                if (lane == 0) insert_agent_neighbor(s, d, who, range_sq);
             }
             range_sq = __shfl(range_sq, 0);
         }
     }
+    if (lane == 0 && w.NA > w.P) w.near_n[j] = 0;  // re-armed for the next step's k_side_robots
     if (lane == 0) {
         if (w.n_obst > 0) {
             const float obst_range_sq = sqr(5.0f * w.amax_speed[j] + 0.5f);  // timeHorizonObst*maxSpeed + radius
@@ -1503,10 +1519,20 @@ __global__ void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
     if (rvo_agents) {
         const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
         const int a = w.P + i;
-        w.apx[a] = (float)r[0];
-        w.apy[a] = (float)r[1];
+        const f2 me = F2((float)r[0], (float)r[1]);
+        w.apx[a] = me.x;
+        w.apy[a] = me.y;
         w.avx[a] = zero_vel ? 0.0f : (float)r[3];
         w.avy[a] = zero_vel ? 0.0f : (float)r[4];
+        // neighborDist is 0.5 m (rvoscene.h:57): tell the few pedestrians this robot can matter to, so that the solve does
+        // not scan every robot of the world for every pedestrian.  The test is the solve's own float expression with a
+        // slightly larger bound; the solve re-tests exactly.
+        for (int j = 0; j < w.P; j++) {
+            if (abs_sq(F2(w.apx[j], w.apy[j]) - me) < 0.2500001f) {
+                const int pos = atomicAdd(&w.near_n[j], 1);
+                if (pos < ORCA_NEAR_CAP) w.near_list[(size_t)j * ORCA_NEAR_CAP + pos] = a;
+            }
+        }
     }
     const int l = i - w.r0;
     if (l >= 0 && l < w.RL) state_robot(w, l);

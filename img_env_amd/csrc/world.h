@@ -10,6 +10,7 @@
 #define OWNER_MULTI 0xFFFFFEu  // 24-bit owner field of the composed layer: several robots cover the cell
 #define RC_INLINE 6           // distinct robot classes (shape, size, sensor) per world, carried in the kernel arguments
 #define PC_INLINE 4           // distinct pedestrian classes per world
+#define ORCA_NEAR_CAP 64       // robot agents a pedestrian can have within its 0.5 m neighbour range before k_orca falls back to the full scan
 
 // composed class layer byte (k_compose): low 3 bits = base class, bit 3 = "some robot covers it"
 #define CLS_STATIC 0   // occupancy value 0: static map / obstacle      (collision code 1)
@@ -114,6 +115,8 @@ struct DevWorld {
     const RvoObstDev* obst;
     const RvoNodeDev* onodes;
     int n_obst, n_onodes, oroot;
+    int* near_n;     // [P] robot agents within neighborDist of pedestrian j this step (from k_side_robots) ...
+    int* near_list;  // [P][ORCA_NEAR_CAP] ... their agent indices, in arrival order
     SfmDev sfm;  // social-force crowd (pedscene)
     // robot-sharded worlds: this rank only needs the rasters under its own robots' views.  bbox = ordered-uint32 encoded
     // float min x, min y, max x, max y of the local robots' centres, accumulated by k_integrate / k_reset_robots
