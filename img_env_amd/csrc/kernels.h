@@ -1513,29 +1513,42 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
 //    from the gathered robot records, so that the solve does not have to wait for the raster;
 //  * Agent::get_state of the local robots (its correctly rounded atan2 is a long serial chain that k_tail, on the
 //    critical path, would otherwise run).
-__global__ void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
+#define SIDE_PED_TILE 1024
+__global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
+    __shared__ float2 ped_xy[SIDE_PED_TILE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.R) return;
+    const bool valid = i < w.R;
     if (rvo_agents) {
-        const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+        const double* r = w.rec + (size_t)(valid ? i : 0) * IMGENV_RECORD_DOUBLES;
         const int a = w.P + i;
         const f2 me = F2((float)r[0], (float)r[1]);
-        w.apx[a] = me.x;
-        w.apy[a] = me.y;
-        w.avx[a] = zero_vel ? 0.0f : (float)r[3];
-        w.avy[a] = zero_vel ? 0.0f : (float)r[4];
+        if (valid) {
+            w.apx[a] = me.x;
+            w.apy[a] = me.y;
+            w.avx[a] = zero_vel ? 0.0f : (float)r[3];
+            w.avy[a] = zero_vel ? 0.0f : (float)r[4];
+        }
         // neighborDist is 0.5 m (rvoscene.h:57): tell the few pedestrians this robot can matter to, so that the solve does
         // not scan every robot of the world for every pedestrian.  The test is the solve's own float expression with a
-        // slightly larger bound; the solve re-tests exactly.
-        for (int j = 0; j < w.P; j++) {
-            if (abs_sq(F2(w.apx[j], w.apy[j]) - me) < 0.2500001f) {
-                const int pos = atomicAdd(&w.near_n[j], 1);
-                if (pos < ORCA_NEAR_CAP) w.near_list[(size_t)j * ORCA_NEAR_CAP + pos] = a;
+        // slightly larger bound; the solve re-tests exactly.  Pedestrian positions go through LDS, a tile at a time.
+        for (int j0 = 0; j0 < w.P; j0 += SIDE_PED_TILE) {
+            const int nt = min(SIDE_PED_TILE, w.P - j0);
+            __syncthreads();
+            for (int q = threadIdx.x; q < nt; q += blockDim.x) ped_xy[q] = make_float2(w.apx[j0 + q], w.apy[j0 + q]);
+            __syncthreads();
+            if (valid) {
+                for (int q = 0; q < nt; q++) {
+                    const float2 pp = ped_xy[q];
+                    if (abs_sq(F2(pp.x, pp.y) - me) < 0.2500001f) {
+                        const int pos = atomicAdd(&w.near_n[j0 + q], 1);
+                        if (pos < ORCA_NEAR_CAP) w.near_list[(size_t)(j0 + q) * ORCA_NEAR_CAP + pos] = a;
+                    }
+                }
             }
         }
     }
     const int l = i - w.r0;
-    if (l >= 0 && l < w.RL) state_robot(w, l);
+    if (valid && l >= 0 && l < w.RL) state_robot(w, l);
 }
 
 // Per-robot scalars, one thread per robot: Agent::get_state (agent.cpp:156-184), the _get_states distances,
