@@ -567,6 +567,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         d.region_margin = (int)ceil(0.5 * sqrt((double)g.Hv * g.Hv + (double)g.Wv * g.Wv)) + max_rad + 3;
         TRY(dev_alloc(h, &d.fp_cells, (size_t)RL * cap));
         TRY(dev_alloc(h, &d.fp_n, RL, 0xFF));  // -1 until the first raster
+        TRY(dev_alloc(h, &d.fp_pose, (size_t)RL * 3));
     }
     TRY(dev_alloc(h, &d.ppx, P)); TRY(dev_alloc(h, &d.ppy, P)); TRY(dev_alloc(h, &d.pyaw, P));
     TRY(dev_alloc(h, &d.plx, P)); TRY(dev_alloc(h, &d.ply, P)); TRY(dev_alloc(h, &d.pvx, P)); TRY(dev_alloc(h, &d.pvy, P));

@@ -639,10 +639,37 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
     const int l = i - w.r0;
     const bool local = l >= 0 && l < w.RL;
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
+    // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
+    if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
+        double* p = w.sfm.p + 3 * (size_t)(w.P + i);
+        p[0] = r[0];
+        p[1] = r[1];
+        p[2] = 1.0;
+    }
     // another rank's robot only matters where this rank's robots can see it (a local robot's footprint is inside the
     // region by construction, so the clip never changes its own cells)
     const int lo_m = local ? 0 : g.m0, hi_m = local ? w.Hg : g.m1, lo_n = local ? 0 : g.n0, hi_n = local ? w.Wg : g.n1;
     if (!local && (cm + rad < lo_m || cm - rad >= hi_m || cn + rad < lo_n || cn - rad >= hi_n)) return;
+    // A robot that has not moved since its cell list was made (frozen after a collision or an arrival, dead, or simply
+    // standing still) covers the same cells: re-stamp them from the list instead of walking the 901 samples again.
+    if (local) {
+        double* cached = w.fp_pose + 3 * (size_t)l;
+        const int n_cached = w.fp_n[l];
+        if (n_cached >= 0 && cached[0] == r[0] && cached[1] == r[1] && cached[2] == r[2]) {
+            const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
+            for (int e = lane; e < n_cached; e += WAVE) {
+                const uint32_t c = list[e].x;
+                atomicMin(&w.own_lo[c], id);
+                atomicMax(&w.own_hi[c], id);
+            }
+            return;
+        }
+        if (lane == 0) {
+            cached[0] = r[0];
+            cached[1] = r[1];
+            cached[2] = r[2];
+        }
+    }
     if (use_box) {
         for (int q = lane; q < ncell; q += WAVE) box[q] = 0;
         __syncthreads();
@@ -706,13 +733,6 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
         if (local && lane == 0) w.fp_n[l] = (n_out <= w.fp_cap && !any_stray) ? n_out : -1;
     } else if (local && lane == 0) {
         w.fp_n[l] = -1;
-    }
-    // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
-    if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
-        double* p = w.sfm.p + 3 * (size_t)(w.P + i);
-        p[0] = r[0];
-        p[1] = r[1];
-        p[2] = 1.0;
     }
 }
 

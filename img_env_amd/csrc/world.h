@@ -100,6 +100,7 @@ struct DevWorld {
     int* pm_n;                                // [RL] their count, -1 = unknown (dense clear needed)
     uint2* fp_cells;                          // [RL][fp_cap] grid cells under the footprint (cell, last sample index + 1), from k_raster
     int* fp_n;                                // [RL] their count, -1 = not available (k_view walks the samples itself)
+    double* fp_pose;                          // [RL][3] pose (x, y, theta) the list was made for
     int fp_cap, box_cells;                    // list capacity; LDS box cells of k_raster (max over classes)
     int hit_stride;                           // max ray_stride over classes (LDS layout of k_view)
     // pedestrians
