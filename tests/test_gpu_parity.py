@@ -343,3 +343,32 @@ def test_ragged_trajectories_and_padded_ped_vector(worlds):
     finally:
         gpu.close()
         cpu.close()
+
+
+def test_equidistant_pedestrians_keep_index_order(worlds):
+    """two (and three) pedestrians at exactly the same distance from a robot: the sort key ties, and the reference's stable
+    Python sort keeps them in index order (yaml_env.py:451) -- the register sort's key-only fast path must notice and fall back"""
+    from test_oracle_known_answers import _layout, _open_world
+    from parity import compare
+    World, OracleWorld = worlds
+    grid, params = _open_world(n_robots=2, n_peds=5, scene="rvoscene")
+    lay = _layout([(10.0, 10.0, 0.0), (14.0, 14.0, 1.5707963267948966)], [(16.0, 10.0), (14.0, 20.0)],
+                  ped_xy=[(12.0, 11.0), (12.0, 9.0), (8.0, 11.0), (16.0, 15.0), (12.0, 13.0)])
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        gpu.reset(lay)
+        cpu.reset(lay)
+        a, b = gpu.snapshot(), cpu.snapshot()
+        assert not compare(a, b)
+        pv = b["ped_vector_states"][0]
+        d = pv[1:].reshape(5, 7)[:, 6]
+        assert d[0] == d[1] == d[2]                                    # a three-way tie in robot 0's list
+        assert np.allclose(pv[1:3], (2.0, 1.0)) and np.allclose(pv[8:10], (2.0, -1.0))  # ... kept in index order
+        for s in range(3):
+            act = np.zeros((2, 3), np.float32)
+            gpu.step(act)
+            cpu.step(act)
+            assert not compare(gpu.snapshot(), cpu.snapshot())
+    finally:
+        gpu.close()
+        cpu.close()
