@@ -1018,15 +1018,6 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                     const uint32_t key = ((uint32_t)src[c] << 24) | ((uint32_t)(8 * ch + j) << 16) | c;
                     found = min(found, key);
                 }
-#ifdef IMGENV_PHASE_PROFILE
-                {   // how many of the 64 beams of this chunk iteration were still looking for a hit
-                    const unsigned long long act_ = __ballot(!((found < 0x01000000u) | (8 * ch >= len)) || false);
-                    if (lane == 0) {
-                        atomicAdd((unsigned long long*)&w.prof[12], (unsigned long long)__popcll(act_));
-                        atomicAdd((unsigned long long*)&w.prof[13], 64ull);
-                    }
-                }
-#endif
                 if (__all((found < 0x01000000u) | (8 * ch + 8 >= len))) break;
             }
             if (b < w.B) {

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from img_env_amd.world import World  # noqa: E402
 
 policy = sys.argv[1] if len(sys.argv) > 1 else "active"
-R, P, res = 8192, 200, 0.25
+R, P, res = int(sys.argv[2]) if len(sys.argv) > 2 else 8192, 200, 0.25
 grid = worldgen.make_grid(400, 0)
 layout = worldgen.make_layout(grid, res, R, P, seed=100, clearance=0.7)
 w = World(worldgen.make_params(R, P, res=res, scene="rvoscene"), grid)
@@ -47,7 +47,3 @@ tot2 = sum(v[8:12]) or 1
 for n, c in zip(names2, v[8:12]):
     print("  %-28s %9.0f cycles/wave  %5.1f %%" % (n, c / waves, 100.0 * c / tot2))
 print("  total %.0f cycles/wave" % (tot2 / waves))
-print("  ray walk: %.1f chunk iterations / robot, %.1f %% of their lanes still had a beam without a hit after the chunk" % (
-    v[13] / 64.0 / waves, 100.0 * v[12] / max(v[13], 1)))
-print("  skip resolution: %.1f cells / robot in %.1f wave-level visits, %.1f list entries walked / robot" % (
-    v[14] / waves, v[7] / waves, v[15] / waves))
