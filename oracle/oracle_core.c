@@ -12,8 +12,8 @@
  *   envs/env/yaml_env.py           ImageEnv._step_req/_get_states/_draw_ped_map/step
  *   envs/wrapper/base.py           SensorsPaperReward / TimeLimit / InfoLog / MultiRobotClean
  *
- * PARITY STATUS.  The ORCA pedestrian advance is pinned against the reference's own RVO2 sources
- * (oracle/_ref).  The Python post-processing (_draw_ped_map, _each_r, step_ds, dones) is pinned by
+ * PARITY STATUS.  The ORCA pedestrian advance is pinned against the reference's own RVO2 sources and the social-force
+ * advance (oracle_sfm.c) against its own pedsim sources (both built into oracle/_ref).  The Python post-processing (_draw_ped_map, _each_r, step_ds, dones) is pinned by
  * golden vectors generated from the reference's Python (tests/golden).  agent.cpp / img_env.cpp /
  * grid_map.cpp need ROS tf + OpenCV + generated message headers that this image lacks, so they
  * cannot be built here: for those rows this oracle is a careful restatement, PARITY UNPINNED
