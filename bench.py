@@ -305,7 +305,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_robot_step": ab, "kernel_avg_us": dur_s * 1e6,
-                         "units_per_launch": RL},
+                         "units_per_launch": RL,
+                         # the whole path against the same peak: all algorithmic bytes of a step over the whole step time
+                         "path_achieved": ab["total"] * value / world_size / 1e9,
+                         "path_frac": ab["total"] * value / world_size / 1e9 / 8000.0},
         }
         if world_size == 1 and not args.no_cpu_baseline:
             p1 = dict(params)
