@@ -372,3 +372,61 @@ def test_equidistant_pedestrians_keep_index_order(worlds):
     finally:
         gpu.close()
         cpu.close()
+
+
+def _fuzz_case(seed):
+    """a random but valid configuration of the same path: geometry, sensor, kinematics, crowd, footprints"""
+    from img_env_amd import _cabi
+    rng = np.random.default_rng(1000 + seed)
+    res = float(rng.choice([0.125, 0.25, 0.1, 0.2]))
+    view_cells = int(rng.choice([24, 32, 40, 48, 50, 64]))
+    beams = int(rng.choice([90, 180, 360, 400, 719]))
+    n = int(rng.integers(3, 40))
+    scene = str(rng.choice(["rvoscene", "ervoscene", "rvoscene", ""]))
+    P = int(rng.integers(1, 70)) if scene else 0
+    kw = dict(res=res, view_cells=view_cells, beams=beams, scene=scene, dt=float(rng.choice([0.1, 0.25, 0.4])),
+              state_dim=int(rng.choice([3, 4, 5])), relation_ped_robo=int(rng.integers(0, 2)),
+              ped_shape=str(rng.choice(["circle", "leg"])), robot_ktype=str(rng.choice(["diff", "omni"])),
+              time_max=int(rng.integers(8, 40)), use_laser=bool(rng.random() > 0.1), laser_norm=bool(rng.random() > 0.3),
+              view_width=(view_cells + 0.5) * res, view_height=(view_cells + 0.5) * res)
+    extent = max(30.0, 1.2 * np.sqrt((n + P) * 2.5))
+    grid_size = int(np.ceil(extent / res / 4) * 4)
+    grid, params, layout = small_world(n, P, seed=seed, grid_size=grid_size, n_obstacles=int(rng.integers(0, 5)),
+                                       clearance=float(rng.choice([0.6, 0.8, 1.0])), **kw)
+    if rng.random() < 0.5:  # mixed footprint classes
+        shape = np.full(n, _cabi.SHAPE_CIRCLE, np.int32)
+        size = np.tile(np.array([0, 0, 0.17, 0], np.float32), (n, 1))
+        size[1::2] = (0.01, 0.02, float(rng.uniform(0.12, 0.3)), 0)
+        if rng.random() < 0.5:
+            shape[::3] = _cabi.SHAPE_RECTANGLE
+            size[::3] = (-0.22, 0.18, -0.12, 0.1)
+        params.update(robot_shape=shape, robot_size=size,
+                      robot_size_last=np.where(shape == _cabi.SHAPE_CIRCLE, size[:, 2], 0.1).astype(np.float64))
+    return grid, params, layout, n, bool(kw["robot_ktype"] == "omni")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzzed_configurations_match_oracle(worlds, seed):
+    World, OracleWorld = worlds
+    grid, params, layout, n, lateral = _fuzz_case(seed)
+    _, _, layout2 = small_world(n, params["n_peds"], seed=seed + 500, grid_size=grid.shape[0], res=params["view_resolution"],
+                                n_obstacles=2, clearance=0.6)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(seed)
+
+        def acts(k):
+            out = []
+            for _ in range(k):
+                a = random_actions(rng, n)
+                if lateral:
+                    a[:, 2] = rng.uniform(-0.3, 0.3, n).astype(np.float32)
+                out.append(a)
+            return out
+        fails = run_pair(gpu, cpu, layout, acts(18))
+        assert not fails, (seed, fails[:2])
+        fails = run_pair(gpu, cpu, layout2, acts(10))  # a second episode on the same handles
+        assert not fails, (seed, "second episode", fails[:2])
+    finally:
+        gpu.close()
+        cpu.close()
