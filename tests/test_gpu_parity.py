@@ -405,7 +405,7 @@ def _fuzz_case(seed):
     return grid, params, layout, n, bool(kw["robot_ktype"] == "omni")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IMGENV_FUZZ_SEEDS", "16"))))  # more seeds for a bug hunt
 def test_fuzzed_configurations_match_oracle(worlds, seed):
     World, OracleWorld = worlds
     grid, params, layout, n, lateral = _fuzz_case(seed)
@@ -427,6 +427,27 @@ def test_fuzzed_configurations_match_oracle(worlds, seed):
         assert not fails, (seed, fails[:2])
         fails = run_pair(gpu, cpu, layout2, acts(10))  # a second episode on the same handles
         assert not fails, (seed, "second episode", fails[:2])
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IMGENV_FUZZ_SEEDS_SFM", "8"))))
+def test_fuzzed_social_force_rooms_match_oracle(worlds, seed):
+    """room-sized social-force worlds (the envelope libpedsim's 10 m quadtree allows), random crowd / robot counts"""
+    World, OracleWorld = worlds
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.integers(1, 8))
+    P = int(rng.integers(2, 16))
+    rel = int(rng.integers(0, 2))
+    grid_size = int(rng.choice([88, 96, 128]))
+    grid, params, layout = small_world(n, P, seed=200 + seed, scene="pedscene", grid_size=grid_size, relation_ped_robo=rel,
+                                       n_obstacles=int(rng.integers(0, 4)), clearance=0.45,
+                                       ped_shape=str(rng.choice(["circle", "leg"])))
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(40)])
+        assert not fails, (seed, fails[:2])
     finally:
         gpu.close()
         cpu.close()
