@@ -50,6 +50,7 @@ class Cfg(C.Structure):
         ("robot_begin", _i32), ("robot_end", _i32),
         ("device", _i32), ("flags", _i32),
         ("out_arena", C.c_void_p), ("out_arena_bytes", _i64),
+        ("n_worlds", _i32), ("reserved_", _i32),
     ]
 
 
@@ -166,6 +167,7 @@ def make_cfg(p):
     c.robot_end = int(p.get("robot_end", R))
     c.device = int(p.get("device", 0))
     c.flags = int(p.get("flags", 0))
+    c.n_worlds = int(p.get("n_worlds", 1))
     c.out_arena = None
     c.out_arena_bytes = 0
     return c, keep
@@ -211,7 +213,7 @@ def make_reset_batch(b, n_robots, n_peds):
 SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_create", "imgenv_arena_bytes",
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
-           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init")
+           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_reset_world")
 K_COUNT = 8
 
 
@@ -233,6 +235,7 @@ def bind(lib):
     lib.imgenv_destroy.argtypes = [C.c_void_p]
     lib.imgenv_destroy.restype = None
     lib.imgenv_reset.argtypes = [C.c_void_p, C.POINTER(ResetBatch), C.c_void_p]
+    lib.imgenv_reset_world.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ResetBatch), C.c_void_p]
     lib.imgenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.imgenv_step_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.imgenv_step_end.argtypes = [C.c_void_p, C.c_void_p]

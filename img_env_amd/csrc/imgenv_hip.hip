@@ -34,6 +34,13 @@ struct imgenv {
     imgenv_cfg cfg;
     ViewGeom geom;
     int R = 0, P = 0, r0 = 0, r1 = 0, RL = 0, NA = 0, Hg = 0, Wg = 0, PP = 2;
+    int W = 1, Rw = 0, Pw = 0;  // independent worlds in this handle, robots / pedestrians per world
+    size_t Gs = 0;              // cells between two worlds' copies of a grid layer
+    std::vector<int> world_epoch;  // h->elapsed at each world's last reset
+    std::vector<char> world_ready;
+    int* d_world_epoch = nullptr;
+    int* d_wobst = nullptr;        // [4][W]: obstacle base, node base, #obstacles, root per world
+    std::vector<int> wobst;
     std::vector<RobotClassHost> rcls;
     std::vector<PedClassHost> pcls;
     std::vector<int> robot_cls, ped_cls;
@@ -78,7 +85,7 @@ struct imgenv {
     bool serial = false;  // IMGENV_SERIAL=1: no side streams (profiling aid)
     volatile int* err_host = nullptr;  // [8] page-locked flags the kernels raise on overflow; checked at every API call
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
-    RvoObstacles rvo;
+    std::vector<RvoObstacles> rvos;  // one obstacle set per world
     int sfm_cap_obs = 0;
     // live timing (imgenv_timing)
     int t_mode = 0, t_which = -1;
@@ -328,9 +335,16 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         FAIL(IMGENV_EINVAL, "imgenv_cfg ABI mismatch (version %d size %d, want %d %d)", cfg->abi_version,
              cfg->struct_size, IMGENV_ABI_VERSION, (int)sizeof(imgenv_cfg));
     if (cfg->n_robots < 1 || cfg->n_peds < 0 || Hg < 1 || Wg < 1) FAIL(IMGENV_EINVAL, "bad sizes");
-    if (cfg->n_peds > cfg->max_ped)
-        FAIL(IMGENV_EINVAL, "n_peds %d > max_ped %d (IndexError in yaml_env.py:401)", cfg->n_peds, cfg->max_ped);
-    if (cfg->n_peds > 65000) FAIL(IMGENV_EINVAL, "n_peds > 65000 unsupported");
+    const int W = cfg->n_worlds > 1 ? cfg->n_worlds : 1;
+    if (cfg->n_robots % W || cfg->n_peds % W)
+        FAIL(IMGENV_EINVAL, "n_robots %d and n_peds %d must be multiples of n_worlds %d", cfg->n_robots, cfg->n_peds, W);
+    if (cfg->n_peds / W > cfg->max_ped)
+        FAIL(IMGENV_EINVAL, "n_peds %d > max_ped %d (IndexError in yaml_env.py:401)", cfg->n_peds / W, cfg->max_ped);
+    if (cfg->n_peds / W > 65000) FAIL(IMGENV_EINVAL, "more than 65000 pedestrians in one world unsupported");
+    if (W > 1 && cfg->ped_scene_type == IMGENV_SCENE_PEDSIM)
+        FAIL(IMGENV_EINVAL, "n_worlds > 1 is not available for the pedsim scene (one social-force crowd per handle)");
+    if (W > 1 && (((size_t)Hg * Wg + 15) & ~(size_t)15) * (size_t)W >= ((size_t)1 << 32))
+        FAIL(IMGENV_EINVAL, "n_worlds x map cells must stay below 2^32");
     if (cfg->n_robots >= (int)OWNER_MULTI) FAIL(IMGENV_EINVAL, "more than 2^24 - 3 robots unsupported");
     if (cfg->global_resolution != cfg->view_resolution)
         FAIL(IMGENV_EINVAL, "global_resolution != view_resolution: load-time cv::resize not supported");
@@ -345,6 +359,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     }
     int r0, r1;
     if (shard_of(*cfg, r0, r1)) FAIL(IMGENV_EINVAL, "bad robot shard [%d,%d)", cfg->robot_begin, cfg->robot_end);
+    if (W > 1 && r1 - r0 != cfg->n_robots)
+        FAIL(IMGENV_EINVAL, "n_worlds > 1 cannot be combined with a robot shard: give each rank whole worlds (its own handle)");
     const ViewGeom g = make_view_geom(*cfg);
     if (cfg->image_size[0] != g.Wv || cfg->image_size[1] != g.Hv)
         FAIL(IMGENV_EINVAL, "image_size (%d,%d) != native view (%d,%d): cv2.resize INTER_CUBIC not supported",
@@ -366,6 +382,13 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->RL = r1 - r0;
     h->Hg = Hg;
     h->Wg = Wg;
+    h->W = W;
+    h->Rw = h->R / W;
+    h->Pw = h->P / W;
+    h->Gs = W > 1 ? (((size_t)Hg * Wg + 15) & ~(size_t)15) : (size_t)Hg * Wg;
+    h->world_epoch.assign(W, 0);
+    h->world_ready.assign(W, 0);
+    h->rvos.resize(W);
     const bool rvo = (cfg->ped_scene_type == IMGENV_SCENE_RVO || cfg->ped_scene_type == IMGENV_SCENE_ERVO);
     h->NA = rvo ? h->P + (cfg->relation_ped_robo == 1 ? h->R : 0) : 0;
     h->static_map.assign(static_map, static_map + (size_t)Hg * Wg);
@@ -425,6 +448,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     DevWorld& d = h->d;
     memset(&d, 0, sizeof(d));
     d.R = R; d.RL = RL; d.r0 = r0; d.P = P; d.NA = h->NA;
+    d.W = W; d.Rw = h->Rw; d.Pw = h->Pw; d.Gs = (uint32_t)h->Gs;
+    d.act_l0 = 0; d.act_l1 = RL; d.act_g0 = 0; d.act_g1 = R; d.act_p0 = 0; d.act_p1 = P;
+    d.act_c0 = 0; d.act_c1 = W > 1 ? h->Gs * W : h->Gs;
     d.Hg = Hg; d.Wg = Wg; d.Hv = g.Hv; d.Wv = g.Wv; d.B = g.B;
     d.Hp = cfg->ped_image_size[0]; d.Wp = cfg->ped_image_size[1];
     d.SD = cfg->state_dim; d.PV = 1 + cfg->ped_vec_dim * cfg->max_ped;
@@ -462,11 +488,16 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         d.lw_min_v = ww.min_velocity; d.lw_max_v = ww.max_velocity; d.lw_min_a = ww.min_acceleration;
         d.lw_max_a = ww.max_acceleration; d.lw_min_j = 0.0; d.lw_max_j = ww.min_jerk;
     }
-    const size_t G = (size_t)Hg * Wg, Gp = (G + 15) & ~(size_t)15;
+    const size_t G = (size_t)Hg * Wg, Gp = W > 1 ? h->Gs * W : ((G + 15) & ~(size_t)15);
 
-    // grids
+    // grids (one copy per world)
     TRY(dev_alloc(h, &h->d_obs_map, Gp));
-    HIPCHK(hipMemcpy(h->d_obs_map, static_map, G, hipMemcpyHostToDevice));
+    for (int k = 0; k < W; k++) HIPCHK(hipMemcpy(h->d_obs_map + (size_t)k * h->Gs, static_map, G, hipMemcpyHostToDevice));
+    TRY(dev_alloc(h, &h->d_world_epoch, W));
+    d.world_epoch = h->d_world_epoch;
+    h->wobst.assign((size_t)4 * W, 0);
+    TRY(dev_alloc(h, &h->d_wobst, (size_t)4 * W));
+    d.obst_base = h->d_wobst; d.node_base = h->d_wobst + W; d.n_obst_w = h->d_wobst + 2 * W; d.oroot_w = h->d_wobst + 3 * W;
     d.obs_map = h->d_obs_map;
     TRY(dev_alloc(h, &d.ped_layer, Gp));
     TRY(dev_alloc(h, &d.own_lo, Gp, 0xFF));
@@ -695,13 +726,13 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK(hipMemset(o.is_clean, 1, RL));
     }
     h->PP = WAVE;  // sort slots of k_obs: a power of two, 64 * E of them in registers up to 1024 pedestrians
-    while (h->PP < P) h->PP <<= 1;
+    while (h->PP < h->Pw) h->PP <<= 1;
     h->obs_E = h->PP <= 1024 ? h->PP / WAVE : 0;
     const size_t NC = (size_t)g.Hv * g.Wv;
     d.hit_stride = (int)max_stride;
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv;  // src u8 (+ dummy cells) | hit u32 | column terms
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
-    h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(P > 0 ? P : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
+    h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);
         FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
@@ -732,9 +763,9 @@ struct ResetRobot {  // per local robot
     Tf2 world_target;
 };
 
-__global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, const ResetRobot* __restrict__ rr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.R) return;
+__global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, const ResetRobot* __restrict__ rr, int whole) {
+    const int i = w.act_g0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.act_g1) return;
     double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     r[0] = pose3[5 * i];  // init_pose (agent.cpp:133-142); Agent::vx, vy persist across resets
     r[1] = pose3[5 * i + 1];
@@ -751,7 +782,7 @@ __global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, con
         w.is_coll[l] = 0;
         w.is_arr[l] = 0;
     }
-    if (i == 0) w.counters[2] = 0;  // frozen robot-steps since this reset
+    if (i == 0 && whole) w.counters[2] = 0;  // frozen robot-steps since this reset (of every world)
 }
 
 // reset of a robot-sharded world: bounding box of the local robots' new positions (k_tail re-arms it every step)
@@ -763,8 +794,8 @@ __global__ void k_reset_bbox(DevWorld w, const double* __restrict__ pose3) {
 }
 
 __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= w.P) return;
+    const int j = w.act_p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= w.act_p1) return;
     w.ppx[j] = pose3[3 * j];
     w.ppy[j] = pose3[3 * j + 1];
     w.pyaw[j] = pose3[3 * j + 2];
@@ -807,7 +838,7 @@ static int launch_obs(imgenv* h, hipStream_t st) {
         HIPCHK(hipEventRecord(h->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(s_obs, h->ev_fork, 0));
     }
-    const dim3 go(h->RL), bo(WAVE);
+    const dim3 go(d.act_l1 - d.act_l0), bo(WAVE);
     switch (h->obs_E) {
         case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
         case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
@@ -823,7 +854,8 @@ static int launch_obs(imgenv* h, hipStream_t st) {
 
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
-    const size_t G = (size_t)h->Hg * h->Wg;
+    const size_t G = d.act_c1 - d.act_c0;
+    const int n_g = d.act_g1 - d.act_g0, n_p = d.act_p1 - d.act_p0, n_l = d.act_l1 - d.act_l0;
     if (h->P > 0) {
         // One fork and one join per step on the caller's stream (every event operation costs it a ~6 us dependency
         // bubble).  Beside the rasters, compose and view run, on two side streams, the pedestrian half of the
@@ -844,10 +876,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
                 HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
             }
         }
-        k_side_robots<<<dim3((h->R + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
+        k_side_robots<<<dim3((n_g + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
         h->launches += 1;
         if (h->NA > 0) {
-            TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(h->P), dim3(WAVE), 0, s_orca>>>(d)));
+            TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(n_p), dim3(WAVE), 0, s_orca>>>(d)));
             h->launches += 1;
         }
         if (overlap) {
@@ -857,12 +889,12 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         }
     }
     if (h->pow2)
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(h->P > h->R ? h->P : h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     else
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(h->P > h->R ? h->P : h->R), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
+        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
     {
-        const dim3 gv(h->RL), bv(WAVE);
+        const dim3 gv(n_l), bv(WAVE);
         const int variant = (h->pow2 ? 2 : 0) | (h->geom.Wv % 4 == 0 ? 1 : 0);
         if (variant == 3) TIMED(h, IMGENV_K_VIEW, st, (k_view<true, true><<<gv, bv, h->lds_view, st>>>(d)));
         else if (variant == 2) TIMED(h, IMGENV_K_VIEW, st, (k_view<true, false><<<gv, bv, h->lds_view, st>>>(d)));
@@ -870,7 +902,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         else TIMED(h, IMGENV_K_VIEW, st, (k_view<false, false><<<gv, bv, h->lds_view, st>>>(d)));
     }
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
-    TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((h->RL + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed, h->P > 0 ? 0 : 1)));
+    TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((n_l + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed, h->P > 0 ? 0 : 1)));
     h->launches += 4;
     HIPCHK(hipGetLastError());
     return 0;
@@ -928,104 +960,142 @@ static int stage_end(imgenv* h, hipStream_t st) {
     do {                             \
         if (int rc_ = (expr)) return rc_; \
     } while (0)
-extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stream) {
-    if (!h || !b) FAIL(IMGENV_EINVAL, "null argument");
-    if (b->struct_size != (int32_t)sizeof(imgenv_reset_batch)) FAIL(IMGENV_EINVAL, "reset batch ABI mismatch");
-    if (b->n_obstacles < 0 || (h->P > 0 && b->ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(h->cfg.device));
-    const bool trace_ = getenv("IMGENV_TRACE_RESET") != nullptr;
-    std::chrono::steady_clock::time_point tp_[8];
-    tp_[0] = std::chrono::steady_clock::now();
-    if (int rc = check_device_flags(h)) {  // report what the abandoned episode raised, then start clean
-        for (int q = 0; q < 8; q++) h->err_host[q] = 0;
-        return rc;
-    }
-    RTRY(stage_begin(h));
-    tp_[1] = std::chrono::steady_clock::now();
+// a launch covers every world (k < 0) or the robots, pedestrians and cells of world k alone
+static void set_active(imgenv* h, int k) {
     DevWorld& d = h->d;
-    const int R = h->R, P = h->P, RL = h->RL;
+    if (k < 0 || h->W == 1) {
+        d.act_l0 = 0; d.act_l1 = h->RL; d.act_g0 = 0; d.act_g1 = h->R; d.act_p0 = 0; d.act_p1 = h->P;
+        d.act_c0 = 0; d.act_c1 = h->W > 1 ? h->Gs * h->W : h->Gs;
+    } else {
+        d.act_l0 = d.act_g0 = k * h->Rw; d.act_l1 = d.act_g1 = (k + 1) * h->Rw;
+        d.act_p0 = k * h->Pw; d.act_p1 = (k + 1) * h->Pw;
+        d.act_c0 = (size_t)k * h->Gs; d.act_c1 = (size_t)(k + 1) * h->Gs;
+    }
+}
+
+__global__ void k_restride3(double* __restrict__ dst, const double* __restrict__ src, int n, int old_cap, int new_cap) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * old_cap * 3) return;
+    const size_t j = t / ((size_t)old_cap * 3), rem = t - j * (size_t)old_cap * 3;
+    dst[j * (size_t)new_cap * 3 + rem] = src[t];
+}
+
+struct WorldObstacles {  // what a reset batch's obstacle list turns into (img_env.cpp:166-193)
+    std::vector<uint8_t> obs;     // obs_map_
+    std::vector<double> sfm_obs;  // PedScene::addObs segments
+    RvoObstacles rvo;             // RVOScene::addObs + processObs
+};
+static void build_obstacles(imgenv* h, const imgenv_reset_batch* b, WorldObstacles& o) {
     const double res = h->geom.res;
-    // obstacles -> obs_map_ and the pedestrian simulator (img_env.cpp:166-193)
-    std::vector<uint8_t> obs(h->static_map);
-    std::vector<double> sfm_obs;
-    h->rvo.clear();
+    o.obs = h->static_map;
+    o.sfm_obs.clear();
+    o.rvo.clear();
     for (int q = 0; q < b->n_obstacles; q++) {
         double sizes[4];
         for (int j = 0; j < 4; j++) sizes[j] = (double)b->obs_size[4 * q + j];
         const Pts bb = b->obs_shape[q] == IMGENV_SHAPE_CIRCLE ? shape_circle(sizes[0], sizes[1], sizes[2]) : shape_rectangle(sizes);
         const double* p = b->obs_pose + 4 * q;
         const Tf2 bw = tf_from_pose(p[0], p[1], tf_yaw_from_quaternion_zw(p[2], p[3]));
-        draw_obstacle(obs.data(), h->Hg, h->Wg, res, bw, bb);
+        draw_obstacle(o.obs.data(), h->Hg, h->Wg, res, bw, bb);
         double pax, pay, pbx, pby;
         get_corners(b->obs_shape[q], sizes, bw, pax, pay, pbx, pby);
         if (!b->ignore_obstacle && h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::addObs: the segment pa -> pb (pedscene.h:22-26)
-            sfm_obs.push_back(pax); sfm_obs.push_back(pay); sfm_obs.push_back(pbx); sfm_obs.push_back(pby);
+            o.sfm_obs.push_back(pax); o.sfm_obs.push_back(pay); o.sfm_obs.push_back(pbx); o.sfm_obs.push_back(pby);
         }
         if (!b->ignore_obstacle && h->NA > 0) {  // RVOScene::addObs (rvoscene.h:19-26)
             const float v[8] = {(float)pax, (float)pay, (float)pax, (float)pby, (float)pbx, (float)pby, (float)pbx, (float)pay};
-            h->rvo.add(v, 4);
+            o.rvo.add(v, 4);
         }
     }
-    h->rvo.process();  // processObs (img_env.cpp:283)
-    tp_[2] = std::chrono::steady_clock::now();
-    RTRY(stage_put(h, h->d_obs_map, obs.data(), obs.size(), st));
-    if ((int)h->rvo.ob.size() > h->cap_obst) {
-        h->cap_obst = (int)h->rvo.ob.size() * 2;
-        if (int rc = dev_alloc(h, &h->d_obst, h->cap_obst)) return rc;
-    }
-    if ((int)h->rvo.nodes.size() > h->cap_nodes) {
-        h->cap_nodes = (int)h->rvo.nodes.size() * 2;
-        if (int rc = dev_alloc(h, &h->d_nodes, h->cap_nodes)) return rc;
-    }
+    o.rvo.process();  // processObs (img_env.cpp:283)
+}
+
+// obstacle segments and their BSP of world k: a slice of cap_obst / cap_nodes entries per world
+static int put_world_rvo(imgenv* h, int k, hipStream_t st) {
     static_assert(sizeof(RvoObstHost) == sizeof(RvoObstDev) && sizeof(RvoNodeHost) == sizeof(RvoNodeDev), "layout");
-    if (!h->rvo.ob.empty())
-        RTRY(stage_put(h, h->d_obst, h->rvo.ob.data(), sizeof(RvoObstDev) * h->rvo.ob.size(), st));
-    if (!h->rvo.nodes.empty())
-        RTRY(stage_put(h, h->d_nodes, h->rvo.nodes.data(), sizeof(RvoNodeDev) * h->rvo.nodes.size(), st));
+    const RvoObstacles& r = h->rvos[k];
+    bool all = false;
+    if ((int)r.ob.size() > h->cap_obst) {
+        h->cap_obst = (int)r.ob.size() * 2;
+        if (int rc = dev_alloc(h, &h->d_obst, (size_t)h->cap_obst * h->W)) return rc;
+        all = true;
+    }
+    if ((int)r.nodes.size() > h->cap_nodes) {
+        h->cap_nodes = (int)r.nodes.size() * 2;
+        if (int rc = dev_alloc(h, &h->d_nodes, (size_t)h->cap_nodes * h->W)) return rc;
+        all = true;
+    }
+    for (int q = all ? 0 : k; q < (all ? h->W : k + 1); q++) {  // a grown array is refilled from the host copies
+        const RvoObstacles& rq = h->rvos[q];
+        if (!rq.ob.empty())
+            RTRY(stage_put(h, h->d_obst + (size_t)q * h->cap_obst, rq.ob.data(), sizeof(RvoObstDev) * rq.ob.size(), st));
+        if (!rq.nodes.empty())
+            RTRY(stage_put(h, h->d_nodes + (size_t)q * h->cap_nodes, rq.nodes.data(), sizeof(RvoNodeDev) * rq.nodes.size(), st));
+        h->wobst[q] = q * h->cap_obst;
+        h->wobst[h->W + q] = q * h->cap_nodes;
+        h->wobst[2 * h->W + q] = (int)rq.ob.size();
+        h->wobst[3 * h->W + q] = rq.root;
+    }
+    DevWorld& d = h->d;
     d.obst = h->d_obst;
     d.onodes = h->d_nodes;
-    d.n_obst = (int)h->rvo.ob.size();
-    d.n_onodes = (int)h->rvo.nodes.size();
-    d.oroot = h->rvo.root;
+    d.n_obst = (int)h->rvos[0].ob.size();  // (W > 1: the kernels read the per-world table instead)
+    d.n_onodes = (int)h->rvos[0].nodes.size();
+    d.oroot = h->rvos[0].root;
+    return 0;
+}
+
+// Everything of a reset but the views, for world k of the handle; the batch holds that world's robots and pedestrians.
+static int reset_one_world(imgenv* h, int k, const imgenv_reset_batch* b, const WorldObstacles& wo, hipStream_t st, int whole) {
+    DevWorld& d = h->d;
+    const int W = h->W, Rw = h->Rw, Pw = h->Pw, P = h->P;
+    const int g_lo = k * Rw, p_lo = k * Pw;  // first robot / pedestrian of the world
+    RTRY(stage_put(h, h->d_obs_map + (size_t)k * h->Gs, wo.obs.data(), wo.obs.size(), st));
+    RTRY(put_world_rvo(h, k, st));
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {
-        const int nob = (int)sfm_obs.size() / 4;
+        const int nob = (int)wo.sfm_obs.size() / 4;
         if (nob > h->sfm_cap_obs) {
             h->sfm_cap_obs = nob * 2;
             if (int rc = dev_alloc(h, &d.sfm.obs, (size_t)h->sfm_cap_obs * 4)) return rc;
         }
-        if (nob) RTRY(stage_put(h, d.sfm.obs, sfm_obs.data(), sizeof(double) * sfm_obs.size(), st));
+        if (nob) RTRY(stage_put(h, d.sfm.obs, wo.sfm_obs.data(), sizeof(double) * wo.sfm_obs.size(), st));
         d.sfm.n_obs = nob;
     }
-    tp_[3] = std::chrono::steady_clock::now();
     // pedestrians (img_env.cpp:220-250)
-    std::vector<double> ped3((size_t)(P > 0 ? P : 1) * 3);
-    std::vector<int> tlen(P > 0 ? P : 1);
-    if (P > 0) {
+    std::vector<double> ped3((size_t)(Pw > 0 ? Pw : 1) * 3);
+    std::vector<int> tlen(Pw > 0 ? Pw : 1);
+    if (Pw > 0) {
         const bool dataset = h->cfg.ped_scene_type == IMGENV_SCENE_DATASET;
         if (dataset && !b->ped_traj_v) FAIL(IMGENV_EINVAL, "dataset scene: ped_traj_v is missing from the reset batch");
-        if (b->ped_traj_cap > h->traj_cap) {
+        if (b->ped_traj_cap > h->traj_cap) {  // longer trajectories than any before: re-lay the table out (other worlds keep theirs)
+            const int old_cap = h->traj_cap;
+            double *old_t = h->d_traj, *old_v = h->d_traj_v;
             h->traj_cap = b->ped_traj_cap;
             if (int rc = dev_alloc(h, &h->d_traj, (size_t)P * h->traj_cap * 3)) return rc;
             if (dataset)
                 if (int rc = dev_alloc(h, &h->d_traj_v, (size_t)P * h->traj_cap * 3)) return rc;
+            if (W > 1 && old_cap > 0) {
+                const size_t n = (size_t)P * old_cap * 3;
+                k_restride3<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(h->d_traj, old_t, P, old_cap, h->traj_cap);
+                if (dataset) k_restride3<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(h->d_traj_v, old_v, P, old_cap, h->traj_cap);
+            }
         }
-        std::vector<double> traj((size_t)P * h->traj_cap * 3, 0.0);
-        for (int j = 0; j < P; j++) {
+        std::vector<double> traj((size_t)Pw * h->traj_cap * 3, 0.0);
+        for (int j = 0; j < Pw; j++) {
             const double* p = b->ped_pose + 4 * j;
             ped3[3 * j] = p[0];
             ped3[3 * j + 1] = p[1];
             ped3[3 * j + 2] = tf_yaw_from_quaternion_zw(p[2], p[3]);
             tlen[j] = b->ped_traj_len[j];
-            if (tlen[j] < 1 || tlen[j] > b->ped_traj_cap) FAIL(IMGENV_EINVAL, "ped %d: bad trajectory length %d", j, tlen[j]);
+            if (tlen[j] < 1 || tlen[j] > b->ped_traj_cap) FAIL(IMGENV_EINVAL, "ped %d: bad trajectory length %d", p_lo + j, tlen[j]);
             for (int q = 0; q < tlen[j]; q++)
                 memcpy(&traj[((size_t)j * h->traj_cap + q) * 3], b->ped_traj + ((size_t)j * b->ped_traj_cap + q) * 3, 24);
         }
-        RTRY(stage_put(h, h->d_traj, traj.data(), traj.size() * 8, st));
-        RTRY(stage_put(h, h->d_traj_len, tlen.data(), sizeof(int) * P, st));
+        RTRY(stage_put(h, h->d_traj + (size_t)p_lo * h->traj_cap * 3, traj.data(), traj.size() * 8, st));
+        RTRY(stage_put(h, h->d_traj_len + p_lo, tlen.data(), sizeof(int) * Pw, st));
         if (dataset) {  // trajectory_v (img_env.cpp:246-247) + the yaw _step_ped_dataset derives from it, with the host's libm
-            std::vector<double> tv((size_t)P * h->traj_cap * 3, 0.0);
-            for (int j = 0; j < P; j++)
+            std::vector<double> tv((size_t)Pw * h->traj_cap * 3, 0.0);
+            for (int j = 0; j < Pw; j++)
                 for (int q = 0; q < tlen[j]; q++) {
                     const double* v = b->ped_traj_v + ((size_t)j * b->ped_traj_cap + q) * 2;
                     double* o = &tv[((size_t)j * h->traj_cap + q) * 3];
@@ -1033,7 +1103,7 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
                     o[1] = v[1];
                     o[2] = atan2(v[1], v[0]);
                 }
-            RTRY(stage_put(h, h->d_traj_v, tv.data(), tv.size() * 8, st));
+            RTRY(stage_put(h, h->d_traj_v + (size_t)p_lo * h->traj_cap * 3, tv.data(), tv.size() * 8, st));
             d.ptraj_v = h->d_traj_v;
         }
         if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::setWayPoint (pedscene.h:38-46): [goal r=1, trajectory r=z]
@@ -1067,11 +1137,11 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         d.ptraj = h->d_traj;
         d.traj_cap = h->traj_cap;
     }
-    tp_[4] = std::chrono::steady_clock::now();
     // robots (img_env.cpp:252-282)
-    std::vector<double> rob3((size_t)R * 5);
-    std::vector<ResetRobot> rr(RL);
-    for (int i = 0; i < R; i++) {
+    const int l_lo = W > 1 ? g_lo : 0, n_l = W > 1 ? Rw : h->RL;  // local robots of this world (a shard exists for W == 1 only)
+    std::vector<double> rob3((size_t)Rw * 5);
+    std::vector<ResetRobot> rr(n_l);
+    for (int i = 0; i < Rw; i++) {
         const double* p = b->robot_pose + 4 * i;
         const double yaw = tf_yaw_from_quaternion_zw(p[2], p[3]);
         rob3[5 * i] = p[0];
@@ -1079,46 +1149,118 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         rob3[5 * i + 2] = yaw;
         rob3[5 * i + 3] = sin(yaw * 0.5);
         rob3[5 * i + 4] = cos(yaw * 0.5);
-        if (i >= h->r0 && i < h->r1) {  // set_goal (agent.cpp:144-154)
-            ResetRobot& q = rr[i - h->r0];
+        const int l = g_lo + i - h->r0;
+        if (l >= 0 && l < h->RL) {  // set_goal (agent.cpp:144-154)
+            ResetRobot& q = rr[l - l_lo];
             q.gx = b->robot_goal[2 * i];
             q.gy = b->robot_goal[2 * i + 1];
             q.world_target = tf_inverse(tf_from_pose(q.gx, q.gy, yaw));
         }
     }
     if (!h->d_rob3) {
-        RTRY(dev_alloc(h, &h->d_rob3, rob3.size()));
-        RTRY(dev_alloc(h, &h->d_ped3, ped3.size()));
+        RTRY(dev_alloc(h, &h->d_rob3, (size_t)h->R * 5));
+        RTRY(dev_alloc(h, &h->d_ped3, (size_t)(P > 0 ? P : 1) * 3));
         ResetRobot* q = nullptr;
-        RTRY(dev_alloc(h, &q, rr.size()));
+        RTRY(dev_alloc(h, &q, (size_t)h->RL));
         h->d_rr = q;
     }
     double *d_rob3 = h->d_rob3, *d_ped3 = h->d_ped3;
     ResetRobot* d_rr = (ResetRobot*)h->d_rr;
-    RTRY(stage_put(h, d_rob3, rob3.data(), rob3.size() * 8, st));
-    RTRY(stage_put(h, d_ped3, ped3.data(), ped3.size() * 8, st));
-    RTRY(stage_put(h, d_rr, rr.data(), rr.size() * sizeof(ResetRobot), st));
-    tp_[5] = std::chrono::steady_clock::now();
-    k_reset_robots<<<dim3((R + 255) / 256), dim3(256), 0, st>>>(d, d_rob3, d_rr);
+    RTRY(stage_put(h, d_rob3 + (size_t)g_lo * 5, rob3.data(), rob3.size() * 8, st));
+    RTRY(stage_put(h, d_ped3 + (size_t)p_lo * 3, ped3.data(), ped3.size() * 8, st));
+    RTRY(stage_put(h, d_rr + l_lo, rr.data(), rr.size() * sizeof(ResetRobot), st));
+    set_active(h, W > 1 ? k : -1);
+    k_reset_robots<<<dim3((Rw + 255) / 256), dim3(256), 0, st>>>(d, d_rob3, d_rr, whole);
     if (d.sharded) {
         const uint32_t init[4] = {BBOX_INIT_MIN, BBOX_INIT_MIN, BBOX_INIT_MAX, BBOX_INIT_MAX};
         RTRY(stage_put(h, d.bbox, init, sizeof(init), st));
-        k_reset_bbox<<<dim3((RL + 255) / 256), dim3(256), 0, st>>>(d, d_rob3);
+        k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, d_rob3);
     }
-    if (P > 0) k_reset_peds<<<dim3((P + 255) / 256), dim3(256), 0, st>>>(d, d_ped3);
+    if (Pw > 0) k_reset_peds<<<dim3((Pw + 255) / 256), dim3(256), 0, st>>>(d, d_ped3);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int reset_checks(imgenv* h, const imgenv_reset_batch* b) {
+    if (!h || !b) FAIL(IMGENV_EINVAL, "null argument");
+    if (b->struct_size != (int32_t)sizeof(imgenv_reset_batch)) FAIL(IMGENV_EINVAL, "reset batch ABI mismatch");
+    if (b->n_obstacles < 0 || (h->P > 0 && b->ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
+    if (h->obs_forked) FAIL(IMGENV_ESTATE, "reset between imgenv_step_begin and imgenv_step_end");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc = check_device_flags(h)) {  // report what the abandoned episode raised, then start clean
+        for (int q = 0; q < 8; q++) h->err_host[q] = 0;
+        return rc;
+    }
+    return 0;
+}
+
+extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stream) {
+    if (int rc = reset_checks(h, b)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool trace_ = getenv("IMGENV_TRACE_RESET") != nullptr;
+    std::chrono::steady_clock::time_point tp_[4];
+    tp_[0] = std::chrono::steady_clock::now();
+    RTRY(stage_begin(h));
+    WorldObstacles wo;
+    build_obstacles(h, b, wo);  // one obstacle list, shared by every world
+    tp_[1] = std::chrono::steady_clock::now();
+    for (int k = 0; k < h->W; k++) {
+        imgenv_reset_batch sub = *b;  // world k's robots and pedestrians (world-major numbering)
+        sub.robot_pose = b->robot_pose + (size_t)4 * k * h->Rw;
+        sub.robot_goal = b->robot_goal + (size_t)2 * k * h->Rw;
+        if (h->P > 0) {
+            sub.ped_pose = b->ped_pose + (size_t)4 * k * h->Pw;
+            sub.ped_goal = b->ped_goal ? b->ped_goal + (size_t)2 * k * h->Pw : nullptr;
+            sub.ped_traj_len = b->ped_traj_len + (size_t)k * h->Pw;
+            sub.ped_traj = b->ped_traj + (size_t)k * h->Pw * b->ped_traj_cap * 3;
+            sub.ped_traj_v = b->ped_traj_v ? b->ped_traj_v + (size_t)k * h->Pw * b->ped_traj_cap * 2 : nullptr;
+        }
+        h->rvos[k] = wo.rvo;
+        RTRY(reset_one_world(h, k, &sub, wo, st, 1));
+        h->world_epoch[k] = 0;
+        h->world_ready[k] = 1;
+    }
+    RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size(), st));
+    RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W, st));
+    tp_[2] = std::chrono::steady_clock::now();
     h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
     h->launches = 2;
+    set_active(h, -1);
     if (int rc = launch_views(h, st, 1)) return rc;  // view_agent + get_states (img_env.cpp:285-286)
-    tp_[6] = std::chrono::steady_clock::now();
     RTRY(stage_end(h, st));
-    tp_[7] = std::chrono::steady_clock::now();
+    tp_[3] = std::chrono::steady_clock::now();
     if (trace_) {
         auto us = [&](int a_, int b_) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(tp_[b_] - tp_[a_]).count(); };
-        if (us(0, 7) > 2000)
-            fprintf(stderr, "[imgenv_reset] stage_begin %ld us, obstacles %ld, map+rvo copies %ld, peds %ld, robots(host+copies) %ld, kernels+views %ld, stage_end %ld\n",
-                    us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7));
+        if (us(0, 3) > 2000)
+            fprintf(stderr, "[imgenv_reset] obstacles %ld us, worlds (host + copies) %ld, views + stage_end %ld\n", us(0, 1), us(1, 2), us(2, 3));
     }  // no host wait: the copies above read the handle's pinned chunks
     h->has_reset = true;
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset_batch* b, void* stream) {
+    if (int rc = reset_checks(h, b)) return rc;
+    if (world < 0 || world >= h->W) FAIL(IMGENV_EINVAL, "world %d out of range (n_worlds %d)", world, h->W);
+    if (h->W == 1) return imgenv_reset(h, b, stream);
+    hipStream_t st = (hipStream_t)stream;
+    RTRY(stage_begin(h));
+    WorldObstacles wo;
+    build_obstacles(h, b, wo);
+    h->rvos[world] = wo.rvo;
+    RTRY(reset_one_world(h, world, b, wo, st, 0));
+    h->world_epoch[world] = h->elapsed;  // its TimeLimitWrapper starts over
+    h->world_ready[world] = 1;
+    RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size(), st));
+    RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W, st));
+    h->launches = 2;
+    set_active(h, world);
+    const int rc = launch_views(h, st, 1);
+    set_active(h, -1);
+    if (rc) return rc;
+    RTRY(stage_end(h, st));
+    bool all = true;
+    for (char r : h->world_ready) all = all && r;
+    h->has_reset = all;
     return IMGENV_OK;
 }
 

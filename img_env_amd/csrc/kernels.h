@@ -77,6 +77,10 @@ __device__ __forceinline__ void bbox_accumulate(const DevWorld& w, bool valid, d
     }
 }
 
+// worlds of a multi-world handle (world-major numbering); a single world never divides
+__device__ __forceinline__ int world_of_robot(const DevWorld& w, int i) { return w.W > 1 ? i / w.Rw : 0; }
+__device__ __forceinline__ int world_of_ped(const DevWorld& w, int j) { return w.W > 1 ? j / w.Pw : 0; }
+
 __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls) {
     return w.rc[cls];
 }
@@ -119,8 +123,16 @@ __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls)
 // then Agent::computeNeighbors + computeNewVelocity for pedestrian j = blockIdx.x.
 __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
     __shared__ OrcaScratch s;
-    const int j = blockIdx.x;
+    const int j = w.act_p0 + blockIdx.x;
     const int lane = lane_id();
+    const int wld = world_of_ped(w, j);
+    const int p_lo = w.W > 1 ? wld * w.Pw : 0, n_p = w.W > 1 ? w.Pw : w.P;  // the pedestrians of this one's world
+    if (w.W > 1) {  // ... and its obstacles
+        w.obst += w.obst_base[wld];
+        w.onodes += w.node_base[wld];
+        w.n_obst = w.n_obst_w[wld];
+        w.oroot = w.oroot_w[wld];
+    }
     // pref velocity: every lane computes the same (uniform) values
     int idx = w.ptraj_idx[j];
     const int len = w.ptraj_len[j];
@@ -153,10 +165,12 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
         if (lane < n_near) near_sorted[rank] = mine;
     }
     __syncthreads();
-    const int n_scan = listed ? w.P + n_near : w.NA;
+    const int n_rob = w.NA > w.P ? (w.W > 1 ? w.Rw : w.R) : 0, rob_lo = w.P + wld * n_rob;  // the robot agents of its world
+    const int n_scan = listed ? n_p + n_near : n_p + n_rob;
     for (int base = 0; base < n_scan; base += WAVE) {
         const int t = base + lane;
-        const int a = (listed && t >= w.P && t < n_scan) ? near_sorted[t - w.P] : t;
+        int a = p_lo + t;
+        if (t >= n_p && t < n_scan) a = listed ? near_sorted[t - n_p] : rob_lo + (t - n_p);
         float dist_sq = 0.0f;
         bool cand = false;
         if (t < n_scan && a != j) {
@@ -423,7 +437,7 @@ __global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions
     if ((int)blockIdx.x >= nb_robot) {
         const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
         if (j < w.P) {
-            if (w.scene == IMGENV_SCENE_DATASET) ped_dataset_one(w, j, step);
+            if (w.scene == IMGENV_SCENE_DATASET) ped_dataset_one(w, j, step - w.world_epoch[world_of_ped(w, j)]);
             else ped_update_one(w, j);
         }
         return;
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
     if ((int)blockIdx.x >= nb_robot) {
         const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
         if (j < w.P) {
-            if (w.scene == IMGENV_SCENE_DATASET) ped_dataset_one(w, j, step);
+            if (w.scene == IMGENV_SCENE_DATASET) ped_dataset_one(w, j, step - w.world_epoch[world_of_ped(w, j)]);
             else ped_update_one(w, j);
         }
         return;
@@ -577,6 +591,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 template <bool POW2>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Region& g) {
     const PedClassDev k = w.pc[w.ped_cls[j]];
+    const size_t cell0 = (size_t)world_of_ped(w, j) * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id();
     const double res = w.res, inv = w.inv_res;
@@ -587,7 +602,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
             int m, n;
             w2m_pair<POW2>(wx, wy, res, inv, m, n);
             if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
-                const size_t c = (size_t)m * w.Wg + n;
+                const size_t c = cell0 + (size_t)m * w.Wg + n;
                 if (w.obs_map[c] > 2) w.ped_layer[c] = 1;
             }
         }
@@ -607,7 +622,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
                 int m, n;
                 w2m_pair<POW2>(wx, wy, res, inv, m, n);
                 if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
-                    const size_t c = (size_t)m * w.Wg + n;
+                    const size_t c = cell0 + (size_t)m * w.Wg + n;
                     if (leg == 1 || w.obs_map[c] != 0) w.ped_layer[c] = 1;
                 }
             }
@@ -638,6 +653,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
     const bool use_box = ncell <= w.box_cells;
     const int l = i - w.r0;
     const bool local = l >= 0 && l < w.RL;
+    const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;  // this world's copy of the layers
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
     // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
     if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
@@ -692,7 +708,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
                 if (use_box && dm >= 0 && dm < side && dn >= 0 && dn < side) {
                     b = dm * side + dn;
                 } else {
-                    const size_t c = (size_t)m * w.Wg + n;
+                    const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
                     stray = true;
@@ -716,7 +732,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
             if (last) {
                 const int bm = b / side;
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
-                c = (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
+                c = cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
 #ifndef IMGENV_EXPERIMENT_NO_OWNER_ATOMICS
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
@@ -744,16 +760,17 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     const int b = blockIdx.x;
     WAVE_T0();
     const Region g = grid_region(w);
-    if (b < w.R) raster_robot<POW2>(w, b, (uint32_t*)smem, zero_vel != 0, g);
-    if (b < w.P) raster_ped<POW2>(w, b, g);
+    if (w.act_g0 + b < w.act_g1) raster_robot<POW2>(w, w.act_g0 + b, (uint32_t*)smem, zero_vel != 0, g);
+    if (w.act_p0 + b < w.act_p1) raster_ped<POW2>(w, w.act_p0 + b, g);
     if (b < w.RL) WAVE_DONE(2);
 }
 
 // class layer: one byte per cell that a robot's view kernel can decode without touching the three
 // raster layers; also re-arms the raster layers for the next step (saves two memsets per step).
 __global__ void k_compose(DevWorld w) {
-    const size_t G = (size_t)w.Hg * w.Wg;
-    const size_t c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    // cells [act_c0, act_c1) of the stacked layers (every world, or the one being reset)
+    const size_t G = w.act_c1;
+    const size_t c0 = w.act_c0 + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_obs tallies this step's dones
     if (c0 >= G) return;
     if (w.sharded) {  // only the region this rank's rasters were clipped to (everything else is clean and unread)
@@ -856,7 +873,7 @@ __device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, co
         int m, n;
         w2m_pair<POW2>(wx, wy, res, inv, m, n);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            const uint32_t cc = cell_class(w, self, (size_t)m * w.Wg + n);
+            const uint32_t cc = cell_class(w, self, (size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n);
             if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
         }
     }
@@ -881,7 +898,7 @@ template <bool POW2, bool A4>
 __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     // A4: Wv % 4 == 0 (a lane's 4 consecutive cells share their row and nothing runs over the end of the view)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int l = blockIdx.x;
+    const int l = w.act_l0 + blockIdx.x;
     const int lane = lane_id();
     if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: every per-robot output keeps its last value (counted in k_integrate)
     const int i = w.r0 + l;
@@ -894,6 +911,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const uint32_t wv_magic = w.wv_magic;
     const bool laser = w.use_laser != 0;
     const uint32_t self = (uint32_t)i;
+    const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;  // this world's copy of the layers
     uint8_t* src = smem;
     uint32_t* hit = (uint32_t*)(smem + NCp);
     double2* colt = (double2*)(smem + NCp + 4 * (size_t)w.hit_stride);
@@ -974,7 +992,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
             for (int q = 0; q < 4; q++) {
                 const bool ok = (A4 || c4 + q < NC) & (((fov >> q) & 1u) != 0) & (m[q] >= 0) & (m[q] < Hg) & (n[q] >= 0) & (n[q] < Wg);
                 okm[q] = ok ? 0xFFu : 0u;
-                idx[q] = ok ? (uint32_t)(m[q] * Wg + n[q]) : 0u;
+                idx[q] = ok ? cell0 + (uint32_t)(m[q] * Wg + n[q]) : 0u;
             }
             uint32_t v[4];
 #pragma unroll
@@ -1315,9 +1333,13 @@ __device__ __forceinline__ void sort_pairs_in_registers(double (&key)[E], uint32
 template <int E>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8 : 4, 8))) void k_obs(DevWorld w, int PP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int l = blockIdx.x, lane = lane_id();
+    const int l = w.act_l0 + blockIdx.x, lane = lane_id();
     const int i = w.r0 + l;
-    const int P = w.P, Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
+    // the pedestrians of this robot's world: indices below are relative to p_lo
+    const int P = w.W > 1 ? w.Pw : w.P, p_lo = w.W > 1 ? world_of_robot(w, i) * w.Pw : 0;
+    const double *g_ppx = w.ppx + p_lo, *g_ppy = w.ppy + p_lo, *g_pvx = w.pvx + p_lo, *g_pvy = w.pvy + p_lo;
+    const double* g_ped_r_round = w.ped_r_round + p_lo;
+    const int Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
     const int Pa = P > 0 ? P : 1;
     const size_t key_bytes = E == 0 ? (size_t)PP * 8 : 0;
     double* key = (double*)smem;
@@ -1350,7 +1372,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
                 sid[q] = 0xFFFFu;
                 if (j < P) {
                     double px, py;
-                    tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
+                    tf_apply(wb, g_ppx[j], g_ppy[j], px, py);
                     const float fx = (float)px, fy = (float)py;
                     info[j] = make_float2(fx, fy);
                     skey[q] = (double)fx * (double)fx + (double)fy * (double)fy;
@@ -1366,7 +1388,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             for (int j = lane; j < PP; j += WAVE) {
                 if (j < P) {
                     double px, py;
-                    tf_apply(wb, w.ppx[j], w.ppy[j], px, py);
+                    tf_apply(wb, g_ppx[j], g_ppy[j], px, py);
                     const float fx = (float)px, fy = (float)py;
                     info[j] = make_float2(fx, fy);
                     key[j] = (double)fx * (double)fx + (double)fy * (double)fy;
@@ -1412,10 +1434,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             if (q < P) {
                 const int j = ord[q];
                 const float2 f = info[j];
-                const double pvx = w.pvx[j], pvy = w.pvy[j];  // PedInfo velocity in the robot frame (img_env.cpp:576-580)
+                const double pvx = g_pvx[j], pvy = g_pvy[j];  // PedInfo velocity in the robot frame (img_env.cpp:576-580)
                 const float fvx = (float)((wb.m00 * pvx + wb.m01 * pvy) + 0.0), fvy = (float)((wb.m10 * pvx + wb.m11 * pvy) + 0.0);
                 const double dpx = f.x, dpy = f.y;
-                const double ped_r = w.ped_r_round[j];
+                const double ped_r = g_ped_r_round[j];
                 const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
                 float* o = stage + lane * 7;
                 o[0] = f.x;
@@ -1467,7 +1489,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             __syncthreads();  // drains this wave's earlier stores: later discs overwrite earlier ones
             const int je = ord[inbox[e]];
             const float2 f = info[je];
-            const double evx = w.pvx[je], evy = w.pvy[je];
+            const double evx = g_pvx[je], evy = g_pvy[je];
             const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
             const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
             int ax, bx, ay, by;
@@ -1527,10 +1549,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
 #define SIDE_PED_TILE 1024
 __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
     __shared__ float2 ped_xy[SIDE_PED_TILE];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < w.R;
+    const int i = w.act_g0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < w.act_g1;
     if (rvo_agents) {
-        const double* r = w.rec + (size_t)(valid ? i : 0) * IMGENV_RECORD_DOUBLES;
+        const double* r = w.rec + (size_t)(valid ? i : w.act_g0) * IMGENV_RECORD_DOUBLES;
         const int a = w.P + i;
         const f2 me = F2((float)r[0], (float)r[1]);
         if (valid) {
@@ -1542,13 +1564,20 @@ __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, i
         // neighborDist is 0.5 m (rvoscene.h:57): tell the few pedestrians this robot can matter to, so that the solve does
         // not scan every robot of the world for every pedestrian.  The test is the solve's own float expression with a
         // slightly larger bound; the solve re-tests exactly.  Pedestrian positions go through LDS, a tile at a time.
-        for (int j0 = 0; j0 < w.P; j0 += SIDE_PED_TILE) {
-            const int nt = min(SIDE_PED_TILE, w.P - j0);
+        // With several worlds a block may straddle two of them (Rw need not divide 256): every thread walks the pedestrian
+        // range of the block's worlds and tests only its own world's.
+        const int first = w.act_g0 + blockIdx.x * blockDim.x, last = min(first + (int)blockDim.x, w.act_g1) - 1;
+        const int p_begin = w.W > 1 ? world_of_robot(w, first) * w.Pw : 0;
+        const int p_end = w.W > 1 ? (world_of_robot(w, max(last, first)) + 1) * w.Pw : w.P;
+        const int my_lo = w.W > 1 ? world_of_robot(w, valid ? i : first) * w.Pw : 0, my_hi = w.W > 1 ? my_lo + w.Pw : w.P;
+        for (int j0 = p_begin; j0 < p_end; j0 += SIDE_PED_TILE) {
+            const int nt = min(SIDE_PED_TILE, p_end - j0);
             __syncthreads();
             for (int q = threadIdx.x; q < nt; q += blockDim.x) ped_xy[q] = make_float2(w.apx[j0 + q], w.apy[j0 + q]);
             __syncthreads();
             if (valid) {
-                for (int q = 0; q < nt; q++) {
+                const int q_lo = max(my_lo - j0, 0), q_hi = min(my_hi - j0, nt);
+                for (int q = q_lo; q < q_hi; q++) {
                     const float2 pp = ped_xy[q];
                     if (abs_sq(F2(pp.x, pp.y) - me) < 0.2500001f) {
                         const int pos = atomicAdd(&w.near_n[j0 + q], 1);
@@ -1565,10 +1594,11 @@ __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, i
 // Per-robot scalars, one thread per robot: Agent::get_state (agent.cpp:156-184), the _get_states distances,
 // ImageEnv.step and the wrapper stack (reward / done).  Runs after k_view (collision code) and k_obs (ped distance).
 __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = l < w.RL;
+    const int l = w.act_l0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = l < w.act_l1;
     int done = 0;
-    if (valid) done = tail_robot(w, l, is_reset, elapsed, do_state);
+    // TimeLimitWrapper counts per world: steps since that world's last reset
+    if (valid) done = tail_robot(w, l, is_reset, elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], do_state);
     if (w.sharded && blockIdx.x == 0 && threadIdx.x < 4)  // the rasters of this step are done with the box: re-arm it
         w.bbox[threadIdx.x] = threadIdx.x < 2 ? BBOX_INIT_MIN : BBOX_INIT_MAX;
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront

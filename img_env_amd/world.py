@@ -51,6 +51,7 @@ class World:
             raise ValueError("imgenv_create: %s" % self.lib.imgenv_last_error().decode())
         self.h = h
         self.n_robots, self.n_peds = cfg.n_robots, cfg.n_peds
+        self.n_worlds = max(1, cfg.n_worlds)
         o = _cabi.Out()
         self._check(self.lib.imgenv_outputs(self.h, C.byref(o)), "imgenv_outputs")
         self.n_local = o.n_local
@@ -77,9 +78,25 @@ class World:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def reset(self, layout):
+        """Reset everything.  A handle of several worlds (``n_worlds`` > 1) takes either one batch of all robots and
+        pedestrians (world-major) with an obstacle list shared by every world, or a list of one layout per world."""
+        if isinstance(layout, (list, tuple)):
+            if len(layout) != self.n_worlds:
+                raise ValueError("expected %d layouts, one per world" % self.n_worlds)
+            for k, lay in enumerate(layout):
+                self.reset_world(k, lay)
+            return self.out
         b, keep = _cabi.make_reset_batch(layout if isinstance(layout, dict) else layout.as_batch(), self.n_robots,
                                          self.n_peds)
         self._check(self.lib.imgenv_reset(self.h, C.byref(b), self._stream()), "imgenv_reset")
+        return self.out
+
+    def reset_world(self, world, layout):
+        """Reset ONE world of a multi-world handle (ImageEnv.reset of one env process, yaml_env.py:296-317); the others
+        keep their state and their time limits.  ``layout`` holds that world's robots, pedestrians and obstacles."""
+        b, keep = _cabi.make_reset_batch(layout if isinstance(layout, dict) else layout.as_batch(),
+                                         self.n_robots // self.n_worlds, self.n_peds // self.n_worlds)
+        self._check(self.lib.imgenv_reset_world(self.h, int(world), C.byref(b), self._stream()), "imgenv_reset_world")
         return self.out
 
     def _actions(self, actions):

@@ -134,6 +134,14 @@ typedef struct imgenv_cfg {
      * with imgenv_arena_bytes(); NULL = the library allocates (and frees) its own. */
     void* out_arena;
     int64_t out_arena_bytes;
+
+    /* ---- independent worlds in one handle: the reference's env_num processes, batched ---- */
+    /* n_worlds copies of the same map and parameters; n_robots and n_peds are TOTALS (multiples of n_worlds), numbered
+     * world-major: world k owns robots [k n_robots / n_worlds, (k + 1) n_robots / n_worlds) and the same share of the
+     * pedestrians.  Robots and pedestrians only ever see their own world.  0 or 1 = a single world.  Each world is reset
+     * on its own with imgenv_reset_world(); its time limit counts from its own reset. */
+    int32_t n_worlds;
+    int32_t reserved_;
 } imgenv_cfg;
 
 #define IMGENV_FLAG_PRIVATE_GRIDS 1 /* oracle only: literal per-robot grid copies (img_env.cpp:620-629) */
@@ -244,6 +252,12 @@ int imgenv_comm_unique_id(void* id128);
 int imgenv_comm_init(imgenv_t* h, const void* id128, int32_t rank, int32_t n_ranks);
 
 int imgenv_outputs(imgenv_t* h, imgenv_out* out);
+
+/* Multi-world handles (imgenv_cfg.n_worlds > 1): reset ONE world while the others keep their state -- what one env
+ * process of the reference does when its episode ends (ImageEnv.reset, yaml_env.py:296-317).  The batch holds that
+ * world's robots (n_robots / n_worlds), pedestrians and obstacles only.  imgenv_reset() on such a handle resets every
+ * world from a batch of all robots / pedestrians (world-major) with one obstacle list shared by all worlds. */
+int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset_batch* batch, void* stream);
 
 /* number of kernels launched by the last step (bench / profiling aid) */
 int imgenv_step_launches(imgenv_t* h);

@@ -375,6 +375,7 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
         FAIL(IMGENV_EINVAL, "imgenv_cfg ABI mismatch (version %d size %d, want %d %d)", cfg->abi_version,
              cfg->struct_size, IMGENV_ABI_VERSION, (int)sizeof(imgenv_cfg));
     if (cfg->n_robots < 1 || cfg->n_peds < 0 || Hg < 1 || Wg < 1) FAIL(IMGENV_EINVAL, "bad sizes");
+    if (cfg->n_worlds > 1) FAIL(IMGENV_EINVAL, "the oracle is one world: check a batched handle against n_worlds oracles");
     if (cfg->n_peds > cfg->max_ped)
         FAIL(IMGENV_EINVAL, "n_peds %d > max_ped %d (IndexError in yaml_env.py:401)", cfg->n_peds, cfg->max_ped);
     if (cfg->global_resolution != cfg->view_resolution)

@@ -1,0 +1,198 @@
+"""Several independent worlds in ONE handle (imgenv_cfg.n_worlds): the reference's ``env_num`` env processes, batched.
+
+Each world of the handle must behave exactly like a world of its own: the checker is one oracle per world, reset and
+stepped with that world's slice of the batch.  Covers per-world reset in mid-flight (the other worlds keep their state
+and their time limits), the whole-handle reset with a shared obstacle list, a dataset crowd (its clock is per world) and
+world sizes that do not divide a workgroup."""
+import numpy as np
+import pytest
+
+from parity import CLOSE, EXACT, compare
+from scenarios import random_actions, small_world
+
+pytestmark = pytest.mark.gpu
+
+PER_ROBOT = tuple(f for f in EXACT + CLOSE if f not in ("counters", "ped_state"))
+
+
+@pytest.fixture(scope="module")
+def worlds():
+    import torch
+    assert torch.cuda.is_available()
+    from img_env_amd.world import World
+    from oracle_binding import OracleWorld, build_oracle
+    build_oracle()
+    return World, OracleWorld
+
+
+def _stack_params(params, W):
+    """the parameter dict of W copies of one world: per-robot / per-pedestrian rows repeat, world-major"""
+    p = dict(params)
+    for k in ("robot_shape", "robot_size", "robot_sensor_cfg", "robot_size_last", "ped_shape", "ped_size", "ped_max_speed"):
+        a = np.asarray(p[k])
+        p[k] = np.concatenate([a] * W, axis=0)
+    p["n_robots"], p["n_peds"], p["n_worlds"] = params["n_robots"] * W, params["n_peds"] * W, W
+    return p
+
+
+def _world_slice(snap, k, Rw, Pw):
+    out = {f: snap[f][k * Rw:(k + 1) * Rw] for f in PER_ROBOT}
+    out["ped_state"] = snap["ped_state"][k * Pw:(k + 1) * Pw]
+    return out
+
+
+def _compare_all(gpu, cpus, Rw, Pw, where, fails):
+    snap = gpu.snapshot()
+    for k, cpu in enumerate(cpus):
+        bad = compare(_world_slice(snap, k, Rw, Pw), cpu.snapshot(), PER_ROBOT + (("ped_state",) if Pw else ()))
+        if bad:
+            fails.append((where, k, bad))
+
+
+def _run(World, OracleWorld, W, Rw, Pw, steps, resets, seed, whole_reset=False, **kw):
+    """``resets``: {step: [worlds reset after that step]}"""
+    grid, params, lay0 = small_world(Rw, Pw, seed=seed, **kw)
+    layouts = [lay0] + [small_world(Rw, Pw, seed=seed + 100 * k, **kw)[2] for k in range(1, W)]
+    gpu = World(_stack_params(params, W), grid)
+    cpus = [OracleWorld(params, grid) for _ in range(W)]
+    fails = []
+    try:
+        if whole_reset:  # one batch of every robot / pedestrian, world 0's obstacles everywhere
+            for lay in layouts[1:]:
+                lay.obs_shape, lay.obs_size, lay.obs_pose = lay0.obs_shape, lay0.obs_size, lay0.obs_pose
+            b = [lay.as_batch() for lay in layouts]
+            big = dict(b[0])
+            for f in ("robot_pose", "robot_goal", "ped_pose", "ped_goal", "ped_traj", "ped_traj_len"):
+                big[f] = np.concatenate([x[f] for x in b], axis=0)
+            gpu.reset(big)
+        else:
+            gpu.reset(layouts)
+        for cpu, lay in zip(cpus, layouts):
+            cpu.reset(lay)
+        _compare_all(gpu, cpus, Rw, Pw, -1, fails)
+        rng = np.random.default_rng(seed + 7)
+        n_reset = 0
+        for s in range(steps):
+            a = random_actions(rng, W * Rw)
+            gpu.step(a)
+            for k, cpu in enumerate(cpus):
+                cpu.step(a[k * Rw:(k + 1) * Rw])
+            _compare_all(gpu, cpus, Rw, Pw, s, fails)
+            for k in resets.get(s, ()):
+                n_reset += 1
+                lay = small_world(Rw, Pw, seed=seed + 1000 * n_reset + k, **kw)[2]
+                gpu.reset_world(k, lay)
+                cpus[k].reset(lay)
+                _compare_all(gpu, cpus, Rw, Pw, (s, "reset", k), fails)
+            if len(fails) > 4:
+                break
+        return fails, gpu.snapshot(), [c.snapshot() for c in cpus]
+    finally:
+        gpu.close()
+        for c in cpus:
+            c.close()
+
+
+def test_worlds_match_one_oracle_each(worlds):
+    """3 worlds x (5 robots, 6 pedestrians, own obstacles): ORCA crowds that must not see each other, per-world resets at
+    steps 6 and 9 and per-world time limits (time_max 12: worlds 0 / 2 run out at step 12, world 1 twelve steps after its
+    own reset)"""
+    World, OracleWorld = worlds
+    fails, snap, cs = _run(World, OracleWorld, 3, 5, 6, 24, {6: [1], 9: [1], 14: [0, 2]}, seed=31, n_obstacles=3, time_max=12)
+    assert not fails, fails[:3]
+
+
+def test_whole_handle_reset_shares_one_obstacle_list(worlds):
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, 4, 3, 4, 10, {4: [2]}, seed=32, whole_reset=True, n_obstacles=4)
+    assert not fails, fails[:3]
+
+
+def test_many_small_worlds_without_pedestrians(worlds):
+    """40 worlds x 7 robots: a workgroup of the per-robot kernels straddles several worlds"""
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, 40, 7, 0, 8, {3: [0, 17, 39]}, seed=33, n_obstacles=2, grid_size=120)
+    assert not fails, fails[:3]
+
+
+def test_worlds_with_legs_ervo_and_odd_sizes(worlds):
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, 5, 9, 11, 12, {5: [4], 6: [0]}, seed=34, n_obstacles=2, ped_shape="leg",
+                       scene="ervoscene", res=0.1, view_cells=37, view_width=3.75, view_height=3.75, grid_size=150)
+    assert not fails, fails[:3]
+
+
+def test_dataset_clock_is_per_world(worlds):
+    """a replayed crowd restarts its record when ITS world is reset (img_env.cpp:361-386 indexes by the env's step count)"""
+    World, OracleWorld = worlds
+    from img_env_amd import spawn
+    W, Rw, Pw, steps = 3, 4, 5, 16
+    grid, params, _ = small_world(Rw, Pw, seed=41, scene="dataset")
+
+    def layout(seed):
+        lay = small_world(Rw, Pw, seed=seed, n_obstacles=2, scene="dataset")[2]
+        rng = np.random.default_rng(seed)
+        T = 9
+        data = np.zeros((Pw, T, 5))
+        pos = lay.ped_pose[:, :2].copy()
+        for t in range(T):
+            v = rng.uniform(-0.5, 0.5, (Pw, 2))
+            data[:, t, :2], data[:, t, 2], data[:, t, 3:] = pos, rng.uniform(-3, 3, Pw), v
+            pos = pos + 0.25 * v
+        spawn.init_ped_dataset(lay, data)
+        return lay
+
+    gpu = World(_stack_params(params, W), grid)
+    cpus = [OracleWorld(params, grid) for _ in range(W)]
+    fails = []
+    try:
+        lays = [layout(50 + k) for k in range(W)]
+        gpu.reset(lays)
+        for c, lay in zip(cpus, lays):
+            c.reset(lay)
+        rng = np.random.default_rng(5)
+        for s in range(steps):
+            a = random_actions(rng, W * Rw)
+            gpu.step(a)
+            for k, c in enumerate(cpus):
+                c.step(a[k * Rw:(k + 1) * Rw])
+            _compare_all(gpu, cpus, Rw, Pw, s, fails)
+            if s == 5:
+                lay = layout(99)
+                gpu.reset_world(1, lay)
+                cpus[1].reset(lay)
+                _compare_all(gpu, cpus, Rw, Pw, (s, "reset"), fails)
+        assert not fails, fails[:3]
+    finally:
+        gpu.close()
+        for c in cpus:
+            c.close()
+
+
+def test_bad_multi_world_configurations_are_rejected(worlds):
+    World, _ = worlds
+    grid, params, _ = small_world(4, 4, seed=1)
+    p = _stack_params(params, 2)
+    p["n_robots"] = 7  # not a multiple of n_worlds
+    for k in ("robot_shape", "robot_size", "robot_sensor_cfg", "robot_size_last"):
+        p[k] = np.asarray(p[k])[:7]
+    with pytest.raises(ValueError, match="multiples of n_worlds"):
+        World(p, grid)
+    grid, params, _ = small_world(4, 4, seed=1, scene="pedscene", grid_size=80)
+    with pytest.raises(ValueError, match="pedsim"):
+        World(_stack_params(params, 2), grid)
+    grid, params, _ = small_world(4, 4, seed=1)
+    p = _stack_params(params, 2)
+    p["robot_begin"], p["robot_end"] = 0, 4
+    with pytest.raises(ValueError, match="shard"):
+        World(p, grid)
+    w = World(_stack_params(params, 2), grid)
+    try:
+        lay = small_world(4, 4, seed=2)[2]
+        w.reset_world(0, lay)
+        with pytest.raises(RuntimeError, match="before reset"):  # world 1 has never been reset
+            w.step(np.zeros((8, 3), np.float32))
+        with pytest.raises(RuntimeError, match="out of range"):
+            w.reset_world(2, lay)
+    finally:
+        w.close()
