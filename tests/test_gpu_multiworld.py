@@ -169,6 +169,48 @@ def test_dataset_clock_is_per_world(worlds):
             c.close()
 
 
+def test_one_world_reset_grows_the_shared_tables(worlds):
+    """a per-world reset that brings longer waypoint lists and more obstacles than any reset before it: the trajectory table
+    and the obstacle slices are re-laid out, and the other worlds' contents must survive the move"""
+    World, OracleWorld = worlds
+    W, Rw, Pw = 3, 4, 5
+    grid, params, _ = small_world(Rw, Pw, seed=61, max_ped=8)
+    lays = [small_world(Rw, Pw, seed=61 + k, n_obstacles=1)[2] for k in range(W)]
+    gpu = World(_stack_params(params, W), grid)
+    cpus = [OracleWorld(params, grid) for _ in range(W)]
+    fails = []
+    try:
+        gpu.reset(lays)
+        for c, lay in zip(cpus, lays):
+            c.reset(lay)
+        rng = np.random.default_rng(61)
+        for s in range(30):
+            a = random_actions(rng, W * Rw)
+            gpu.step(a)
+            for k, c in enumerate(cpus):
+                c.step(a[k * Rw:(k + 1) * Rw])
+            _compare_all(gpu, cpus, Rw, Pw, s, fails)
+            if s in (4, 11):
+                k = 1 if s == 4 else 2
+                lay = small_world(Rw, Pw, seed=200 + s, n_obstacles=6 if s == 4 else 14)[2]
+                cap = 4 if s == 4 else 7
+                traj = np.zeros((Pw, cap, 3))
+                lens = rng.integers(1, cap + 1, Pw).astype(np.int32)
+                lens[0] = cap
+                for j in range(Pw):
+                    for q in range(lens[j]):
+                        traj[j, q, :2] = lay.ped_pose[j, :2] + rng.uniform(-2.0, 2.0, 2)
+                lay.ped_traj, lay.ped_traj_len = traj, lens
+                gpu.reset_world(k, lay)
+                cpus[k].reset(lay)
+                _compare_all(gpu, cpus, Rw, Pw, (s, "reset"), fails)
+        assert not fails, fails[:3]
+    finally:
+        gpu.close()
+        for c in cpus:
+            c.close()
+
+
 def test_bad_multi_world_configurations_are_rejected(worlds):
     World, _ = worlds
     grid, params, _ = small_world(4, 4, seed=1)
