@@ -213,7 +213,7 @@ def make_reset_batch(b, n_robots, n_peds):
 SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_create", "imgenv_arena_bytes",
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
-           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_reset_world")
+           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_reset_world", "imgenv_reset_worlds")
 K_COUNT = 8
 
 
@@ -236,6 +236,7 @@ def bind(lib):
     lib.imgenv_destroy.restype = None
     lib.imgenv_reset.argtypes = [C.c_void_p, C.POINTER(ResetBatch), C.c_void_p]
     lib.imgenv_reset_world.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ResetBatch), C.c_void_p]
+    lib.imgenv_reset_worlds.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(ResetBatch), C.c_void_p]
     lib.imgenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.imgenv_step_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.imgenv_step_end.argtypes = [C.c_void_p, C.c_void_p]

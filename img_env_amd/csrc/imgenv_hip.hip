@@ -62,6 +62,19 @@ struct imgenv {
     // pinned host staging of imgenv_reset: copies are truly asynchronous and reset never waits for the stream
     struct Chunk { unsigned char* p; size_t cap, used; };
     std::vector<Chunk> stage;
+    struct StageSegHost { void* dst; const void* src; size_t bytes; };
+    std::vector<StageSegHost> segs;  // copies queued for the next stage_flush
+    size_t seg_max = 0;
+    uint8_t* d_static_map = nullptr;  // the map every reset starts from
+    struct ObstClass { int shape; float size[4]; int n; const double2* pts; };
+    std::vector<ObstClass> ocls;      // obstacle footprints seen so far (device sample lists)
+    struct ObstInstHost { double x, y, sh, ch; const void* pts; int n_pts, world; };
+    std::vector<ObstInstHost> oinst;  // obstacles of the reset being staged
+    void* d_oinst = nullptr;
+    size_t cap_oinst = 0;
+    int* d_act_list = nullptr;
+    std::vector<double> tmp_d0, tmp_d1;
+    std::vector<int> tmp_i0;
     hipEvent_t ev_stage = nullptr;
     bool stage_pending = false;
     void* d_rr = nullptr;
@@ -449,8 +462,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     memset(&d, 0, sizeof(d));
     d.R = R; d.RL = RL; d.r0 = r0; d.P = P; d.NA = h->NA;
     d.W = W; d.Rw = h->Rw; d.Pw = h->Pw; d.Gs = (uint32_t)h->Gs;
-    d.act_l0 = 0; d.act_l1 = RL; d.act_g0 = 0; d.act_g1 = R; d.act_p0 = 0; d.act_p1 = P;
-    d.act_c0 = 0; d.act_c1 = W > 1 ? h->Gs * W : h->Gs;
+    d.act_list = nullptr; d.act_nw = W; d.act_nl = RL; d.act_ng = R; d.act_np = P;
+    d.act_cells = W > 1 ? h->Gs * W : h->Gs;
     d.Hg = Hg; d.Wg = Wg; d.Hv = g.Hv; d.Wv = g.Wv; d.B = g.B;
     d.Hp = cfg->ped_image_size[0]; d.Wp = cfg->ped_image_size[1];
     d.SD = cfg->state_dim; d.PV = 1 + cfg->ped_vec_dim * cfg->max_ped;
@@ -493,6 +506,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     // grids (one copy per world)
     TRY(dev_alloc(h, &h->d_obs_map, Gp));
     for (int k = 0; k < W; k++) HIPCHK(hipMemcpy(h->d_obs_map + (size_t)k * h->Gs, static_map, G, hipMemcpyHostToDevice));
+    TRY(dev_alloc(h, &h->d_static_map, (G + 15) & ~(size_t)15));
+    HIPCHK(hipMemcpy(h->d_static_map, static_map, G, hipMemcpyHostToDevice));
     TRY(dev_alloc(h, &h->d_world_epoch, W));
     d.world_epoch = h->d_world_epoch;
     h->wobst.assign((size_t)4 * W, 0);
@@ -764,8 +779,9 @@ struct ResetRobot {  // per local robot
 };
 
 __global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, const ResetRobot* __restrict__ rr, int whole) {
-    const int i = w.act_g0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.act_g1) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= w.act_ng) return;
+    const int i = act_member(w, w.Rw, t);
     double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     r[0] = pose3[5 * i];  // init_pose (agent.cpp:133-142); Agent::vx, vy persist across resets
     r[1] = pose3[5 * i + 1];
@@ -782,7 +798,7 @@ __global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, con
         w.is_coll[l] = 0;
         w.is_arr[l] = 0;
     }
-    if (i == 0 && whole) w.counters[2] = 0;  // frozen robot-steps since this reset (of every world)
+    if (t == 0 && whole) w.counters[2] = 0;  // frozen robot-steps since this reset (of every world)
 }
 
 // reset of a robot-sharded world: bounding box of the local robots' new positions (k_tail re-arms it every step)
@@ -794,8 +810,9 @@ __global__ void k_reset_bbox(DevWorld w, const double* __restrict__ pose3) {
 }
 
 __global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
-    const int j = w.act_p0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= w.act_p1) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= w.act_np) return;
+    const int j = act_member(w, w.Pw, t);
     w.ppx[j] = pose3[3 * j];
     w.ppy[j] = pose3[3 * j + 1];
     w.pyaw[j] = pose3[3 * j + 2];
@@ -838,7 +855,7 @@ static int launch_obs(imgenv* h, hipStream_t st) {
         HIPCHK(hipEventRecord(h->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(s_obs, h->ev_fork, 0));
     }
-    const dim3 go(d.act_l1 - d.act_l0), bo(WAVE);
+    const dim3 go(d.act_nl), bo(WAVE);
     switch (h->obs_E) {
         case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
         case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
@@ -854,8 +871,9 @@ static int launch_obs(imgenv* h, hipStream_t st) {
 
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
-    const size_t G = d.act_c1 - d.act_c0;
-    const int n_g = d.act_g1 - d.act_g0, n_p = d.act_p1 - d.act_p0, n_l = d.act_l1 - d.act_l0;
+    const int n_g = d.act_ng, n_p = d.act_np, n_l = d.act_nl;
+    // k_compose: 4 cells per thread over everything, or a fixed number of 256-thread blocks per listed world
+    const unsigned compose_blocks = d.act_list ? (unsigned)(((h->Gs / 4 + 255) / 256) * d.act_nw) : (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
     if (h->P > 0) {
         // One fork and one join per step on the caller's stream (every event operation costs it a ~6 us dependency
         // bubble).  Beside the rasters, compose and view run, on two side streams, the pedestrian half of the
@@ -892,7 +910,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     else
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
-    TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3((unsigned)((G / 4 + 255) / 256 + 1)), dim3(256), 0, st>>>(d)));
+    TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     {
         const dim3 gv(n_l), bv(WAVE);
         const int variant = (h->pow2 ? 2 : 0) | (h->geom.Wv % 4 == 0 ? 1 : 0);
@@ -908,11 +926,27 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     return 0;
 }
 
-// ---- pinned staging for reset: H2D copies out of page-locked chunks owned by the handle ----
-__global__ void k_stage_copy(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, size_t bytes) {
-    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t q = t; q < n16; q += stride) ((uint4*)dst)[q] = ((const uint4*)src)[q];
-    for (size_t q = n16 * 16 + t; q < bytes; q += stride) dst[q] = src[q];
+// ---- pinned staging for reset: everything a reset uploads goes through page-locked chunks owned by the handle and
+// reaches the device in ONE launch (a table of segments), however many worlds the reset covers ----
+struct StageSeg {
+    unsigned char* dst;
+    const unsigned char* src;
+    size_t bytes;
+};
+// a kernel pulls the bytes out of the page-locked chunks: unlike hipMemcpyAsync (which was seen to block the host for
+// several milliseconds on a busy stream once a copy exceeds a few hundred KB) a launch never waits
+__global__ __launch_bounds__(256) void k_stage_copy(const StageSeg* __restrict__ table) {
+    const StageSeg g = table[blockIdx.y];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)g.dst | (uintptr_t)g.src) & 15) == 0) {
+        const size_t n16 = g.bytes / 16;
+        for (size_t q = t; q < n16; q += stride) ((uint4*)g.dst)[q] = ((const uint4*)g.src)[q];
+        for (size_t q = n16 * 16 + t; q < g.bytes; q += stride) g.dst[q] = g.src[q];
+    } else if ((((uintptr_t)g.dst | (uintptr_t)g.src | g.bytes) & 3) == 0) {
+        for (size_t q = t; q < g.bytes / 4; q += stride) ((uint32_t*)g.dst)[q] = ((const uint32_t*)g.src)[q];
+    } else {
+        for (size_t q = t; q < g.bytes; q += stride) g.dst[q] = g.src[q];
+    }
 }
 static int stage_begin(imgenv* h) {
     if (!h->ev_stage) HIPCHK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
@@ -921,10 +955,11 @@ static int stage_begin(imgenv* h) {
         h->stage_pending = false;
     }
     for (auto& c : h->stage) c.used = 0;
+    h->segs.clear();
+    h->seg_max = 0;
     return 0;
 }
-static int stage_put(imgenv* h, void* dst, const void* src, size_t bytes, hipStream_t st) {
-    if (bytes == 0) return 0;
+static int stage_room(imgenv* h, size_t bytes, unsigned char** out) {
     imgenv::Chunk* use = nullptr;
     for (auto& c : h->stage)
         if (c.cap - c.used >= bytes) {
@@ -937,16 +972,35 @@ static int stage_put(imgenv* h, void* dst, const void* src, size_t bytes, hipStr
         h->stage.push_back(c);
         use = &h->stage.back();
     }
-    unsigned char* p = use->p + use->used;
+    *out = use->p + use->used;
     use->used += (bytes + 255) & ~(size_t)255;
     if (use->used > use->cap) use->used = use->cap;
+    return 0;
+}
+static int stage_put(imgenv* h, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return 0;
+    unsigned char* p = nullptr;
+    if (int rc = stage_room(h, bytes, &p)) return rc;
     memcpy(p, src, bytes);
-    // a kernel pulls the bytes out of the page-locked chunk: unlike hipMemcpyAsync (which was seen to block the host for
-    // several milliseconds on a busy stream once a copy exceeds a few hundred KB) a launch never waits
-    const size_t n16 = bytes / 16;
-    const unsigned blocks = (unsigned)std::min<size_t>((std::max<size_t>(n16, 1) + 255) / 256, 1024);
-    k_stage_copy<<<dim3(blocks), dim3(256), 0, st>>>((unsigned char*)dst, (const unsigned char*)p, bytes);
+    h->segs.push_back(imgenv::StageSegHost{dst, p, bytes});
+    h->seg_max = std::max(h->seg_max, bytes);
+    return 0;
+}
+// launch the copies queued so far
+static int stage_flush(imgenv* h, hipStream_t st) {
+    if (h->segs.empty()) return 0;
+    static_assert(sizeof(imgenv::StageSegHost) == sizeof(StageSeg), "layout");
+    unsigned char* table = nullptr;
+    if (int rc = stage_room(h, h->segs.size() * sizeof(StageSeg), &table)) return rc;
+    memcpy(table, h->segs.data(), h->segs.size() * sizeof(StageSeg));
+    const unsigned bx = (unsigned)std::min<size_t>((h->seg_max / 16 + 255) / 256 + 1, 64);
+    for (size_t q0 = 0; q0 < h->segs.size(); q0 += 65535) {
+        const unsigned ny = (unsigned)std::min<size_t>(h->segs.size() - q0, 65535);
+        k_stage_copy<<<dim3(bx, ny), dim3(256), 0, st>>>((const StageSeg*)table + q0);
+    }
     HIPCHK(hipGetLastError());
+    h->segs.clear();
+    h->seg_max = 0;
     return 0;
 }
 static int stage_end(imgenv* h, hipStream_t st) {
@@ -960,16 +1014,15 @@ static int stage_end(imgenv* h, hipStream_t st) {
     do {                             \
         if (int rc_ = (expr)) return rc_; \
     } while (0)
-// a launch covers every world (k < 0) or the robots, pedestrians and cells of world k alone
-static void set_active(imgenv* h, int k) {
+
+// a launch covers every world (list == nullptr) or the robots, pedestrians and cells of the n listed worlds
+static void set_active(imgenv* h, const int* list, int n) {
     DevWorld& d = h->d;
-    if (k < 0 || h->W == 1) {
-        d.act_l0 = 0; d.act_l1 = h->RL; d.act_g0 = 0; d.act_g1 = h->R; d.act_p0 = 0; d.act_p1 = h->P;
-        d.act_c0 = 0; d.act_c1 = h->W > 1 ? h->Gs * h->W : h->Gs;
+    d.act_cells = h->W > 1 ? h->Gs * h->W : h->Gs;
+    if (!list) {
+        d.act_list = nullptr; d.act_nw = h->W; d.act_nl = h->RL; d.act_ng = h->R; d.act_np = h->P;
     } else {
-        d.act_l0 = d.act_g0 = k * h->Rw; d.act_l1 = d.act_g1 = (k + 1) * h->Rw;
-        d.act_p0 = k * h->Pw; d.act_p1 = (k + 1) * h->Pw;
-        d.act_c0 = (size_t)k * h->Gs; d.act_c1 = (size_t)(k + 1) * h->Gs;
+        d.act_list = list; d.act_nw = n; d.act_nl = d.act_ng = n * h->Rw; d.act_np = n * h->Pw;
     }
 }
 
@@ -980,38 +1033,97 @@ __global__ void k_restride3(double* __restrict__ dst, const double* __restrict__
     dst[j * (size_t)new_cap * 3 + rem] = src[t];
 }
 
-struct WorldObstacles {  // what a reset batch's obstacle list turns into (img_env.cpp:166-193)
-    std::vector<uint8_t> obs;     // obs_map_
-    std::vector<double> sfm_obs;  // PedScene::addObs segments
-    RvoObstacles rvo;             // RVOScene::addObs + processObs
+// obs_map_ of the worlds being reset starts from the static map again (img_env.cpp:166-168) ...
+__global__ __launch_bounds__(256) void k_restore_maps(DevWorld w, const uint8_t* __restrict__ static_map) {
+    const int world = w.act_list ? w.act_list[blockIdx.y] : blockIdx.y;
+    const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;  // (both buffers are padded to 16 bytes)
+    uint4* dst = (uint4*)(const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs);
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += (size_t)gridDim.x * blockDim.x)
+        dst[q] = ((const uint4*)static_map)[q];
+}
+// ... and every obstacle is drawn into it with value 0: Agent::draw(obs_map, 0, "world_map") (img_env.cpp:169-193,
+// agent.cpp:285-327) writes unless the cell holds 0 / 1 / 2 -- and only ever writes 0, so the order does not matter.
+// One workgroup per obstacle; its footprint samples were uploaded once per (shape, size).
+struct ObstInst {
+    double x, y, sh, ch;  // pose; sin / cos of yaw/2, evaluated on the host
+    const double2* pts;
+    int n_pts, world;
 };
-static void build_obstacles(imgenv* h, const imgenv_reset_batch* b, WorldObstacles& o) {
-    const double res = h->geom.res;
-    o.obs = h->static_map;
-    o.sfm_obs.clear();
-    o.rvo.clear();
-    for (int q = 0; q < b->n_obstacles; q++) {
-        double sizes[4];
-        for (int j = 0; j < 4; j++) sizes[j] = (double)b->obs_size[4 * q + j];
-        const Pts bb = b->obs_shape[q] == IMGENV_SHAPE_CIRCLE ? shape_circle(sizes[0], sizes[1], sizes[2]) : shape_rectangle(sizes);
-        const double* p = b->obs_pose + 4 * q;
-        const Tf2 bw = tf_from_pose(p[0], p[1], tf_yaw_from_quaternion_zw(p[2], p[3]));
-        draw_obstacle(o.obs.data(), h->Hg, h->Wg, res, bw, bb);
-        double pax, pay, pbx, pby;
-        get_corners(b->obs_shape[q], sizes, bw, pax, pay, pbx, pby);
-        if (!b->ignore_obstacle && h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::addObs: the segment pa -> pb (pedscene.h:22-26)
-            o.sfm_obs.push_back(pax); o.sfm_obs.push_back(pay); o.sfm_obs.push_back(pbx); o.sfm_obs.push_back(pby);
-        }
-        if (!b->ignore_obstacle && h->NA > 0) {  // RVOScene::addObs (rvoscene.h:19-26)
-            const float v[8] = {(float)pax, (float)pay, (float)pax, (float)pby, (float)pbx, (float)pby, (float)pbx, (float)pay};
-            o.rvo.add(v, 4);
+template <bool POW2>
+__global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst) {
+    const ObstInst o = inst[blockIdx.x];
+    const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
+    uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)o.world * w.Gs;
+    for (int q = threadIdx.x; q < o.n_pts; q += blockDim.x) {
+        const double2 p = o.pts[q];
+        double wx, wy;
+        tf_apply(bw, p.x, p.y, wx, wy);
+        int m, n;
+        w2m_pair<POW2>(wx, wy, w.res, w.inv_res, m, n);
+        if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+            uint8_t* c = map + (size_t)m * w.Wg + n;
+            if (*c > 2) *c = 0;
         }
     }
-    o.rvo.process();  // processObs (img_env.cpp:283)
+}
+
+// the footprint samples of an obstacle class (agent.cpp:18-62), uploaded the first time a reset brings the class
+static int obstacle_class(imgenv* h, int shape, const float* size4, const double2** pts, int* n_pts) {
+    for (const auto& c : h->ocls)
+        if (c.shape == shape && !memcmp(c.size, size4, 16)) {
+            *pts = c.pts;
+            *n_pts = c.n;
+            return 0;
+        }
+    double sizes[4];
+    for (int j = 0; j < 4; j++) sizes[j] = (double)size4[j];
+    const Pts bb = shape == IMGENV_SHAPE_CIRCLE ? shape_circle(sizes[0], sizes[1], sizes[2]) : shape_rectangle(sizes);
+    std::vector<double2> v(bb.n() > 0 ? bb.n() : 1);
+    for (int q = 0; q < bb.n(); q++) v[q] = make_double2(bb.x[q], bb.y[q]);
+    imgenv::ObstClass c;
+    c.shape = shape;
+    memcpy(c.size, size4, 16);
+    c.n = bb.n();
+    if (int rc = dev_upload(h, &c.pts, v)) return rc;
+    h->ocls.push_back(c);
+    *pts = c.pts;
+    *n_pts = c.n;
+    return 0;
+}
+
+// the obstacle list of one world's reset batch: instances for k_reset_obstacles, the RVO polygons with their BSP
+// (RVOScene::addObs + processObs, rvoscene.h:19-26, img_env.cpp:283) and the social-force segments (pedscene.h:22-26)
+static int world_obstacles(imgenv* h, int k, const imgenv_reset_batch* b, std::vector<double>& sfm_obs) {
+    RvoObstacles& rvo = h->rvos[k];
+    rvo.clear();
+    for (int q = 0; q < b->n_obstacles; q++) {
+        const int shape = b->obs_shape[q];
+        double sizes[4];
+        for (int j = 0; j < 4; j++) sizes[j] = (double)b->obs_size[4 * q + j];
+        const double* p = b->obs_pose + 4 * q;
+        const double yaw = tf_yaw_from_quaternion_zw(p[2], p[3]);
+        imgenv::ObstInstHost oi;
+        oi.x = p[0]; oi.y = p[1]; oi.sh = sin(yaw * 0.5); oi.ch = cos(yaw * 0.5);
+        oi.world = k;
+        if (int rc = obstacle_class(h, shape, b->obs_size + 4 * q, (const double2**)&oi.pts, &oi.n_pts)) return rc;
+        h->oinst.push_back(oi);
+        const Tf2 bw = tf_from_pose_sc(p[0], p[1], oi.sh, oi.ch);
+        double pax, pay, pbx, pby;
+        get_corners(shape, sizes, bw, pax, pay, pbx, pby);
+        if (!b->ignore_obstacle && h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::addObs: the segment pa -> pb
+            sfm_obs.push_back(pax); sfm_obs.push_back(pay); sfm_obs.push_back(pbx); sfm_obs.push_back(pby);
+        }
+        if (!b->ignore_obstacle && h->NA > 0) {  // RVOScene::addObs
+            const float v[8] = {(float)pax, (float)pay, (float)pax, (float)pby, (float)pbx, (float)pby, (float)pbx, (float)pay};
+            rvo.add(v, 4);
+        }
+    }
+    rvo.process();
+    return 0;
 }
 
 // obstacle segments and their BSP of world k: a slice of cap_obst / cap_nodes entries per world
-static int put_world_rvo(imgenv* h, int k, hipStream_t st) {
+static int put_world_rvo(imgenv* h, int k) {
     static_assert(sizeof(RvoObstHost) == sizeof(RvoObstDev) && sizeof(RvoNodeHost) == sizeof(RvoNodeDev), "layout");
     const RvoObstacles& r = h->rvos[k];
     bool all = false;
@@ -1027,10 +1139,8 @@ static int put_world_rvo(imgenv* h, int k, hipStream_t st) {
     }
     for (int q = all ? 0 : k; q < (all ? h->W : k + 1); q++) {  // a grown array is refilled from the host copies
         const RvoObstacles& rq = h->rvos[q];
-        if (!rq.ob.empty())
-            RTRY(stage_put(h, h->d_obst + (size_t)q * h->cap_obst, rq.ob.data(), sizeof(RvoObstDev) * rq.ob.size(), st));
-        if (!rq.nodes.empty())
-            RTRY(stage_put(h, h->d_nodes + (size_t)q * h->cap_nodes, rq.nodes.data(), sizeof(RvoNodeDev) * rq.nodes.size(), st));
+        if (!rq.ob.empty()) RTRY(stage_put(h, h->d_obst + (size_t)q * h->cap_obst, rq.ob.data(), sizeof(RvoObstDev) * rq.ob.size()));
+        if (!rq.nodes.empty()) RTRY(stage_put(h, h->d_nodes + (size_t)q * h->cap_nodes, rq.nodes.data(), sizeof(RvoNodeDev) * rq.nodes.size()));
         h->wobst[q] = q * h->cap_obst;
         h->wobst[h->W + q] = q * h->cap_nodes;
         h->wobst[2 * h->W + q] = (int)rq.ob.size();
@@ -1045,29 +1155,29 @@ static int put_world_rvo(imgenv* h, int k, hipStream_t st) {
     return 0;
 }
 
-// Everything of a reset but the views, for world k of the handle; the batch holds that world's robots and pedestrians.
-static int reset_one_world(imgenv* h, int k, const imgenv_reset_batch* b, const WorldObstacles& wo, hipStream_t st, int whole) {
+// Host half of one world's reset: its obstacles, pedestrians and robots go into the staging chunks.
+static int stage_world(imgenv* h, int k, const imgenv_reset_batch* b, hipStream_t st) {
     DevWorld& d = h->d;
     const int W = h->W, Rw = h->Rw, Pw = h->Pw, P = h->P;
     const int g_lo = k * Rw, p_lo = k * Pw;  // first robot / pedestrian of the world
-    RTRY(stage_put(h, h->d_obs_map + (size_t)k * h->Gs, wo.obs.data(), wo.obs.size(), st));
-    RTRY(put_world_rvo(h, k, st));
+    std::vector<double> sfm_obs;
+    RTRY(world_obstacles(h, k, b, sfm_obs));
+    RTRY(put_world_rvo(h, k));
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {
-        const int nob = (int)wo.sfm_obs.size() / 4;
+        const int nob = (int)sfm_obs.size() / 4;
         if (nob > h->sfm_cap_obs) {
             h->sfm_cap_obs = nob * 2;
             if (int rc = dev_alloc(h, &d.sfm.obs, (size_t)h->sfm_cap_obs * 4)) return rc;
         }
-        if (nob) RTRY(stage_put(h, d.sfm.obs, wo.sfm_obs.data(), sizeof(double) * wo.sfm_obs.size(), st));
+        if (nob) RTRY(stage_put(h, d.sfm.obs, sfm_obs.data(), sizeof(double) * sfm_obs.size()));
         d.sfm.n_obs = nob;
     }
     // pedestrians (img_env.cpp:220-250)
-    std::vector<double> ped3((size_t)(Pw > 0 ? Pw : 1) * 3);
-    std::vector<int> tlen(Pw > 0 ? Pw : 1);
     if (Pw > 0) {
         const bool dataset = h->cfg.ped_scene_type == IMGENV_SCENE_DATASET;
         if (dataset && !b->ped_traj_v) FAIL(IMGENV_EINVAL, "dataset scene: ped_traj_v is missing from the reset batch");
         if (b->ped_traj_cap > h->traj_cap) {  // longer trajectories than any before: re-lay the table out (other worlds keep theirs)
+            RTRY(stage_flush(h, st));  // (queued copies aim at the old table)
             const int old_cap = h->traj_cap;
             double *old_t = h->d_traj, *old_v = h->d_traj_v;
             h->traj_cap = b->ped_traj_cap;
@@ -1080,7 +1190,12 @@ static int reset_one_world(imgenv* h, int k, const imgenv_reset_batch* b, const 
                 if (dataset) k_restride3<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(h->d_traj_v, old_v, P, old_cap, h->traj_cap);
             }
         }
-        std::vector<double> traj((size_t)Pw * h->traj_cap * 3, 0.0);
+        std::vector<double>& ped3 = h->tmp_d0;
+        std::vector<int>& tlen = h->tmp_i0;
+        std::vector<double>& traj = h->tmp_d1;
+        ped3.resize((size_t)Pw * 3);
+        tlen.resize(Pw);
+        traj.assign((size_t)Pw * h->traj_cap * 3, 0.0);
         for (int j = 0; j < Pw; j++) {
             const double* p = b->ped_pose + 4 * j;
             ped3[3 * j] = p[0];
@@ -1091,10 +1206,12 @@ static int reset_one_world(imgenv* h, int k, const imgenv_reset_batch* b, const 
             for (int q = 0; q < tlen[j]; q++)
                 memcpy(&traj[((size_t)j * h->traj_cap + q) * 3], b->ped_traj + ((size_t)j * b->ped_traj_cap + q) * 3, 24);
         }
-        RTRY(stage_put(h, h->d_traj + (size_t)p_lo * h->traj_cap * 3, traj.data(), traj.size() * 8, st));
-        RTRY(stage_put(h, h->d_traj_len + p_lo, tlen.data(), sizeof(int) * Pw, st));
+        RTRY(stage_put(h, h->d_traj + (size_t)p_lo * h->traj_cap * 3, traj.data(), traj.size() * 8));
+        RTRY(stage_put(h, h->d_traj_len + p_lo, tlen.data(), sizeof(int) * Pw));
+        RTRY(stage_put(h, h->d_ped3 + (size_t)p_lo * 3, ped3.data(), ped3.size() * 8));
         if (dataset) {  // trajectory_v (img_env.cpp:246-247) + the yaw _step_ped_dataset derives from it, with the host's libm
-            std::vector<double> tv((size_t)Pw * h->traj_cap * 3, 0.0);
+            std::vector<double>& tv = h->tmp_d1;
+            tv.assign((size_t)Pw * h->traj_cap * 3, 0.0);
             for (int j = 0; j < Pw; j++)
                 for (int q = 0; q < tlen[j]; q++) {
                     const double* v = b->ped_traj_v + ((size_t)j * b->ped_traj_cap + q) * 2;
@@ -1103,7 +1220,7 @@ static int reset_one_world(imgenv* h, int k, const imgenv_reset_batch* b, const 
                     o[1] = v[1];
                     o[2] = atan2(v[1], v[0]);
                 }
-            RTRY(stage_put(h, h->d_traj_v + (size_t)p_lo * h->traj_cap * 3, tv.data(), tv.size() * 8, st));
+            RTRY(stage_put(h, h->d_traj_v + (size_t)p_lo * h->traj_cap * 3, tv.data(), tv.size() * 8));
             d.ptraj_v = h->d_traj_v;
         }
         if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::setWayPoint (pedscene.h:38-46): [goal r=1, trajectory r=z]
@@ -1126,20 +1243,21 @@ static int reset_one_world(imgenv* h, int k, const imgenv_reset_batch* b, const 
                 dest[j] = 0;  // addWaypoint leaves destination = waypoints.front() without popping it (ped_agent.cpp:97-100)
             }
             const SfmDev& f = d.sfm;
-            RTRY(stage_put(h, f.wpx, wx.data(), wx.size() * 8, st));
-            RTRY(stage_put(h, f.wpy, wy.data(), wy.size() * 8, st));
-            RTRY(stage_put(h, f.wpr, wr.data(), wr.size() * 8, st));
-            RTRY(stage_put(h, f.dq, dq.data(), dq.size() * 4, st));
-            RTRY(stage_put(h, f.dq_n, dqn.data(), dqn.size() * 4, st));
-            RTRY(stage_put(h, f.dest, dest.data(), dest.size() * 4, st));
-            RTRY(stage_put(h, f.last, last.data(), last.size() * 4, st));
+            RTRY(stage_put(h, f.wpx, wx.data(), wx.size() * 8));
+            RTRY(stage_put(h, f.wpy, wy.data(), wy.size() * 8));
+            RTRY(stage_put(h, f.wpr, wr.data(), wr.size() * 8));
+            RTRY(stage_put(h, f.dq, dq.data(), dq.size() * 4));
+            RTRY(stage_put(h, f.dq_n, dqn.data(), dqn.size() * 4));
+            RTRY(stage_put(h, f.dest, dest.data(), dest.size() * 4));
+            RTRY(stage_put(h, f.last, last.data(), last.size() * 4));
         }
         d.ptraj = h->d_traj;
         d.traj_cap = h->traj_cap;
     }
     // robots (img_env.cpp:252-282)
     const int l_lo = W > 1 ? g_lo : 0, n_l = W > 1 ? Rw : h->RL;  // local robots of this world (a shard exists for W == 1 only)
-    std::vector<double> rob3((size_t)Rw * 5);
+    std::vector<double>& rob3 = h->tmp_d0;
+    rob3.resize((size_t)Rw * 5);
     std::vector<ResetRobot> rr(n_l);
     for (int i = 0; i < Rw; i++) {
         const double* p = b->robot_pose + 4 * i;
@@ -1157,55 +1275,84 @@ static int reset_one_world(imgenv* h, int k, const imgenv_reset_batch* b, const 
             q.world_target = tf_inverse(tf_from_pose(q.gx, q.gy, yaw));
         }
     }
-    if (!h->d_rob3) {
-        RTRY(dev_alloc(h, &h->d_rob3, (size_t)h->R * 5));
-        RTRY(dev_alloc(h, &h->d_ped3, (size_t)(P > 0 ? P : 1) * 3));
-        ResetRobot* q = nullptr;
-        RTRY(dev_alloc(h, &q, (size_t)h->RL));
-        h->d_rr = q;
-    }
-    double *d_rob3 = h->d_rob3, *d_ped3 = h->d_ped3;
-    ResetRobot* d_rr = (ResetRobot*)h->d_rr;
-    RTRY(stage_put(h, d_rob3 + (size_t)g_lo * 5, rob3.data(), rob3.size() * 8, st));
-    RTRY(stage_put(h, d_ped3 + (size_t)p_lo * 3, ped3.data(), ped3.size() * 8, st));
-    RTRY(stage_put(h, d_rr + l_lo, rr.data(), rr.size() * sizeof(ResetRobot), st));
-    set_active(h, W > 1 ? k : -1);
-    k_reset_robots<<<dim3((Rw + 255) / 256), dim3(256), 0, st>>>(d, d_rob3, d_rr, whole);
-    if (d.sharded) {
-        const uint32_t init[4] = {BBOX_INIT_MIN, BBOX_INIT_MIN, BBOX_INIT_MAX, BBOX_INIT_MAX};
-        RTRY(stage_put(h, d.bbox, init, sizeof(init), st));
-        k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, d_rob3);
-    }
-    if (Pw > 0) k_reset_peds<<<dim3((Pw + 255) / 256), dim3(256), 0, st>>>(d, d_ped3);
-    HIPCHK(hipGetLastError());
+    RTRY(stage_put(h, h->d_rob3 + (size_t)g_lo * 5, rob3.data(), rob3.size() * 8));
+    RTRY(stage_put(h, (ResetRobot*)h->d_rr + l_lo, rr.data(), rr.size() * sizeof(ResetRobot)));
     return 0;
 }
 
-static int reset_checks(imgenv* h, const imgenv_reset_batch* b) {
+static int reset_checks(imgenv* h, int n, const imgenv_reset_batch* b) {
     if (!h || !b) FAIL(IMGENV_EINVAL, "null argument");
-    if (b->struct_size != (int32_t)sizeof(imgenv_reset_batch)) FAIL(IMGENV_EINVAL, "reset batch ABI mismatch");
-    if (b->n_obstacles < 0 || (h->P > 0 && b->ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
+    for (int q = 0; q < n; q++) {
+        if (b[q].struct_size != (int32_t)sizeof(imgenv_reset_batch)) FAIL(IMGENV_EINVAL, "reset batch ABI mismatch");
+        if (b[q].n_obstacles < 0 || (h->P > 0 && b[q].ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
+    }
     if (h->obs_forked) FAIL(IMGENV_ESTATE, "reset between imgenv_step_begin and imgenv_step_end");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (int rc = check_device_flags(h)) {  // report what the abandoned episode raised, then start clean
         for (int q = 0; q < 8; q++) h->err_host[q] = 0;
         return rc;
     }
+    if (!h->d_rob3) {
+        RTRY(dev_alloc(h, &h->d_rob3, (size_t)h->R * 5));
+        RTRY(dev_alloc(h, &h->d_ped3, (size_t)(h->P > 0 ? h->P : 1) * 3));
+        ResetRobot* q = nullptr;
+        RTRY(dev_alloc(h, &q, (size_t)h->RL));
+        h->d_rr = q;
+        RTRY(dev_alloc(h, &h->d_act_list, (size_t)h->W));
+    }
     return 0;
 }
 
+// Device half of a reset, for every world (list == nullptr) or the n worlds listed: one upload launch, the obstacle
+// maps, the robot / pedestrian state, then view_agent + get_states (img_env.cpp:285-286) for those worlds' robots.
+static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int whole) {
+    DevWorld& d = h->d;
+    RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size()));
+    RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W));
+    if (list) RTRY(stage_put(h, h->d_act_list, list, sizeof(int) * n));
+    const size_t n_inst = h->oinst.size();
+    if (n_inst > h->cap_oinst) {
+        h->cap_oinst = n_inst * 2;
+        void* q = nullptr;
+        {
+            unsigned char* raw = nullptr;
+            RTRY(dev_alloc(h, &raw, h->cap_oinst * sizeof(ObstInst)));
+            q = raw;
+        }
+        h->d_oinst = q;
+    }
+    static_assert(sizeof(imgenv::ObstInstHost) == sizeof(ObstInst), "layout");
+    if (n_inst) RTRY(stage_put(h, h->d_oinst, h->oinst.data(), n_inst * sizeof(ObstInst)));
+    h->oinst.clear();
+    RTRY(stage_flush(h, st));
+    set_active(h, list ? h->d_act_list : nullptr, n);
+    {
+        const size_t n16 = ((size_t)h->Hg * h->Wg + 15) / 16;
+        const unsigned bx = (unsigned)std::min<size_t>((n16 + 255) / 256, 64);
+        k_restore_maps<<<dim3(bx, (unsigned)d.act_nw), dim3(256), 0, st>>>(d, h->d_static_map);
+    }
+    if (n_inst) {
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst);
+        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst);
+    }
+    k_reset_robots<<<dim3((d.act_ng + 255) / 256), dim3(256), 0, st>>>(d, h->d_rob3, (const ResetRobot*)h->d_rr, whole);
+    if (d.sharded) k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, h->d_rob3);
+    if (d.act_np > 0) k_reset_peds<<<dim3((d.act_np + 255) / 256), dim3(256), 0, st>>>(d, h->d_ped3);
+    HIPCHK(hipGetLastError());
+    h->launches = 2;
+    const int rc = launch_views(h, st, 1);
+    set_active(h, nullptr, 0);
+    if (rc) return rc;
+    return stage_end(h, st);
+}
+
 extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stream) {
-    if (int rc = reset_checks(h, b)) return rc;
+    if (int rc = reset_checks(h, 1, b)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const bool trace_ = getenv("IMGENV_TRACE_RESET") != nullptr;
-    std::chrono::steady_clock::time_point tp_[4];
-    tp_[0] = std::chrono::steady_clock::now();
     RTRY(stage_begin(h));
-    WorldObstacles wo;
-    build_obstacles(h, b, wo);  // one obstacle list, shared by every world
-    tp_[1] = std::chrono::steady_clock::now();
+    h->oinst.clear();
     for (int k = 0; k < h->W; k++) {
-        imgenv_reset_batch sub = *b;  // world k's robots and pedestrians (world-major numbering)
+        imgenv_reset_batch sub = *b;  // world k's robots and pedestrians (world-major numbering); one obstacle list for all
         sub.robot_pose = b->robot_pose + (size_t)4 * k * h->Rw;
         sub.robot_goal = b->robot_goal + (size_t)2 * k * h->Rw;
         if (h->P > 0) {
@@ -1215,53 +1362,51 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
             sub.ped_traj = b->ped_traj + (size_t)k * h->Pw * b->ped_traj_cap * 3;
             sub.ped_traj_v = b->ped_traj_v ? b->ped_traj_v + (size_t)k * h->Pw * b->ped_traj_cap * 2 : nullptr;
         }
-        h->rvos[k] = wo.rvo;
-        RTRY(reset_one_world(h, k, &sub, wo, st, 1));
+        RTRY(stage_world(h, k, &sub, st));
         h->world_epoch[k] = 0;
         h->world_ready[k] = 1;
     }
-    RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size(), st));
-    RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W, st));
-    tp_[2] = std::chrono::steady_clock::now();
+    if (h->d.sharded) {
+        const uint32_t init[4] = {BBOX_INIT_MIN, BBOX_INIT_MIN, BBOX_INIT_MAX, BBOX_INIT_MAX};
+        RTRY(stage_put(h, h->d.bbox, init, sizeof(init)));
+    }
     h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
-    h->launches = 2;
-    set_active(h, -1);
-    if (int rc = launch_views(h, st, 1)) return rc;  // view_agent + get_states (img_env.cpp:285-286)
-    RTRY(stage_end(h, st));
-    tp_[3] = std::chrono::steady_clock::now();
-    if (trace_) {
-        auto us = [&](int a_, int b_) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(tp_[b_] - tp_[a_]).count(); };
-        if (us(0, 3) > 2000)
-            fprintf(stderr, "[imgenv_reset] obstacles %ld us, worlds (host + copies) %ld, views + stage_end %ld\n", us(0, 1), us(1, 2), us(2, 3));
-    }  // no host wait: the copies above read the handle's pinned chunks
+    RTRY(reset_launch(h, nullptr, 0, st, 1));  // no host wait: the copies read the handle's pinned chunks
     h->has_reset = true;
     return IMGENV_OK;
 }
 
-extern "C" int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset_batch* b, void* stream) {
-    if (int rc = reset_checks(h, b)) return rc;
-    if (world < 0 || world >= h->W) FAIL(IMGENV_EINVAL, "world %d out of range (n_worlds %d)", world, h->W);
-    if (h->W == 1) return imgenv_reset(h, b, stream);
+extern "C" int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_reset_batch* batches, void* stream) {
+    if (n <= 0) return h ? IMGENV_OK : IMGENV_EINVAL;
+    if (!worlds) FAIL(IMGENV_EINVAL, "null argument");
+    if (int rc = reset_checks(h, n, batches)) return rc;
+    if (h->W == 1) {
+        if (n != 1 || worlds[0] != 0) FAIL(IMGENV_EINVAL, "world out of range (n_worlds 1)");
+        return imgenv_reset(h, batches, stream);
+    }
+    std::vector<char> seen(h->W, 0);
+    for (int q = 0; q < n; q++) {
+        if (worlds[q] < 0 || worlds[q] >= h->W) FAIL(IMGENV_EINVAL, "world %d out of range (n_worlds %d)", worlds[q], h->W);
+        if (seen[worlds[q]]) FAIL(IMGENV_EINVAL, "world %d listed twice", worlds[q]);
+        seen[worlds[q]] = 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     RTRY(stage_begin(h));
-    WorldObstacles wo;
-    build_obstacles(h, b, wo);
-    h->rvos[world] = wo.rvo;
-    RTRY(reset_one_world(h, world, b, wo, st, 0));
-    h->world_epoch[world] = h->elapsed;  // its TimeLimitWrapper starts over
-    h->world_ready[world] = 1;
-    RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size(), st));
-    RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W, st));
-    h->launches = 2;
-    set_active(h, world);
-    const int rc = launch_views(h, st, 1);
-    set_active(h, -1);
-    if (rc) return rc;
-    RTRY(stage_end(h, st));
+    h->oinst.clear();
+    for (int q = 0; q < n; q++) {
+        RTRY(stage_world(h, worlds[q], batches + q, st));
+        h->world_epoch[worlds[q]] = h->elapsed;  // its TimeLimitWrapper starts over
+        h->world_ready[worlds[q]] = 1;
+    }
+    RTRY(reset_launch(h, worlds, n, st, 0));
     bool all = true;
     for (char r : h->world_ready) all = all && r;
     h->has_reset = all;
     return IMGENV_OK;
+}
+
+extern "C" int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset_batch* b, void* stream) {
+    return imgenv_reset_worlds(h, 1, &world, b, stream);
 }
 
 // ---------------------------------------------------------------------------------------- step

@@ -80,6 +80,12 @@ __device__ __forceinline__ void bbox_accumulate(const DevWorld& w, bool valid, d
 // worlds of a multi-world handle (world-major numbering); a single world never divides
 __device__ __forceinline__ int world_of_robot(const DevWorld& w, int i) { return w.W > 1 ? i / w.Rw : 0; }
 __device__ __forceinline__ int world_of_ped(const DevWorld& w, int j) { return w.W > 1 ? j / w.Pw : 0; }
+// the t-th robot (per_world = Rw) or pedestrian (Pw) of a launch: everything, or the members of the listed worlds
+__device__ __forceinline__ int act_member(const DevWorld& w, int per_world, int t) {
+    if (!w.act_list) return t;
+    const int q = t / per_world;
+    return w.act_list[q] * per_world + (t - q * per_world);
+}
 
 __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls) {
     return w.rc[cls];
@@ -123,7 +129,7 @@ __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls)
 // then Agent::computeNeighbors + computeNewVelocity for pedestrian j = blockIdx.x.
 __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
     __shared__ OrcaScratch s;
-    const int j = w.act_p0 + blockIdx.x;
+    const int j = act_member(w, w.Pw, blockIdx.x);
     const int lane = lane_id();
     const int wld = world_of_ped(w, j);
     const int p_lo = w.W > 1 ? wld * w.Pw : 0, n_p = w.W > 1 ? w.Pw : w.P;  // the pedestrians of this one's world
@@ -760,17 +766,22 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     const int b = blockIdx.x;
     WAVE_T0();
     const Region g = grid_region(w);
-    if (w.act_g0 + b < w.act_g1) raster_robot<POW2>(w, w.act_g0 + b, (uint32_t*)smem, zero_vel != 0, g);
-    if (w.act_p0 + b < w.act_p1) raster_ped<POW2>(w, w.act_p0 + b, g);
+    if (b < w.act_ng) raster_robot<POW2>(w, act_member(w, w.Rw, b), (uint32_t*)smem, zero_vel != 0, g);
+    if (b < w.act_np) raster_ped<POW2>(w, act_member(w, w.Pw, b), g);
     if (b < w.RL) WAVE_DONE(2);
 }
 
 // class layer: one byte per cell that a robot's view kernel can decode without touching the three
 // raster layers; also re-arms the raster layers for the next step (saves two memsets per step).
 __global__ void k_compose(DevWorld w) {
-    // cells [act_c0, act_c1) of the stacked layers (every world, or the one being reset)
-    const size_t G = w.act_c1;
-    const size_t c0 = w.act_c0 + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    // every cell of the stacked layers, or the cells of the listed worlds (a fixed number of blocks per world)
+    size_t G = w.act_cells, c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (w.act_list) {
+        const unsigned per_world = (w.Gs / 4 + blockDim.x - 1) / blockDim.x, q = blockIdx.x / per_world;
+        const size_t base = (size_t)w.act_list[q] * w.Gs;
+        c0 = base + ((size_t)(blockIdx.x - q * per_world) * blockDim.x + threadIdx.x) * 4;
+        G = base + w.Gs;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_obs tallies this step's dones
     if (c0 >= G) return;
     if (w.sharded) {  // only the region this rank's rasters were clipped to (everything else is clean and unread)
@@ -898,7 +909,7 @@ template <bool POW2, bool A4>
 __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     // A4: Wv % 4 == 0 (a lane's 4 consecutive cells share their row and nothing runs over the end of the view)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int l = w.act_l0 + blockIdx.x;
+    const int l = act_member(w, w.Rw, blockIdx.x);
     const int lane = lane_id();
     if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: every per-robot output keeps its last value (counted in k_integrate)
     const int i = w.r0 + l;
@@ -1333,7 +1344,7 @@ __device__ __forceinline__ void sort_pairs_in_registers(double (&key)[E], uint32
 template <int E>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8 : 4, 8))) void k_obs(DevWorld w, int PP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int l = w.act_l0 + blockIdx.x, lane = lane_id();
+    const int l = act_member(w, w.Rw, blockIdx.x), lane = lane_id();
     const int i = w.r0 + l;
     // the pedestrians of this robot's world: indices below are relative to p_lo
     const int P = w.W > 1 ? w.Pw : w.P, p_lo = w.W > 1 ? world_of_robot(w, i) * w.Pw : 0;
@@ -1549,10 +1560,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
 #define SIDE_PED_TILE 1024
 __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
     __shared__ float2 ped_xy[SIDE_PED_TILE];
-    const int i = w.act_g0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < w.act_g1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = t < w.act_ng;
+    const int i = act_member(w, w.Rw, valid ? t : 0);
     if (rvo_agents) {
-        const double* r = w.rec + (size_t)(valid ? i : w.act_g0) * IMGENV_RECORD_DOUBLES;
+        const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
         const int a = w.P + i;
         const f2 me = F2((float)r[0], (float)r[1]);
         if (valid) {
@@ -1563,25 +1575,27 @@ __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, i
         }
         // neighborDist is 0.5 m (rvoscene.h:57): tell the few pedestrians this robot can matter to, so that the solve does
         // not scan every robot of the world for every pedestrian.  The test is the solve's own float expression with a
-        // slightly larger bound; the solve re-tests exactly.  Pedestrian positions go through LDS, a tile at a time.
-        // With several worlds a block may straddle two of them (Rw need not divide 256): every thread walks the pedestrian
-        // range of the block's worlds and tests only its own world's.
-        const int first = w.act_g0 + blockIdx.x * blockDim.x, last = min(first + (int)blockDim.x, w.act_g1) - 1;
-        const int p_begin = w.W > 1 ? world_of_robot(w, first) * w.Pw : 0;
-        const int p_end = w.W > 1 ? (world_of_robot(w, max(last, first)) + 1) * w.Pw : w.P;
-        const int my_lo = w.W > 1 ? world_of_robot(w, valid ? i : first) * w.Pw : 0, my_hi = w.W > 1 ? my_lo + w.Pw : w.P;
-        for (int j0 = p_begin; j0 < p_end; j0 += SIDE_PED_TILE) {
-            const int nt = min(SIDE_PED_TILE, p_end - j0);
-            __syncthreads();
-            for (int q = threadIdx.x; q < nt; q += blockDim.x) ped_xy[q] = make_float2(w.apx[j0 + q], w.apy[j0 + q]);
-            __syncthreads();
-            if (valid) {
-                const int q_lo = max(my_lo - j0, 0), q_hi = min(my_hi - j0, nt);
-                for (int q = q_lo; q < q_hi; q++) {
-                    const float2 pp = ped_xy[q];
-                    if (abs_sq(F2(pp.x, pp.y) - me) < 0.2500001f) {
-                        const int pos = atomicAdd(&w.near_n[j0 + q], 1);
-                        if (pos < ORCA_NEAR_CAP) w.near_list[(size_t)(j0 + q) * ORCA_NEAR_CAP + pos] = a;
+        // slightly larger bound; the solve re-tests exactly.
+        if (w.W > 1) {  // several small worlds: every robot walks its own world's pedestrians
+            const int p_lo = world_of_robot(w, i) * w.Pw;
+            for (int j = p_lo; valid && j < p_lo + w.Pw; j++)
+                if (abs_sq(F2(w.apx[j], w.apy[j]) - me) < 0.2500001f) {
+                    const int pos = atomicAdd(&w.near_n[j], 1);
+                    if (pos < ORCA_NEAR_CAP) w.near_list[(size_t)j * ORCA_NEAR_CAP + pos] = a;
+                }
+        } else {  // one big world: pedestrian positions go through LDS, a tile at a time
+            for (int j0 = 0; j0 < w.P; j0 += SIDE_PED_TILE) {
+                const int nt = min(SIDE_PED_TILE, w.P - j0);
+                __syncthreads();
+                for (int q = threadIdx.x; q < nt; q += blockDim.x) ped_xy[q] = make_float2(w.apx[j0 + q], w.apy[j0 + q]);
+                __syncthreads();
+                if (valid) {
+                    for (int q = 0; q < nt; q++) {
+                        const float2 pp = ped_xy[q];
+                        if (abs_sq(F2(pp.x, pp.y) - me) < 0.2500001f) {
+                            const int pos = atomicAdd(&w.near_n[j0 + q], 1);
+                            if (pos < ORCA_NEAR_CAP) w.near_list[(size_t)(j0 + q) * ORCA_NEAR_CAP + pos] = a;
+                        }
                     }
                 }
             }
@@ -1594,8 +1608,9 @@ __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, i
 // Per-robot scalars, one thread per robot: Agent::get_state (agent.cpp:156-184), the _get_states distances,
 // ImageEnv.step and the wrapper stack (reward / done).  Runs after k_view (collision code) and k_obs (ped distance).
 __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
-    const int l = w.act_l0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = l < w.act_l1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = t < w.act_nl;
+    const int l = act_member(w, w.Rw, valid ? t : 0);
     int done = 0;
     // TimeLimitWrapper counts per world: steps since that world's last reset
     if (valid) done = tail_robot(w, l, is_reset, elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], do_state);

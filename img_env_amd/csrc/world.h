@@ -64,13 +64,14 @@ struct DevWorld {
     int R, RL, r0, P, NA;  // world robots, local robots, first local robot, peds, RVO agents
     // Independent worlds in one handle (the reference's env_num idiom): W worlds of Rw robots and Pw pedestrians each, world-major
     // robot / pedestrian numbering, one copy of every grid layer per world, Gs cells apart (Gs = Hg Wg rounded up to 16 when W > 1).
-    // A launch covers everything, or the robots / pedestrians / rows of one world at its reset (act_* below).
     int W, Rw, Pw;
-    int act_l0, act_l1;  // local robots of this launch
-    int act_g0, act_g1;  // world-wide robot indices of this launch (rasters, RVO records)
-    int act_p0, act_p1;  // pedestrians of this launch
+    // A launch covers everything (act_list == nullptr), or the robots / pedestrians / cells of the worlds listed in
+    // act_list (a reset of some worlds while the others carry on).
+    const int* act_list;  // [act_nw] worlds of this launch
+    int act_nw;
+    int act_nl, act_ng, act_np;  // local robots, world-wide robots (rasters, RVO records) and pedestrians of this launch
     uint32_t Gs;
-    size_t act_c0, act_c1;  // grid cells of this launch (k_compose)
+    size_t act_cells;  // grid cells of an everything-launch (k_compose)
     const int* world_epoch;                              // [W] global step count at the world's last reset
     const int *obst_base, *node_base, *n_obst_w, *oroot_w;  // [W] slices of obst / onodes per world (W > 1)
     int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;

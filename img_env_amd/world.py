@@ -83,12 +83,27 @@ class World:
         if isinstance(layout, (list, tuple)):
             if len(layout) != self.n_worlds:
                 raise ValueError("expected %d layouts, one per world" % self.n_worlds)
-            for k, lay in enumerate(layout):
-                self.reset_world(k, lay)
-            return self.out
+            return self.reset_worlds(list(range(self.n_worlds)), layout)
         b, keep = _cabi.make_reset_batch(layout if isinstance(layout, dict) else layout.as_batch(), self.n_robots,
                                          self.n_peds)
         self._check(self.lib.imgenv_reset(self.h, C.byref(b), self._stream()), "imgenv_reset")
+        return self.out
+
+    def prepare_reset(self, layout):
+        """The C-ABI reset batch of one world's layout, built once and reusable: ``(batch, keepalive)`` for ``reset_worlds``."""
+        return _cabi.make_reset_batch(layout if isinstance(layout, dict) else layout.as_batch(),
+                                      self.n_robots // self.n_worlds, self.n_peds // self.n_worlds)
+
+    def reset_worlds(self, worlds, layouts):
+        """Reset several worlds of a multi-world handle in one call (one set of launches): ``layouts[q]`` -- a layout or
+        what ``prepare_reset`` returned for it -- goes to world ``worlds[q]``."""
+        n = len(worlds)
+        if n == 0:
+            return self.out
+        prepared = [lay if isinstance(lay, tuple) else self.prepare_reset(lay) for lay in layouts]
+        arr = (_cabi.ResetBatch * n)(*[b for b, _ in prepared])
+        ids = (C.c_int32 * n)(*[int(k) for k in worlds])
+        self._check(self.lib.imgenv_reset_worlds(self.h, n, ids, arr, self._stream()), "imgenv_reset_worlds")
         return self.out
 
     def reset_world(self, world, layout):

@@ -258,6 +258,10 @@ int imgenv_outputs(imgenv_t* h, imgenv_out* out);
  * world's robots (n_robots / n_worlds), pedestrians and obstacles only.  imgenv_reset() on such a handle resets every
  * world from a batch of all robots / pedestrians (world-major) with one obstacle list shared by all worlds. */
 int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset_batch* batch, void* stream);
+/* The same for n distinct worlds at once (batches[q] belongs to worlds[q]): one upload launch and one set of reset / view
+ * launches however many worlds ended their episode on this step -- NeverStopWrapper (base.py:198-211) for a whole batch
+ * of envs. */
+int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_reset_batch* batches, void* stream);
 
 /* number of kernels launched by the last step (bench / profiling aid) */
 int imgenv_step_launches(imgenv_t* h);
