@@ -61,7 +61,13 @@ struct imgenv {
     double *d_rob3 = nullptr, *d_ped3 = nullptr;  // reset staging (persistent: no pool traffic per reset)
     // pinned host staging of imgenv_reset: copies are truly asynchronous and reset never waits for the stream
     struct Chunk { unsigned char* p; size_t cap, used; };
-    std::vector<Chunk> stage;
+    // STAGE_GENS generations of chunks, used round-robin: a reset only ever waits for the reset STAGE_GENS calls back (the
+    // host may run several steps ahead of the device; waiting for the previous reset would drain that queue every time)
+    static constexpr int STAGE_GENS = 4;
+    std::vector<Chunk> stage_gen[STAGE_GENS];
+    hipEvent_t ev_gen[STAGE_GENS] = {nullptr, nullptr, nullptr, nullptr};
+    bool gen_pending[STAGE_GENS] = {false, false, false, false};
+    int gen = 0;
     struct StageSegHost { void* dst; const void* src; size_t bytes; };
     std::vector<StageSegHost> segs;  // copies queued for the next stage_flush
     size_t seg_max = 0;
@@ -73,10 +79,11 @@ struct imgenv {
     void* d_oinst = nullptr;
     size_t cap_oinst = 0;
     int* d_act_list = nullptr;
+    bool sparse = false;     // sparse compose (tile lists) instead of the dense pass over every cell
+    uint32_t tile_seq = 1;
+    size_t n_tiles = 0;
     std::vector<double> tmp_d0, tmp_d1;
     std::vector<int> tmp_i0;
-    hipEvent_t ev_stage = nullptr;
-    bool stage_pending = false;
     void* d_rr = nullptr;
     int* d_traj_len = nullptr;
     int traj_cap = 0;
@@ -330,8 +337,10 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamDestroy(h->side2);
     }
     if (h->err_host) (void)hipHostFree((void*)h->err_host);
-    for (auto& c : h->stage) (void)hipHostFree(c.p);
-    if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
+    for (int g = 0; g < imgenv::STAGE_GENS; g++) {
+        for (auto& c : h->stage_gen[g]) (void)hipHostFree(c.p);
+        if (h->ev_gen[g]) (void)hipEventDestroy(h->ev_gen[g]);
+    }
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -615,6 +624,43 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_alloc(h, &d.fp_n, RL, 0xFF));  // -1 until the first raster
         TRY(dev_alloc(h, &d.fp_pose, (size_t)RL * 3));
     }
+    {   // dense or sparse compose?  Dense touches every cell of every world each step (14 bytes a cell); sparse only the
+        // 8 x 8 tiles under a robot or a pedestrian, twice (now and to clean up one step later).
+        const size_t cells = (size_t)Hg * Wg * W;
+        h->sparse = !d.sharded && cells > (size_t)256 * (R + P);
+        if (cfg->flags & IMGENV_FLAG_COMPOSE_DENSE) h->sparse = false;
+        if ((cfg->flags & IMGENV_FLAG_COMPOSE_SPARSE) && !d.sharded) h->sparse = true;
+        if (h->sparse) {
+            d.tiles_x = (Wg + 7) / 8;
+            d.tiles_pw = d.tiles_x * ((Hg + 7) / 8);
+            h->n_tiles = (size_t)d.tiles_pw * W;
+            size_t per_robot = 1, per_ped = 1;
+            for (const RobotClassHost& k : h->rcls) {
+                const size_t t = (size_t)(2 * k.box_rad + 1 + 6) / 8 + 1;
+                per_robot = std::max(per_robot, t * t);
+            }
+            for (const PedClassHost& k : h->pcls) {
+                double ext = 0;
+                for (const Pts* q : {&k.bbox, &k.left, &k.right})
+                    for (int e = 0; e < q->n(); e++) ext = std::max(ext, std::max(fabs(q->x[e]), fabs(q->y[e])));
+                const size_t side = 2 * (size_t)ceil((ext + 0.35) / g.res) + 3, t = (side + 6) / 8 + 1;
+                per_ped = std::max(per_ped, t * t);
+            }
+            // per list: a step's touches plus those of a reset right behind it (both land in the same lists), spread over
+            // TILE_LISTS lists by workgroup index, with room for an uneven spread
+            const size_t all = 2 * ((size_t)R * per_robot + (size_t)P * per_ped);
+            const size_t cap = std::min(h->n_tiles, std::max<size_t>(4 * ((all + TILE_LISTS - 1) / TILE_LISTS), 8 * std::max(per_robot, per_ped)));
+            if (cap > 0x7FFFFFFFu || h->n_tiles > 0xFFFFFFFFu) {
+                imgenv_destroy(h);
+                FAIL(IMGENV_EINVAL, "too many map tiles for the sparse compose");
+            }
+            d.tile_cap = (int)cap;
+            TRY(dev_alloc(h, &d.tile_mark, h->n_tiles));
+            TRY(dev_alloc(h, &d.tile_list, 2 * TILE_LISTS * cap));
+            TRY(dev_alloc(h, &d.tile_count, 2 * TILE_LISTS));
+            d.tile_seq = h->tile_seq;
+        }
+    }
     TRY(dev_alloc(h, &d.ppx, P)); TRY(dev_alloc(h, &d.ppy, P)); TRY(dev_alloc(h, &d.pyaw, P));
     TRY(dev_alloc(h, &d.plx, P)); TRY(dev_alloc(h, &d.ply, P)); TRY(dev_alloc(h, &d.pvx, P)); TRY(dev_alloc(h, &d.pvy, P));
     TRY(dev_alloc(h, &d.prem, P)); TRY(dev_alloc(h, &d.llx, P)); TRY(dev_alloc(h, &d.lly, P));
@@ -838,6 +884,7 @@ static int check_device_flags(imgenv* h) {
     if (!e) return 0;
     if (e[0]) FAIL(IMGENV_EDEVICE, "ORCA: a pedestrian sees more obstacle segments than the neighbour scratch holds");
     if (e[1]) FAIL(IMGENV_EDEVICE, "ORCA: obstacle BSP walk overflowed its stack");
+    if (e[2]) FAIL(IMGENV_EDEVICE, "sparse compose: more touched map tiles than the list holds");
     if (e[4])
         FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth) -- more than "
                              "8 agents piled up outside the tree's 10 m x 10 m root square, where the reference recurses forever "
@@ -910,7 +957,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
     else
         TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
-    TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
+    if (h->sparse && !is_reset)
+        TIMED(h, IMGENV_K_COMPOSE, st, (k_compose_tiles<<<dim3(2, 2 * TILE_LISTS), dim3(256), 0, st>>>(d)));
+    else
+        TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     {
         const dim3 gv(n_l), bv(WAVE);
         const int variant = (h->pow2 ? 2 : 0) | (h->geom.Wv % 4 == 0 ? 1 : 0);
@@ -949,19 +999,22 @@ __global__ __launch_bounds__(256) void k_stage_copy(const StageSeg* __restrict__
     }
 }
 static int stage_begin(imgenv* h) {
-    if (!h->ev_stage) HIPCHK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
-    if (h->stage_pending) {  // the previous reset's copies (long finished in practice) still own the chunks
-        HIPCHK(hipEventSynchronize(h->ev_stage));
-        h->stage_pending = false;
+    h->gen = (h->gen + 1) % imgenv::STAGE_GENS;
+    const int g = h->gen;
+    if (!h->ev_gen[g]) HIPCHK(hipEventCreateWithFlags(&h->ev_gen[g], hipEventDisableTiming));
+    if (h->gen_pending[g]) {  // the copies of the reset STAGE_GENS calls ago (long finished in practice) still own these chunks
+        HIPCHK(hipEventSynchronize(h->ev_gen[g]));
+        h->gen_pending[g] = false;
     }
-    for (auto& c : h->stage) c.used = 0;
+    for (auto& c : h->stage_gen[g]) c.used = 0;
     h->segs.clear();
     h->seg_max = 0;
     return 0;
 }
 static int stage_room(imgenv* h, size_t bytes, unsigned char** out) {
     imgenv::Chunk* use = nullptr;
-    for (auto& c : h->stage)
+    std::vector<imgenv::Chunk>& chunks = h->stage_gen[h->gen];
+    for (auto& c : chunks)
         if (c.cap - c.used >= bytes) {
             use = &c;
             break;
@@ -969,8 +1022,8 @@ static int stage_room(imgenv* h, size_t bytes, unsigned char** out) {
     if (!use) {
         imgenv::Chunk c{nullptr, std::max(bytes, (size_t)1 << 20), 0};
         HIPCHK(hipHostMalloc((void**)&c.p, c.cap, hipHostMallocDefault));
-        h->stage.push_back(c);
-        use = &h->stage.back();
+        chunks.push_back(c);
+        use = &chunks.back();
     }
     *out = use->p + use->used;
     use->used += (bytes + 255) & ~(size_t)255;
@@ -1004,8 +1057,8 @@ static int stage_flush(imgenv* h, hipStream_t st) {
     return 0;
 }
 static int stage_end(imgenv* h, hipStream_t st) {
-    HIPCHK(hipEventRecord(h->ev_stage, st));
-    h->stage_pending = true;
+    HIPCHK(hipEventRecord(h->ev_gen[h->gen], st));
+    h->gen_pending[h->gen] = true;
     return 0;
 }
 
@@ -1445,6 +1498,13 @@ extern "C" int imgenv_step_end(imgenv_t* h, void* stream) {
     if (!h) FAIL(IMGENV_EINVAL, "null argument");
     if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
     h->elapsed += 1;  // TimeLimitWrapper._elapsed_steps (base.py:224)
+    if (h->sparse) {  // a new list of touched tiles
+        if (++h->tile_seq == 0) {  // (wrapped after 2^32 steps: forget every mark)
+            HIPCHK(hipMemsetAsync(h->d.tile_mark, 0, sizeof(uint32_t) * h->n_tiles, (hipStream_t)stream));
+            h->tile_seq = 1;
+        }
+        h->d.tile_seq = h->tile_seq;
+    }
     return launch_views(h, (hipStream_t)stream, 0);
 }
 

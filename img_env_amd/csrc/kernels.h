@@ -80,6 +80,20 @@ __device__ __forceinline__ void bbox_accumulate(const DevWorld& w, bool valid, d
 // worlds of a multi-world handle (world-major numbering); a single world never divides
 __device__ __forceinline__ int world_of_robot(const DevWorld& w, int i) { return w.W > 1 ? i / w.Rw : 0; }
 __device__ __forceinline__ int world_of_ped(const DevWorld& w, int j) { return w.W > 1 ? j / w.Pw : 0; }
+#define TILE_LISTS 256
+// sparse compose: cell (m, n) of `world` holds raster content in this step
+__device__ __forceinline__ void mark_tile(const DevWorld& w, int world, int m, int n) {
+    if (!w.tile_mark) return;
+    const uint32_t t = (uint32_t)world * (uint32_t)w.tiles_pw + (uint32_t)(m >> 3) * (uint32_t)w.tiles_x + (uint32_t)(n >> 3);
+    if (w.tile_mark[t] == w.tile_seq) return;  // (a stale read only costs the atomic below)
+    if (atomicMax(&w.tile_mark[t], w.tile_seq) != w.tile_seq) {  // the first toucher lists the tile
+        // TILE_LISTS lists per step, picked by workgroup: one shared counter would serialise ~4 appends per robot
+        const uint32_t sub = (w.tile_seq & 1u) * TILE_LISTS + (blockIdx.x & (TILE_LISTS - 1));
+        const int pos = atomicAdd(&w.tile_count[sub], 1);
+        if (pos < w.tile_cap) w.tile_list[(size_t)sub * w.tile_cap + pos] = t;
+        else w.err[2] = 1;
+    }
+}
 // the t-th robot (per_world = Rw) or pedestrian (Pw) of a launch: everything, or the members of the listed worlds
 __device__ __forceinline__ int act_member(const DevWorld& w, int per_world, int t) {
     if (!w.act_list) return t;
@@ -597,7 +611,8 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 template <bool POW2>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Region& g) {
     const PedClassDev k = w.pc[w.ped_cls[j]];
-    const size_t cell0 = (size_t)world_of_ped(w, j) * w.Gs;  // this world's copy of the layers
+    const int world = world_of_ped(w, j);
+    const size_t cell0 = (size_t)world * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id();
     const double res = w.res, inv = w.inv_res;
@@ -609,7 +624,10 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
             w2m_pair<POW2>(wx, wy, res, inv, m, n);
             if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
                 const size_t c = cell0 + (size_t)m * w.Wg + n;
-                if (w.obs_map[c] > 2) w.ped_layer[c] = 1;
+                if (w.obs_map[c] > 2) {
+                    w.ped_layer[c] = 1;
+                    mark_tile(w, world, m, n);
+                }
             }
         }
     } else if (k.shape == IMGENV_SHAPE_LEG) {
@@ -629,7 +647,10 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
                 w2m_pair<POW2>(wx, wy, res, inv, m, n);
                 if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
                     const size_t c = cell0 + (size_t)m * w.Wg + n;
-                    if (leg == 1 || w.obs_map[c] != 0) w.ped_layer[c] = 1;
+                    if (leg == 1 || w.obs_map[c] != 0) {
+                        w.ped_layer[c] = 1;
+                        mark_tile(w, world, m, n);
+                    }
                 }
             }
         }
@@ -659,7 +680,8 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
     const bool use_box = ncell <= w.box_cells;
     const int l = i - w.r0;
     const bool local = l >= 0 && l < w.RL;
-    const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;  // this world's copy of the layers
+    const int world = world_of_robot(w, i);
+    const uint32_t cell0 = (uint32_t)world * w.Gs;  // this world's copy of the layers
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
     // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
     if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
@@ -683,6 +705,10 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
                 const uint32_t c = list[e].x;
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
+                if (w.tile_mark) {
+                    const uint32_t rel = c - cell0, m = rel / (uint32_t)w.Wg;
+                    mark_tile(w, world, (int)m, (int)(rel - m * (uint32_t)w.Wg));
+                }
             }
             return;
         }
@@ -717,6 +743,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
+                    mark_tile(w, world, m, n);
                     stray = true;
                 }
             }
@@ -743,6 +770,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
 #endif
+                mark_tile(w, world, m, n);
             }
             if (local) {
                 const unsigned long long mask = __ballot(last != 0);
@@ -769,6 +797,55 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     if (b < w.act_ng) raster_robot<POW2>(w, act_member(w, w.Rw, b), (uint32_t*)smem, zero_vel != 0, g);
     if (b < w.act_np) raster_ped<POW2>(w, act_member(w, w.Pw, b), g);
     if (b < w.RL) WAVE_DONE(2);
+}
+
+// `cell` of the cells [c0, min(c0 + 4, G)) from the map and the raster layers; re-arms the raster layers
+__device__ __forceinline__ void compose_cells_scalar(const DevWorld& w, size_t c0, size_t G) {
+    for (size_t c = c0; c < G; c++) {
+        const uint32_t base = w.ped_layer[c] ? 1u : w.obs_map[c];
+        uint32_t b = base <= 2 ? base : (base < 250 ? CLS_LOW : CLS_HIGH);
+        uint32_t own = 0;
+        if (b >= CLS_LOW && w.own_hi[c] != 0) {
+            b |= CLS_ROBOT;
+            own = (w.own_lo[c] == w.own_hi[c]) ? w.own_lo[c] - 1 : OWNER_MULTI;
+        }
+        w.cell[c] = b | (own << 8);
+        w.ped_layer[c] = 0;
+        w.own_lo[c] = 0xFFFFFFFFu;
+        w.own_hi[c] = 0;
+    }
+}
+__device__ __forceinline__ void compose_cells(const DevWorld& w, size_t c0, size_t G) {
+    if (c0 + 4 <= G) {
+        const uint32_t obs = *(const uint32_t*)(w.obs_map + c0);
+        const uint32_t ped = *(const uint32_t*)(w.ped_layer + c0);
+        const uint4 lo = *(const uint4*)(w.own_lo + c0);
+        const uint4 hi = *(const uint4*)(w.own_hi + c0);
+        const uint32_t los[4] = {lo.x, lo.y, lo.z, lo.w}, his[4] = {hi.x, hi.y, hi.z, hi.w};
+        uint32_t out = 0;
+        uint32_t own[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t o = (obs >> (8 * q)) & 0xff, p = (ped >> (8 * q)) & 0xff;
+            const uint32_t base = p ? 1u : o;
+            uint32_t b = base <= 2 ? base : (base < 250 ? CLS_LOW : CLS_HIGH);
+            own[q] = 0;
+            if (b >= CLS_LOW && his[q] != 0) {
+                b |= CLS_ROBOT;
+                own[q] = (los[q] == his[q]) ? los[q] - 1 : OWNER_MULTI;
+            }
+            out |= b << (8 * q);
+        }
+        *(uint4*)(w.cell + c0) = make_uint4(((out >> 0) & 0xFFu) | (own[0] << 8), ((out >> 8) & 0xFFu) | (own[1] << 8),
+                                             ((out >> 16) & 0xFFu) | (own[2] << 8), ((out >> 24) & 0xFFu) | (own[3] << 8));
+        if (ped) *(uint32_t*)(w.ped_layer + c0) = 0;
+        if (his[0] | his[1] | his[2] | his[3]) {
+            *(uint4*)(w.own_lo + c0) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            *(uint4*)(w.own_hi + c0) = make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        compose_cells_scalar(w, c0, G);
+    }
 }
 
 // class layer: one byte per cell that a robot's view kernel can decode without touching the three
@@ -798,47 +875,30 @@ __global__ void k_compose(DevWorld w) {
         }
         if (!any) return;
     }
-    if (c0 + 4 <= G) {
-        const uint32_t obs = *(const uint32_t*)(w.obs_map + c0);
-        const uint32_t ped = *(const uint32_t*)(w.ped_layer + c0);
-        const uint4 lo = *(const uint4*)(w.own_lo + c0);
-        const uint4 hi = *(const uint4*)(w.own_hi + c0);
-        const uint32_t los[4] = {lo.x, lo.y, lo.z, lo.w}, his[4] = {hi.x, hi.y, hi.z, hi.w};
-        uint32_t out = 0;
-        uint32_t own[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t o = (obs >> (8 * q)) & 0xff, p = (ped >> (8 * q)) & 0xff;
-            const uint32_t base = p ? 1u : o;
-            uint32_t b = base <= 2 ? base : (base < 250 ? CLS_LOW : CLS_HIGH);
-            own[q] = 0;
-            if (b >= CLS_LOW && his[q] != 0) {
-                b |= CLS_ROBOT;
-                own[q] = (los[q] == his[q]) ? los[q] - 1 : OWNER_MULTI;
-            }
-            out |= b << (8 * q);
-        }
-        *(uint4*)(w.cell + c0) = make_uint4(((out >> 0) & 0xFFu) | (own[0] << 8), ((out >> 8) & 0xFFu) | (own[1] << 8),
-                                             ((out >> 16) & 0xFFu) | (own[2] << 8), ((out >> 24) & 0xFFu) | (own[3] << 8));
-        if (ped) *(uint32_t*)(w.ped_layer + c0) = 0;
-        if (his[0] | his[1] | his[2] | his[3]) {
-            *(uint4*)(w.own_lo + c0) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            *(uint4*)(w.own_hi + c0) = make_uint4(0, 0, 0, 0);
-        }
-    } else {
-        for (size_t c = c0; c < G; c++) {
-            const uint32_t base = w.ped_layer[c] ? 1u : w.obs_map[c];
-            uint32_t b = base <= 2 ? base : (base < 250 ? CLS_LOW : CLS_HIGH);
-            uint32_t own = 0;
-            if (b >= CLS_LOW && w.own_hi[c] != 0) {
-                b |= CLS_ROBOT;
-                own = (w.own_lo[c] == w.own_hi[c]) ? w.own_lo[c] - 1 : OWNER_MULTI;
-            }
-            w.cell[c] = b | (own << 8);
-            w.ped_layer[c] = 0;
-            w.own_lo[c] = 0xFFFFFFFFu;
-            w.own_hi[c] = 0;
-        }
+    compose_cells(w, c0, G);
+}
+
+// Sparse compose: the tiles listed in this step (raster content now) and in the previous one (raster content then: back
+// to the plain map class unless touched again).  16 threads per tile, 4 cells of a row each; a fixed grid strides over
+// the lists, whose lengths only the device knows.
+__global__ __launch_bounds__(256) void k_compose_tiles(DevWorld w) {
+    // blockIdx.y: one of the 2 * TILE_LISTS lists (this step's, then the previous step's)
+    const uint32_t cur = w.tile_seq & 1u, sub = blockIdx.y & (TILE_LISTS - 1);
+    const bool prev = blockIdx.y >= TILE_LISTS;
+    const uint32_t which = (prev ? cur ^ 1u : cur) * TILE_LISTS + sub;
+    const int n_list = min(w.tile_count[which], w.tile_cap);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_obs tallies this step's dones
+    const int part = threadIdx.x & 15;
+    for (int slot = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4); slot < n_list; slot += (int)((gridDim.x * blockDim.x) >> 4)) {
+        const uint32_t t = w.tile_list[(size_t)which * w.tile_cap + slot];
+        if (prev && w.tile_mark[t] == w.tile_seq) continue;  // touched again: composed as one of this step's tiles
+        const uint32_t world = t / (uint32_t)w.tiles_pw, rel = t - world * (uint32_t)w.tiles_pw;
+        const int ty = (int)(rel / (uint32_t)w.tiles_x), tx = (int)(rel - (uint32_t)ty * (uint32_t)w.tiles_x);
+        const int m = ty * 8 + (part >> 1), n = tx * 8 + (part & 1) * 4;
+        if (m >= w.Hg || n >= w.Wg) continue;
+        const size_t c0 = (size_t)world * w.Gs + (size_t)m * w.Wg + n;
+        if ((w.Wg & 3) == 0) compose_cells(w, c0, c0 + 4);
+        else compose_cells_scalar(w, c0, c0 + (size_t)min(4, w.Wg - n));
     }
 }
 
@@ -1616,6 +1676,8 @@ __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
     if (valid) done = tail_robot(w, l, is_reset, elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], do_state);
     if (w.sharded && blockIdx.x == 0 && threadIdx.x < 4)  // the rasters of this step are done with the box: re-arm it
         w.bbox[threadIdx.x] = threadIdx.x < 2 ? BBOX_INIT_MIN : BBOX_INIT_MAX;
+    if (w.tile_mark && blockIdx.x == 0)  // consumed: the next step's lists
+        for (int q = threadIdx.x; q < TILE_LISTS; q += blockDim.x) w.tile_count[((w.tile_seq & 1u) ^ 1u) * TILE_LISTS + q] = 0;
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
 }

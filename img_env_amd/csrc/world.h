@@ -73,6 +73,14 @@ struct DevWorld {
     uint32_t Gs;
     size_t act_cells;  // grid cells of an everything-launch (k_compose)
     const int* world_epoch;                              // [W] global step count at the world's last reset
+    // Sparse compose (worlds much larger than what their robots and pedestrians cover): the class layer `cell` persists and
+    // only 8 x 8-cell tiles a raster touched in this step or the previous one are recomposed.  tile_mark holds the step
+    // sequence number of a tile's last touch; the first toucher appends the tile to this step's list.
+    uint32_t* tile_mark;  // [W * tiles_pw]; nullptr = dense compose over every cell
+    uint32_t* tile_list;  // [2][TILE_LISTS][tile_cap]: parity of tile_seq, then one list per group of workgroups
+    int* tile_count;      // [2][TILE_LISTS]
+    uint32_t tile_seq;
+    int tile_cap, tiles_x, tiles_pw;
     const int *obst_base, *node_base, *n_obst_w, *oroot_w;  // [W] slices of obst / onodes per world (W > 1)
     int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;
     int scene, relation, ktype, use_laser, laser_norm, time_max;

@@ -145,6 +145,11 @@ typedef struct imgenv_cfg {
 } imgenv_cfg;
 
 #define IMGENV_FLAG_PRIVATE_GRIDS 1 /* oracle only: literal per-robot grid copies (img_env.cpp:620-629) */
+/* How the per-step class layer is rebuilt.  Default: the library picks -- dense (every map cell of every world) when the
+ * robots and pedestrians cover a good part of the map, sparse (only the 8 x 8-cell tiles they touch) for big or many
+ * maps with few agents each.  The result is the same either way. */
+#define IMGENV_FLAG_COMPOSE_DENSE 2
+#define IMGENV_FLAG_COMPOSE_SPARSE 4
 
 /* ResetEnv.srv:1-6 (img_env.cpp:162-292).  Poses are (x, y, qz, qw): geometry_msgs/Pose with a
  * planar orientation; yaw is recovered with tf::Matrix3x3(q).getRPY as the node does. */

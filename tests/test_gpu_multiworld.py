@@ -217,6 +217,20 @@ def test_one_world_reset_grows_the_shared_tables(worlds):
             c.close()
 
 
+@pytest.mark.parametrize("flags", [2, 4], ids=["dense_compose", "sparse_compose"])
+def test_compose_modes_give_the_same_worlds(worlds, flags):
+    """the class layer rebuilt densely (every cell) or sparsely (touched 8 x 8 tiles, now and one step later): crowded
+    worlds, legs, per-world resets, a map width that is not a multiple of the tile"""
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, 4, 12, 9, 30, {5: [1], 6: [1, 3], 20: [0, 1, 2, 3]}, seed=35, n_obstacles=3, ped_shape="leg",
+                       grid_size=100, clearance=0.6, flags=flags)
+    assert not fails, fails[:3]
+    fails, _, _ = _run(World, OracleWorld, 1, 40, 12, 30, {}, seed=36, n_obstacles=3, grid_size=116, clearance=0.6, flags=flags)
+    assert not fails, fails[:3]
+    fails, _, _ = _run(World, OracleWorld, 3, 10, 5, 16, {7: [2]}, seed=37, n_obstacles=2, grid_size=117, clearance=0.6, flags=flags)
+    assert not fails, fails[:3]
+
+
 def test_bad_multi_world_configurations_are_rejected(worlds):
     World, _ = worlds
     grid, params, _ = small_world(4, 4, seed=1)
