@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--peds", type=int, default=N_PEDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true")
+    ap.add_argument("--no-multi-world", action="store_true", help="skip the secondary env_num-style measurement")
     ap.add_argument("--spinup", type=int, default=2000, help="untimed steps before the warm-up (clock ramp)")
     ap.add_argument("--timing-mode", type=int, default=2, help="diagnostic: 0 = no HIP events in the timed pass")
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
@@ -273,6 +274,18 @@ def main():
         dte, _, frozen_ep = run("episode", args.steps, args.warmup)
         episode = dict(value=R * args.steps / dte, frozen_fraction=frozen_ep)
 
+    launches_per_step = world.launches()
+    multi_world = None
+    if world_size == 1 and not args.no_multi_world and not args.force_dist:
+        # secondary: the reference's own env_num idiom -- E independent worlds of R/E robots at
+        # 0.125 m in ONE handle, every world with its own obstacle map, crowd and time limit, reset on its own when its
+        # time limit runs out (imgenv_reset_worlds); no collective, so N GPUs simply hold N times the worlds
+        world.close()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from multiworld_probe import measure
+        multi_world = [measure(E, RL // E, pw, 200, res=0.125, steps=args.steps, warmup=300, time_max=TIME_MAX, kernels=False, device=local_rank)
+                       for E, pw in ((64, 16), (RL, 0))]
+
     if rank == 0:
         ab = algorithmic_bytes(P)
         kernel_bytes = ab.get(dominant, ab["total"]) * RL
@@ -299,9 +312,10 @@ def main():
                            world_size, "ncclAllGather inside imgenv_step" if native else "torch.distributed between step_begin/step_end"))
                        if use_dist else "single GPU"},
             "frozen_fraction": frozen_active,
+            "multi_world": multi_world,
             "episode_policy": episode,
             "kernel_us": per_kernel_us,
-            "launches_per_step": world.launches(),
+            "launches_per_step": launches_per_step,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_robot_step": ab, "kernel_avg_us": dur_s * 1e6,

@@ -953,10 +953,15 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             HIPCHK(hipEventRecord(h->ev_join2, s_obs));
         }
     }
-    if (h->pow2)
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<true><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
-    else
-        TIMED(h, IMGENV_K_RASTER, st, (k_raster<false><<<dim3(n_p > n_g ? n_p : n_g), dim3(WAVE), 4 * (size_t)d.box_cells, st>>>(d, is_reset)));
+    {
+        const dim3 gr(n_p > n_g ? n_p : n_g), br(WAVE);
+        const size_t lds = 4 * (size_t)d.box_cells;
+        const int variant = (h->pow2 ? 2 : 0) | (h->sparse ? 1 : 0);
+        if (variant == 3) TIMED(h, IMGENV_K_RASTER, st, (k_raster<true, true><<<gr, br, lds, st>>>(d, is_reset)));
+        else if (variant == 2) TIMED(h, IMGENV_K_RASTER, st, (k_raster<true, false><<<gr, br, lds, st>>>(d, is_reset)));
+        else if (variant == 1) TIMED(h, IMGENV_K_RASTER, st, (k_raster<false, true><<<gr, br, lds, st>>>(d, is_reset)));
+        else TIMED(h, IMGENV_K_RASTER, st, (k_raster<false, false><<<gr, br, lds, st>>>(d, is_reset)));
+    }
     if (h->sparse && !is_reset)
         TIMED(h, IMGENV_K_COMPOSE, st, (k_compose_tiles<<<dim3(2, 2 * TILE_LISTS), dim3(256), 0, st>>>(d)));
     else

@@ -83,7 +83,6 @@ __device__ __forceinline__ int world_of_ped(const DevWorld& w, int j) { return w
 #define TILE_LISTS 256
 // sparse compose: cell (m, n) of `world` holds raster content in this step
 __device__ __forceinline__ void mark_tile(const DevWorld& w, int world, int m, int n) {
-    if (!w.tile_mark) return;
     const uint32_t t = (uint32_t)world * (uint32_t)w.tiles_pw + (uint32_t)(m >> 3) * (uint32_t)w.tiles_x + (uint32_t)(n >> 3);
     if (w.tile_mark[t] == w.tile_seq) return;  // (a stale read only costs the atomic below)
     if (atomicMax(&w.tile_mark[t], w.tile_seq) != w.tile_seq) {  // the first toucher lists the tile
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 //   left leg      : writes unless the cell is 0                   (agent.cpp:751-754)
 //   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
-template <bool POW2>
+template <bool POW2, bool TILES>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Region& g) {
     const PedClassDev k = w.pc[w.ped_cls[j]];
     const int world = world_of_ped(w, j);
@@ -626,7 +625,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
                 const size_t c = cell0 + (size_t)m * w.Wg + n;
                 if (w.obs_map[c] > 2) {
                     w.ped_layer[c] = 1;
-                    mark_tile(w, world, m, n);
+                    if (TILES) mark_tile(w, world, m, n);
                 }
             }
         }
@@ -649,7 +648,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
                     const size_t c = cell0 + (size_t)m * w.Wg + n;
                     if (leg == 1 || w.obs_map[c] != 0) {
                         w.ped_layer[c] = 1;
-                        mark_tile(w, world, m, n);
+                        if (TILES) mark_tile(w, world, m, n);
                     }
                 }
             }
@@ -668,7 +667,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
 // (cell, last sample) pairs go to fp_cells so that the collision test of k_view (agent.cpp:294-326:
 // the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
 // second pass over the samples.
-template <bool POW2>
+template <bool POW2, bool TILES>
 __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel, const Region& g) {
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
@@ -705,9 +704,9 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
                 const uint32_t c = list[e].x;
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
-                if (w.tile_mark) {
+                if (TILES) {
                     const uint32_t rel = c - cell0, m = rel / (uint32_t)w.Wg;
-                    mark_tile(w, world, (int)m, (int)(rel - m * (uint32_t)w.Wg));
+                    if (TILES) mark_tile(w, world, (int)m, (int)(rel - m * (uint32_t)w.Wg));
                 }
             }
             return;
@@ -743,7 +742,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
-                    mark_tile(w, world, m, n);
+                    if (TILES) mark_tile(w, world, m, n);
                     stray = true;
                 }
             }
@@ -770,7 +769,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
                 atomicMin(&w.own_lo[c], id);
                 atomicMax(&w.own_hi[c], id);
 #endif
-                mark_tile(w, world, m, n);
+                if (TILES) mark_tile(w, world, m, n);
             }
             if (local) {
                 const unsigned long long mask = __ballot(last != 0);
@@ -786,7 +785,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t*
     }
 }
 
-template <bool POW2>
+template <bool POW2, bool TILES>
 __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
@@ -794,8 +793,8 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     const int b = blockIdx.x;
     WAVE_T0();
     const Region g = grid_region(w);
-    if (b < w.act_ng) raster_robot<POW2>(w, act_member(w, w.Rw, b), (uint32_t*)smem, zero_vel != 0, g);
-    if (b < w.act_np) raster_ped<POW2>(w, act_member(w, w.Pw, b), g);
+    if (b < w.act_ng) raster_robot<POW2, TILES>(w, act_member(w, w.Rw, b), (uint32_t*)smem, zero_vel != 0, g);
+    if (b < w.act_np) raster_ped<POW2, TILES>(w, act_member(w, w.Pw, b), g);
     if (b < w.RL) WAVE_DONE(2);
 }
 
