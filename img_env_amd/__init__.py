@@ -14,6 +14,9 @@ def __getattr__(name):
     if name in ("make_env", "ImageEnv", "ImageState", "ContinuousAction", "DiscreteActions", "wrapper_dict"):
         from . import envs
         return getattr(envs, name)
+    if name == "VecImageEnv":
+        from .vec_env import VecImageEnv
+        return VecImageEnv
     if name == "World":
         from .world import World
         return World

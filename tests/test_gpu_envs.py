@@ -66,3 +66,64 @@ def test_reference_action_objects_and_random_spawn():
         assert cfg["node_id"] == 1    # make_env post-increments node_id (envs/__init__.py:32)
     finally:
         env.close()
+
+
+def test_vec_env_matches_one_make_env_per_env():
+    """env_num envs in one handle (VecImageEnv) against env_num separate make_env stacks with the same spawn seeds:
+    same observations, rewards, dones and infos on every step, through time-limit auto-resets (all envs at once) and a
+    manual reset that puts one env out of phase with the others"""
+    import copy
+    import torch
+    from img_env_amd import make_env, worldgen
+    from img_env_amd.vec_env import VecImageEnv
+    E, R, P = 3, 4, 3
+    grid = worldgen.make_grid(200, 2)
+    cfg = worldgen.make_yaml_cfg(R, P, grid, time_max=6, n_obstacles=2, seed=21,
+                                 wrappers=["VelActionWrapper", "TimeLimitWrapper", "SensorsPaperRewardWrapper",
+                                           "InfoLogWrapper", "MultiRobotCleanWrapper", "NeverStopWrapper"])
+    envs = []
+    for k in range(E):
+        c = copy.deepcopy(cfg)
+        c["seed"] = 21 + k
+        envs.append(make_env(c))
+    vec = VecImageEnv(copy.deepcopy(cfg), env_num=E, seed=21)
+
+    def same_state(sv, refs, where):
+        v = sv.numpy()
+        for k, sr in enumerate(refs):
+            r, sl = sr.numpy(), slice(k * R, (k + 1) * R)
+            assert np.array_equal(v.sensor_maps[sl], r.sensor_maps), (where, k)
+            assert np.array_equal(v.is_collisions[sl], r.is_collisions), (where, k)
+            assert np.array_equal(v.is_arrives[sl], r.is_arrives), (where, k)
+            for f in ("vector_states", "lasers", "ped_vector_states", "ped_maps", "step_ds"):
+                assert np.abs(getattr(v, f)[sl] - getattr(r, f)).max() <= 1e-4, (where, k, f)
+
+    try:
+        same_state(vec.reset(), [e.reset() for e in envs], "reset")
+        rng = np.random.default_rng(5)
+        n_auto = 0
+        for s in range(30):
+            a = np.zeros((E * R, 3), np.float32)
+            a[:, 0], a[:, 1] = rng.uniform(0, 0.6, E * R), rng.uniform(-0.9, 0.9, E * R)
+            at = torch.as_tensor(a, device="cuda")
+            sv, rew, done, info = vec.step(at)
+            refs = []
+            for k, e in enumerate(envs):
+                sr, rr, dr, ir = e.step(at[k * R:(k + 1) * R])
+                refs.append(sr)
+                sl = slice(k * R, (k + 1) * R)
+                assert np.abs(rew[sl].cpu().numpy() - rr.cpu().numpy()).max() <= 1e-4, (s, k)
+                assert np.array_equal(done[sl].cpu().numpy() > 0, dr.cpu().numpy() > 0), (s, k)
+                assert np.array_equal(info["dones_info"][sl].cpu().numpy(), ir["dones_info"].cpu().numpy()), (s, k)
+                assert np.array_equal(info["is_clean"][sl].cpu().numpy() > 0, ir["is_clean"].cpu().numpy() > 0), (s, k)
+                assert bool(ir["all_down"][0]) == (k in info["reset_envs"]), (s, k)
+            same_state(sv, refs, s)
+            n_auto += len(info["reset_envs"])
+            if s == 2:  # env 1 starts over on its own: from now on it times out three steps after the others
+                refs[1] = envs[1].reset()
+                same_state(vec.reset_envs([1]), refs, "manual reset")
+        assert n_auto >= 3 * E
+    finally:
+        vec.close()
+        for e in envs:
+            e.close()
