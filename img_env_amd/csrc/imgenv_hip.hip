@@ -58,7 +58,10 @@ struct imgenv {
     int cap_obst = 0, cap_nodes = 0;
     double* d_traj = nullptr;
     double* d_traj_v = nullptr;  // dataset scene
-    double *d_rob3 = nullptr, *d_ped3 = nullptr;  // reset staging (persistent: no pool traffic per reset)
+    // the robots / pedestrians of the reset being staged, in list order, in page-locked memory the reset kernel reads
+    double *pin_rob3 = nullptr, *pin_ped3 = nullptr;
+    void* pin_rr = nullptr;
+    int* pin_list = nullptr;
     // pinned host staging of imgenv_reset: copies are truly asynchronous and reset never waits for the stream
     struct Chunk { unsigned char* p; size_t cap, used; };
     // STAGE_GENS generations of chunks, used round-robin: a reset only ever waits for the reset STAGE_GENS calls back (the
@@ -84,7 +87,6 @@ struct imgenv {
     size_t n_tiles = 0;
     std::vector<double> tmp_d0, tmp_d1;
     std::vector<int> tmp_i0;
-    void* d_rr = nullptr;
     int* d_traj_len = nullptr;
     int traj_cap = 0;
     int elapsed = 0;
@@ -824,23 +826,24 @@ struct ResetRobot {  // per local robot
     Tf2 world_target;
 };
 
-__global__ void k_reset_robots(DevWorld w, const double* __restrict__ pose3, const ResetRobot* __restrict__ rr, int whole) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= w.act_ng) return;
-    const int i = act_member(w, w.Rw, t);
+// the t-th robot of a reset (list order): pose3 / rr hold the reset's robots in that order, in page-locked host memory
+__device__ __forceinline__ void reset_robot(const DevWorld& w, const int* list, int t, const double* __restrict__ pose3,
+                                            const ResetRobot* __restrict__ rr, int whole) {
+    const int i = list ? list[t / w.Rw] * w.Rw + t % w.Rw : t;
     double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    r[0] = pose3[5 * i];  // init_pose (agent.cpp:133-142); Agent::vx, vy persist across resets
-    r[1] = pose3[5 * i + 1];
-    r[2] = pose3[5 * i + 2];
-    r[5] = pose3[5 * i + 3];  // sin / cos of yaw/2, evaluated on the host
-    r[6] = pose3[5 * i + 4];
+    r[0] = pose3[5 * t];  // init_pose (agent.cpp:133-142); Agent::vx, vy persist across resets
+    r[1] = pose3[5 * t + 1];
+    r[2] = pose3[5 * t + 2];
+    r[5] = pose3[5 * t + 3];  // sin / cos of yaw/2, evaluated on the host
+    r[6] = pose3[5 * t + 4];
     const int l = i - w.r0;
     if (l >= 0 && l < w.RL) {
+        const ResetRobot q = rr[w.W > 1 ? t : l];
         w.l0v[l] = 0;  // last0_vw_ = (0,0); last1_vw_ is not touched by init_pose
         w.l0w[l] = 0;
-        w.gx[l] = rr[l].gx;
-        w.gy[l] = rr[l].gy;
-        w.world_target[l] = rr[l].world_target;
+        w.gx[l] = q.gx;
+        w.gy[l] = q.gy;
+        w.world_target[l] = q.world_target;
         w.is_coll[l] = 0;
         w.is_arr[l] = 0;
     }
@@ -855,25 +858,24 @@ __global__ void k_reset_bbox(DevWorld w, const double* __restrict__ pose3) {
     bbox_accumulate(w, valid, p[0], p[1]);
 }
 
-__global__ void k_reset_peds(DevWorld w, const double* __restrict__ pose3) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= w.act_np) return;
-    const int j = act_member(w, w.Pw, t);
-    w.ppx[j] = pose3[3 * j];
-    w.ppy[j] = pose3[3 * j + 1];
-    w.pyaw[j] = pose3[3 * j + 2];
+__device__ __forceinline__ void reset_ped(const DevWorld& w, const int* list, int t, const double* __restrict__ pose3) {
+    const int j = list ? list[t / w.Pw] * w.Pw + t % w.Pw : t;
+    const double x = pose3[3 * t], y = pose3[3 * t + 1];
+    w.ppx[j] = x;
+    w.ppy[j] = y;
+    w.pyaw[j] = pose3[3 * t + 2];
     w.ptraj_idx[j] = 0;
     if (w.NA > 0) {  // setPedPos (rvoscene.h:32-34); the agent's velocity persists
-        w.apx[j] = (float)pose3[3 * j];
-        w.apy[j] = (float)pose3[3 * j + 1];
+        w.apx[j] = (float)x;
+        w.apy[j] = (float)y;
     }
     if (w.scene == IMGENV_SCENE_PEDSIM) {  // setPosition(x, y, 0) (pedscene.h:34-36); velocity persists
-        w.sfm.p[3 * j] = pose3[3 * j];
-        w.sfm.p[3 * j + 1] = pose3[3 * j + 1];
+        w.sfm.p[3 * j] = x;
+        w.sfm.p[3 * j + 1] = y;
         w.sfm.p[3 * j + 2] = 0.0;
     }
-    w.ped_state[4 * j] = pose3[3 * j];
-    w.ped_state[4 * j + 1] = pose3[3 * j + 1];
+    w.ped_state[4 * j] = x;
+    w.ped_state[4 * j + 1] = y;
     w.ped_state[4 * j + 2] = w.pvx[j];
     w.ped_state[4 * j + 3] = w.pvy[j];
 }
@@ -990,9 +992,7 @@ struct StageSeg {
 };
 // a kernel pulls the bytes out of the page-locked chunks: unlike hipMemcpyAsync (which was seen to block the host for
 // several milliseconds on a busy stream once a copy exceeds a few hundred KB) a launch never waits
-__global__ __launch_bounds__(256) void k_stage_copy(const StageSeg* __restrict__ table) {
-    const StageSeg g = table[blockIdx.y];
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+__device__ __forceinline__ void copy_segment(const StageSeg g, size_t t, size_t stride) {
     if ((((uintptr_t)g.dst | (uintptr_t)g.src) & 15) == 0) {
         const size_t n16 = g.bytes / 16;
         for (size_t q = t; q < n16; q += stride) ((uint4*)g.dst)[q] = ((const uint4*)g.src)[q];
@@ -1003,6 +1003,27 @@ __global__ __launch_bounds__(256) void k_stage_copy(const StageSeg* __restrict__
         for (size_t q = t; q < g.bytes; q += stride) g.dst[q] = g.src[q];
     }
 }
+__global__ __launch_bounds__(256) void k_stage_copy(const StageSeg* __restrict__ table, int per_seg) {
+    copy_segment(table[blockIdx.x / per_seg], (size_t)(blockIdx.x % per_seg) * blockDim.x + threadIdx.x, (size_t)per_seg * blockDim.x);
+}
+
+// Everything of a reset that only depends on the staged bytes, in ONE launch (each dependent launch of the reset chain
+// costs the stream ~10 us, whatever its size).  Workgroups, in order:
+//   n_seg * per_seg : the segment copies (trajectories, RVO polygons, per-world tables, the world list)
+//   n_worlds * MAP_BLOCKS : obs_map_ of each world being reset starts from the static map again (img_env.cpp:166-168)
+//   robots, pedestrians : init_pose / set_goal / setPedPos ..., straight from the page-locked host blocks
+#define MAP_BLOCKS 8
+struct ResetArgs {
+    const StageSeg* table;
+    int n_seg, per_seg;
+    const int* list;  // the worlds of this reset (page-locked host copy), nullptr = every world
+    int n_worlds;
+    const uint8_t* static_map;
+    const double* rob3;
+    const ResetRobot* rr;
+    const double* ped3;
+    int n_robots, n_peds, whole;
+};
 static int stage_begin(imgenv* h) {
     h->gen = (h->gen + 1) % imgenv::STAGE_GENS;
     const int g = h->gen;
@@ -1051,11 +1072,8 @@ static int stage_flush(imgenv* h, hipStream_t st) {
     unsigned char* table = nullptr;
     if (int rc = stage_room(h, h->segs.size() * sizeof(StageSeg), &table)) return rc;
     memcpy(table, h->segs.data(), h->segs.size() * sizeof(StageSeg));
-    const unsigned bx = (unsigned)std::min<size_t>((h->seg_max / 16 + 255) / 256 + 1, 64);
-    for (size_t q0 = 0; q0 < h->segs.size(); q0 += 65535) {
-        const unsigned ny = (unsigned)std::min<size_t>(h->segs.size() - q0, 65535);
-        k_stage_copy<<<dim3(bx, ny), dim3(256), 0, st>>>((const StageSeg*)table + q0);
-    }
+    const int per_seg = (int)std::min<size_t>((h->seg_max / 16 + 255) / 256 + 1, 16);
+    k_stage_copy<<<dim3((unsigned)(h->segs.size() * per_seg)), dim3(256), 0, st>>>((const StageSeg*)table, per_seg);
     HIPCHK(hipGetLastError());
     h->segs.clear();
     h->seg_max = 0;
@@ -1091,15 +1109,32 @@ __global__ void k_restride3(double* __restrict__ dst, const double* __restrict__
     dst[j * (size_t)new_cap * 3 + rem] = src[t];
 }
 
-// obs_map_ of the worlds being reset starts from the static map again (img_env.cpp:166-168) ...
-__global__ __launch_bounds__(256) void k_restore_maps(DevWorld w, const uint8_t* __restrict__ static_map) {
-    const int world = w.act_list ? w.act_list[blockIdx.y] : blockIdx.y;
-    const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;  // (both buffers are padded to 16 bytes)
-    uint4* dst = (uint4*)(const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs);
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += (size_t)gridDim.x * blockDim.x)
-        dst[q] = ((const uint4*)static_map)[q];
+__global__ __launch_bounds__(256) void k_reset_apply(DevWorld w, ResetArgs a) {
+    int b = blockIdx.x;
+    if (b < a.n_seg * a.per_seg) {
+        copy_segment(a.table[b / a.per_seg], (size_t)(b % a.per_seg) * blockDim.x + threadIdx.x, (size_t)a.per_seg * blockDim.x);
+        return;
+    }
+    b -= a.n_seg * a.per_seg;
+    if (b < a.n_worlds * MAP_BLOCKS) {
+        const int q = b / MAP_BLOCKS, world = a.list ? a.list[q] : q;
+        const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;  // (both buffers are padded to 16 bytes)
+        uint4* dst = (uint4*)(const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs);
+        for (size_t e = (size_t)(b - q * MAP_BLOCKS) * blockDim.x + threadIdx.x; e < n16; e += (size_t)MAP_BLOCKS * blockDim.x)
+            dst[e] = ((const uint4*)a.static_map)[e];
+        return;
+    }
+    b -= a.n_worlds * MAP_BLOCKS;
+    const int robot_blocks = (a.n_robots + 255) / 256;
+    if (b < robot_blocks) {
+        const int t = b * 256 + threadIdx.x;
+        if (t < a.n_robots) reset_robot(w, a.list, t, a.rob3, a.rr, a.whole);
+        return;
+    }
+    const int t = (b - robot_blocks) * 256 + threadIdx.x;
+    if (t < a.n_peds) reset_ped(w, a.list, t, a.ped3);
 }
-// ... and every obstacle is drawn into it with value 0: Agent::draw(obs_map, 0, "world_map") (img_env.cpp:169-193,
+// Every obstacle is then drawn into its world's map with value 0: Agent::draw(obs_map, 0, "world_map") (img_env.cpp:169-193,
 // agent.cpp:285-327) writes unless the cell holds 0 / 1 / 2 -- and only ever writes 0, so the order does not matter.
 // One workgroup per obstacle; its footprint samples were uploaded once per (shape, size).
 struct ObstInst {
@@ -1214,7 +1249,7 @@ static int put_world_rvo(imgenv* h, int k) {
 }
 
 // Host half of one world's reset: its obstacles, pedestrians and robots go into the staging chunks.
-static int stage_world(imgenv* h, int k, const imgenv_reset_batch* b, hipStream_t st) {
+static int stage_world(imgenv* h, int k, int q_list, const imgenv_reset_batch* b, hipStream_t st) {
     DevWorld& d = h->d;
     const int W = h->W, Rw = h->Rw, Pw = h->Pw, P = h->P;
     const int g_lo = k * Rw, p_lo = k * Pw;  // first robot / pedestrian of the world
@@ -1248,10 +1283,9 @@ static int stage_world(imgenv* h, int k, const imgenv_reset_batch* b, hipStream_
                 if (dataset) k_restride3<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(h->d_traj_v, old_v, P, old_cap, h->traj_cap);
             }
         }
-        std::vector<double>& ped3 = h->tmp_d0;
+        double* ped3 = h->pin_ped3 + (size_t)q_list * Pw * 3;
         std::vector<int>& tlen = h->tmp_i0;
         std::vector<double>& traj = h->tmp_d1;
-        ped3.resize((size_t)Pw * 3);
         tlen.resize(Pw);
         traj.assign((size_t)Pw * h->traj_cap * 3, 0.0);
         for (int j = 0; j < Pw; j++) {
@@ -1266,7 +1300,6 @@ static int stage_world(imgenv* h, int k, const imgenv_reset_batch* b, hipStream_
         }
         RTRY(stage_put(h, h->d_traj + (size_t)p_lo * h->traj_cap * 3, traj.data(), traj.size() * 8));
         RTRY(stage_put(h, h->d_traj_len + p_lo, tlen.data(), sizeof(int) * Pw));
-        RTRY(stage_put(h, h->d_ped3 + (size_t)p_lo * 3, ped3.data(), ped3.size() * 8));
         if (dataset) {  // trajectory_v (img_env.cpp:246-247) + the yaw _step_ped_dataset derives from it, with the host's libm
             std::vector<double>& tv = h->tmp_d1;
             tv.assign((size_t)Pw * h->traj_cap * 3, 0.0);
@@ -1314,9 +1347,8 @@ static int stage_world(imgenv* h, int k, const imgenv_reset_batch* b, hipStream_
     }
     // robots (img_env.cpp:252-282)
     const int l_lo = W > 1 ? g_lo : 0, n_l = W > 1 ? Rw : h->RL;  // local robots of this world (a shard exists for W == 1 only)
-    std::vector<double>& rob3 = h->tmp_d0;
-    rob3.resize((size_t)Rw * 5);
-    std::vector<ResetRobot> rr(n_l);
+    double* rob3 = h->pin_rob3 + (size_t)q_list * Rw * 5;
+    ResetRobot* rr = (ResetRobot*)h->pin_rr + (size_t)q_list * n_l;
     for (int i = 0; i < Rw; i++) {
         const double* p = b->robot_pose + 4 * i;
         const double yaw = tf_yaw_from_quaternion_zw(p[2], p[3]);
@@ -1333,8 +1365,6 @@ static int stage_world(imgenv* h, int k, const imgenv_reset_batch* b, hipStream_
             q.world_target = tf_inverse(tf_from_pose(q.gx, q.gy, yaw));
         }
     }
-    RTRY(stage_put(h, h->d_rob3 + (size_t)g_lo * 5, rob3.data(), rob3.size() * 8));
-    RTRY(stage_put(h, (ResetRobot*)h->d_rr + l_lo, rr.data(), rr.size() * sizeof(ResetRobot)));
     return 0;
 }
 
@@ -1350,52 +1380,74 @@ static int reset_checks(imgenv* h, int n, const imgenv_reset_batch* b) {
         for (int q = 0; q < 8; q++) h->err_host[q] = 0;
         return rc;
     }
-    if (!h->d_rob3) {
-        RTRY(dev_alloc(h, &h->d_rob3, (size_t)h->R * 5));
-        RTRY(dev_alloc(h, &h->d_ped3, (size_t)(h->P > 0 ? h->P : 1) * 3));
-        ResetRobot* q = nullptr;
-        RTRY(dev_alloc(h, &q, (size_t)h->RL));
-        h->d_rr = q;
-        RTRY(dev_alloc(h, &h->d_act_list, (size_t)h->W));
-    }
+    if (!h->d_act_list) RTRY(dev_alloc(h, &h->d_act_list, (size_t)h->W));
     return 0;
 }
 
 // Device half of a reset, for every world (list == nullptr) or the n worlds listed: one upload launch, the obstacle
 // maps, the robot / pedestrian state, then view_agent + get_states (img_env.cpp:285-286) for those worlds' robots.
+// page-locked blocks for the robots / pedestrians of the n worlds of this reset, in list order (read by k_reset_apply)
+static int reset_blocks(imgenv* h, int n, const int* list) {
+    unsigned char* p = nullptr;
+    const size_t n_local = h->W > 1 ? (size_t)n * h->Rw : (size_t)h->RL;
+    RTRY(stage_room(h, sizeof(double) * 5 * n * h->Rw, &p));
+    h->pin_rob3 = (double*)p;
+    RTRY(stage_room(h, sizeof(ResetRobot) * std::max<size_t>(n_local, 1), &p));
+    h->pin_rr = p;
+    RTRY(stage_room(h, sizeof(double) * 3 * std::max<size_t>((size_t)n * h->Pw, 1), &p));
+    h->pin_ped3 = (double*)p;
+    h->pin_list = nullptr;
+    if (list) {
+        RTRY(stage_room(h, sizeof(int) * n, &p));
+        h->pin_list = (int*)p;
+        memcpy(h->pin_list, list, sizeof(int) * n);
+    }
+    return 0;
+}
+
 static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int whole) {
     DevWorld& d = h->d;
     RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size()));
     RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W));
-    if (list) RTRY(stage_put(h, h->d_act_list, list, sizeof(int) * n));
+    if (list) RTRY(stage_put(h, h->d_act_list, list, sizeof(int) * n));  // for the launches after k_reset_apply
     const size_t n_inst = h->oinst.size();
     if (n_inst > h->cap_oinst) {
         h->cap_oinst = n_inst * 2;
-        void* q = nullptr;
-        {
-            unsigned char* raw = nullptr;
-            RTRY(dev_alloc(h, &raw, h->cap_oinst * sizeof(ObstInst)));
-            q = raw;
-        }
-        h->d_oinst = q;
+        unsigned char* raw = nullptr;
+        RTRY(dev_alloc(h, &raw, h->cap_oinst * sizeof(ObstInst)));
+        h->d_oinst = raw;
     }
     static_assert(sizeof(imgenv::ObstInstHost) == sizeof(ObstInst), "layout");
     if (n_inst) RTRY(stage_put(h, h->d_oinst, h->oinst.data(), n_inst * sizeof(ObstInst)));
     h->oinst.clear();
-    RTRY(stage_flush(h, st));
     set_active(h, list ? h->d_act_list : nullptr, n);
-    {
-        const size_t n16 = ((size_t)h->Hg * h->Wg + 15) / 16;
-        const unsigned bx = (unsigned)std::min<size_t>((n16 + 255) / 256, 64);
-        k_restore_maps<<<dim3(bx, (unsigned)d.act_nw), dim3(256), 0, st>>>(d, h->d_static_map);
+    {   // one launch: segment copies | map restore | robot state | pedestrian state
+        ResetArgs a;
+        unsigned char* table = nullptr;
+        RTRY(stage_room(h, std::max<size_t>(h->segs.size(), 1) * sizeof(StageSeg), &table));
+        memcpy(table, h->segs.data(), h->segs.size() * sizeof(StageSeg));
+        a.table = (const StageSeg*)table;
+        a.n_seg = (int)h->segs.size();
+        a.per_seg = (int)std::min<size_t>((h->seg_max / 16 + 255) / 256 + 1, 16);
+        a.list = h->pin_list;
+        a.n_worlds = d.act_nw;
+        a.static_map = h->d_static_map;
+        a.rob3 = h->pin_rob3;
+        a.rr = (const ResetRobot*)h->pin_rr;
+        a.ped3 = h->pin_ped3;
+        a.n_robots = d.act_ng;
+        a.n_peds = d.act_np;
+        a.whole = whole;
+        const size_t blocks = (size_t)a.n_seg * a.per_seg + (size_t)a.n_worlds * MAP_BLOCKS + (a.n_robots + 255) / 256 + (a.n_peds + 255) / 256;
+        k_reset_apply<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d, a);
+        h->segs.clear();
+        h->seg_max = 0;
     }
     if (n_inst) {
         if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst);
         else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst);
     }
-    k_reset_robots<<<dim3((d.act_ng + 255) / 256), dim3(256), 0, st>>>(d, h->d_rob3, (const ResetRobot*)h->d_rr, whole);
-    if (d.sharded) k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, h->d_rob3);
-    if (d.act_np > 0) k_reset_peds<<<dim3((d.act_np + 255) / 256), dim3(256), 0, st>>>(d, h->d_ped3);
+    if (d.sharded) k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, h->pin_rob3);
     HIPCHK(hipGetLastError());
     h->launches = 2;
     const int rc = launch_views(h, st, 1);
@@ -1408,6 +1460,7 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
     if (int rc = reset_checks(h, 1, b)) return rc;
     hipStream_t st = (hipStream_t)stream;
     RTRY(stage_begin(h));
+    RTRY(reset_blocks(h, h->W, nullptr));
     h->oinst.clear();
     for (int k = 0; k < h->W; k++) {
         imgenv_reset_batch sub = *b;  // world k's robots and pedestrians (world-major numbering); one obstacle list for all
@@ -1420,7 +1473,7 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
             sub.ped_traj = b->ped_traj + (size_t)k * h->Pw * b->ped_traj_cap * 3;
             sub.ped_traj_v = b->ped_traj_v ? b->ped_traj_v + (size_t)k * h->Pw * b->ped_traj_cap * 2 : nullptr;
         }
-        RTRY(stage_world(h, k, &sub, st));
+        RTRY(stage_world(h, k, k, &sub, st));
         h->world_epoch[k] = 0;
         h->world_ready[k] = 1;
     }
@@ -1449,14 +1502,31 @@ extern "C" int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds
         seen[worlds[q]] = 1;
     }
     hipStream_t st = (hipStream_t)stream;
+    static const bool trace = getenv("IMGENV_TRACE_RESET") != nullptr;
+    std::chrono::steady_clock::time_point tp[4];
+    if (trace) tp[0] = std::chrono::steady_clock::now();
     RTRY(stage_begin(h));
+    RTRY(reset_blocks(h, n, worlds));
     h->oinst.clear();
+    if (trace) tp[1] = std::chrono::steady_clock::now();
     for (int q = 0; q < n; q++) {
-        RTRY(stage_world(h, worlds[q], batches + q, st));
+        RTRY(stage_world(h, worlds[q], q, batches + q, st));
         h->world_epoch[worlds[q]] = h->elapsed;  // its TimeLimitWrapper starts over
         h->world_ready[worlds[q]] = 1;
     }
+    if (trace) tp[2] = std::chrono::steady_clock::now();
     RTRY(reset_launch(h, worlds, n, st, 0));
+    if (trace) {
+        tp[3] = std::chrono::steady_clock::now();
+        auto us = [&](int a_, int b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(tp[b_] - tp[a_]).count() * 1e-3; };
+        static double acc[3] = {0, 0, 0};
+        static long calls = 0, worlds_n = 0;
+        acc[0] += us(0, 1); acc[1] += us(1, 2); acc[2] += us(2, 3);
+        calls++; worlds_n += n;
+        if (calls % 200 == 0)
+            fprintf(stderr, "[imgenv_reset_worlds] %ld calls, %.1f worlds/call: begin %.1f us, stage worlds %.1f us, launches %.1f us per call\n",
+                    calls, (double)worlds_n / calls, acc[0] / calls, acc[1] / calls, acc[2] / calls);
+    }
     bool all = true;
     for (char r : h->world_ready) all = all && r;
     h->has_reset = all;

@@ -5,6 +5,7 @@ view of library-written HBM), provides the stream, and runs the RCCL all-gather 
 world.  All simulation work happens in ``csrc/libimgenv_hip.so``.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -52,6 +53,7 @@ class World:
         self.h = h
         self.n_robots, self.n_peds = cfg.n_robots, cfg.n_peds
         self.n_worlds = max(1, cfg.n_worlds)
+        self._trace = [0.0, 0] if os.environ.get("IMGENV_TRACE_RESET") else None  # seconds inside imgenv_reset_worlds, calls
         o = _cabi.Out()
         self._check(self.lib.imgenv_outputs(self.h, C.byref(o)), "imgenv_outputs")
         self.n_local = o.n_local
@@ -103,6 +105,14 @@ class World:
         prepared = [lay if isinstance(lay, tuple) else self.prepare_reset(lay) for lay in layouts]
         arr = (_cabi.ResetBatch * n)(*[b for b, _ in prepared])
         ids = (C.c_int32 * n)(*[int(k) for k in worlds])
+        if self._trace is not None:
+            import time
+            t0 = time.perf_counter()
+            rc = self.lib.imgenv_reset_worlds(self.h, n, ids, arr, self._stream())
+            self._trace[0] += time.perf_counter() - t0
+            self._trace[1] += 1
+            self._check(rc, "imgenv_reset_worlds")
+            return self.out
         self._check(self.lib.imgenv_reset_worlds(self.h, n, ids, arr, self._stream()), "imgenv_reset_worlds")
         return self.out
 

@@ -84,6 +84,9 @@ def measure(E, Rw, Pw, grid_cells, res=0.125, steps=300, warmup=100, time_max=10
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     frozen = float(((world.out["is_collisions"] != 0) | (world.out["is_arrives"] != 0)).float().mean().item())
+    if world._trace is not None and world._trace[1]:
+        print("python side: %.1f us per reset call inside the C call, %.1f us around it"
+              % (1e6 * world._trace[0] / world._trace[1], 1e6 * (st["reset_s"] - world._trace[0]) / max(world._trace[1], 1)), file=sys.stderr)
     world.close()
     return dict(worlds=E, robots_per_world=Rw, peds_per_world=Pw, grid=grid_cells, resolution=res, policy=policy,
                 value=R * steps / dt, unit="robot-steps/s", us_per_step=1e6 * dt / steps, steps=steps,
