@@ -4,6 +4,8 @@ Each world of the handle must behave exactly like a world of its own: the checke
 stepped with that world's slice of the batch.  Covers per-world reset in mid-flight (the other worlds keep their state
 and their time limits), the whole-handle reset with a shared obstacle list, a dataset crowd (its clock is per world) and
 world sizes that do not divide a workgroup."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,31 @@ def test_compose_modes_give_the_same_worlds(worlds, flags):
     assert not fails, fails[:3]
     fails, _, _ = _run(World, OracleWorld, 3, 10, 5, 16, {7: [2]}, seed=37, n_obstacles=2, grid_size=117, clearance=0.6, flags=flags)
     assert not fails, fails[:3]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IMGENV_FUZZ_SEEDS_WORLDS", "10"))))  # more seeds for a bug hunt
+def test_fuzzed_world_batches_match_one_oracle_each(worlds, seed):
+    """random world counts and sizes, scenes, geometry, compose mode and reset schedules (single worlds, subsets, all)"""
+    World, OracleWorld = worlds
+    rng = np.random.default_rng(4000 + seed)
+    W, Rw = int(rng.integers(2, 9)), int(rng.integers(1, 12))
+    scene = str(rng.choice(["rvoscene", "ervoscene", ""]))
+    Pw = int(rng.integers(1, 14)) if scene else 0
+    res = float(rng.choice([0.125, 0.25, 0.1]))
+    view_cells = int(rng.choice([32, 48, 50]))
+    steps = int(rng.integers(10, 22))
+    resets = {}
+    for s in range(steps - 1):
+        if rng.random() < 0.4:
+            resets[s] = sorted(int(k) for k in rng.choice(W, size=int(rng.integers(1, W + 1)), replace=False))
+    extent = max(22.0, 1.5 * np.sqrt((Rw + Pw) * 2.5))
+    kw = dict(res=res, view_cells=view_cells, view_width=(view_cells + 0.5) * res, view_height=(view_cells + 0.5) * res,
+              beams=int(rng.choice([90, 360])), scene=scene, ped_shape=str(rng.choice(["circle", "leg"])),
+              relation_ped_robo=int(rng.integers(0, 2)), time_max=int(rng.integers(5, 14)), dt=float(rng.choice([0.25, 0.4])),
+              grid_size=int(np.ceil(extent / res)) | int(rng.integers(0, 2)), n_obstacles=int(rng.integers(0, 4)),
+              clearance=float(rng.choice([0.6, 0.8])), flags=int(rng.choice([0, 2, 4])))
+    fails, _, _ = _run(World, OracleWorld, W, Rw, Pw, steps, resets, seed=300 + seed, whole_reset=bool(rng.random() < 0.3), **kw)
+    assert not fails, (seed, W, Rw, Pw, kw, fails[:2])
 
 
 def test_bad_multi_world_configurations_are_rejected(worlds):
