@@ -260,19 +260,6 @@ static uint16_t f32_to_f16(float f) {
     return h;
 }
 
-// Agent::draw(obs_map, 0, "world_map") for an obstacle at reset (img_env.cpp:169-193, agent.cpp:285-327)
-static void draw_obstacle(uint8_t* grid, int Hg, int Wg, double res, const Tf2& bw, const Pts& bb) {
-    for (int q = 0; q < bb.n(); q++) {
-        double wx, wy;
-        tf_apply(bw, bb.x[q], bb.y[q], wx, wy);
-        const int m = w2m(wx, res), n = w2m(wy, res);
-        if (m >= 0 && m < Hg && n >= 0 && n < Wg) {
-            uint8_t& c = grid[(size_t)m * Wg + n];
-            if (c != 0 && c != 1 && c != 2) c = 0;
-        }
-    }
-}
-
 // Agent::get_corners (agent.cpp:626-651)
 static void get_corners(int shape, const double* s, const Tf2& bw, double& pax, double& pay, double& pbx, double& pby) {
     if (shape == IMGENV_SHAPE_CIRCLE) {

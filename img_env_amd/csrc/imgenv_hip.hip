@@ -85,7 +85,7 @@ struct imgenv {
     bool sparse = false;     // sparse compose (tile lists) instead of the dense pass over every cell
     uint32_t tile_seq = 1;
     size_t n_tiles = 0;
-    std::vector<double> tmp_d0, tmp_d1;
+    std::vector<double> tmp_d1;  // scratch of stage_world
     std::vector<int> tmp_i0;
     int* d_traj_len = nullptr;
     int traj_cap = 0;
@@ -566,6 +566,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             FAIL(IMGENV_EINVAL, "more than %d robot or %d pedestrian classes (shape, size, sensor) in one world", RC_INLINE, PC_INLINE);
         }
         for (size_t c = 0; c < rc.size(); c++) d.rc[c] = rc[c];
+        TRY(dev_upload(h, &d.rc_mem, rc));
         std::vector<PedClassDev> pc(h->pcls.size());
         for (size_t c = 0; c < h->pcls.size(); c++) {
             const PedClassHost& k = h->pcls[c];

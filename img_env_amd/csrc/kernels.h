@@ -468,12 +468,94 @@ __global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions
         const double* r = w.rec + (size_t)(w.r0 + (valid ? l : 0)) * IMGENV_RECORD_DOUBLES;
         bbox_accumulate(w, valid, r[0], r[1]);
     }
-    const bool frozen = valid && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
-    const unsigned long long mask = __ballot(frozen);
-    if (mask != 0 && lane_id() == 0) {
-        atomicAdd(&w.counters[2], __popcll(mask));
-        atomicAdd(&w.counters[3], __popcll(mask));
+}
+
+// The limited command of local robot l (SpeedLimiter::limit, speed_limit.cpp:92-173) ...
+__device__ __forceinline__ void integrate_command(const DevWorld& w, const float* __restrict__ actions, int l, double& v, double& wv, double& v_y) {
+    v = (double)actions[3 * l];
+    wv = (double)actions[3 * l + 1];
+    v_y = (double)actions[3 * l + 2];
+    limiter_limit(w.lv_has_v, w.lv_has_a, w.lv_has_j, w.lv_min_v, w.lv_max_v, w.lv_min_a, w.lv_max_a, w.lv_min_j,
+                  w.lv_max_j, v, w.l0v[l], w.l1v[l], w.step_hz);
+    limiter_limit(w.lw_has_v, w.lw_has_a, w.lw_has_j, w.lw_min_v, w.lw_max_v, w.lw_min_a, w.lw_max_a, w.lw_min_j,
+                  w.lw_max_j, wv, w.l0w[l], w.l1w[l], w.step_hz);
+}
+// ... (cos, sin) of table item `it`: the heading of sub-step it < n_sub (odom.z, rounded as the reference's loop rounds it),
+// the new heading (it == n_sub) and its half (it == n_sub + 1) ...
+__device__ __forceinline__ double2 integrate_heading(double theta, double wv, double step_hz, int it, int n_sub) {
+    double a;
+    if (it < n_sub) {
+        a = theta;
+        for (int q = 0; q < it; q++) a += wv * 0.05;
+    } else {
+        a = theta + wv * step_hz;
+        if (it == n_sub + 1) a = a * 0.5;
     }
+    return make_double2(cos(a), sin(a));
+}
+// ... and the position recurrence with the arrive tests plus the exact arc, over that table (one lane)
+__device__ __forceinline__ void integrate_finish(const DevWorld& w, int l, double* r, double v, double wv, double v_y, double theta,
+                                                 const double2* trig, int n_sub) {
+    const double step_hz = w.step_hz, control_hz = 0.05;
+    w.l1v[l] = w.l0v[l];
+    w.l1w[l] = w.l0w[l];
+    w.l0v[l] = v;
+    w.l0w[l] = wv;
+    bool is_arrive = false;
+    const double gx = w.gx[l], gy = w.gy[l];
+    double ox = r[0], oy = r[1];
+    double vx = r[3], vy = r[4];
+    const bool omni = w.ktype == IMGENV_KTYPE_OMNI;
+    for (int q = 0; q < n_sub; q++) {
+        const double c = trig[q].x, s = trig[q].y;
+        if (!omni) {
+            ox += v * control_hz * c;
+            oy += v * control_hz * s;
+            vx = v * c;
+            vy = v * s;
+        } else {
+            ox += v * control_hz * c - v_y * control_hz * s;
+            oy += v * control_hz * s + v_y * control_hz * c;
+        }
+        const double cur_dist = sqrt((ox - gx) * (ox - gx) + (oy - gy) * (oy - gy));
+        if (cur_dist <= 0.3) {
+            is_arrive = true;
+            break;
+        }
+    }
+    const double dt = step_hz;
+    const double c0 = trig[0].x, s0 = trig[0].y;          // cos / sin(theta): sub-step 0's heading is theta
+    const double c1 = trig[n_sub].x, s1 = trig[n_sub].y;  // cos / sin(theta + w dt)
+    double x = r[0], y = r[1];
+    if (wv == 0) {
+        if (!omni) {
+            x += v * dt * c0;
+            y += v * dt * s0;
+        } else {
+            x += v * dt * c0 - v_y * dt * s0;
+            y += v * dt * s0 + v_y * dt * c0;
+        }
+    } else {
+        const double vw = v / wv;
+        x += -vw * s0 + vw * s1;
+        y += vw * c0 - vw * c1;
+        if (omni) {
+            const double v_yw = v_y / wv;
+            x += -v_yw * c0 + v_yw * c1;
+            y += -v_yw * s0 + v_yw * s1;
+        }
+    }
+    const double th = theta + wv * dt;
+    const double cur_dist = sqrt((x - gx) * (x - gx) + (y - gy) * (y - gy));
+    if (cur_dist <= 0.3) is_arrive = true;
+    r[0] = x;
+    r[1] = y;
+    r[2] = th;
+    r[3] = vx;
+    r[4] = vy;
+    r[5] = trig[n_sub + 1].y;  // Quaternion::setRPY(0,0,theta) of the new pose, shared by the next kernels
+    r[6] = trig[n_sub + 1].x;
+    w.is_arr[l] = is_arrive ? 1 : 0;
 }
 
 #define INT_G 8        // lanes per robot in k_integrate
@@ -502,100 +584,15 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
     const bool valid = l < w.RL;
     const bool alive = valid && !w.py_done[l];  // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
     double* r = w.rec + (size_t)(w.r0 + (valid ? l : 0)) * IMGENV_RECORD_DOUBLES;
-    const double step_hz = w.step_hz, control_hz = 0.05;
     double v = 0, wv = 0, v_y = 0, theta = 0;
     if (alive) {
-        v = (double)actions[3 * l];
-        wv = (double)actions[3 * l + 1];
-        v_y = (double)actions[3 * l + 2];
-        limiter_limit(w.lv_has_v, w.lv_has_a, w.lv_has_j, w.lv_min_v, w.lv_max_v, w.lv_min_a, w.lv_max_a, w.lv_min_j,
-                      w.lv_max_j, v, w.l0v[l], w.l1v[l], step_hz);
-        limiter_limit(w.lw_has_v, w.lw_has_a, w.lw_has_j, w.lw_min_v, w.lw_max_v, w.lw_min_a, w.lw_max_a, w.lw_min_j,
-                      w.lw_max_j, wv, w.l0w[l], w.l1w[l], step_hz);
+        integrate_command(w, actions, l, v, wv, v_y);
         theta = r[2];
-        for (int it = g; it < n_sub + 2; it += INT_G) {
-            double a;
-            if (it < n_sub) {
-                a = theta;
-                for (int q = 0; q < it; q++) a += wv * control_hz;  // odom.z of sub-step `it`, rounded as the loop rounds it
-            } else {
-                a = theta + wv * step_hz;
-                if (it == n_sub + 1) a = a * 0.5;
-            }
-            trig[rb][it] = make_double2(cos(a), sin(a));
-        }
+        for (int it = g; it < n_sub + 2; it += INT_G) trig[rb][it] = integrate_heading(theta, wv, w.step_hz, it, n_sub);
     }
     __syncthreads();
-    if (alive && g == 0) {
-        w.l1v[l] = w.l0v[l];
-        w.l1w[l] = w.l0w[l];
-        w.l0v[l] = v;
-        w.l0w[l] = wv;
-        bool is_arrive = false;
-        const double gx = w.gx[l], gy = w.gy[l];
-        double ox = r[0], oy = r[1];
-        double vx = r[3], vy = r[4];
-        const bool omni = w.ktype == IMGENV_KTYPE_OMNI;
-        for (int q = 0; q < n_sub; q++) {
-            const double c = trig[rb][q].x, s = trig[rb][q].y;
-            if (!omni) {
-                ox += v * control_hz * c;
-                oy += v * control_hz * s;
-                vx = v * c;
-                vy = v * s;
-            } else {
-                ox += v * control_hz * c - v_y * control_hz * s;
-                oy += v * control_hz * s + v_y * control_hz * c;
-            }
-            const double cur_dist = sqrt((ox - gx) * (ox - gx) + (oy - gy) * (oy - gy));
-            if (cur_dist <= 0.3) {
-                is_arrive = true;
-                break;
-            }
-        }
-        const double dt = step_hz;
-        const double c0 = trig[rb][0].x, s0 = trig[rb][0].y;          // cos / sin(theta): sub-step 0's heading is theta
-        const double c1 = trig[rb][n_sub].x, s1 = trig[rb][n_sub].y;  // cos / sin(theta + w dt)
-        double x = r[0], y = r[1];
-        if (wv == 0) {
-            if (!omni) {
-                x += v * dt * c0;
-                y += v * dt * s0;
-            } else {
-                x += v * dt * c0 - v_y * dt * s0;
-                y += v * dt * s0 + v_y * dt * c0;
-            }
-        } else {
-            const double vw = v / wv;
-            x += -vw * s0 + vw * s1;
-            y += vw * c0 - vw * c1;
-            if (omni) {
-                const double v_yw = v_y / wv;
-                x += -v_yw * c0 + v_yw * c1;
-                y += -v_yw * s0 + v_yw * s1;
-            }
-        }
-        const double th = theta + wv * dt;
-        const double cur_dist = sqrt((x - gx) * (x - gx) + (y - gy) * (y - gy));
-        if (cur_dist <= 0.3) is_arrive = true;
-        r[0] = x;
-        r[1] = y;
-        r[2] = th;
-        r[3] = vx;
-        r[4] = vy;
-        r[5] = trig[rb][n_sub + 1].y;  // Quaternion::setRPY(0,0,theta) of the new pose, shared by the next kernels
-        r[6] = trig[rb][n_sub + 1].x;
-        w.is_arr[l] = is_arrive ? 1 : 0;
-    }
+    if (alive && g == 0) integrate_finish(w, l, r, v, wv, v_y, theta, trig[rb], n_sub);
     if (w.sharded) bbox_accumulate(w, valid && g == 0, r[0], r[1]);
-    // robots whose view is frozen this step (agent.cpp:358-360), one atomic per wavefront:
-    // counters[2] since the last reset, counters[3] since create
-    const bool frozen = valid && g == 0 && (w.is_coll[l] != 0 || w.is_arr[l] != 0);
-    const unsigned long long mask = __ballot(frozen);
-    if (mask != 0 && lane_id() == 0) {
-        atomicAdd(&w.counters[2], __popcll(mask));
-        atomicAdd(&w.counters[3], __popcll(mask));
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -608,8 +605,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 //   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
 template <bool POW2, bool TILES>
-__device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Region& g) {
-    const PedClassDev k = w.pc[w.ped_cls[j]];
+__device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     const int world = world_of_ped(w, j);
     const size_t cell0 = (size_t)world * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
@@ -668,8 +664,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const Regio
 // the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
 // second pass over the samples.
 template <bool POW2, bool TILES>
-__device__ __forceinline__ void raster_robot(const DevWorld& w, int i, uint32_t* box, bool zero_vel, const Region& g) {
-    const RobotClassDev k = robot_class(w, w.robot_cls[i]);
+__device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const RobotClassDev& k, uint32_t* box, const Region& g) {
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id();
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
@@ -793,8 +788,14 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     const int b = blockIdx.x;
     WAVE_T0();
     const Region g = grid_region(w);
-    if (b < w.act_ng) raster_robot<POW2, TILES>(w, act_member(w, w.Rw, b), (uint32_t*)smem, zero_vel != 0, g);
-    if (b < w.act_np) raster_ped<POW2, TILES>(w, act_member(w, w.Pw, b), g);
+    if (b < w.act_ng) {
+        const int i = act_member(w, w.Rw, b);
+        raster_robot<POW2, TILES>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
+    }
+    if (b < w.act_np) {
+        const int j = act_member(w, w.Pw, b);
+        raster_ped<POW2, TILES>(w, j, w.pc[w.ped_cls[j]], g);
+    }
     if (b < w.RL) WAVE_DONE(2);
 }
 
@@ -1671,6 +1672,9 @@ __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
     const bool valid = t < w.act_nl;
     const int l = act_member(w, w.Rw, valid ? t : 0);
     int done = 0;
+    // robots whose view was frozen this step (agent.cpp:358-360: collided before this step, or arrived): the collision code
+    // the previous step published, the arrive flag this step's integrate left
+    const bool frozen = valid && !is_reset && (w.is_collisions[l] != 0 || w.is_arr[l] != 0);
     // TimeLimitWrapper counts per world: steps since that world's last reset
     if (valid) done = tail_robot(w, l, is_reset, elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], do_state);
     if (w.sharded && blockIdx.x == 0 && threadIdx.x < 4)  // the rasters of this step are done with the box: re-arm it
@@ -1679,5 +1683,10 @@ __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
         for (int q = threadIdx.x; q < TILE_LISTS; q += blockDim.x) w.tile_count[((w.tile_seq & 1u) ^ 1u) * TILE_LISTS + q] = 0;
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
+    const unsigned long long fmask = __ballot(frozen);  // counters[2] since the last reset, counters[3] since create
+    if (fmask != 0 && lane_id() == 0) {
+        atomicAdd(&w.counters[2], __popcll(fmask));
+        atomicAdd(&w.counters[3], __popcll(fmask));
+    }
 }
 

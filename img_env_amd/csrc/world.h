@@ -103,6 +103,7 @@ struct DevWorld {
     RobotClassDev rc[RC_INLINE];
     PedClassDev pc[PC_INLINE];
     const PedClassDev* pc_mem;  // the same records in HBM, for per-lane (divergent) class lookups
+    const RobotClassDev* rc_mem;
     const int* robot_cls;  // [R]
     const int* ped_cls;    // [P]
     const double* robot_size_last;  // [R]
