@@ -918,9 +918,9 @@ __device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, si
 // bresenhamLine (agent.cpp:511-624) writes laser_map beam after beam, later beams overwriting earlier
 // ones, so a cell ends with the value of the HIGHEST beam that writes it.  Beam paths are static, so
 //   (a) hit[b]: every lane walks the precomputed path of its beams in LDS (8 steps per 16-byte load);
-//       a step contributes key = value << 24 | step << 16 | cell and the minimum key is the first
-//       occupied cell (value 0) -- no compares, no selects; the wave leaves the loop as soon as all
-//       its beams have hit or ended;
+//       a step contributes a 16-bit key = value << 8 | step, two steps side by side in one register, and
+//       the minimum key is the first occupied cell (value 0) -- no compares, no selects; the wave leaves
+//       the loop as soon as all its beams have hit or ended;
 //   (b) every view cell looks at the highest beam through it (static table `top_ent`): 255 before that
 //       beam's hit, 0 at the hit, 200 behind it -- unless the cell shares a row or column with the hit
 //       cell, where that beam leaves the cell alone (agent.cpp:555-560) and the next lower beam through
@@ -949,6 +949,12 @@ __device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, co
         }
     }
     return best;
+}
+
+// v_pk_min_u16: the minimum of the low halves and of the high halves
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 
 // laser_map value of a cell its top beam leaves alone: the next lower beam through the cell that writes decides
@@ -982,6 +988,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const uint32_t wv_magic = w.wv_magic;
     const bool laser = w.use_laser != 0;
     const uint32_t self = (uint32_t)i;
+    const uint32_t free_plain = CLS_HIGH, free_own = CLS_HIGH | CLS_ROBOT | (self << 8);  // the two `cell` values this robot sees as free
     const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;  // this world's copy of the layers
     uint8_t* src = smem;
     uint32_t* hit = (uint32_t*)(smem + NCp);
@@ -1061,17 +1068,21 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
             uint32_t idx[4], okm[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const bool ok = (A4 || c4 + q < NC) & (((fov >> q) & 1u) != 0) & (m[q] >= 0) & (m[q] < Hg) & (n[q] >= 0) & (n[q] < Wg);
+                const bool ok = (A4 || c4 + q < NC) & (((fov >> q) & 1u) != 0) & ((uint32_t)m[q] < (uint32_t)Hg) & ((uint32_t)n[q] < (uint32_t)Wg);
                 okm[q] = ok ? 0xFFu : 0u;
                 idx[q] = ok ? cell0 + (uint32_t)(m[q] * Wg + n[q]) : 0u;
             }
             uint32_t v[4];
 #pragma unroll
+#ifdef IMGENV_EXP_CROP_U8
+            for (int q = 0; q < 4; q++) v[q] = ((const uint8_t*)w.cell)[idx[q]];  // timing experiment: byte gathers
+#else
             for (int q = 0; q < 4; q++) v[q] = w.cell[idx[q]];
+#endif
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const bool other = ((v[q] & CLS_ROBOT) != 0) & ((v[q] >> 8) != self);
-                const bool free_cell = ((v[q] & 7u) == CLS_HIGH) & !other;
+                // free (>= 250, agent.cpp:394-401) and no other robot on it: the plain class, or this robot as the only owner
+                const bool free_cell = (v[q] == free_plain) | (v[q] == free_own);
                 const uint32_t val = free_cell ? 255u : 0u;
                 packed = (packed & ~(okm[q] << (8 * q))) | ((val & okm[q]) << (8 * q));
             }
@@ -1095,26 +1106,33 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
             const int b = b0 + lane;
             const int bb = min(b, w.B - 1);
             const int len = b < w.B ? (int)k.ray_len[bb] : 0;
-            uint32_t found = 0xFFFFFFFFu;
+            // two 16-bit keys side by side, value << 8 | step (a path has at most 255 steps): even steps in the low half,
+            // odd ones in the high half, one packed min for both
+            uint32_t found2 = 0xFFFFFFFFu;
             uint4 nxt = rows[bb];
             for (int ch = 0; ch < n_chunks; ch++) {
                 const uint4 cur = nxt;
                 if (ch + 1 < n_chunks) nxt = rows[(size_t)(ch + 1) * k.ray_stride + bb];  // in flight while this chunk is walked
                 const uint32_t wds[4] = {cur.x, cur.y, cur.z, cur.w};
+                const uint32_t steps0 = (uint32_t)(8 * ch) * 0x00010001u + 0x00010000u;  // (8 ch + 1) << 16 | 8 ch
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t c = (wds[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;  // padded entries point at the free dummy cell
-                    const uint32_t key = ((uint32_t)src[c] << 24) | ((uint32_t)(8 * ch + j) << 16) | c;
-                    found = min(found, key);
+                for (int j = 0; j < 4; j++) {  // padded entries point at the free dummy cell
+                    const uint32_t lo = src[wds[j] & 0xFFFFu], hi = src[wds[j] >> 16];
+                    const uint32_t two = __builtin_amdgcn_perm(hi, lo, 0x040C000Cu) | (steps0 + (uint32_t)j * 0x00020002u);
+                    found2 = pk_min_u16(found2, two);
                 }
-                if (__all((found < 0x01000000u) | (8 * ch + 8 >= len))) break;
+                const uint32_t first = min(found2 & 0xFFFFu, found2 >> 16);
+                if (__all((first < 0x0100u) | (8 * ch + 8 >= len))) break;
             }
             if (b < w.B) {
-                const bool has = found < 0x01000000u;  // value 0 in the top byte
-                const uint32_t hk = (found >> 16) & 0xFFu, hc = found & 0xFFFFu;
+                const uint32_t first = min(found2 & 0xFFFFu, found2 >> 16);
+                const bool has = first < 0x0100u;  // value 0 in the key's top byte
+                const uint32_t hk = first & 0xFFu;
+                // the cell of that step comes back out of the path table (one more load per beam, beside the distance's)
+                const uint32_t hc = has ? ((const uint16_t*)rows)[((size_t)(hk >> 3) * k.ray_stride + b) * 8 + (hk & 7u)] : 0u;
+                const float hd = has ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
                 const uint32_t hx = __umulhi(hc, wv_magic), hy = hc - hx * (uint32_t)Wv;
                 hit[b] = has ? ((hk << 16) | (hx << 8) | hy) : 0xFFFFFFFFu;
-                const float hd = has ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
                 w.lasers_raw[(size_t)l * w.B + b] = hd;
                 w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
             }
@@ -1684,9 +1702,9 @@ __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
     const unsigned long long fmask = __ballot(frozen);  // counters[2] since the last reset, counters[3] since create
-    if (fmask != 0 && lane_id() == 0) {
-        atomicAdd(&w.counters[2], __popcll(fmask));
-        atomicAdd(&w.counters[3], __popcll(fmask));
+    if (fmask != 0 && lane_id() == 0) {  // (both counters with one 64-bit add: neither gets anywhere near 2^31 between resets)
+        const unsigned long long n = (unsigned long long)__popcll(fmask);
+        atomicAdd((unsigned long long*)(w.counters + 2), n | (n << 32));
     }
 }
 
