@@ -301,6 +301,27 @@ def test_two_thousand_robots_match_oracle(worlds):
         cpu.close()
 
 
+def test_headline_world_matches_oracle(worlds):
+    """BASELINE cfg-3 at full size, the world `bench.py` times: 8192 robots and 200 ORCA pedestrians on the 400 x 400 map at
+    0.25 m, every output of every robot against the oracle for a few steps (the oracle needs ~0.6 s per step)"""
+    World, OracleWorld = worlds
+    from img_env_amd import worldgen
+    n, P = 8192, 200
+    grid = worldgen.make_grid(400, 0)
+    params = worldgen.make_params(n, P, res=0.25, view_cells=48, beams=360, scene="rvoscene", time_max=100)
+    layout = worldgen.make_layout(grid, 0.25, n, P, seed=100, clearance=0.7)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(10)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(5)])
+        assert not fails, fails[:3]
+        snap = cpu.snapshot()
+        assert (snap["is_collisions"] != 0).sum() > 50 and snap["counters"][0] == 5
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def test_quadtree_overflow_is_reported(worlds):
     """more than 8 social-force agents outside the 10 m x 10 m root square of libpedsim's quadtree: the reference recurses
     forever (ped_tree.cpp:65-96); the library raises the device flag and the next call fails loudly"""
