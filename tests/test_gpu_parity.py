@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from parity import compare, run_pair
+from parity import CLOSE, EXACT, compare, run_pair
 from scenarios import clip_actions, golden_scenario, random_actions, small_world
 
 pytestmark = pytest.mark.gpu
@@ -317,6 +317,93 @@ def test_headline_world_matches_oracle(worlds):
         assert not fails, fails[:3]
         snap = cpu.snapshot()
         assert (snap["is_collisions"] != 0).sum() > 50 and snap["counters"][0] == 5
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_cfg5_world_matches_oracle(worlds):
+    """BASELINE cfg-5 at full size (one GPU's worth of it): 8192 robots, 1000 ERVO pedestrians, 800 x 800 map at 0.125 m,
+    96 x 96 views, 720 beams -- the 16-slot register sort of k_obs, 36 KB of LDS per view"""
+    World, OracleWorld = worlds
+    from img_env_amd import worldgen
+    n, P = 8192, 1000
+    grid = worldgen.make_grid(800, 0)
+    params = worldgen.make_params(n, P, res=0.125, view_cells=96, beams=720, scene="ervoscene", time_max=100)
+    layout = worldgen.make_layout(grid, 0.125, n, P, seed=100, clearance=0.7)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(11)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(2)])
+        assert not fails, fails[:3]
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_cfg2_world_matches_oracle(worlds):
+    """BASELINE cfg-2 at full size: 1024 robots, no pedestrians, 400 x 400 map at 0.125 m"""
+    World, OracleWorld = worlds
+    from img_env_amd import worldgen
+    n = 1024
+    grid = worldgen.make_grid(400, 0)
+    params = worldgen.make_params(n, 0, res=0.125, view_cells=48, beams=360, scene="", time_max=100)
+    layout = worldgen.make_layout(grid, 0.125, n, 0, seed=100, clearance=1.0)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(12)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(12)])
+        assert not fails, fails[:3]
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_cfg4_share_matches_oracle(worlds):
+    """one GPU's share of BASELINE cfg-4: 8192 robots at 0.5 m cells beside a 200-agent social-force crowd (the crowd ignores
+    the robots: with relation_ped_robo = 1 the reference node itself recurses forever beyond 8 robots).
+
+    What a crowd of this size shows and the small pedsim cases do not: Tagent::socialForce switches a full-size force term on
+    sign(theta), theta being the difference of two atan2 of NEARLY PARALLEL vectors -- exactly parallel up to rounding while
+    everybody stands still, i.e. on the first step after a reset.  The device's atan2 is correctly rounded (cr_atan2.h);
+    glibc 2.35's, which the reference and hence the oracle use, misrounds ~0.03-0.1 % of its inputs by one ulp, and each of
+    those 40 000 pair terms then has a small chance to come out with the other sign (checked on the CPU: exactly the
+    pedestrians that deviate are the ones with such a pair).  Which sign is "right" depends on the libm the reference happens
+    to run on, so the bar here is: everything that does not depend on that coin is exact on the first step, and only about
+    one pedestrian in twelve (40 000 pairs x ~0.05 %) carries a flipped term.  Velocities persist across resets
+    (pedscene.h:34-36 only sets positions), so this state -- a whole crowd exactly at rest -- exists once per handle, on the
+    first step of its first episode."""
+    World, OracleWorld = worlds
+    from img_env_amd import worldgen
+    n, P = 8192, 200
+    grid = worldgen.make_grid(400, 0)
+    params = worldgen.make_params(n, P, res=0.5, view_cells=48, beams=360, scene="pedscene", time_max=100, relation_ped_robo=0)
+    layout = worldgen.make_layout(grid, 0.5, n, P, seed=100, clearance=0.55)
+    # the crowd stays inside libpedsim's 10 m x 10 m quadtree root (pedscene.h:17-20)
+    rng = np.random.default_rng(13)
+    layout.ped_pose[:, :2] = rng.uniform(0.5, 9.5, (P, 2))
+    layout.ped_traj[:, :, :2] = rng.uniform(0.5, 9.5, layout.ped_traj[:, :, :2].shape)
+    layout.ped_goal[:] = rng.uniform(0.5, 9.5, (P, 2))
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        gpu.reset(layout)
+        cpu.reset(layout)
+        assert not compare(gpu.snapshot(), cpu.snapshot())
+        a = random_actions(rng, n)
+        gpu.step(a)
+        cpu.step(a)
+        g, c = gpu.snapshot(), cpu.snapshot()
+        crowd_velocity = ("ped_state", "ped_vector_states", "ped_maps")  # the fields that carry pedestrian velocities
+        bad = compare(g, c, tuple(f for f in EXACT + CLOSE if f not in crowd_velocity))
+        assert not bad, bad
+        assert np.abs(g["ped_state"][:, :2] - c["ped_state"][:, :2]).max() <= 1e-9  # nobody has moved yet (v was 0)
+        dv = np.abs(g["ped_state"][:, 2:] - c["ped_state"][:, 2:]).max(axis=1)
+        assert (dv > 1e-9).sum() <= 0.15 * P and dv.max() < 0.2, (int((dv > 1e-9).sum()), float(dv.max()))
+        for _ in range(2):  # and the crowd keeps running
+            a = random_actions(rng, n)
+            gpu.step(a)
+            cpu.step(a)
+        assert np.abs(gpu.snapshot()["ped_state"] - cpu.snapshot()["ped_state"]).max() < 0.5
     finally:
         gpu.close()
         cpu.close()
