@@ -25,7 +25,8 @@
  *  - all *output* pointers handed out by imgenv_outputs() are DEVICE pointers owned by the
  *    handle, valid until imgenv_destroy(); their contents are valid after the stream work of
  *    the last reset/step has completed and are overwritten by the next step.
- *  - one handle is one world (one ImgEnv node, img_env.h:171-172) and is single-threaded
+ *  - one handle is one world (one ImgEnv node, img_env.h:171-172) -- or imgenv_cfg.n_worlds of them,
+ *    the reference's env_num nodes batched into one set of launches -- and is single-threaded
  *    like the node (ros::spin, img_env_node.cpp:8); distinct handles are independent.
  *  - fields that are float32 in the ROS messages are `float` here and are promoted to
  *    double inside exactly where the node reads them (img_env.cpp:58-81, 113-160), so the
@@ -203,7 +204,8 @@ typedef struct imgenv_out {
     /* simulator state mirrors, handy for tests and GUIs */
     double* robot_pose;           /* [R][3] x, y, theta */
     double* ped_state;            /* [n_peds][4] x, y, vx, vy (world copy) */
-    int32_t* counters;            /* [4]: steps since reset, #done robots of the last step (local), #frozen views since reset (local), #frozen views since create */
+    int32_t* counters;            /* [4]: steps since reset (n_worlds > 1: of world 0), #done robots of the last step (local),
+                                   * #frozen views since the last imgenv_reset (local), #frozen views since create */
 } imgenv_out;
 
 typedef struct imgenv imgenv_t;
