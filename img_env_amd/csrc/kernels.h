@@ -4,12 +4,15 @@
 //                                        write-back, leg gait (img_env.cpp:344-358) or the recorded trajectory (361-386)
 //   k_sfm          1 workgroup / world   libpedsim crowd step (pedscene only)
 //   k_raster       1 wave / ped + robot  view_ped + the shared robot-owner layers (img_env.cpp:594-629)
-//   k_compose      1 thread / 4 cells    composed layer = obstacles + peds + robot owners
+//   k_compose      1 thread / 4 cells    composed layer = obstacles + peds + robot owners (k_compose_tiles: only the 8 x 8 tiles
+//                                        the rasters touched, for big or many maps)
 //   k_view         1 wave / robot        Agent::view: collision, crop, laser, stamp (agent.cpp:356-509)
 //   k_obs<E>       1 wave / robot        PedInfo, sorted ped vector, ped_map (img_env.cpp:568-584, yaml_env.py:392-456)
 //   k_side_robots  1 thread / robot      RVO robot records + Agent::get_state (agent.cpp:156-184), on a side stream
 //   k_orca         1 wave / pedestrian   waypoint logic + ORCA half-planes + LP (img_env.cpp:304-343), on a side stream
 //   k_tail         1 thread / robot      step_ds, reward / done wrappers (yaml_env.py:446-481, base.py:153-254)
+// A handle may hold several independent worlds (DevWorld::W): robots and pedestrians are numbered world-major, every grid
+// layer exists once per world, and a launch covers everything or the worlds listed in DevWorld::act_list (a reset).
 //
 // This is gather / raster / scan work on bytes and small integers: no MFMA.  What matters is
 // wave-per-robot decomposition, LDS staging of the 48x48 windows and pedestrian lists, coalesced
@@ -859,7 +862,7 @@ __global__ void k_compose(DevWorld w) {
         c0 = base + ((size_t)(blockIdx.x - q * per_world) * blockDim.x + threadIdx.x) * 4;
         G = base + w.Gs;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_obs tallies this step's dones
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_tail tallies this step's dones
     if (c0 >= G) return;
     if (w.sharded) {  // only the region this rank's rasters were clipped to (everything else is clean and unread)
         const Region g = grid_region(w);
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(256) void k_compose_tiles(DevWorld w) {
     const bool prev = blockIdx.y >= TILE_LISTS;
     const uint32_t which = (prev ? cur ^ 1u : cur) * TILE_LISTS + sub;
     const int n_list = min(w.tile_count[which], w.tile_cap);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_obs tallies this step's dones
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_tail tallies this step's dones
     const int part = threadIdx.x & 15;
     for (int slot = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4); slot < n_list; slot += (int)((gridDim.x * blockDim.x) >> 4)) {
         const uint32_t t = w.tile_list[(size_t)which * w.tile_cap + slot];
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = act_member(w, w.Rw, blockIdx.x);
     const int lane = lane_id();
-    if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: every per-robot output keeps its last value (counted in k_integrate)
+    if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: every per-robot output keeps its last value (counted in k_tail)
     const int i = w.r0 + l;
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
