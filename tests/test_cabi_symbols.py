@@ -31,8 +31,8 @@ def hip_lib():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    for must in ("imgenv_create", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end", "imgenv_outputs",
-                 "imgenv_destroy", "imgenv_comm_init"):
+    for must in ("imgenv_create", "imgenv_reset", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_step", "imgenv_step_begin",
+                 "imgenv_step_end", "imgenv_outputs", "imgenv_destroy", "imgenv_comm_init"):
         assert must in names
 
 

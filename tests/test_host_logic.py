@@ -107,3 +107,20 @@ def test_unsupported_spawn_layouts_fail_loudly():
     cfg["robot"]["begin_poses_type"] = ["circle", "circle"]
     with pytest.raises(NotImplementedError):
         spawn.EnvPos(cfg, seed=0).reset(25.0)
+
+
+def test_stack_params_repeats_one_env_world_major():
+    """VecImageEnv's parameter dict: env_num copies of one env's per-robot / per-pedestrian rows, totals and n_worlds"""
+    from img_env_amd import worldgen
+    from img_env_amd.vec_env import stack_params
+    p = worldgen.make_params(3, 2, ped_shape="leg")
+    p["robot_size"][1, 2] = 0.25
+    q = stack_params(p, 4)
+    assert (q["n_robots"], q["n_peds"], q["n_worlds"]) == (12, 8, 4)
+    assert q["robot_size"].shape == (12, 4) and q["ped_size"].shape == (8, 6) and q["robot_size_last"].shape == (12,)
+    for k in range(4):
+        assert np.array_equal(q["robot_size"][3 * k:3 * k + 3], p["robot_size"])
+        assert np.array_equal(q["ped_max_speed"][2 * k:2 * k + 2], p["ped_max_speed"])
+    assert p["n_robots"] == 3 and "n_worlds" not in p  # the input is left alone
+    cfg, keep = __import__("img_env_amd._cabi", fromlist=["make_cfg"]).make_cfg(q)
+    assert (cfg.n_worlds, cfg.n_robots, cfg.n_peds) == (4, 12, 8)
