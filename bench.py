@@ -283,8 +283,11 @@ def main():
         world.close()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from multiworld_probe import measure
-        multi_world = [measure(E, RL // E, pw, 200, res=0.125, steps=args.steps, warmup=300, time_max=TIME_MAX, kernels=False, device=local_rank)
-                       for E, pw in ((64, 16), (RL, 0))]
+        try:
+            multi_world = [measure(E, RL // E, pw, 200, res=0.125, steps=args.steps, warmup=300, time_max=TIME_MAX, kernels=False,
+                                   device=local_rank) for E, pw in ((64, 16), (RL, 0))]
+        except Exception as e:  # a secondary number must never cost the headline line
+            multi_world = {"error": repr(e)}
 
     if rank == 0:
         ab = algorithmic_bytes(P)
@@ -326,7 +329,10 @@ def main():
         }
         if world_size == 1 and not args.no_cpu_baseline:
             p1 = dict(params)
-            out["cpu_baseline"] = cpu_baseline(p1, grid, layouts[0])
+            try:
+                out["cpu_baseline"] = cpu_baseline(p1, grid, layouts[0])
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "unit": "robot-steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
     world.close()
     if use_dist:
