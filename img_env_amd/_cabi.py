@@ -65,6 +65,24 @@ class ResetBatch(C.Structure):
     ]
 
 
+POSE_FIX, POSE_RAND_ANGLE, POSE_RANGE, POSE_RANGE_YAW, POSE_RANGE_VIEW = 0, 1, 2, 3, 4
+
+
+class SpawnAgent(C.Structure):
+    _fields_ = [("begin_type", _i32), ("target_type", _i32), ("begin", C.c_double * 6), ("target", C.c_double * 6),
+                ("module_size", C.c_double)]
+
+
+class SpawnObstacle(C.Structure):
+    _fields_ = [("shape", _i32), ("pose_type", _i32), ("size_range", C.c_double * 4), ("pose", C.c_double * 6)]
+
+
+class SpawnCfg(C.Structure):
+    _fields_ = [("struct_size", _i32), ("n_robots", _i32), ("n_peds", _i32), ("n_obstacles", _i32),
+                ("agents", C.POINTER(SpawnAgent)), ("obstacles", C.POINTER(SpawnObstacle)),
+                ("clearance", C.c_double), ("target_min_dist", C.c_double), ("go_back", _i32), ("ignore_obstacle", _i32)]
+
+
 class Out(C.Structure):
     _fields_ = [
         ("struct_size", _i32), ("n_local", _i32), ("view_h", _i32), ("view_w", _i32), ("n_beams", _i32),
@@ -213,7 +231,8 @@ def make_reset_batch(b, n_robots, n_peds):
 SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_create", "imgenv_arena_bytes",
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
-           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_reset_world", "imgenv_reset_worlds")
+           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
+           "imgenv_reset_worlds_spawn")
 K_COUNT = 8
 
 
@@ -237,6 +256,9 @@ def bind(lib):
     lib.imgenv_reset.argtypes = [C.c_void_p, C.POINTER(ResetBatch), C.c_void_p]
     lib.imgenv_reset_world.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ResetBatch), C.c_void_p]
     lib.imgenv_reset_worlds.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(ResetBatch), C.c_void_p]
+    lib.imgenv_spawn.argtypes = [C.POINTER(SpawnCfg), C.c_uint64] + [C.c_void_p] * 9
+    lib.imgenv_reset_worlds_spawn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(SpawnCfg),
+                                              C.POINTER(C.c_uint64), C.c_void_p]
     lib.imgenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.imgenv_step_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.imgenv_step_end.argtypes = [C.c_void_p, C.c_void_p]

@@ -15,6 +15,7 @@
 #define WAVE_SZ 64
 #include "../../include/imgenv.h"
 #include "host_tables.h"
+#include "spawn_host.h"
 #include "kernels.h"
 #include "world.h"
 
@@ -1532,6 +1533,57 @@ extern "C" int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds
     for (char r : h->world_ready) all = all && r;
     h->has_reset = all;
     return IMGENV_OK;
+}
+
+static int spawn_cfg_check(const imgenv_spawn_cfg* c) {
+    if (!c) FAIL(IMGENV_EINVAL, "null argument");
+    if (c->struct_size != (int32_t)sizeof(imgenv_spawn_cfg)) FAIL(IMGENV_EINVAL, "spawn cfg ABI mismatch");
+    if (c->n_robots < 0 || c->n_peds < 0 || c->n_obstacles < 0 || (c->n_robots + c->n_peds > 0 && !c->agents) ||
+        (c->n_obstacles > 0 && !c->obstacles) || !(c->clearance >= 0))
+        FAIL(IMGENV_EINVAL, "bad spawn cfg");
+    for (int i = 0; i < c->n_robots + c->n_peds; i++) {
+        const imgenv_spawn_agent& a = c->agents[i];
+        if (a.begin_type < IMGENV_POSE_FIX || a.begin_type > IMGENV_POSE_RANGE_YAW || a.target_type < IMGENV_POSE_FIX ||
+            a.target_type > IMGENV_POSE_RANGE_VIEW)
+            FAIL(IMGENV_EINVAL, "agent %d: unsupported pose type (%d, %d)", i, a.begin_type, a.target_type);
+    }
+    return 0;
+}
+
+extern "C" int imgenv_spawn(const imgenv_spawn_cfg* cfg, uint64_t seed, double* robot_pose, double* robot_goal, double* ped_pose,
+                            double* ped_goal, double* ped_traj, int32_t* ped_traj_len, int32_t* obs_shape, float* obs_size,
+                            double* obs_pose) {
+    if (int rc = spawn_cfg_check(cfg)) return rc;
+    SpawnOut o;
+    if (const char* why = spawn_world(*cfg, seed, o)) FAIL(IMGENV_EINVAL, "spawn: %s", why);
+    const size_t R = cfg->n_robots, P = cfg->n_peds, O = cfg->n_obstacles;
+    if (robot_pose) memcpy(robot_pose, o.robot_pose.data(), sizeof(double) * 4 * R);
+    if (robot_goal) memcpy(robot_goal, o.robot_goal.data(), sizeof(double) * 2 * R);
+    if (ped_pose) memcpy(ped_pose, o.ped_pose.data(), sizeof(double) * 4 * P);
+    if (ped_goal) memcpy(ped_goal, o.ped_goal.data(), sizeof(double) * 2 * P);
+    if (ped_traj) memcpy(ped_traj, o.ped_traj.data(), sizeof(double) * 6 * P);
+    if (ped_traj_len) memcpy(ped_traj_len, o.ped_traj_len.data(), sizeof(int32_t) * P);
+    if (obs_shape) memcpy(obs_shape, o.obs_shape.data(), sizeof(int32_t) * O);
+    if (obs_size) memcpy(obs_size, o.obs_size.data(), sizeof(float) * 4 * O);
+    if (obs_pose) memcpy(obs_pose, o.obs_pose.data(), sizeof(double) * 4 * O);
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_reset_worlds_spawn(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_spawn_cfg* cfg,
+                                         const uint64_t* seeds, void* stream) {
+    if (!h || !worlds || !seeds) FAIL(IMGENV_EINVAL, "null argument");
+    if (int rc = spawn_cfg_check(cfg)) return rc;
+    if (cfg->n_robots != h->Rw || cfg->n_peds != h->Pw)
+        FAIL(IMGENV_EINVAL, "spawn cfg is for %d robots / %d pedestrians, a world of this handle has %d / %d", cfg->n_robots,
+             cfg->n_peds, h->Rw, h->Pw);
+    if (n <= 0) return IMGENV_OK;
+    std::vector<SpawnOut> outs((size_t)n);
+    std::vector<imgenv_reset_batch> batches((size_t)n);
+    for (int q = 0; q < n; q++) {
+        if (const char* why = spawn_world(*cfg, seeds[q], outs[q])) FAIL(IMGENV_EINVAL, "spawn of world %d: %s", worlds[q], why);
+        batches[q] = outs[q].batch;
+    }
+    return imgenv_reset_worlds(h, n, worlds, batches.data(), stream);
 }
 
 extern "C" int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset_batch* b, void* stream) {

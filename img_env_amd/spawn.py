@@ -175,3 +175,81 @@ def init_ped_dataset(layout, ped_pos_v_datas):
     pose[:, 2], pose[:, 3] = np.sin(d[:, 0, 2] / 2.0), np.cos(d[:, 0, 2] / 2.0)
     layout.ped_pose = pose
     return layout
+
+
+# ------------------------------------------------------------------------------------------------ native spawn
+def _pose_type(t, values, target):
+    """pose type string of the reference YAML (reset_helper.py:187-300) -> IMGENV_POSE_*"""
+    if "circle" in t or "multi" in t or "plus" in t:
+        raise NotImplementedError("pose type %r (reset_helper.py circle/multi layouts) is not implemented" % t)
+    if t == "fix":
+        return _cabi.POSE_FIX
+    if t == "rand_angle":
+        return _cabi.POSE_RAND_ANGLE
+    if target and "view" in t:
+        return _cabi.POSE_RANGE_VIEW
+    return _cabi.POSE_RANGE if len(values) == 4 else _cabi.POSE_RANGE_YAW
+
+
+def make_spawn_cfg(cfg):
+    """The reference YAML's spawn section as an ``imgenv_spawn_cfg`` (one env's cast): ``(struct, keepalive)``.
+    The same fields ``EnvPos`` reads; the placement then runs inside the library (``csrc/spawn_host.h``)."""
+    import ctypes as C
+    nr, npd = int(cfg["robot"]["total"]), int(cfg["ped_sim"]["total"])
+    n = nr + npd
+    btype = cfg["robot"]["begin_poses_type"][:nr] + cfg["ped_sim"]["begin_poses_type"][:npd]
+    ttype = cfg["robot"]["target_poses_type"][:nr] + cfg["ped_sim"]["target_poses_type"][:npd]
+    bpose = cfg["robot"]["begin_poses"][:nr] + cfg["ped_sim"]["begin_poses"][:npd]
+    tpose = cfg["robot"]["target_poses"][:nr] + cfg["ped_sim"]["target_poses"][:npd]
+    sizes = cfg["robot"]["size"][:nr] + cfg["ped_sim"]["size"][:npd]
+    shapes = cfg["robot"]["shape"][:nr] + cfg["ped_sim"]["shape"][:npd]
+    agents = (_cabi.SpawnAgent * max(n, 1))()
+    for i in range(n):
+        a = agents[i]
+        a.begin_type, a.target_type = _pose_type(btype[i], bpose[i], False), _pose_type(ttype[i], tpose[i], True)
+        for k, v in enumerate(bpose[i][:6]):
+            a.begin[k] = float(v)
+        for k, v in enumerate(tpose[i][:6]):
+            a.target[k] = float(v)
+        a.module_size = 2 * _module_size(sizes[i], shapes[i])
+    o = cfg["object"]
+    nob = int(o["total"])
+    obstacles = (_cabi.SpawnObstacle * max(nob, 1))()
+    for i in range(nob):
+        q = obstacles[i]
+        q.shape = _cabi.SHAPE_CIRCLE if o["shape"][i] == "circle" else _cabi.SHAPE_RECTANGLE
+        pr = o["poses"][i]
+        if o["poses_type"][i] == "fix":
+            q.pose_type = _cabi.POSE_FIX
+            pr = list(pr) + [0] if len(pr) == 2 else list(pr)
+        else:
+            q.pose_type = _cabi.POSE_RANGE if len(pr) == 4 else _cabi.POSE_RANGE_YAW
+        for k, v in enumerate(o["size_range"][i][:4]):
+            q.size_range[k] = float(v)
+        for k, v in enumerate(pr[:6]):
+            q.pose[k] = float(v)
+    c = _cabi.SpawnCfg()
+    c.struct_size = C.sizeof(_cabi.SpawnCfg)
+    c.n_robots, c.n_peds, c.n_obstacles = nr, npd, nob
+    c.agents = C.cast(agents, C.POINTER(_cabi.SpawnAgent))
+    c.obstacles = C.cast(obstacles, C.POINTER(_cabi.SpawnObstacle))
+    c.clearance = float(cfg.get("spawn_clearance", 1.0))
+    c.target_min_dist = float(cfg["target_min_dist"])
+    c.go_back = {"yes": 1, "random": 2}.get(cfg["ped_sim"].get("go_back", "yes"), 0)
+    c.ignore_obstacle = int(bool(cfg["ped_sim"].get("ignore_obstacle", False)))
+    return c, (agents, obstacles)
+
+
+def native_spawn(cfg, seed, spawn_cfg=None):
+    """One placement by the library's own spawn (``imgenv_spawn``; no device needed) as a ``ResetLayout``."""
+    import ctypes as C
+    lib = _cabi.load_library()
+    c, keep = spawn_cfg if spawn_cfg is not None else make_spawn_cfg(cfg)
+    R, P, O = c.n_robots, c.n_peds, c.n_obstacles
+    out = dict(robot_pose=np.zeros((R, 4)), robot_goal=np.zeros((R, 2)), ped_pose=np.zeros((P, 4)), ped_goal=np.zeros((P, 2)),
+               ped_traj=np.zeros((P, 2, 3)), ped_traj_len=np.zeros(P, np.int32), obs_shape=np.zeros(O, np.int32),
+               obs_size=np.zeros((O, 4), np.float32), obs_pose=np.zeros((O, 4)))
+    rc = lib.imgenv_spawn(C.byref(c), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), *[a.ctypes.data for a in out.values()])
+    if rc != 0:
+        raise RuntimeError("imgenv_spawn failed (%d): %s" % (rc, lib.imgenv_last_error().decode()))
+    return ResetLayout(ignore_obstacle=bool(c.ignore_obstacle), **out)

@@ -116,6 +116,18 @@ class World:
         self._check(self.lib.imgenv_reset_worlds(self.h, n, ids, arr, self._stream()), "imgenv_reset_worlds")
         return self.out
 
+    def reset_worlds_spawn(self, worlds, spawn_cfg, seeds):
+        """Reset the listed worlds from fresh random placements made inside the library (``imgenv_reset_worlds_spawn``):
+        ``spawn_cfg`` = what ``spawn.make_spawn_cfg`` returned, ``seeds[q]`` seeds world ``worlds[q]``."""
+        n = len(worlds)
+        if n == 0:
+            return self.out
+        ids = (C.c_int32 * n)(*[int(k) for k in worlds])
+        sd = (C.c_uint64 * n)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds])
+        self._check(self.lib.imgenv_reset_worlds_spawn(self.h, n, ids, C.byref(spawn_cfg[0]), sd, self._stream()),
+                    "imgenv_reset_worlds_spawn")
+        return self.out
+
     def reset_world(self, world, layout):
         """Reset ONE world of a multi-world handle (ImageEnv.reset of one env process, yaml_env.py:296-317); the others
         keep their state and their time limits.  ``layout`` holds that world's robots, pedestrians and obstacles."""

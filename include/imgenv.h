@@ -270,6 +270,51 @@ int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset_batch* bat
  * of envs. */
 int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_reset_batch* batches, void* stream);
 
+/* ---- spawn: the random placement EnvPos.reset does for one episode (envs/utils/reset_helper.py:104-345), natively ----
+ * A world of a multi-world handle is reset whenever its episode ends -- dozens of worlds on every step -- so the placement
+ * itself has to be cheap.  Rules as in the reference (starts > clearance apart and clear of the obstacles; targets
+ * > target_min_dist from their start, > clearance apart, clear of the obstacles; range_view targets in the 4 m box around
+ * the start but outside its 2.5 m box; pedestrians walk to their target and, with go_back, back); the random stream is
+ * the library's own (seeded per world), not Python's.  Pose types of reset_helper.py:187-300: */
+#define IMGENV_POSE_FIX 0         /* [x, y, yaw] */
+#define IMGENV_POSE_RAND_ANGLE 1  /* [x, y, yaw_lo, yaw_hi] */
+#define IMGENV_POSE_RANGE 2       /* [x_lo, x_hi, y_lo, y_hi], yaw uniform in +-3.14 */
+#define IMGENV_POSE_RANGE_YAW 3   /* [x_lo, x_hi, y_lo, y_hi, yaw_lo, yaw_hi] */
+#define IMGENV_POSE_RANGE_VIEW 4  /* targets only: [x_lo, x_hi, y_lo, y_hi], drawn around the start (random_view, 62-82) */
+
+typedef struct imgenv_spawn_agent {   /* a robot or a pedestrian */
+    int32_t begin_type, target_type;  /* IMGENV_POSE_* */
+    double begin[6], target[6];
+    double module_size;               /* 2 x the footprint's radius (reset_helper.py:167-186): what must clear the obstacles */
+} imgenv_spawn_agent;
+
+typedef struct imgenv_spawn_obstacle {
+    int32_t shape;                    /* IMGENV_SHAPE_CIRCLE (radius uniform in size_range[0..1]) | _RECTANGLE (size_range = size) */
+    int32_t pose_type;                /* IMGENV_POSE_FIX | _RANGE | _RANGE_YAW */
+    double size_range[4];
+    double pose[6];
+} imgenv_spawn_obstacle;
+
+typedef struct imgenv_spawn_cfg {     /* ONE world's cast */
+    int32_t struct_size;
+    int32_t n_robots, n_peds, n_obstacles;
+    const imgenv_spawn_agent* agents;        /* [n_robots + n_peds], robots first */
+    const imgenv_spawn_obstacle* obstacles;  /* [n_obstacles] */
+    double clearance;                 /* free_check_robo_ped distance (1.0) */
+    double target_min_dist;
+    int32_t go_back;                  /* pedestrians return to their start: 0 no, 1 yes, 2 a coin per pedestrian */
+    int32_t ignore_obstacle;
+} imgenv_spawn_cfg;
+
+/* One placement into caller-owned host arrays (any of them may be NULL): robot_pose [R][4] (x, y, qz, qw), robot_goal [R][2],
+ * ped_pose [P][4], ped_goal [P][2], ped_traj [P][2][3], ped_traj_len [P], obs_shape [O], obs_size [O][4], obs_pose [O][4].
+ * Needs no device. */
+int imgenv_spawn(const imgenv_spawn_cfg* cfg, uint64_t seed, double* robot_pose, double* robot_goal, double* ped_pose,
+                 double* ped_goal, double* ped_traj, int32_t* ped_traj_len, int32_t* obs_shape, float* obs_size, double* obs_pose);
+/* imgenv_reset_worlds() with a fresh placement for each listed world, world worlds[q] from seeds[q]. */
+int imgenv_reset_worlds_spawn(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_spawn_cfg* cfg, const uint64_t* seeds,
+                              void* stream);
+
 /* number of kernels launched by the last step (bench / profiling aid) */
 int imgenv_step_launches(imgenv_t* h);
 

@@ -31,7 +31,8 @@ def hip_lib():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    for must in ("imgenv_create", "imgenv_reset", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_step", "imgenv_step_begin",
+    for must in ("imgenv_create", "imgenv_reset", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_reset_worlds_spawn",
+                 "imgenv_spawn", "imgenv_step", "imgenv_step_begin",
                  "imgenv_step_end", "imgenv_outputs", "imgenv_destroy", "imgenv_comm_init"):
         assert must in names
 
@@ -64,7 +65,10 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     fields = {"imgenv_cfg": ["abi_version", "view_resolution", "robot_shape", "limiter_w", "image_size", "ped_image_r",
                              "robot_size_last", "time_max", "out_arena", "out_arena_bytes"],
               "imgenv_reset_batch": ["n_obstacles", "obs_pose", "ped_traj", "ped_traj_cap", "ignore_obstacle", "ped_traj_v"],
-              "imgenv_out": ["n_local", "vector_states", "lasers", "paper_rewards", "counters"]}
+              "imgenv_out": ["n_local", "vector_states", "lasers", "paper_rewards", "counters"],
+              "imgenv_spawn_agent": ["target_type", "begin", "target", "module_size"],
+              "imgenv_spawn_obstacle": ["pose_type", "size_range", "pose"],
+              "imgenv_spawn_cfg": ["n_obstacles", "agents", "obstacles", "clearance", "target_min_dist", "go_back", "ignore_obstacle"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "imgenv.h"', "int main(void) {"]
     for st, fs in fields.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
@@ -75,7 +79,8 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     exe = tmp_path / "probe"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)])
     got = dict(ln.split() for ln in subprocess.check_output([str(exe)]).decode().splitlines())
-    mirror = {"imgenv_cfg": _cabi.Cfg, "imgenv_reset_batch": _cabi.ResetBatch, "imgenv_out": _cabi.Out}
+    mirror = {"imgenv_cfg": _cabi.Cfg, "imgenv_reset_batch": _cabi.ResetBatch, "imgenv_out": _cabi.Out,
+              "imgenv_spawn_agent": _cabi.SpawnAgent, "imgenv_spawn_obstacle": _cabi.SpawnObstacle, "imgenv_spawn_cfg": _cabi.SpawnCfg}
     for st, fs in fields.items():
         assert int(got[st]) == C.sizeof(mirror[st]), st
         for f in fs:

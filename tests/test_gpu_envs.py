@@ -127,3 +127,60 @@ def test_vec_env_matches_one_make_env_per_env():
         vec.close()
         for e in envs:
             e.close()
+
+
+def test_vec_env_with_native_spawn_matches_oracles_fed_the_same_placements():
+    """VecImageEnv(native_spawn=True): every episode's placement is drawn inside the library (imgenv_reset_worlds_spawn).
+    The same placements, re-drawn through imgenv_spawn with the seeds the env used, go to one oracle per env."""
+    import copy
+    import torch
+    from img_env_amd import spawn, worldgen
+    from img_env_amd.vec_env import VecImageEnv
+    from oracle_binding import OracleWorld, build_oracle
+    from parity import compare
+    build_oracle()
+    E, R, P = 5, 3, 4
+    grid = worldgen.make_grid(200, 3)
+    cfg = worldgen.make_yaml_cfg(R, P, grid, time_max=5, n_obstacles=3, seed=9)
+    vec = VecImageEnv(copy.deepcopy(cfg), env_num=E, seed=9, native_spawn=True)
+    cpus = [OracleWorld(vec.params, vec.grid) for _ in range(E)]
+    fields = tuple(f for f in ("is_collisions", "is_arrives", "view_maps", "sensor_maps", "vector_states", "lasers", "ped_maps",
+                               "ped_vector_states", "rewards", "dones", "dones_info", "robot_pose"))
+
+    def check(where):
+        snap = vec.world.snapshot()
+        for k, c in enumerate(cpus):
+            mine = {f: snap[f][k * R:(k + 1) * R] for f in fields}
+            bad = compare(mine, c.snapshot(), fields)
+            assert not bad, (where, k, bad)
+
+    try:
+        seed0, n_eps = vec._spawn_seed, 0
+        vec.reset()
+        for k in range(E):
+            cpus[k].reset(spawn.native_spawn(cfg, seed0 + n_eps + k))
+        n_eps += E
+        check("reset")
+        rng = np.random.default_rng(2)
+        resets = 0
+        for s in range(20):
+            a = np.zeros((E * R, 3), np.float32)
+            a[:, 0], a[:, 1] = rng.uniform(0, 0.6, E * R), rng.uniform(-0.9, 0.9, E * R)
+            _, rew, done, info = vec.step(torch.as_tensor(a, device="cuda"))
+            for k, c in enumerate(cpus):
+                c.step(a[k * R:(k + 1) * R])
+            for q, k in enumerate(info["reset_envs"]):  # the envs that ended: the same placements for their oracles
+                cpus[k].reset(spawn.native_spawn(cfg, seed0 + n_eps + q))
+            n_eps += len(info["reset_envs"])
+            resets += len(info["reset_envs"])
+            check(s)
+            if s == 2:  # put env 1 out of phase with the others
+                vec.reset_envs([1])
+                cpus[1].reset(spawn.native_spawn(cfg, seed0 + n_eps))
+                n_eps += 1
+                check("manual reset")
+        assert resets >= 2 * E
+    finally:
+        vec.close()
+        for c in cpus:
+            c.close()

@@ -124,3 +124,35 @@ def test_stack_params_repeats_one_env_world_major():
     assert p["n_robots"] == 3 and "n_worlds" not in p  # the input is left alone
     cfg, keep = __import__("img_env_amd._cabi", fromlist=["make_cfg"]).make_cfg(q)
     assert (cfg.n_worlds, cfg.n_robots, cfg.n_peds) == (4, 12, 8)
+
+
+def test_native_spawn_follows_the_envpos_rules():
+    """the library's own placement (csrc/spawn_host.h, no device needed) against the rules test_envpos_spawn_rules holds the
+    Python EnvPos to (reset_helper.py:35-82, 245-300)"""
+    grid = worldgen.make_grid(320, 0)
+    cfg = worldgen.make_yaml_cfg(16, 6, grid, n_obstacles=2)
+    sc = spawn.make_spawn_cfg(cfg)
+    lay = spawn.native_spawn(cfg, 11, sc)
+    starts = np.vstack([lay.robot_pose[:, :2], lay.ped_pose[:, :2]])
+    goals = np.vstack([lay.robot_goal, lay.ped_goal])
+    assert _pairwise_min(starts) > 1.0 - 1e-9 and _pairwise_min(goals) > 1.0 - 1e-9     # free_check_robo_ped d = 1.0
+    assert (np.linalg.norm(goals - starts, axis=1) > float(cfg["target_min_dist"]) - 1e-9).all()
+    for q in range(2):                                                                   # starts / goals clear of the obstacles
+        radius = lay.obs_size[q, 2] if lay.obs_shape[q] == _cabi.SHAPE_CIRCLE else np.hypot(lay.obs_size[q, 0], lay.obs_size[q, 2])
+        assert radius > 0
+        for pts in (starts, goals):
+            assert (np.linalg.norm(pts - lay.obs_pose[q, :2], axis=1) > radius).all()
+    assert np.allclose(lay.robot_pose[:, 2] ** 2 + lay.robot_pose[:, 3] ** 2, 1.0)       # (x, y, qz, qw)
+    assert (lay.ped_traj_len == 2).all() and np.array_equal(lay.ped_traj[:, 0, :2], lay.ped_goal)  # go_back: target, then start
+    assert np.array_equal(lay.ped_traj[:, 1, :2], lay.ped_pose[:, :2])
+    same = spawn.native_spawn(cfg, 11, sc)
+    assert np.array_equal(same.robot_pose, lay.robot_pose) and np.array_equal(same.ped_goal, lay.ped_goal)
+    assert not np.array_equal(spawn.native_spawn(cfg, 12, sc).robot_pose, lay.robot_pose)
+    # range_view targets: inside the 4 m box around the start, outside its 2.5 m box (random_view, reset_helper.py:62-82)
+    cfg["robot"]["target_poses_type"] = ["range_view"] * 16
+    lay = spawn.native_spawn(cfg, 3)
+    d = np.abs(lay.robot_goal - lay.robot_pose[:, :2])
+    assert (d.max(axis=1) <= 4.0 + 1e-9).all() and (d.max(axis=1) > 2.5).all()
+    cfg["robot"]["begin_poses_type"] = ["circle"] * 16
+    with pytest.raises(NotImplementedError):
+        spawn.make_spawn_cfg(cfg)
