@@ -95,4 +95,5 @@ def params_from_cfg(cfg):
         max_ped=cfg["max_ped"], ped_vec_dim=cfg["ped_vec_dim"], ped_image_r=cfg["ped_image_r"],
         laser_max=cfg["laser_max"], laser_norm=cfg.get("laser_norm", True),
         ped_safety_space=cfg["ped_safety_space"], time_max=cfg["time_max"],
+        flags=int(cfg.get("flags", 0)),  # IMGENV_FLAG_* (not a reference key: library knobs such as the compose mode)
     )
