@@ -794,6 +794,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     while (h->PP < h->Pw) h->PP <<= 1;
     h->obs_E = h->PP <= 1024 ? h->PP / WAVE : 0;
     const size_t NC = (size_t)g.Hv * g.Wv;
+    max_stride += 4;  // + the dummy beam of view cells that no beam crosses (kept a multiple of 16 bytes)
     d.hit_stride = (int)max_stride;
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv;  // src u8 (+ dummy cells) | hit u32 | column terms
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");

@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
 #ifdef IMGENV_EXP_SKIP_HITS
     for (int b = lane; b < w.B; b += WAVE) hit[b] = 0xFFFFFFFFu;
+    if (lane == 0) hit[w.B] = 0x0000FFFFu;
     __syncthreads();
     if (false) {
 #else
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                 w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
             }
         }
+        if (lane == 0) hit[w.B] = 0x0000FFFFu;  // the dummy beam of cells without any (see the final pass)
         __syncthreads();
     }
     PHASE_MARK(2);
@@ -1181,13 +1183,13 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                         cx = __umulhi((uint32_t)(c4 + q), wv_magic);
                         cy = (uint32_t)(c4 + q) - cx * (uint32_t)Wv;
                     }
-                    const bool has = top[q] != 0xFFFFFFFFu;
-                    const uint32_t bq = has ? (top[q] >> 16) : 0u, kk = top[q] & 0xFFFFu;
+                    // a cell no beam crosses (top = 0xFFFFFFFF) looks up the dummy beam B, whose "hit" is step 0 at a
+                    // row / column no cell has: its step 0xFFFF lies behind that, class 200, never "left alone"
+                    const uint32_t bq = min(top[q] >> 16, (uint32_t)w.B), kk = top[q] & 0xFFFFu;
                     const uint32_t hp = hit[bq], hk = hp >> 16;  // hk = 0xFFFF when the beam never hits
                     const bool alone = (cx == ((hp >> 8) & 0xFFu)) | (cy == (hp & 0xFFu));
-                    uint32_t v = kk < hk ? 3u : (kk == hk ? 0u : 2u);
-                    v = has ? v : 2u;
-                    skips |= (has & (kk > hk) & alone) ? (1u << q) : 0u;
+                    const uint32_t v = kk < hk ? 3u : (kk == hk ? 0u : 2u);
+                    skips |= ((kk > hk) & alone) ? (1u << q) : 0u;
                     I |= v << (8 * q);
                 }
                 if (__any(skips != 0)) {  // left alone by their top beam: provisional 200 now, resolved after the pass
