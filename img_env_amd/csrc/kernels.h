@@ -83,18 +83,47 @@ __device__ __forceinline__ void bbox_accumulate(const DevWorld& w, bool valid, d
 // worlds of a multi-world handle (world-major numbering); a single world never divides
 __device__ __forceinline__ int world_of_robot(const DevWorld& w, int i) { return w.W > 1 ? i / w.Rw : 0; }
 __device__ __forceinline__ int world_of_ped(const DevWorld& w, int j) { return w.W > 1 ? j / w.Pw : 0; }
-#define TILE_LISTS 256
-// sparse compose: cell (m, n) of `world` holds raster content in this step
-__device__ __forceinline__ void mark_tile(const DevWorld& w, int world, int m, int n) {
-    const uint32_t t = (uint32_t)world * (uint32_t)w.tiles_pw + (uint32_t)(m >> 3) * (uint32_t)w.tiles_x + (uint32_t)(n >> 3);
-    if (w.tile_mark[t] == w.tile_seq) return;  // (a stale read only costs the atomic below)
-    if (atomicMax(&w.tile_mark[t], w.tile_seq) != w.tile_seq) {  // the first toucher lists the tile
-        // TILE_LISTS lists per step, picked by workgroup: one shared counter would serialise ~4 appends per robot
-        const uint32_t sub = (w.tile_seq & 1u) * TILE_LISTS + (blockIdx.x & (TILE_LISTS - 1));
-        const int pos = atomicAdd(&w.tile_count[sub], 1);
-        if (pos < w.tile_cap) w.tile_list[(size_t)sub * w.tile_cap + pos] = t;
-        else w.err[2] = 1;
+// ---- STAMP mode (layout in world.h).  The merge is a lattice -- nothing < one robot < several robots < pedestrian -- so the
+// final word does not depend on the order in which the rasters of a step arrive. ----
+__device__ __forceinline__ bool stamp_is_current(uint32_t v, uint32_t tag) { return ((v >> STAMP_TAG_SHIFT) & 0xFFu) == tag; }
+// view_robot (img_env.cpp:620-629): robot i covers the cell
+__device__ __forceinline__ void stamp_robot(uint32_t* cell, uint32_t i, uint32_t tag) {
+    uint32_t old = *cell;
+    for (;;) {
+        const uint32_t kind = stamp_is_current(old, tag) ? (old >> STAMP_KIND_SHIFT) & 3u : 0u;
+        uint32_t nw;
+        if (kind == 0u) nw = (old & 7u) | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (i << STAMP_OWNER_SHIFT);
+        else if (kind == STAMP_ONE && (old >> STAMP_OWNER_SHIFT) != i) nw = (old & 7u) | (STAMP_MANY << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT);
+        else return;  // this robot already, several already, or a pedestrian
+        const uint32_t seen = atomicCAS(cell, old, nw);
+        if (seen == old) return;
+        old = seen;
     }
+}
+// view_ped (img_env.cpp:594-618): a pedestrian sample lands on the cell
+__device__ __forceinline__ void stamp_ped(uint32_t* cell, uint32_t tag) {
+    uint32_t old = *cell;
+    for (;;) {
+        if (stamp_is_current(old, tag) && ((old >> STAMP_KIND_SHIFT) & 3u) == STAMP_PED) return;
+        const uint32_t seen = atomicCAS(cell, old, (old & 7u) | (STAMP_PED << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT));
+        if (seen == old) return;
+        old = seen;
+    }
+}
+// value of a cell in robots_[self].global_map_ as a class code 0..4 (img_env.cpp:594-629), from the layer word v: a
+// pedestrian reads as 1; another robot (or several) as 2 unless the map already holds 0 / 1 / 2 there (agent.cpp:315-322)
+template <bool STAMP>
+__device__ __forceinline__ uint32_t cell_seen_class(uint32_t v, uint32_t self, uint32_t tag) {
+    if (!STAMP) {
+        if ((v & CLS_ROBOT) && (v >> 8) != self) return CLS_TWO;
+        return v & 7u;
+    }
+    const uint32_t base = v & 7u;
+    if (!stamp_is_current(v, tag)) return base;
+    const uint32_t kind = (v >> STAMP_KIND_SHIFT) & 3u;
+    if (kind == STAMP_PED) return CLS_PED;
+    if (base >= CLS_LOW && (kind == STAMP_MANY || (kind == STAMP_ONE && (v >> STAMP_OWNER_SHIFT) != self))) return CLS_TWO;
+    return base;
 }
 // the t-th robot (per_world = Rw) or pedestrian (Pw) of a launch: everything, or the members of the listed worlds
 __device__ __forceinline__ int act_member(const DevWorld& w, int per_world, int t) {
@@ -607,7 +636,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 //   left leg      : writes unless the cell is 0                   (agent.cpp:751-754)
 //   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
-template <bool POW2, bool TILES>
+template <bool POW2, bool STAMP>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     const int world = world_of_ped(w, j);
     const size_t cell0 = (size_t)world * w.Gs;  // this world's copy of the layers
@@ -623,8 +652,8 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
             if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
                 const size_t c = cell0 + (size_t)m * w.Wg + n;
                 if (w.obs_map[c] > 2) {
-                    w.ped_layer[c] = 1;
-                    if (TILES) mark_tile(w, world, m, n);
+                    if (STAMP) stamp_ped(w.cell + c, w.stamp_tag);
+                    else w.ped_layer[c] = 1;
                 }
             }
         }
@@ -646,8 +675,8 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
                 if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
                     const size_t c = cell0 + (size_t)m * w.Wg + n;
                     if (leg == 1 || w.obs_map[c] != 0) {
-                        w.ped_layer[c] = 1;
-                        if (TILES) mark_tile(w, world, m, n);
+                        if (STAMP) stamp_ped(w.cell + c, w.stamp_tag);
+                        else w.ped_layer[c] = 1;
                     }
                 }
             }
@@ -666,7 +695,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
 // (cell, last sample) pairs go to fp_cells so that the collision test of k_view (agent.cpp:294-326:
 // the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
 // second pass over the samples.
-template <bool POW2, bool TILES>
+template <bool POW2, bool STAMP>
 __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const RobotClassDev& k, uint32_t* box, const Region& g) {
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id();
@@ -700,11 +729,11 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
             for (int e = lane; e < n_cached; e += WAVE) {
                 const uint32_t c = list[e].x;
-                atomicMin(&w.own_lo[c], id);
-                atomicMax(&w.own_hi[c], id);
-                if (TILES) {
-                    const uint32_t rel = c - cell0, m = rel / (uint32_t)w.Wg;
-                    if (TILES) mark_tile(w, world, (int)m, (int)(rel - m * (uint32_t)w.Wg));
+                if (STAMP) {
+                    stamp_robot(w.cell + c, (uint32_t)i, w.stamp_tag);
+                } else {
+                    atomicMin(&w.own_lo[c], id);
+                    atomicMax(&w.own_hi[c], id);
                 }
             }
             return;
@@ -738,9 +767,12 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                     b = dm * side + dn;
                 } else {
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
-                    atomicMin(&w.own_lo[c], id);
-                    atomicMax(&w.own_hi[c], id);
-                    if (TILES) mark_tile(w, world, m, n);
+                    if (STAMP) {
+                        stamp_robot(w.cell + c, (uint32_t)i, w.stamp_tag);
+                    } else {
+                        atomicMin(&w.own_lo[c], id);
+                        atomicMax(&w.own_hi[c], id);
+                    }
                     stray = true;
                 }
             }
@@ -763,11 +795,12 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 const int bm = b / side;
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c = cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
-#ifndef IMGENV_EXPERIMENT_NO_OWNER_ATOMICS
-                atomicMin(&w.own_lo[c], id);
-                atomicMax(&w.own_hi[c], id);
-#endif
-                if (TILES) mark_tile(w, world, m, n);
+                if (STAMP) {
+                    stamp_robot(w.cell + c, (uint32_t)i, w.stamp_tag);
+                } else {
+                    atomicMin(&w.own_lo[c], id);
+                    atomicMax(&w.own_hi[c], id);
+                }
             }
             if (local) {
                 const unsigned long long mask = __ballot(last != 0);
@@ -783,21 +816,22 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
     }
 }
 
-template <bool POW2, bool TILES>
+template <bool POW2, bool STAMP>
 __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
     const int b = blockIdx.x;
     WAVE_T0();
+    if (STAMP && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_tail tallies this step's dones (k_compose does this otherwise)
     const Region g = grid_region(w);
     if (b < w.act_ng) {
         const int i = act_member(w, w.Rw, b);
-        raster_robot<POW2, TILES>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
+        raster_robot<POW2, STAMP>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
     }
     if (b < w.act_np) {
         const int j = act_member(w, w.Pw, b);
-        raster_ped<POW2, TILES>(w, j, w.pc[w.ped_cls[j]], g);
+        raster_ped<POW2, STAMP>(w, j, w.pc[w.ped_cls[j]], g);
     }
     if (b < w.RL) WAVE_DONE(2);
 }
@@ -881,35 +915,40 @@ __global__ void k_compose(DevWorld w) {
     compose_cells(w, c0, G);
 }
 
-// Sparse compose: the tiles listed in this step (raster content now) and in the previous one (raster content then: back
-// to the plain map class unless touched again).  16 threads per tile, 4 cells of a row each; a fixed grid strides over
-// the lists, whose lengths only the device knows.
-__global__ __launch_bounds__(256) void k_compose_tiles(DevWorld w) {
-    // blockIdx.y: one of the 2 * TILE_LISTS lists (this step's, then the previous step's)
-    const uint32_t cur = w.tile_seq & 1u, sub = blockIdx.y & (TILE_LISTS - 1);
-    const bool prev = blockIdx.y >= TILE_LISTS;
-    const uint32_t which = (prev ? cur ^ 1u : cur) * TILE_LISTS + sub;
-    const int n_list = min(w.tile_count[which], w.tile_cap);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_tail tallies this step's dones
-    const int part = threadIdx.x & 15;
-    for (int slot = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4); slot < n_list; slot += (int)((gridDim.x * blockDim.x) >> 4)) {
-        const uint32_t t = w.tile_list[(size_t)which * w.tile_cap + slot];
-        if (prev && w.tile_mark[t] == w.tile_seq) continue;  // touched again: composed as one of this step's tiles
-        const uint32_t world = t / (uint32_t)w.tiles_pw, rel = t - world * (uint32_t)w.tiles_pw;
-        const int ty = (int)(rel / (uint32_t)w.tiles_x), tx = (int)(rel - (uint32_t)ty * (uint32_t)w.tiles_x);
-        const int m = ty * 8 + (part >> 1), n = tx * 8 + (part & 1) * 4;
-        if (m >= w.Hg || n >= w.Wg) continue;
-        const size_t c0 = (size_t)world * w.Gs + (size_t)m * w.Wg + n;
-        if ((w.Wg & 3) == 0) compose_cells(w, c0, c0 + 4);
-        else compose_cells_scalar(w, c0, c0 + (size_t)min(4, w.Wg - n));
+// STAMP mode: the class layer without stamps.  from_map: base class of every cell out of the obstacle map -- at a reset,
+// for the worlds being reset (a fixed number of blocks per listed world) or for everything.  Otherwise: the sweep that
+// drops every stamp once per STAMP_TAGS steps, before their tags come round again.
+__global__ __launch_bounds__(256) void k_cell_base(DevWorld w, int from_map) {
+    size_t G = w.act_cells, c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (w.act_list) {
+        const unsigned per_world = (w.Gs / 4 + blockDim.x - 1) / blockDim.x, q = blockIdx.x / per_world;
+        const size_t base = (size_t)w.act_list[q] * w.Gs;
+        c0 = base + ((size_t)(blockIdx.x - q * per_world) * blockDim.x + threadIdx.x) * 4;
+        G = base + w.Gs;
     }
-}
-
-// value of cell c in robots_[i].global_map_ (img_env.cpp:623-628), as a small class code: one dword gather
-__device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, size_t c) {
-    const uint32_t v = w.cell[c];
-    if ((v & CLS_ROBOT) && (v >> 8) != i) return CLS_TWO;  // another robot (or several): value 2
-    return v & 7u;
+    if (c0 >= G) return;
+    if (c0 + 4 <= G) {
+        uint4 out;
+        if (from_map) {
+            const uint32_t obs = *(const uint32_t*)(w.obs_map + c0);
+            uint32_t b[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t o = (obs >> (8 * q)) & 0xFFu;
+                b[q] = o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH);
+            }
+            out = make_uint4(b[0], b[1], b[2], b[3]);
+        } else {
+            const uint4 v = *(const uint4*)(w.cell + c0);
+            out = make_uint4(v.x & 7u, v.y & 7u, v.z & 7u, v.w & 7u);
+        }
+        *(uint4*)(w.cell + c0) = out;
+    } else {
+        for (size_t c = c0; c < G; c++) {
+            const uint32_t o = w.obs_map[c];
+            w.cell[c] = from_map ? (o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH)) : (w.cell[c] & 7u);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,7 +974,7 @@ __device__ __forceinline__ uint32_t cell_class(const DevWorld& w, uint32_t i, si
 // wavefront per robot the instruction issue rate, not memory, bounds it.
 
 // collision code from the footprint samples themselves (classes whose box does not fit k_raster's LDS)
-template <bool POW2>
+template <bool POW2, bool STAMP>
 __device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, const RobotClassDev& k, const Tf2& bw, uint32_t self) {
     const int lane = lane_id();
     const double res = w.res, inv = w.inv_res;
@@ -947,7 +986,7 @@ __device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, co
         int m, n;
         w2m_pair<POW2>(wx, wy, res, inv, m, n);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            const uint32_t cc = cell_class(w, self, (size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n);
+            const uint32_t cc = cell_seen_class<STAMP>(w.cell[(size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n], self, w.stamp_tag);
             if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
         }
     }
@@ -974,7 +1013,7 @@ __device__ __forceinline__ uint32_t resolve_skipped_cell(const RobotClassDev& k,
     return 2u;
 }
 
-template <bool POW2, bool A4>
+template <bool POW2, bool A4, bool STAMP>
 __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     // A4: Wv % 4 == 0 (a lane's 4 consecutive cells share their row and nothing runs over the end of the view)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -991,7 +1030,14 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     const uint32_t wv_magic = w.wv_magic;
     const bool laser = w.use_laser != 0;
     const uint32_t self = (uint32_t)i;
-    const uint32_t free_plain = CLS_HIGH, free_own = CLS_HIGH | CLS_ROBOT | (self << 8);  // the two `cell` values this robot sees as free
+    // the `cell` values this robot sees as free (>= 250, agent.cpp:394-401).  Composed layer: the plain class, or this robot as
+    // the only owner.  STAMP layer: base class HIGH under this robot's own stamp of this step, or under no stamp of this step
+    // (tested on the word with base and tag XORed against HIGH and our tag: a non-zero multiple of 32)
+    const uint32_t tag = STAMP ? w.stamp_tag : 0u;
+    const uint32_t free_plain = CLS_HIGH;
+    const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
+                                    : (CLS_HIGH | CLS_ROBOT | (self << 8));
+    const uint32_t base_tag_mask = 7u | (0xFFu << STAMP_TAG_SHIFT), base_tag_ours = CLS_HIGH | (tag << STAMP_TAG_SHIFT);
     const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;  // this world's copy of the layers
     uint8_t* src = smem;
     uint32_t* hit = (uint32_t*)(smem + NCp);
@@ -1006,13 +1052,11 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
         const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
         for (int e = lane; e < n_cov; e += WAVE) {
             const uint2 ce = list[e];
-            const uint32_t v = w.cell[ce.x];
-            const bool other = ((v & CLS_ROBOT) != 0) & ((v >> 8) != self);
-            const uint32_t cc = other ? (uint32_t)CLS_TWO : (v & 7u);
+            const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, w.stamp_tag);
             best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
         }
     } else {
-        best = collision_from_samples<POW2>(w, k, bw, self);
+        best = collision_from_samples<POW2, STAMP>(w, k, bw, self);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
@@ -1085,7 +1129,13 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 // free (>= 250, agent.cpp:394-401) and no other robot on it: the plain class, or this robot as the only owner
-                const bool free_cell = (v[q] == free_plain) | (v[q] == free_own);
+                bool free_cell;
+                if (STAMP) {
+                    const uint32_t x = (v[q] & base_tag_mask) ^ base_tag_ours;
+                    free_cell = (v[q] == free_own) | (((x & 7u) == 0u) & (x != 0u));
+                } else {
+                    free_cell = (v[q] == free_plain) | (v[q] == free_own);
+                }
                 const uint32_t val = free_cell ? 255u : 0u;
                 packed = (packed & ~(okm[q] << (8 * q))) | ((val & okm[q]) << (8 * q));
             }
@@ -1702,8 +1752,6 @@ __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
     if (valid) done = tail_robot(w, l, is_reset, elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], do_state);
     if (w.sharded && blockIdx.x == 0 && threadIdx.x < 4)  // the rasters of this step are done with the box: re-arm it
         w.bbox[threadIdx.x] = threadIdx.x < 2 ? BBOX_INIT_MIN : BBOX_INIT_MAX;
-    if (w.tile_mark && blockIdx.x == 0)  // consumed: the next step's lists
-        for (int q = threadIdx.x; q < TILE_LISTS; q += blockDim.x) w.tile_count[((w.tile_seq & 1u) ^ 1u) * TILE_LISTS + q] = 0;
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
     const unsigned long long fmask = __ballot(frozen);  // counters[2] since the last reset, counters[3] since create

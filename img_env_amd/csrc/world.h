@@ -20,6 +20,22 @@
 #define CLS_HIGH 4     // free (>= 250)
 #define CLS_ROBOT 8    // flag: covered by >= 1 robot footprint; owner[] says which
 
+// The same layer in STAMP mode (maps much larger than what their robots and pedestrians cover -- many small worlds): the
+// rasters write their stamps straight onto `cell` and nothing is composed or cleared per step.
+//   bits  0-2   base class of the obstacle map (written at reset, untouched by the rasters)
+//   bits  3-4   what the rasters of ONE step put on the cell: nothing / one robot / several robots / a pedestrian
+//   bits  5-12  the tag of that step (1..255, the step count modulo 255): a stamp with another tag has expired; every 255
+//               steps one sweep drops the stale stamps before their tag comes round again
+//   bits 13-31  the robot of a "one robot" stamp
+#define STAMP_ONE 1u
+#define STAMP_MANY 2u
+#define STAMP_PED 3u
+#define STAMP_KIND_SHIFT 3
+#define STAMP_TAG_SHIFT 5
+#define STAMP_OWNER_SHIFT 13
+#define STAMP_MAX_ROBOTS (1 << 19)
+#define STAMP_TAGS 255
+
 // Everything of a robot class that does not depend on the pose: footprint samples
 // (agent.cpp:18-62), field-of-view mask of the crop (agent.cpp:373-386), Bresenham ray paths of
 // the laser (agent.cpp:405-438, 511-624) and the own-footprint stamp (agent.cpp:503).
@@ -71,16 +87,9 @@ struct DevWorld {
     int act_nw;
     int act_nl, act_ng, act_np;  // local robots, world-wide robots (rasters, RVO records) and pedestrians of this launch
     uint32_t Gs;
-    size_t act_cells;  // grid cells of an everything-launch (k_compose)
+    size_t act_cells;  // grid cells of an everything-launch (k_compose, k_cell_base)
     const int* world_epoch;                              // [W] global step count at the world's last reset
-    // Sparse compose (worlds much larger than what their robots and pedestrians cover): the class layer `cell` persists and
-    // only 8 x 8-cell tiles a raster touched in this step or the previous one are recomposed.  tile_mark holds the step
-    // sequence number of a tile's last touch; the first toucher appends the tile to this step's list.
-    uint32_t* tile_mark;  // [W * tiles_pw]; nullptr = dense compose over every cell
-    uint32_t* tile_list;  // [2][TILE_LISTS][tile_cap]: parity of tile_seq, then one list per group of workgroups
-    int* tile_count;      // [2][TILE_LISTS]
-    uint32_t tile_seq;
-    int tile_cap, tiles_x, tiles_pw;
+    uint32_t stamp_tag;  // STAMP mode: tag of the stamps this launch writes and reads
     const int *obst_base, *node_base, *n_obst_w, *oroot_w;  // [W] slices of obst / onodes per world (W > 1)
     int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;
     int scene, relation, ktype, use_laser, laser_norm, time_max;
@@ -98,6 +107,7 @@ struct DevWorld {
     uint32_t* own_lo;        // min (robot index + 1) covering the cell, 0xFFFFFFFF = none
     uint32_t* own_hi;        // max (robot index + 1) covering the cell, 0 = none
     uint32_t* cell;          // composed layer: class byte | (owning robot or OWNER_MULTI) << 8, one gather per lookup
+                             // (STAMP mode: base class | this step's stamp, and the three layers above do not exist)
     // class records travel by value in the kernel arguments: scalar loads, and their table pointers are known
     // to be global (no flat loads, no reloads after stores)
     RobotClassDev rc[RC_INLINE];

@@ -146,9 +146,10 @@ typedef struct imgenv_cfg {
 } imgenv_cfg;
 
 #define IMGENV_FLAG_PRIVATE_GRIDS 1 /* oracle only: literal per-robot grid copies (img_env.cpp:620-629) */
-/* How the per-step class layer is rebuilt.  Default: the library picks -- dense (every map cell of every world) when the
- * robots and pedestrians cover a good part of the map, sparse (only the 8 x 8-cell tiles they touch) for big or many
- * maps with few agents each.  The result is the same either way. */
+/* How the class layer (what a robot's view looks up per map cell) is kept up to date.  Default: the library picks --
+ * DENSE: the rasters fill owner layers and every step merges them over every map cell of every world, best when the robots
+ * and pedestrians cover a good part of the map; SPARSE: the rasters stamp the class layer directly and stamps expire with
+ * their step, nothing per cell, best for big or many maps with few agents each.  The result is the same either way. */
 #define IMGENV_FLAG_COMPOSE_DENSE 2
 #define IMGENV_FLAG_COMPOSE_SPARSE 4
 
