@@ -219,9 +219,9 @@ def test_one_world_reset_grows_the_shared_tables(worlds):
             c.close()
 
 
-@pytest.mark.parametrize("flags", [2, 4], ids=["dense_compose", "sparse_compose"])
+@pytest.mark.parametrize("flags", [2, 4], ids=["composed_layer", "stamped_layer"])
 def test_compose_modes_give_the_same_worlds(worlds, flags):
-    """the class layer rebuilt densely (every cell) or sparsely (touched 8 x 8 tiles, now and one step later): crowded
+    """the class layer composed every step from owner layers, or stamped directly by the rasters (STAMP mode): crowded
     worlds, legs, per-world resets, a map width that is not a multiple of the tile"""
     World, OracleWorld = worlds
     fails, _, _ = _run(World, OracleWorld, 4, 12, 9, 30, {5: [1], 6: [1, 3], 20: [0, 1, 2, 3]}, seed=35, n_obstacles=3, ped_shape="leg",
