@@ -287,3 +287,12 @@ def test_bad_multi_world_configurations_are_rejected(worlds):
             w.reset_worlds([1, 1], [lay, lay])
     finally:
         w.close()
+
+
+def test_stamped_layer_survives_its_tag_coming_round(worlds):
+    """STAMP mode tags every stamp with the step count modulo 255 and sweeps the layer when the tag wraps: 300 steps of two
+    small worlds (with a per-world reset in between) stay on the oracles across the wrap"""
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, 2, 3, 2, 300, {120: [1], 254: [0], 255: [1]}, seed=38, n_obstacles=2, grid_size=100,
+                       clearance=0.6, time_max=1000, flags=4)
+    assert not fails, fails[:3]
