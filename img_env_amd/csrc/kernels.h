@@ -101,8 +101,7 @@ __device__ __forceinline__ void stamp_robot(uint32_t* cell, uint32_t i, uint32_t
     }
 }
 // view_ped (img_env.cpp:594-618): a pedestrian sample lands on the cell
-__device__ __forceinline__ void stamp_ped(uint32_t* cell, uint32_t tag) {
-    uint32_t old = *cell;
+__device__ __forceinline__ void stamp_ped(uint32_t* cell, uint32_t old /* the word as just read */, uint32_t tag) {
     for (;;) {
         if (stamp_is_current(old, tag) && ((old >> STAMP_KIND_SHIFT) & 3u) == STAMP_PED) return;
         const uint32_t seen = atomicCAS(cell, old, (old & 7u) | (STAMP_PED << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT));
@@ -636,26 +635,42 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 //   left leg      : writes unless the cell is 0                   (agent.cpp:751-754)
 //   right leg     : writes unless the cell is 1 -> always ends 1  (agent.cpp:767-770)
 // so the sequential result is order independent: peds_map = ped_layer ? 1 : obs_map.
+// One pedestrian sample on cell c (or on none).  rule: 0 circle sample, 1 left-leg sample, 2 right-leg sample (see above).
+// Composed mode writes the pedestrian layer.  STAMP mode reads the base class out of the class layer itself and lets only
+// the last lane of each run of equal cells stamp (consecutive samples are lattice neighbours and mostly share their cell:
+// ~10 compare-and-swaps per pedestrian instead of 900 dependent loads).  Call from wave-uniform control flow.
+template <bool STAMP>
+__device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t c, int rule, int lane) {
+    if (!STAMP) {
+        if (in) {
+            const uint32_t o = w.obs_map[c];
+            if (rule == 2 || (rule == 1 ? o != 0u : o > 2u)) w.ped_layer[c] = 1;
+        }
+        return;
+    }
+    const uint32_t ci = in ? c : 0xFFFFFFFFu;
+    const uint32_t next = (uint32_t)__shfl_down((int)ci, 1);
+    if (in && (lane == WAVE - 1 || next != ci)) {
+        const uint32_t v = w.cell[c], base = v & 7u;
+        if (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW)) stamp_ped(w.cell + c, v, w.stamp_tag);
+    }
+}
+
 template <bool POW2, bool STAMP>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
-    const int world = world_of_ped(w, j);
-    const size_t cell0 = (size_t)world * w.Gs;  // this world's copy of the layers
+    const uint32_t cell0 = (uint32_t)world_of_ped(w, j) * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id();
     const double res = w.res, inv = w.inv_res;
     if (k.shape == IMGENV_SHAPE_CIRCLE) {
-        for (int q = lane; q < k.n_bbox; q += WAVE) {
+        for (int q0 = 0; q0 < k.n_bbox; q0 += WAVE) {  // wave-uniform trip count (lane shuffles inside)
+            const int q = min(q0 + lane, k.n_bbox - 1);
             double wx, wy;
             tf_apply(bw, k.bx[q], k.by[q], wx, wy);
             int m, n;
             w2m_pair<POW2>(wx, wy, res, inv, m, n);
-            if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
-                const size_t c = cell0 + (size_t)m * w.Wg + n;
-                if (w.obs_map[c] > 2) {
-                    if (STAMP) stamp_ped(w.cell + c, w.stamp_tag);
-                    else w.ped_layer[c] = 1;
-                }
-            }
+            const bool in = q0 + lane < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+            ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), 0, lane);
         }
     } else if (k.shape == IMGENV_SHAPE_LEG) {
         for (int leg = 0; leg < 2; leg++) {
@@ -666,19 +681,15 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
             const int n_s = leg == 0 ? k.n_left : k.n_right;
             const double* sx = leg == 0 ? k.lx : k.rx;
             const double* sy = leg == 0 ? k.ly : k.ry;
-            for (int q = lane; q < n_s; q += WAVE) {
+            for (int q0 = 0; q0 < n_s; q0 += WAVE) {
+                const int q = min(q0 + lane, n_s - 1);
                 double bx, by, wx, wy;
                 tf_apply(lb, sx[q], sy[q], bx, by);
                 tf_apply(bw, bx, by, wx, wy);
                 int m, n;
                 w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                if (m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1) {
-                    const size_t c = cell0 + (size_t)m * w.Wg + n;
-                    if (leg == 1 || w.obs_map[c] != 0) {
-                        if (STAMP) stamp_ped(w.cell + c, w.stamp_tag);
-                        else w.ped_layer[c] = 1;
-                    }
-                }
+                const bool in = q0 + lane < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+                ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), leg + 1, lane);
             }
         }
     }
