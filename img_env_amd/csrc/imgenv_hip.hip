@@ -935,12 +935,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             HIPCHK(hipEventRecord(h->ev_join2, s_obs));
         }
     }
-    // STAMP mode: no compose.  A reset gives the worlds it covers their base classes (the obstacle map has just been
-    // redrawn); every STAMP_TAGS steps one sweep drops all stamps before their tags come round again.
-    if (h->stamp && is_reset)
-        TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d, 1)));
-    else if (h->stamp && h->stamp_seq % STAMP_TAGS == 0)
-        TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d, 0)));
+    // STAMP mode: no compose.  A reset has given the worlds it covers their base classes together with their obstacle maps
+    // (k_reset_apply, k_reset_obstacles); every STAMP_TAGS steps one sweep drops all stamps before their tags come round again.
+    if (h->stamp && !is_reset && h->stamp_seq % STAMP_TAGS == 0)
+        TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     {
         const dim3 gr(n_p > n_g ? n_p : n_g), br(WAVE);
         const size_t lds = 4 * (size_t)d.box_cells;
@@ -1012,6 +1010,7 @@ struct ResetArgs {
     const ResetRobot* rr;
     const double* ped3;
     int n_robots, n_peds, whole;
+    int stamp;  // STAMP mode: the class layer gets its base classes here too (k_reset_obstacles keeps it in step)
 };
 static int stage_begin(imgenv* h) {
     h->gen = (h->gen + 1) % imgenv::STAGE_GENS;
@@ -1109,8 +1108,24 @@ __global__ __launch_bounds__(256) void k_reset_apply(DevWorld w, ResetArgs a) {
         const int q = b / MAP_BLOCKS, world = a.list ? a.list[q] : q;
         const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;  // (both buffers are padded to 16 bytes)
         uint4* dst = (uint4*)(const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs);
-        for (size_t e = (size_t)(b - q * MAP_BLOCKS) * blockDim.x + threadIdx.x; e < n16; e += (size_t)MAP_BLOCKS * blockDim.x)
-            dst[e] = ((const uint4*)a.static_map)[e];
+        uint4* cls = (uint4*)(w.cell + (size_t)world * w.Gs);
+        for (size_t e = (size_t)(b - q * MAP_BLOCKS) * blockDim.x + threadIdx.x; e < n16; e += (size_t)MAP_BLOCKS * blockDim.x) {
+            const uint4 v = ((const uint4*)a.static_map)[e];
+            dst[e] = v;
+            if (a.stamp) {  // base class of 16 cells, no stamp
+                const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t c4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t o = (wd[k] >> (8 * j)) & 0xFFu;
+                        c4[j] = o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH);
+                    }
+                    cls[4 * e + k] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+                }
+            }
+        }
         return;
     }
     b -= a.n_worlds * MAP_BLOCKS;
@@ -1132,7 +1147,7 @@ struct ObstInst {
     int n_pts, world;
 };
 template <bool POW2>
-__global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst) {
+__global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst, int stamp) {
     const ObstInst o = inst[blockIdx.x];
     const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
     uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)o.world * w.Gs;
@@ -1143,8 +1158,11 @@ __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstI
         int m, n;
         w2m_pair<POW2>(wx, wy, w.res, w.inv_res, m, n);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            uint8_t* c = map + (size_t)m * w.Wg + n;
-            if (*c > 2) *c = 0;
+            const size_t at = (size_t)m * w.Wg + n;
+            if (map[at] > 2) {
+                map[at] = 0;
+                if (stamp) w.cell[(size_t)o.world * w.Gs + at] = CLS_STATIC;  // the class layer's base class follows
+            }
         }
     }
 }
@@ -1427,14 +1445,15 @@ static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int w
         a.n_robots = d.act_ng;
         a.n_peds = d.act_np;
         a.whole = whole;
+        a.stamp = h->stamp ? 1 : 0;
         const size_t blocks = (size_t)a.n_seg * a.per_seg + (size_t)a.n_worlds * MAP_BLOCKS + (a.n_robots + 255) / 256 + (a.n_peds + 255) / 256;
         k_reset_apply<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d, a);
         h->segs.clear();
         h->seg_max = 0;
     }
     if (n_inst) {
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst);
-        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst);
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0);
+        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0);
     }
     if (d.sharded) k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, h->pin_rob3);
     HIPCHK(hipGetLastError());

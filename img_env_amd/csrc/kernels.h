@@ -926,39 +926,16 @@ __global__ void k_compose(DevWorld w) {
     compose_cells(w, c0, G);
 }
 
-// STAMP mode: the class layer without stamps.  from_map: base class of every cell out of the obstacle map -- at a reset,
-// for the worlds being reset (a fixed number of blocks per listed world) or for everything.  Otherwise: the sweep that
-// drops every stamp once per STAMP_TAGS steps, before their tags come round again.
-__global__ __launch_bounds__(256) void k_cell_base(DevWorld w, int from_map) {
-    size_t G = w.act_cells, c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (w.act_list) {
-        const unsigned per_world = (w.Gs / 4 + blockDim.x - 1) / blockDim.x, q = blockIdx.x / per_world;
-        const size_t base = (size_t)w.act_list[q] * w.Gs;
-        c0 = base + ((size_t)(blockIdx.x - q * per_world) * blockDim.x + threadIdx.x) * 4;
-        G = base + w.Gs;
-    }
+// STAMP mode: the sweep that drops every stamp once per STAMP_TAGS steps, before their tags come round again (the base classes
+// themselves are written at reset, with the obstacle maps).
+__global__ __launch_bounds__(256) void k_cell_base(DevWorld w) {
+    const size_t G = w.act_cells, c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (c0 >= G) return;
     if (c0 + 4 <= G) {
-        uint4 out;
-        if (from_map) {
-            const uint32_t obs = *(const uint32_t*)(w.obs_map + c0);
-            uint32_t b[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t o = (obs >> (8 * q)) & 0xFFu;
-                b[q] = o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH);
-            }
-            out = make_uint4(b[0], b[1], b[2], b[3]);
-        } else {
-            const uint4 v = *(const uint4*)(w.cell + c0);
-            out = make_uint4(v.x & 7u, v.y & 7u, v.z & 7u, v.w & 7u);
-        }
-        *(uint4*)(w.cell + c0) = out;
+        const uint4 v = *(const uint4*)(w.cell + c0);
+        *(uint4*)(w.cell + c0) = make_uint4(v.x & 7u, v.y & 7u, v.z & 7u, v.w & 7u);
     } else {
-        for (size_t c = c0; c < G; c++) {
-            const uint32_t o = w.obs_map[c];
-            w.cell[c] = from_map ? (o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH)) : (w.cell[c] & 7u);
-        }
+        for (size_t c = c0; c < G; c++) w.cell[c] &= 7u;
     }
 }
 
