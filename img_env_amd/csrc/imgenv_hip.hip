@@ -773,7 +773,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     const size_t NC = (size_t)g.Hv * g.Wv;
     max_stride += 4;  // + the dummy beam of view cells that no beam crosses (kept a multiple of 16 bytes)
     d.hit_stride = (int)max_stride;
-    h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv;  // src u8 (+ dummy cells) | hit u32 | column terms
+    h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16;  // src u8 (+ dummy cells) | hit u32 | column terms | skip count
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
     h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
@@ -781,10 +781,14 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
     }
     if (h->lds_view > 64 * 1024) {
-        for (const void* f : {(const void*)k_view<true, true, false>, (const void*)k_view<true, false, false>,
-                              (const void*)k_view<false, true, false>, (const void*)k_view<false, false, false>,
-                              (const void*)k_view<true, true, true>, (const void*)k_view<true, false, true>,
-                              (const void*)k_view<false, true, true>, (const void*)k_view<false, false, true>})
+        for (const void* f : {(const void*)k_view<true, true, false, 1>, (const void*)k_view<true, false, false, 1>,
+                              (const void*)k_view<false, true, false, 1>, (const void*)k_view<false, false, false, 1>,
+                              (const void*)k_view<true, true, true, 1>, (const void*)k_view<true, false, true, 1>,
+                              (const void*)k_view<false, true, true, 1>, (const void*)k_view<false, false, true, 1>,
+                              (const void*)k_view<true, true, false, 4>, (const void*)k_view<true, false, false, 4>,
+                              (const void*)k_view<false, true, false, 4>, (const void*)k_view<false, false, false, 4>,
+                              (const void*)k_view<true, true, true, 4>, (const void*)k_view<true, false, true, 4>,
+                              (const void*)k_view<false, true, true, 4>, (const void*)k_view<false, false, true, 4>})
             HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
     }
     if (h->lds_obs > 64 * 1024)
@@ -950,18 +954,27 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     }
     if (!h->stamp) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     {
-        const dim3 gv(n_l), bv(WAVE);
+        // one wavefront per robot when the launch fills the machine, four when it is small (a reset of a few worlds): then
+        // the single wavefront's latency is all there is
+        const bool small = n_l <= 1024;
+        const dim3 gv(n_l), bv(small ? 4 * WAVE : WAVE);
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
+#define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
+    case N:                                                                                                                     \
+        if (small) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 4><<<gv, bv, h->lds_view, st>>>(d)));                        \
+        else TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 1><<<gv, bv, h->lds_view, st>>>(d)));                              \
+        break;
         switch (variant) {
-            case 7: TIMED(h, IMGENV_K_VIEW, st, (k_view<true, true, true><<<gv, bv, h->lds_view, st>>>(d))); break;
-            case 6: TIMED(h, IMGENV_K_VIEW, st, (k_view<true, true, false><<<gv, bv, h->lds_view, st>>>(d))); break;
-            case 5: TIMED(h, IMGENV_K_VIEW, st, (k_view<true, false, true><<<gv, bv, h->lds_view, st>>>(d))); break;
-            case 4: TIMED(h, IMGENV_K_VIEW, st, (k_view<true, false, false><<<gv, bv, h->lds_view, st>>>(d))); break;
-            case 3: TIMED(h, IMGENV_K_VIEW, st, (k_view<false, true, true><<<gv, bv, h->lds_view, st>>>(d))); break;
-            case 2: TIMED(h, IMGENV_K_VIEW, st, (k_view<false, true, false><<<gv, bv, h->lds_view, st>>>(d))); break;
-            case 1: TIMED(h, IMGENV_K_VIEW, st, (k_view<false, false, true><<<gv, bv, h->lds_view, st>>>(d))); break;
-            default: TIMED(h, IMGENV_K_VIEW, st, (k_view<false, false, false><<<gv, bv, h->lds_view, st>>>(d))); break;
+            VIEW_CASE(7, true, true, true)
+            VIEW_CASE(6, true, true, false)
+            VIEW_CASE(5, true, false, true)
+            VIEW_CASE(4, true, false, false)
+            VIEW_CASE(3, false, true, true)
+            VIEW_CASE(2, false, true, false)
+            VIEW_CASE(1, false, false, true)
+            VIEW_CASE(0, false, false, false)
         }
+#undef VIEW_CASE
     }
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((n_l + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed, h->P > 0 ? 0 : 1)));

@@ -1001,8 +1001,12 @@ __device__ __forceinline__ uint32_t resolve_skipped_cell(const RobotClassDev& k,
     return 2u;
 }
 
-template <bool POW2, bool A4, bool STAMP>
-__global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
+// NW: wavefronts per robot.  1 when a launch fills the machine (instruction issue bounds it); 4 for small launches (a reset of
+// a few worlds), where the single wavefront's latency is all there is: the cells and beams are then spread over 256 lanes.
+template <bool POW2, bool A4, bool STAMP, int NW>
+__global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
+    constexpr int NT = WAVE * NW;
+    const int tid = threadIdx.x;
     // A4: Wv % 4 == 0 (a lane's 4 consecutive cells share their row and nothing runs over the end of the view)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = act_member(w, w.Rw, blockIdx.x);
@@ -1030,6 +1034,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     uint8_t* src = smem;
     uint32_t* hit = (uint32_t*)(smem + NCp);
     double2* colt = (double2*)(smem + NCp + 4 * (size_t)w.hit_stride);
+    int* skip_cnt = (int*)(colt + Wv);  // NW > 1: the wavefronts' common count of skipped cells
     PHASE_BEGIN();
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
@@ -1055,17 +1060,18 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     //     world = (m00 * (a res) + m01 * (b res)) + ox: the column products come from an LDS table, the row
     //     products are shared by the 4 cells of a lane
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
-    for (int b = lane; b < Wv; b += WAVE) {
+    for (int b = tid; b < Wv; b += NT) {
         const double y = b * res;
         colt[b] = make_double2(vw.m01 * y, vw.m11 * y);
     }
-    if (lane < 16) src[NC + lane] = 255;  // dummy free cells behind the view (padded path entries)
+    if (tid < 16) src[NC + tid] = 255;  // dummy free cells behind the view (padded path entries)
+    if (NW > 1 && tid == 0) *skip_cnt = 0;
     __syncthreads();
 #ifdef IMGENV_EXP_SKIP_CROP
-    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) *(uint32_t*)(src + c4) = 0xFFFFFFFFu;
+    for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) *(uint32_t*)(src + c4) = 0xFFFFFFFFu;
     if (false)
 #endif
-    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
+    for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
         const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds the 4 bits
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
         if (fov) {
@@ -1135,8 +1141,8 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
 
     // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
 #ifdef IMGENV_EXP_SKIP_HITS
-    for (int b = lane; b < w.B; b += WAVE) hit[b] = 0xFFFFFFFFu;
-    if (lane == 0) hit[w.B] = 0x0000FFFFu;
+    for (int b = tid; b < w.B; b += NT) hit[b] = 0xFFFFFFFFu;
+    if (tid == 0) hit[w.B] = 0x0000FFFFu;
     __syncthreads();
     if (false) {
 #else
@@ -1144,8 +1150,8 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
 #endif
         const uint4* rows = (const uint4*)k.ray_rows;
         const int n_chunks = k.ray_kpad >> 3;
-        for (int b0 = 0; b0 < w.B; b0 += WAVE) {
-            const int b = b0 + lane;
+        for (int b0 = 0; b0 < w.B; b0 += NT) {
+            const int b = b0 + tid;
             const int bb = min(b, w.B - 1);
             const int len = b < w.B ? (int)k.ray_len[bb] : 0;
             // two 16-bit keys side by side, value << 8 | step (a path has at most 255 steps): even steps in the low half,
@@ -1179,7 +1185,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                 w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
             }
         }
-        if (lane == 0) hit[w.B] = 0x0000FFFFu;  // the dummy beam of cells without any (see the final pass)
+        if (tid == 0) hit[w.B] = 0x0000FFFFu;  // the dummy beam of cells without any (see the final pass)
         __syncthreads();
     }
     PHASE_MARK(2);
@@ -1198,7 +1204,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     uint16_t* skip_list = (uint16_t*)src;  // the crop is dead once the beams have their hits
     const int skip_cap = laser ? NC / 2 : 0;
     int n_skip = 0;
-    for (int c4 = lane * 4; c4 < NC; c4 += WAVE * 4) {
+    for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
         uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
         if (laser) {
             uint32_t top[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -1235,7 +1241,12 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
                     for (int q = 0; q < 4; q++) {
                         const bool sk = ((skips >> q) & 1u) != 0;
                         const unsigned long long mask = __ballot(sk);
-                        const int pos = n_skip + __popcll(mask & ((1ull << lane) - 1ull));
+                        int pos = n_skip + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (NW > 1 && mask != 0ull) {  // several wavefronts share the list: one LDS atomic per wavefront and round
+                            int first = 0;
+                            if (lane == 0) first = atomicAdd(skip_cnt, __popcll(mask));
+                            pos = __shfl(first, 0) + __popcll(mask & ((1ull << lane) - 1ull));
+                        }
                         if (sk) {
                             if (pos < skip_cap) {
                                 skip_list[pos] = (uint16_t)(c4 + q);
@@ -1280,11 +1291,16 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
     }
     // (5) the cells a top beam left alone, one per lane: the next lower beam through the cell that writes decides
     //     (agent.cpp:555-560); only values other than the provisional 200 are patched into the two output planes
-    n_skip = min(__builtin_amdgcn_readfirstlane(n_skip), skip_cap);  // lane 0 ran every round of the loop above
+    if (NW > 1) {
+        __syncthreads();
+        n_skip = min(*skip_cnt, skip_cap);
+    } else {
+        n_skip = min(__builtin_amdgcn_readfirstlane(n_skip), skip_cap);  // lane 0 ran every round of the loop above
+    }
     if (n_skip > 0) {
         __builtin_amdgcn_s_waitcnt(0);  // the provisional stores of this wave have landed
         __syncthreads();
-        for (int t = lane; t < n_skip; t += WAVE) {
+        for (int t = tid; t < n_skip; t += NT) {
             const uint32_t c = skip_list[t];
             const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
             uint32_t v = resolve_skipped_cell(k, hit, c, cx, cy);
@@ -1296,7 +1312,7 @@ __global__ __launch_bounds__(WAVE) void k_view(DevWorld w) {
             }
         }
     }
-    if (lane == 0) w.is_coll[l] = code;
+    if (tid == 0) w.is_coll[l] = code;
     PHASE_MARK(4);
     WAVE_DONE(0);
 }
