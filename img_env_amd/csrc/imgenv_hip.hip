@@ -944,13 +944,23 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     if (h->stamp && !is_reset && h->stamp_seq % STAMP_TAGS == 0)
         TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     {
-        const dim3 gr(n_p > n_g ? n_p : n_g), br(WAVE);
-        const size_t lds = 4 * (size_t)d.box_cells;
+        const int n_blocks = n_p > n_g ? n_p : n_g;
+        const bool small = n_blocks <= 1024;  // four wavefronts per robot / pedestrian when the launch cannot fill the machine
+        const dim3 gr(n_blocks), br(small ? 4 * WAVE : WAVE);
+        const size_t lds = 4 * (size_t)d.box_cells + 16;
         const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
-        if (variant == 3) TIMED(h, IMGENV_K_RASTER, st, (k_raster<true, true><<<gr, br, lds, st>>>(d, is_reset)));
-        else if (variant == 2) TIMED(h, IMGENV_K_RASTER, st, (k_raster<true, false><<<gr, br, lds, st>>>(d, is_reset)));
-        else if (variant == 1) TIMED(h, IMGENV_K_RASTER, st, (k_raster<false, true><<<gr, br, lds, st>>>(d, is_reset)));
-        else TIMED(h, IMGENV_K_RASTER, st, (k_raster<false, false><<<gr, br, lds, st>>>(d, is_reset)));
+#define RASTER_CASE(N, P2, ST)                                                                                    \
+    case N:                                                                                                       \
+        if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, is_reset)));         \
+        else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, is_reset)));               \
+        break;
+        switch (variant) {
+            RASTER_CASE(3, true, true)
+            RASTER_CASE(2, true, false)
+            RASTER_CASE(1, false, true)
+            RASTER_CASE(0, false, false)
+        }
+#undef RASTER_CASE
     }
     if (!h->stamp) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     {

@@ -656,20 +656,21 @@ __device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t 
     }
 }
 
-template <bool POW2, bool STAMP>
+template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
+    constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
     const uint32_t cell0 = (uint32_t)world_of_ped(w, j) * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
-    const int lane = lane_id();
+    const int lane = lane_id(), tid = threadIdx.x;
     const double res = w.res, inv = w.inv_res;
     if (k.shape == IMGENV_SHAPE_CIRCLE) {
-        for (int q0 = 0; q0 < k.n_bbox; q0 += WAVE) {  // wave-uniform trip count (lane shuffles inside)
-            const int q = min(q0 + lane, k.n_bbox - 1);
+        for (int q0 = 0; q0 < k.n_bbox; q0 += NT) {  // wave-uniform trip count (lane shuffles inside)
+            const int q = min(q0 + tid, k.n_bbox - 1);
             double wx, wy;
             tf_apply(bw, k.bx[q], k.by[q], wx, wy);
             int m, n;
             w2m_pair<POW2>(wx, wy, res, inv, m, n);
-            const bool in = q0 + lane < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+            const bool in = q0 + tid < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
             ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), 0, lane);
         }
     } else if (k.shape == IMGENV_SHAPE_LEG) {
@@ -681,14 +682,14 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
             const int n_s = leg == 0 ? k.n_left : k.n_right;
             const double* sx = leg == 0 ? k.lx : k.rx;
             const double* sy = leg == 0 ? k.ly : k.ry;
-            for (int q0 = 0; q0 < n_s; q0 += WAVE) {
-                const int q = min(q0 + lane, n_s - 1);
+            for (int q0 = 0; q0 < n_s; q0 += NT) {
+                const int q = min(q0 + tid, n_s - 1);
                 double bx, by, wx, wy;
                 tf_apply(lb, sx[q], sy[q], bx, by);
                 tf_apply(bw, bx, by, wx, wy);
                 int m, n;
                 w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                const bool in = q0 + lane < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+                const bool in = q0 + tid < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
                 ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), leg + 1, lane);
             }
         }
@@ -706,10 +707,11 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
 // (cell, last sample) pairs go to fp_cells so that the collision test of k_view (agent.cpp:294-326:
 // the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
 // second pass over the samples.
-template <bool POW2, bool STAMP>
+template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const RobotClassDev& k, uint32_t* box, const Region& g) {
+    constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    const int lane = lane_id();
+    const int lane = lane_id(), tid = threadIdx.x;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
     const double res = w.res, inv = w.inv_res;
     const uint32_t id = (uint32_t)i + 1;
@@ -721,7 +723,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
     const uint32_t cell0 = (uint32_t)world * w.Gs;  // this world's copy of the layers
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
     // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
-    if (lane == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
+    if (tid == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
         double* p = w.sfm.p + 3 * (size_t)(w.P + i);
         p[0] = r[0];
         p[1] = r[1];
@@ -738,7 +740,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         const int n_cached = w.fp_n[l];
         if (n_cached >= 0 && cached[0] == r[0] && cached[1] == r[1] && cached[2] == r[2]) {
             const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
-            for (int e = lane; e < n_cached; e += WAVE) {
+            for (int e = tid; e < n_cached; e += NT) {
                 const uint32_t c = list[e].x;
                 if (STAMP) {
                     stamp_robot(w.cell + c, (uint32_t)i, w.stamp_tag);
@@ -749,24 +751,27 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             }
             return;
         }
-        if (lane == 0) {
+        if (NW > 1) __syncthreads();  // every wavefront has compared before the pose is replaced
+        if (tid == 0) {
             cached[0] = r[0];
             cached[1] = r[1];
             cached[2] = r[2];
         }
     }
+    uint32_t* stray_flag = box + w.box_cells;  // NW > 1: "some sample fell outside the box", seen by any wavefront
     if (use_box) {
-        for (int q = lane; q < ncell; q += WAVE) box[q] = 0;
+        for (int q = tid; q < ncell; q += NT) box[q] = 0;
+        if (NW > 1 && tid == 0) *stray_flag = 0;
         __syncthreads();
     }
     bool stray = false;
-    for (int q0 = 0; q0 < k.n_fp; q0 += WAVE * 4) {  // wave-uniform trip count (lane shuffles inside), 4 loads in flight
+    for (int q0 = 0; q0 < k.n_fp; q0 += NT * 4) {  // wave-uniform trip count (lane shuffles inside), 4 loads in flight
         double2 fp[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) fp[u] = k.fp[min(q0 + u * WAVE + lane, k.n_fp - 1)];
+        for (int u = 0; u < 4; u++) fp[u] = k.fp[min(q0 + u * NT + tid, k.n_fp - 1)];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int q = q0 + u * WAVE + lane;
+            const int q = q0 + u * NT + tid;
             double wx, wy;
             tf_apply(bw, fp[u].x, fp[u].y, wx, wy);
             int m, n;
@@ -795,7 +800,9 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         }
     }
     if (use_box) {
+        if (NW > 1 && stray) *stray_flag = 1;
         __syncthreads();
+        if (NW > 1 && tid >= WAVE) return;  // the first wavefront turns the box into stamps and the cell list
         uint2* list = w.fp_cells + (size_t)(local ? l : 0) * w.fp_cap;
         int n_out = 0;
         for (int b0 = 0; b0 < ncell; b0 += WAVE) {  // wave-uniform trip count (ballot inside)
@@ -820,15 +827,17 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 n_out += __popcll(mask);
             }
         }
-        const bool any_stray = __any(stray);
+        const bool any_stray = NW > 1 ? *stray_flag != 0 : __any(stray);
         if (local && lane == 0) w.fp_n[l] = (n_out <= w.fp_cap && !any_stray) ? n_out : -1;
-    } else if (local && lane == 0) {
+    } else if (local && tid == 0) {
         w.fp_n[l] = -1;
     }
 }
 
-template <bool POW2, bool STAMP>
-__global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
+// NW: wavefronts per workgroup.  1 when a launch fills the machine; 4 in small launches (a reset of a few worlds), where the
+// 15 rounds of footprint samples of one wavefront are pure latency.
+template <bool POW2, bool STAMP, int NW>
+__global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
@@ -838,11 +847,11 @@ __global__ __launch_bounds__(WAVE) void k_raster(DevWorld w, int zero_vel) {
     const Region g = grid_region(w);
     if (b < w.act_ng) {
         const int i = act_member(w, w.Rw, b);
-        raster_robot<POW2, STAMP>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
+        raster_robot<POW2, STAMP, NW>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
     }
     if (b < w.act_np) {
         const int j = act_member(w, w.Pw, b);
-        raster_ped<POW2, STAMP>(w, j, w.pc[w.ped_cls[j]], g);
+        raster_ped<POW2, STAMP, NW>(w, j, w.pc[w.ped_cls[j]], g);
     }
     if (b < w.RL) WAVE_DONE(2);
 }
