@@ -33,6 +33,10 @@ int oracle_private_grid(oracle_world* w, int32_t robot, uint8_t* dst);
 /* obs_map_ / peds_map_ (img_env.h:43-46) */
 int oracle_grids(oracle_world* w, const uint8_t** obs_map, const uint8_t** peds_map);
 
+/* unit-test hooks: Agent::bresenhamLine (agent.cpp:511-624) and the planar tf operations of tfmath.h on hand-made inputs */
+double oracle_test_bresenham(int x1, int y1, int x2, int y2, const uint8_t* src, uint8_t* dst, int Hv, int Wv, double res);
+void oracle_test_tf(int op, const double* in, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1362,3 +1362,39 @@ int oracle_outputs(oracle_world* w, imgenv_out* out) {
     *out = w->out;
     return IMGENV_OK;
 }
+
+/* ------------------------------------------------------------------ unit-test hooks (tests/test_oracle_tf.py,
+ * tests/test_oracle_known_answers.py): the static restatements above, callable one at a time on hand-made inputs */
+double oracle_test_bresenham(int x1, int y1, int x2, int y2, const uint8_t* src, uint8_t* dst, int Hv, int Wv, double res) {
+    return bresenham(x1, y1, x2, y2, src, dst, Hv, Wv, res);
+}
+/* op 0: from_pose(x, y, yaw) -> tf | 1: apply(tf[6], x, y) -> (x, y) | 2: inverse(tf) -> tf | 3: mul(tf a, tf b) -> tf
+ * | 4: basis yaw via quaternion (tf) -> yaw | 5: yaw from quaternion (z, w) -> yaw | 6: set_rotation_zw(z, w) -> tf (origin 0) */
+void oracle_test_tf(int op, const double* in, double* out) {
+    tf2d a, b, r;
+    memset(&r, 0, sizeof(r));
+    if (op == 0) {
+        r = tf_from_pose(in[0], in[1], in[2]);
+    } else if (op == 1) {
+        memcpy(&a, in, sizeof(a));
+        tf_apply(&a, in[6], in[7], &out[0], &out[1]);
+        return;
+    } else if (op == 2) {
+        memcpy(&a, in, sizeof(a));
+        r = tf_inverse(&a);
+    } else if (op == 3) {
+        memcpy(&a, in, sizeof(a));
+        memcpy(&b, in + 6, sizeof(b));
+        r = tf_mul(&a, &b);
+    } else if (op == 4) {
+        memcpy(&a, in, sizeof(a));
+        out[0] = tf_basis_yaw_via_quaternion(&a);
+        return;
+    } else if (op == 5) {
+        out[0] = tf_yaw_from_quaternion_zw(in[0], in[1]);
+        return;
+    } else if (op == 6) {
+        tf_set_rotation_zw(&r, in[0], in[1]);
+    }
+    memcpy(out, &r, sizeof(r));
+}

@@ -38,6 +38,7 @@
 #include "oracle_sfm.h"
 
 #include <math.h>
+#include <quadmath.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -66,10 +67,19 @@ static inline v3 vnormalized(v3 a) { /* Tvector::normalized */
 static inline v3 vdivs(v3 a, double d) { return vscaled(a, 1 / d); } /* operator/ */
 static inline double vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y + a.z * b.z); }
 
+/* atan2 as the reference's libm evaluates it (glibc: <= 1 ulp, misrounds ~0.05 % of its inputs), or -- test-only switch
+ * sfm_set_cr_atan2(1) -- correctly rounded by an independent route: libquadmath's 113-bit atan2q rounded once to double.
+ * Tagent::socialForce branches on the SIGN of a difference of two atan2 of nearly parallel vectors, so on a crowd at rest
+ * a last-bit difference flips a full-size force term; the device's atan2 is correctly rounded (csrc/cr_atan2.h), and in CR
+ * mode the oracle is too, which makes the two comparable on every field without a tolerance for that coin. */
+static int g_cr_atan2 = 0;
+void sfm_set_cr_atan2(int on) { g_cr_atan2 = on; }
+static double at2(double y, double x) { return g_cr_atan2 ? (double)atan2q((__float128)y, (__float128)x) : atan2(y, x); }
+
 /* Tvector::angleTo via polarAngle = atan2(y, x) */
 static double angle_to(v3 a, v3 b) {
-    double angle_this = atan2(a.y, a.x);
-    double angle_other = atan2(b.y, b.x);
+    double angle_this = at2(a.y, a.x);
+    double angle_other = at2(b.y, b.x);
     double diff = angle_other - angle_this;
     if (diff > M_PI)
         diff -= 2 * M_PI;
@@ -459,9 +469,9 @@ static v3 lookahead_force(const sfm_scene* s, int self, v3 e) {
         double dy = other->p.y - me->p.y;
         double dist2 = (dx * dx + dy * dy);
         if (dist2 < 400) {
-            double at2v = atan2(-e.x, -e.y);
-            double at2d = atan2(-dx, -dy);
-            double at2v2 = atan2(-other->v.x, -other->v.y);
+            double at2v = at2(-e.x, -e.y);
+            double at2d = at2(-dx, -dy);
+            double at2v2 = at2(-other->v.x, -other->v.y);
             double sdiff = at2d - at2v;
             if (sdiff > pi) sdiff -= 2 * pi;
             if (sdiff < -pi) sdiff += 2 * pi;

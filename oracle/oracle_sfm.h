@@ -28,6 +28,8 @@ void sfm_get_agent(const sfm_scene* s, int idx, double* out6);
 double sfm_get_vmax(const sfm_scene* s, int idx);
 /* restart the two process-global random streams (minstd_rand0 for vmax, glibc rand() for the tree positions) */
 void sfm_reseed(void);
+/* test-only: 1 = every atan2 of the model correctly rounded (libquadmath atan2q rounded once), 0 = the host libm's (default) */
+void sfm_set_cr_atan2(int on);
 
 #ifdef __cplusplus
 }

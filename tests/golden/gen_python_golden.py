@@ -11,6 +11,7 @@ AgentState outputs (state, laser, view_map, is_collision, is_arrive, pedinfo -- 
 are recorded as the fixture's INPUTS.  The fixture's EXPECTED values are what the reference Python
 made of those inputs.
 """
+import json
 import os
 import sys
 
@@ -25,6 +26,33 @@ sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
 from img_env_amd import config, worldgen  # noqa: E402
 from oracle_binding import OracleWorld  # noqa: E402
+from scenarios import golden_cfg  # noqa: E402
+
+
+def _field(m, k, default=0):
+    """a message field as the wire would carry it: what the reference assigned, else the ROS default (0 / "" / [])"""
+    return m.__dict__.get(k, default)
+
+
+def capture_init_request(req):
+    """InitEnvRequest exactly as ImageEnv._init_req + EnvPos.init built it (yaml_env.py:183-209, reset_helper.py:348-412):
+    every field of InitEnv.srv / Env.msg / Agent.msg / SpeedLimiter.msg that reaches the step() path"""
+    def limiter(m):
+        return {k: _field(m, k) for k in ("has_velocity_limits", "has_acceleration_limits", "has_jerk_limits", "min_velocity",
+                                          "max_velocity", "min_acceleration", "max_acceleration", "min_jerk", "max_jerk")}
+    env = req.env
+    out = {k: _field(req, k) for k in ("view_resolution", "view_width", "view_height", "step_hz", "state_dim", "use_laser",
+                                       "range_total", "view_angle_begin", "view_angle_end", "view_min_dist", "view_max_dist",
+                                       "beep_r", "ped_ca_p", "relation_ped_robo", "sleep_t", "is_show_gui")}
+    out["global_resolution"] = _field(env, "global_resolution")
+    out["ped_scene_type"] = _field(env, "ped_scene_type", "")
+    out["robots"] = [dict(ktype=_field(a, "ktype", ""), shape=_field(a, "shape", ""), size=[float(x) for x in _field(a, "size", [])],
+                          sensor_cfg=[float(x) for x in _field(a, "sensor_cfg", [])],
+                          speed_limiter_v=limiter(_field(a, "speed_limiter_v", ref_import.Msg())),
+                          speed_limiter_w=limiter(_field(a, "speed_limiter_w", ref_import.Msg()))) for a in env.robots]
+    out["peds"] = [dict(ktype=_field(a, "ktype", ""), shape=_field(a, "shape", ""), size=[float(x) for x in _field(a, "size", [])],
+                        max_speed=float(_field(a, "max_speed", 0.0))) for a in env.peds]
+    return out
 
 
 def agent_states(world):
@@ -46,17 +74,20 @@ def agent_states(world):
 
 
 def run(name, n_robots, n_peds, steps, seed, time_max, ped_shape="circle", state_dim=3, n_obstacles=2,
-        near_goals=False):
+        near_goals=False, cfg_over=None):
     envs = ref_import.import_reference_envs()
     grid = worldgen.make_grid(200, seed)
-    cfg = worldgen.make_yaml_cfg(n_robots, n_peds, grid, time_max=time_max, ped_shape=ped_shape, state_dim=state_dim,
-                                 n_obstacles=n_obstacles)
+    meta = dict(n_robots=n_robots, n_peds=n_peds, steps=steps, seed=seed, time_max=time_max, ped_shape=ped_shape,
+                state_dim=state_dim, n_obstacles=n_obstacles, near_goals=near_goals)
+    if cfg_over:
+        meta["cfg_over"] = cfg_over
+    cfg = golden_cfg(meta, grid)
     world = OracleWorld(config.params_from_cfg(cfg), grid)
     layout = worldgen.make_layout(grid, 0.125, n_robots, n_peds, seed=seed + 100, n_obstacles=n_obstacles)
     if near_goals:  # goals 0.9 m ahead of each robot so that arrivals (and the +500 reward) occur
         yaw = 2.0 * np.arctan2(layout.robot_pose[:, 2], layout.robot_pose[:, 3])
         layout.robot_goal = layout.robot_pose[:, :2] + 0.9 * np.stack([np.cos(yaw), np.sin(yaw)], 1)
-    rec_in, rec_alive = [], []
+    rec_in, rec_alive, rec_init = [], [], []
 
     def record_inputs():
         o = world.out
@@ -65,6 +96,7 @@ def run(name, n_robots, n_peds, steps, seed, time_max, ped_shape="circle", state
                            is_arrives=o["is_arrives"].copy(), pedinfo=world.pedinfo()))
 
     def init_srv(req):
+        rec_init.append(capture_init_request(req))
         return ref_import.Msg()
 
     def reset_srv(req):
@@ -133,9 +165,8 @@ def run(name, n_robots, n_peds, steps, seed, time_max, ped_shape="circle", state
     for k in ("rewards", "dones", "dones_info", "is_clean"):
         a, b = np.stack(ora[k][1:]).astype(np.float64), out["exp_" + k].astype(np.float64)
         print("  %-18s max|oracle-ref| = %.3g" % (k, np.abs(a - b).max()))
-    meta = dict(n_robots=n_robots, n_peds=n_peds, steps=steps, seed=seed, time_max=time_max, ped_shape=ped_shape,
-                state_dim=state_dim, n_obstacles=n_obstacles, near_goals=near_goals)
     out["meta"] = np.array(repr(meta))
+    out["init_req"] = np.array(json.dumps(rec_init[-1]))  # the InitEnvRequest the reference sent (test_oracle_python_golden.py)
     path = os.path.join(HERE, "python_post_%s.npz" % name)
     np.savez_compressed(path, **out)
     print("wrote %s (%.1f KiB) collisions=%s arrives=%s" % (path, os.path.getsize(path) / 1024,
@@ -148,3 +179,15 @@ if __name__ == "__main__":
     run("b", n_robots=4, n_peds=7, steps=16, seed=11, time_max=100, ped_shape="leg", state_dim=5)
     run("c", n_robots=3, n_peds=0, steps=8, seed=5, time_max=100, state_dim=4, n_obstacles=0)
     run("d", n_robots=5, n_peds=3, steps=12, seed=21, time_max=100, near_goals=True)
+    # every InitEnv field off its default: omni robots of mixed footprints with sensor offsets, both speed limiters, ERVO legs
+    run("e", n_robots=4, n_peds=4, steps=10, seed=31, time_max=100, ped_shape="leg", state_dim=5, cfg_over={
+        "robot_type": "omni", "relation_ped_robo": 0, "range_total": 180, "view_angle_begin": -1.2, "view_angle_end": 0.9,
+        "view_min_dist": 0.25, "view_max_dist": 2.5, "control_hz": 0.4,
+        "robot.shape": ["circle", "rectangle", "circle", "rectangle"],
+        "robot.size": [[0, 0, 0.17], [-0.2, 0.2, -0.1, 0.1], [0.02, -0.01, 0.24], [-0.25, 0.15, -0.12, 0.12]],
+        "robot.sensor_cfgs": [[0.0, 0.0], [0.08, -0.03], [0.05, 0.0], [0.0, 0.04]],
+        "speed_limiter_v": {"has_velocity_limits": True, "has_acceleration_limits": True, "max_velocity": 0.5,
+                            "min_acceleration": -0.8, "max_acceleration": 0.6},
+        "speed_limiter_w": {"has_velocity_limits": True, "has_jerk_limits": True, "min_velocity": -0.7, "max_velocity": 0.7,
+                            "min_jerk": -1.5},
+        "ped_sim.type": "ervoscene", "ped_sim.max_speed": [0.4, 0.5, 0.6, 0.3]})

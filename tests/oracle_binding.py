@@ -33,7 +33,14 @@ def load_oracle():
     lib.oracle_pedinfo.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.oracle_private_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.oracle_grids.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.sfm_set_cr_atan2.argtypes = [C.c_int]
+    lib.sfm_set_cr_atan2.restype = None
     return lib
+
+
+def set_cr_atan2(on):
+    """social-force oracle: every atan2 correctly rounded (libquadmath) instead of the host libm's -- process-wide switch"""
+    load_oracle().sfm_set_cr_atan2(1 if on else 0)
 
 
 class OracleWorld:

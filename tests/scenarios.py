@@ -4,12 +4,30 @@ import numpy as np
 from img_env_amd import config, worldgen
 
 
-def golden_scenario(meta):
-    """rebuilds exactly what tests/golden/gen_python_golden.py::run() set up"""
-    grid = worldgen.make_grid(200, meta["seed"])
+def apply_cfg_over(cfg, over):
+    """``over``: {"key" or "section.key": value} laid over a YAML-schema config dict (sections are copied, not shared)"""
+    for k, v in (over or {}).items():
+        if "." in k:
+            sec, sub = k.split(".", 1)
+            cfg[sec] = dict(cfg[sec])
+            cfg[sec][sub] = v
+        else:
+            cfg[k] = v
+    return cfg
+
+
+def golden_cfg(meta, grid):
+    """the YAML-schema config of a golden fixture (what tests/golden/gen_python_golden.py::run() handed to make_env)"""
     cfg = worldgen.make_yaml_cfg(meta["n_robots"], meta["n_peds"], grid, time_max=meta["time_max"],
                                  ped_shape=meta["ped_shape"], state_dim=meta["state_dim"],
                                  n_obstacles=meta["n_obstacles"])
+    return apply_cfg_over(cfg, meta.get("cfg_over"))
+
+
+def golden_scenario(meta):
+    """rebuilds exactly what tests/golden/gen_python_golden.py::run() set up"""
+    grid = worldgen.make_grid(200, meta["seed"])
+    cfg = golden_cfg(meta, grid)
     layout = worldgen.make_layout(grid, 0.125, meta["n_robots"], meta["n_peds"], seed=meta["seed"] + 100,
                                   n_obstacles=meta["n_obstacles"])
     if meta.get("near_goals"):

@@ -137,3 +137,188 @@ def test_shared_owner_layers_equal_the_literal_private_grids(oracle_lib, seed):
     finally:
         a.close()
         b.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Agent::bresenhamLine (agent.cpp:511-624), one ray at a time on hand-made maps.  SENT marks cells the ray must not touch.
+SENT = 77
+
+
+def _ray(lib, src, x1, y1, x2, y2, res=0.5):
+    import ctypes as C
+    lib.oracle_test_bresenham.restype = C.c_double
+    lib.oracle_test_bresenham.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.full_like(src, SENT)
+    hit = lib.oracle_test_bresenham(x1, y1, x2, y2, src.ctypes.data, dst.ctypes.data, src.shape[0], src.shape[1], res)
+    return hit, dst
+
+
+def test_bresenham_axis_ray_leaves_the_hit_row_alone(oracle_lib):
+    """a ray along +x in column 2 that hits at (4, 2): 255 before, 0 at the hit, and the cells BEHIND it share the hit's column
+    (y == end_y), so `(cur.x != end_x) && (cur.y != end_y)` is false and they are left alone (agent.cpp:555-560)"""
+    src = np.full((8, 8), 255, np.uint8)
+    src[4, 2] = 0
+    hit, dst = _ray(oracle_lib, src, 1, 2, 7, 2)
+    assert hit == 3 * 0.5                                             # distance between cell centres (map2world), 3 cells
+    assert list(dst[1:4, 2]) == [255, 255, 255] and dst[4, 2] == 0
+    assert list(dst[5:8, 2]) == [SENT, SENT, SENT]                    # same column as the hit: untouched; (7, 2) is the excluded endpoint
+    assert (dst == SENT).sum() == 64 - 4                              # nothing else was written
+
+
+def test_bresenham_diagonal_ray_marks_200_behind_the_hit(oracle_lib):
+    """w == h takes the y-stepping branch (`w > h` is false): cells (1,1) .. (6,6), endpoint excluded; behind the hit at (3,3)
+    every cell differs from it in row AND column -> 200"""
+    src = np.full((8, 8), 255, np.uint8)
+    src[3, 3] = 0
+    src[5, 5] = 0                                                     # a second obstacle behind the first is not a hit
+    hit, dst = _ray(oracle_lib, src, 1, 1, 7, 7)
+    assert hit == pytest.approx(2 * np.sqrt(2.0) * 0.5, abs=1e-15)
+    assert dst[1, 1] == 255 and dst[2, 2] == 255 and dst[3, 3] == 0
+    assert dst[4, 4] == 200 and dst[5, 5] == 200 and dst[6, 6] == 200 and dst[7, 7] == SENT
+    assert (dst != SENT).sum() == 6
+
+
+def test_bresenham_shallow_ray_mixes_alone_and_200(oracle_lib):
+    """(0,0) -> (6,2): f = 2h - w = -2, delta1 = 4, delta2 = -8 gives the cells (0,0) (1,0) (2,1) (3,1) (4,1) (5,2).  Hit at
+    (2,1): (3,1) and (4,1) share its column -> left alone; (5,2) shares neither -> 200"""
+    src = np.full((8, 8), 255, np.uint8)
+    src[2, 1] = 0
+    hit, dst = _ray(oracle_lib, src, 0, 0, 6, 2)
+    assert hit == pytest.approx(np.sqrt(5.0) * 0.5, abs=1e-15)
+    assert dst[0, 0] == 255 and dst[1, 0] == 255 and dst[2, 1] == 0
+    assert dst[3, 1] == SENT and dst[4, 1] == SENT and dst[5, 2] == 200
+    assert (dst != SENT).sum() == 4
+    # the same ray mirrored (dx = dy = -1): (6,2) -> (0,0) visits (6,2) (5,2) (4,1) (3,1) (2,1) (1,0)
+    src = np.full((8, 8), 255, np.uint8)
+    src[4, 1] = 0
+    hit, dst = _ray(oracle_lib, src, 6, 2, 0, 0)
+    assert hit == pytest.approx(np.sqrt(5.0) * 0.5, abs=1e-15)
+    assert dst[6, 2] == 255 and dst[5, 2] == 255 and dst[4, 1] == 0
+    assert dst[3, 1] == SENT and dst[2, 1] == SENT and dst[1, 0] == 200 and dst[0, 0] == SENT
+
+
+def test_bresenham_edge_cases(oracle_lib):
+    free = np.full((8, 8), 255, np.uint8)
+    hit, dst = _ray(oracle_lib, free, 3, 3, 3, 3)                     # start == end: `y != y2` fails at once, no cell is touched
+    assert hit == 6.0 and (dst == SENT).all()                          # 6 is the hard-coded "no hit" (agent.cpp:513)
+    hit, dst = _ray(oracle_lib, free, 5, 5, 12, 5)                    # the ray leaves the view: returns at the first outside cell
+    assert hit == 6.0 and list(dst[5:8, 5]) == [255, 255, 255] and (dst != SENT).sum() == 3
+    unknown = np.full((8, 8), 200, np.uint8)                          # 200 (outside the field of view) counts as free: `cur_data != 0`
+    unknown[6, 5] = 0
+    hit, dst = _ray(oracle_lib, unknown, 2, 5, 7, 5)
+    assert hit == 4 * 0.5 and list(dst[2:7, 5]) == [255, 255, 255, 255, 0]
+    start_on_obstacle = free.copy()
+    start_on_obstacle[2, 2] = 0                                       # the sensor's own cell is on the path: distance 0
+    hit, dst = _ray(oracle_lib, start_on_obstacle, 2, 2, 2, 6)
+    assert hit == 0.0 and dst[2, 2] == 0 and list(dst[2, 3:6]) == [SENT, SENT, SENT]  # same row as the hit: left alone
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SpeedLimiter::limit (speed_limit.cpp:92-173) and Agent::cmd (agent.cpp:186-283) through one-robot worlds; state_dim = 4
+# puts the limited (v, w) into the vector state (agent.cpp:172-175).  Every number below is a dyadic fraction, so the
+# expected values are exact.
+def _one_robot(oracle_lib, goal=(90.0, 90.0), yaw=0.0, **kw):
+    grid = np.full((800, 800), 255, np.uint8)
+    params = worldgen.make_params(1, 0, res=RES, state_dim=4, **kw)
+    w = OracleWorld(params, grid)
+    w.reset(_layout([(10.0, 10.0, yaw)], [goal]))
+    return w
+
+
+def _cmd(w, v, wv, v_y=0.0):
+    w.step(np.array([[v, wv, v_y]], np.float32))
+    s = w.snapshot()
+    return float(s["vector_states"][0, 2]), float(s["vector_states"][0, 3]), s["robot_pose"][0].copy()
+
+
+def test_acceleration_limiter_known_sequence(oracle_lib):
+    """limit_acceleration with min / max acceleration -+0.5 and dt = 0.25: |dv| <= 0.125 per step, and the zero-crossing
+    branch (`v_sign + v0_sign == 0`) first brakes to a stop"""
+    lim = dict(has_acceleration_limits=True, min_acceleration=-0.5, max_acceleration=0.5)
+    w = _one_robot(oracle_lib, limiter_v=lim)
+    try:
+        assert _cmd(w, 0.5, 0.0)[0] == 0.125        # from rest: dv = +0.5 -> clamp(|dv|, -0.125, 0.125) = 0.125
+        assert _cmd(w, 0.5, 0.0)[0] == 0.25         # v0 = 0.125, again +0.125
+        assert _cmd(w, 0.0, 0.0)[0] == 0.125        # braking: dv_sign = -1 matches neither sign -> -|clamp(-0.25, ...)| = -0.125
+        assert _cmd(w, -0.5, 0.0)[0] == 0.0         # signs oppose: zero_dt = |0.125 / -0.5| = 0.25 >= dt -> v0 - 0.5 * 0.25 = 0
+        assert _cmd(w, -0.5, 0.0)[0] == -0.125      # from rest backwards
+        v, _, _ = _cmd(w, 0.5, 0.0)                 # signs oppose again: -(0.125 - 0.125) = -0.0
+        assert v == 0.0
+    finally:
+        w.close()
+
+
+def test_velocity_and_jerk_limiters_known_values(oracle_lib):
+    """limit_velocity clamps last; limit_jerk works on the last two commands with da in [min_jerk, max_jerk] * 2 dt^2 where the
+    node's constructor copies msg.min_jerk into max_jerk and never sets min_jerk (speed_limit.cpp:56-65; 0 here)"""
+    w = _one_robot(oracle_lib, limiter_v=dict(has_velocity_limits=True, min_velocity=0.0, max_velocity=0.25),
+                   limiter_w=dict(has_velocity_limits=True, min_velocity=-0.5, max_velocity=0.5))
+    try:
+        v, wv, _ = _cmd(w, 0.5, 0.875)
+        assert (v, wv) == (0.25, 0.5)
+        v, wv, _ = _cmd(w, 0.125, -0.75)
+        assert (v, wv) == (0.125, -0.5)
+    finally:
+        w.close()
+    w = _one_robot(oracle_lib, limiter_v=dict(has_jerk_limits=True, min_jerk=1.0, max_jerk=-123.0))  # msg.max_jerk is ignored
+    try:
+        assert _cmd(w, 0.5, 0.0)[0] == 0.125        # dv = 0.5, dv0 = 0: da = clamp(0.5, 0, 1 * 0.125) = 0.125
+        assert _cmd(w, 0.5, 0.0)[0] == 0.375        # v0 = 0.125, v1 = 0: dv0 = 0.125, da = clamp(0.25, 0, 0.125) -> 0.125 + 0.125 + 0.125
+        assert _cmd(w, 0.0, 0.0)[0] == 0.625        # dv - dv0 = -0.625 clamps to min_jerk * dt2 = 0: v0 + dv0 = 0.375 + 0.25
+    finally:
+        w.close()
+
+
+def test_diff_drive_pose_update_known_values(oracle_lib):
+    """the exact arc of agent.cpp:221-236: w == 0 straight, else r = v / w about the instantaneous centre; theta is not wrapped"""
+    w = _one_robot(oracle_lib)
+    try:
+        _, _, p = _cmd(w, 0.5, 0.0)
+        assert list(p) == [10.125, 10.0, 0.0]                                    # x += v dt cos(0)
+        assert list(w.records[0, 3:5]) == [0.5, 0.0]                             # Agent::vx, vy of the last 0.05 s sub-step
+        _, _, p = _cmd(w, 0.5, 0.5)                                              # r = 1: x += sin(0.125), y += 1 - cos(0.125)
+        assert p[0] == pytest.approx(10.125 + np.sin(0.125), abs=2e-15) and p[1] == pytest.approx(10.0 + (1.0 - np.cos(0.125)), abs=2e-15)
+        assert p[2] == 0.125
+        for _ in range(60):
+            _, _, p = _cmd(w, 0.0, 0.875)
+        assert p[2] == pytest.approx(0.125 + 60 * 0.875 * 0.25, abs=1e-12) and p[2] > 4 * np.pi   # never wrapped (agent.cpp:233)
+    finally:
+        w.close()
+    w = _one_robot(oracle_lib, yaw=np.pi / 2)
+    try:
+        _, _, p = _cmd(w, 0.5, 0.0)
+        assert p[0] == pytest.approx(10.0, abs=1e-15) and p[1] == pytest.approx(10.125, abs=1e-15)
+    finally:
+        w.close()
+
+
+def test_omni_pose_update_known_values(oracle_lib):
+    """omni adds the lateral terms (agent.cpp:238-274) and, unlike diff, never updates Agent::vx / vy"""
+    w = _one_robot(oracle_lib, robot_ktype="omni")
+    try:
+        _, _, p = _cmd(w, 0.5, 0.0, 0.25)
+        assert list(p) == [10.125, 10.0625, 0.0]                                 # x += v dt, y += v_y dt at theta = 0
+        assert list(w.records[0, 3:5]) == [0.0, 0.0]                             # vx, vy untouched
+        _, _, p = _cmd(w, 0.5, 0.5, 0.25)                                        # v / w = 1, v_y / w = 0.5, theta: 0 -> 0.125
+        s, c = np.sin(0.125), np.cos(0.125)
+        assert p[0] == pytest.approx(10.125 + s + (-0.5 + 0.5 * c), abs=2e-15)
+        assert p[1] == pytest.approx(10.0625 + (1.0 - c) + 0.5 * s, abs=2e-15)
+        assert p[2] == 0.125
+    finally:
+        w.close()
+
+
+def test_substep_loop_runs_six_times_for_a_quarter_second(oracle_lib):
+    """`while (cur_control <= step_hz_)` with cur_control += 0.05 reaches exactly 0.25 on the fifth addition, so the loop body
+    runs SIX times: odom_pose_ travels 0.3 s worth (0.18 m at 0.6 m/s) although the pose itself advances 0.25 s (0.15 m).  A goal
+    0.47 m ahead is therefore reached by the sub-step test (0.29 <= 0.3) but not by the final one (0.32); at 0.49 m by neither."""
+    for goal_x, arrives in ((10.47, 1), (10.49, 0)):
+        w = _one_robot(oracle_lib, goal=(goal_x, 10.0))
+        try:
+            w.step(np.array([[0.6, 0.0, 0.0]], np.float32))
+            s = w.snapshot()
+            assert s["is_arrives"][0] == arrives, goal_x
+            assert s["robot_pose"][0, 0] == pytest.approx(10.0 + float(np.float32(0.6)) * 0.25, abs=1e-15)
+        finally:
+            w.close()

@@ -60,3 +60,54 @@ def test_python_half_matches_reference_python(oracle_lib, path):
         assert np.array_equal(s["is_clean"].astype(bool), z["exp_is_clean"][t - 1])
         # _step_req: alive = (dones == 0) from the previous ImageEnv.step (yaml_env.py:319-331)
         assert np.array_equal(snaps[t - 1]["base_dones"] == 0, z["in_alive"][t - 1])
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_params_from_cfg_reproduce_the_reference_init_request(path):
+    """YAML -> InitEnv mapping: `config.params_from_cfg` (shared by the HIP library and the oracle) against the
+    InitEnvRequest the reference's own `ImageEnv._init_req` + `EnvPos.init` built from the same YAML dict
+    (yaml_env.py:183-209, reset_helper.py:348-412), captured by gen_python_golden.py::init_srv.  Fields that are float32
+    on the wire (InitEnv.srv, Agent.msg, SpeedLimiter.msg) are compared after float32 rounding -- what the node reads."""
+    import json
+
+    from img_env_amd import _cabi, config, worldgen
+    from scenarios import golden_cfg
+    z = np.load(path)
+    if "init_req" not in z.files:
+        pytest.skip("fixture predates the InitEnvRequest capture")
+    meta = ast.literal_eval(str(z["meta"]))
+    req = json.loads(str(z["init_req"]))
+    cfg = golden_cfg(meta, worldgen.make_grid(200, meta["seed"]))
+    p = config.params_from_cfg(cfg)
+    c, _keep = _cabi.make_cfg(p)  # what crosses the C ABI
+    f32 = np.float32
+    for k in ("view_resolution", "view_width", "view_height", "step_hz", "view_angle_begin", "view_angle_end", "view_min_dist",
+              "view_max_dist", "beep_r", "ped_ca_p", "global_resolution"):
+        assert f32(getattr(c, k)) == f32(req[k]), k
+    for k in ("state_dim", "range_total", "relation_ped_robo"):
+        assert int(getattr(c, k)) == int(req[k]), k
+    assert bool(c.use_laser) == bool(req["use_laser"])
+    assert req["sleep_t"] == 0 and not req["is_show_gui"]  # pacing / GUI are outside the path
+    scene_names = {v: k for k, v in _cabi.SCENES.items()}
+    assert scene_names.get(c.ped_scene_type, "") == (req["ped_scene_type"] if meta["n_peds"] else "")
+    assert c.n_robots == len(req["robots"]) and c.n_peds == len(req["peds"])
+    shape_names = {v: k for k, v in _cabi.SHAPES.items()}
+    ktype_names = {v: k for k, v in _cabi.KTYPES.items()}
+    for i, a in enumerate(req["robots"]):
+        assert ktype_names[c.robot_ktype] == a["ktype"]
+        assert shape_names[c.robot_shape[i]] == a["shape"]
+        n = len(a["size"])
+        assert np.array_equal(np.array([c.robot_size[4 * i + q] for q in range(n)], f32), np.array(a["size"], f32))
+        assert np.array_equal(np.array([c.robot_sensor_cfg[2 * i + q] for q in range(2)], f32), np.array(a["sensor_cfg"], f32))
+        assert c.robot_size_last[i] == a["size"][-1]  # yaml_env.py:407 reads robot.size[i][-1] as the Python float
+        for name in ("speed_limiter_v", "speed_limiter_w"):
+            lim, want = getattr(c, name.replace("speed_", "")), a[name]
+            for fl in ("has_velocity_limits", "has_acceleration_limits", "has_jerk_limits"):
+                assert bool(getattr(lim, fl)) == bool(want[fl]), (name, fl)
+            for fl in ("min_velocity", "max_velocity", "min_acceleration", "max_acceleration", "min_jerk", "max_jerk"):
+                assert f32(getattr(lim, fl)) == f32(want[fl]), (name, fl)
+    for j, a in enumerate(req["peds"]):
+        assert shape_names[c.ped_shape[j]] == a["shape"]
+        n = len(a["size"])
+        assert np.array_equal(np.array([c.ped_size[6 * j + q] for q in range(n)], f32), np.array(a["size"], f32))
+        assert f32(c.ped_max_speed[j]) == f32(a["max_speed"])
