@@ -412,6 +412,32 @@ struct RvoObstacles {
 
 
 // ---------------------------------------------------------------------------------------------
+// glibc rand() for the beep lottery (img_env.cpp:327), in the form k_beep consumes: the last 31 words of the TYPE_3 stream
+// of a fresh process (seed 1, 310 discarded draws: glibc stdlib/random_r.c) and the jump table of the linear recurrence
+// r[i] = r[i-3] + r[i-31] (mod 2^32).
+static void beep_initial_state(uint32_t s[31]) {
+    std::vector<uint32_t> r(344);
+    r[0] = 1;
+    for (int i = 1; i < 31; i++) {
+        const long prev = (int32_t)r[i - 1];
+        long word = 16807 * (prev % 127773) - 2836 * (prev / 127773);
+        if (word < 0) word += 2147483647;
+        r[i] = (uint32_t)word;
+    }
+    for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+    for (int i = 34; i < 344; i++) r[i] = r[i - 31] + r[i - 3];
+    for (int j = 0; j < 31; j++) s[j] = r[344 - 31 + j];
+}
+// coef[k][j]: next word k (0-based) = sum_j coef[k][j] * last31[j]
+static std::vector<uint32_t> beep_coefficients(int n_words) {
+    std::vector<uint32_t> c((size_t)(31 + n_words) * 31, 0u);
+    for (int j = 0; j < 31; j++) c[(size_t)j * 31 + j] = 1u;
+    for (int k = 31; k < 31 + n_words; k++)
+        for (int j = 0; j < 31; j++) c[(size_t)k * 31 + j] = c[(size_t)(k - 31) * 31 + j] + c[(size_t)(k - 3) * 31 + j];
+    return std::vector<uint32_t>(c.begin() + 31 * 31, c.end());
+}
+
+// ---------------------------------------------------------------------------------------------
 // libpedsim / PedScene construction on the host (pedscene.h:57-80, ped_agent.cpp:24-58): the per-agent
 // random vmax and the peds' rand() start positions that seed the quadtree.  Both generators are
 // third-party (libstdc++ <random>, glibc rand()), restated from their published algorithms; one handle is one

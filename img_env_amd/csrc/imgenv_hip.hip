@@ -76,9 +76,7 @@ struct imgenv {
     std::vector<StageSegHost> segs;  // copies queued for the next stage_flush
     size_t seg_max = 0;
     uint8_t* d_static_map = nullptr;  // the map every reset starts from
-    struct ObstClass { int shape; float size[4]; int n; const double2* pts; };
-    std::vector<ObstClass> ocls;      // obstacle footprints seen so far (device sample lists)
-    struct ObstInstHost { double x, y, sh, ch; const void* pts; int n_pts, world; };
+    struct ObstInstHost { double x, y, sh, ch, cx, cy, r; int m0, m1, n0, n1, shape, world; };
     std::vector<ObstInstHost> oinst;  // obstacles of the reset being staged
     void* d_oinst = nullptr;
     size_t cap_oinst = 0;
@@ -231,7 +229,15 @@ extern "C" int imgenv_timing_read(imgenv_t* h, double* total_ms, int64_t* launch
     return IMGENV_OK;
 }
 
+// "hip-gfx950" is the product build only: a library compiled with any work-skipping experiment switch or with the
+// profiling instrumentation says so, so that a number measured on it can never pass for the product's
+#if defined(IMGENV_EXP_SKIP_CROP) || defined(IMGENV_EXP_SKIP_HITS) || defined(IMGENV_EXP_SKIP_FINAL) || defined(IMGENV_EXP_CROP_U8)
+extern "C" const char* imgenv_backend(void) { return "hip-gfx950-EXPERIMENT-work-skipped"; }
+#elif defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE)
+extern "C" const char* imgenv_backend(void) { return "hip-gfx950-profile-instrumented"; }
+#else
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950"; }
+#endif
 extern "C" int32_t imgenv_abi_version(void) { return IMGENV_ABI_VERSION; }
 extern "C" const char* imgenv_last_error(void) { return g_err; }
 
@@ -316,6 +322,16 @@ static int dev_upload(imgenv* h, const T** out, const std::vector<T>& v) {
     *out = p;
     return 0;
 }
+// inside imgenv_create once the handle exists: a failing HIP call must not leak the handle and what it has allocated so far
+#define HIPCHK_H(expr)                                                                                        \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            snprintf(g_err, sizeof(g_err), "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            imgenv_destroy(h);                                                                                \
+            return IMGENV_EDEVICE;                                                                            \
+        }                                                                                                     \
+    } while (0)
 #define TRY(expr)              \
     do {                       \
         int rc_ = (expr);      \
@@ -383,6 +399,10 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     }
     int r0, r1;
     if (shard_of(*cfg, r0, r1)) FAIL(IMGENV_EINVAL, "bad robot shard [%d,%d)", cfg->robot_begin, cfg->robot_end);
+    // The lottery only ever has an effect in the ERVO scene (rs_ / ps_ are ignored by the others, img_env.cpp:343).
+    const bool beep_on = cfg->ped_scene_type == IMGENV_SCENE_ERVO && cfg->n_peds > 0 && cfg->beep_r > 0 && cfg->ped_ca_p > 0;
+    if (beep_on && r1 - r0 != cfg->n_robots)
+        FAIL(IMGENV_EINVAL, "beep_r / ped_ca_p > 0 in a robot shard: the beep lottery needs every robot's action on every rank");
     if (W > 1 && r1 - r0 != cfg->n_robots)
         FAIL(IMGENV_EINVAL, "n_worlds > 1 cannot be combined with a robot shard: give each rank whole worlds (its own handle)");
     const ViewGeom g = make_view_geom(*cfg);
@@ -516,9 +536,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
 
     // grids (one copy per world)
     TRY(dev_alloc(h, &h->d_obs_map, Gp));
-    for (int k = 0; k < W; k++) HIPCHK(hipMemcpy(h->d_obs_map + (size_t)k * h->Gs, static_map, G, hipMemcpyHostToDevice));
+    for (int k = 0; k < W; k++) HIPCHK_H(hipMemcpy(h->d_obs_map + (size_t)k * h->Gs, static_map, G, hipMemcpyHostToDevice));
     TRY(dev_alloc(h, &h->d_static_map, (G + 15) & ~(size_t)15));
-    HIPCHK(hipMemcpy(h->d_static_map, static_map, G, hipMemcpyHostToDevice));
+    HIPCHK_H(hipMemcpy(h->d_static_map, static_map, G, hipMemcpyHostToDevice));
     TRY(dev_alloc(h, &h->d_world_epoch, W));
     d.world_epoch = h->d_world_epoch;
     h->wobst.assign((size_t)4 * W, 0);
@@ -658,13 +678,28 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         for (int j = 0; j < P && j < NA; j++) ms[j] = (float)(double)h->pmax[j];
         TRY(dev_upload(h, &d.amax_speed, ms));
     }
+    d.beep_on = beep_on ? 1 : 0;
+    d.beep_r = cfg->beep_r;
+    d.ped_ca_p = (double)cfg->ped_ca_p;
+    if (beep_on) {  // one rand() stream per world = per node process of the reference, as a fresh process starts it
+        uint32_t s0[31];
+        beep_initial_state(s0);
+        std::vector<uint32_t> st((size_t)31 * W);
+        for (int k = 0; k < W; k++) memcpy(&st[(size_t)31 * k], s0, sizeof(s0));
+        const uint32_t* up = nullptr;
+        TRY(dev_upload(h, &up, st));
+        d.beep_state = const_cast<uint32_t*>(up);
+        TRY(dev_upload(h, &d.beep_coef, beep_coefficients(BEEP_T)));
+        TRY(dev_alloc(h, &d.beep_flag, R));
+        TRY(dev_alloc(h, &d.beep_xy, R));
+    }
     {   // overflow flags live in page-locked host memory the device writes through: no copy, no sync to read them
         int* e = nullptr;
-        HIPCHK(hipHostMalloc((void**)&e, 8 * sizeof(int), hipHostMallocMapped));
+        HIPCHK_H(hipHostMalloc((void**)&e, 8 * sizeof(int), hipHostMallocMapped));
         memset(e, 0, 8 * sizeof(int));
         h->err_host = e;
         int* dev = nullptr;
-        HIPCHK(hipHostGetDevicePointer((void**)&dev, e, 0));
+        HIPCHK_H(hipHostGetDevicePointer((void**)&dev, e, 0));
         d.err = dev;
         d.sfm.err = dev + 4;
     }
@@ -700,11 +735,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_alloc(h, &f.dest, n, 0xFF)); TRY(dev_alloc(h, &f.last, n, 0xFF));  // -1
         TRY(dev_alloc(h, &f.nodes, f.cap_nodes)); TRY(dev_alloc(h, &f.n_nodes, 1)); TRY(dev_alloc(h, &f.treehash, n));
         TRY(dev_alloc(h, &f.pair_f, (size_t)(n ? n : 1) * (n ? n : 1) * 3)); TRY(dev_alloc(h, &f.pair_code, (size_t)(n ? n : 1) * (n ? n : 1)));
-        HIPCHK(hipMemcpy(f.p, p0.data(), sizeof(double) * 3 * (n ? n : 1), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(f.vmax, vmax.data(), sizeof(double) * (n ? n : 1), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(f.nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(f.n_nodes, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemcpy(f.p, p0.data(), sizeof(double) * 3 * (n ? n : 1), hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemcpy(f.vmax, vmax.data(), sizeof(double) * (n ? n : 1), hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemcpy(f.nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemcpy(f.n_nodes, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
     }
     TRY(dev_alloc(h, &d.prof, 16 + 12 * (size_t)RL));
     TRY(dev_alloc(h, &d.dbg, 32));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
@@ -728,7 +763,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         h->arena = (unsigned char*)p;
         h->own_arena = true;
     }
-    HIPCHK(hipMemset(h->arena, 0, plan.total));
+    HIPCHK_H(hipMemset(h->arena, 0, plan.total));
     unsigned char* A = h->arena;
     imgenv_out& o = h->out;
     o.struct_size = (int32_t)sizeof(imgenv_out);
@@ -764,8 +799,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     d.is_clean = o.is_clean; d.robot_pose = o.robot_pose; d.ped_state = o.ped_state; d.counters = o.counters;
     {   // NearbyPed starts at +inf and is never re-initialised (reset_helper.py:85-99); is_clean starts True
         std::vector<double> inf(RL, INFINITY);
-        HIPCHK(hipMemcpy(o.ped_min_dists, inf.data(), sizeof(double) * RL, hipMemcpyHostToDevice));
-        HIPCHK(hipMemset(o.is_clean, 1, RL));
+        HIPCHK_H(hipMemcpy(o.ped_min_dists, inf.data(), sizeof(double) * RL, hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemset(o.is_clean, 1, RL));
     }
     h->PP = WAVE;  // sort slots of k_obs: a power of two, 64 * E of them in registers up to 1024 pedestrians
     while (h->PP < h->Pw) h->PP <<= 1;
@@ -789,18 +824,18 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
                               (const void*)k_view<false, true, false, 4>, (const void*)k_view<false, false, false, 4>,
                               (const void*)k_view<true, true, true, 4>, (const void*)k_view<true, false, true, 4>,
                               (const void*)k_view<false, true, true, 4>, (const void*)k_view<false, false, true, 4>})
-            HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
+            HIPCHK_H(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
     }
     if (h->lds_obs > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+        HIPCHK_H(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     h->serial = getenv("IMGENV_SERIAL") && getenv("IMGENV_SERIAL")[0] == '1';
-    HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK_H(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIPCHK_H(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    HIPCHK_H(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_H(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_H(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_H(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK_H(hipDeviceSynchronize());
     *out = h;
     return IMGENV_OK;
 }
@@ -1163,55 +1198,43 @@ __global__ __launch_bounds__(256) void k_reset_apply(DevWorld w, ResetArgs a) {
 }
 // Every obstacle is then drawn into its world's map with value 0: Agent::draw(obs_map, 0, "world_map") (img_env.cpp:169-193,
 // agent.cpp:285-327) writes unless the cell holds 0 / 1 / 2 -- and only ever writes 0, so the order does not matter.
-// One workgroup per obstacle; its footprint samples were uploaded once per (shape, size).
+// One workgroup per obstacle.  Its footprint samples (agent.cpp:18-30, 51-62: a 0.01 m lattice, for circles the points within
+// the radius) are generated on the fly from the lattice bounds the host computed: random obstacle radii (EnvPos draws a fresh
+// one per episode, reset_helper.py:131-133) then cost nothing -- no per-size sample list to upload, cache or free.
 struct ObstInst {
     double x, y, sh, ch;  // pose; sin / cos of yaw/2, evaluated on the host
-    const double2* pts;
-    int n_pts, world;
+    double cx, cy, r;     // circle: centre offset and radius (sizes[0..2]); rectangle: unused
+    int m0, m1, n0, n1;   // lattice range: circle -bb..bb with bb = ceil(r / 0.01); rectangle floor(min / 0.01)..ceil(max / 0.01)
+    int shape, world;
 };
 template <bool POW2>
 __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst, int stamp) {
     const ObstInst o = inst[blockIdx.x];
     const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
     uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)o.world * w.Gs;
-    for (int q = threadIdx.x; q < o.n_pts; q += blockDim.x) {
-        const double2 p = o.pts[q];
+    const double resolution = 0.01;
+    const int nn = o.n1 - o.n0 + 1, total = (o.m1 - o.m0 + 1) * nn;
+    const bool circle = o.shape == IMGENV_SHAPE_CIRCLE;
+    for (int q = threadIdx.x; q < total; q += blockDim.x) {
+        const int m = o.m0 + q / nn, n = o.n0 + q % nn;
+        double px = m * resolution, py = n * resolution;
+        if (circle) {
+            if (!(sqrt(m * resolution * m * resolution + n * resolution * n * resolution) <= o.r)) continue;
+            px = px + o.cx;
+            py = py + o.cy;
+        }
         double wx, wy;
-        tf_apply(bw, p.x, p.y, wx, wy);
-        int m, n;
-        w2m_pair<POW2>(wx, wy, w.res, w.inv_res, m, n);
-        if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            const size_t at = (size_t)m * w.Wg + n;
+        tf_apply(bw, px, py, wx, wy);
+        int gm, gn;
+        w2m_pair<POW2>(wx, wy, w.res, w.inv_res, gm, gn);
+        if (gm >= 0 && gm < w.Hg && gn >= 0 && gn < w.Wg) {
+            const size_t at = (size_t)gm * w.Wg + gn;
             if (map[at] > 2) {
                 map[at] = 0;
                 if (stamp) w.cell[(size_t)o.world * w.Gs + at] = CLS_STATIC;  // the class layer's base class follows
             }
         }
     }
-}
-
-// the footprint samples of an obstacle class (agent.cpp:18-62), uploaded the first time a reset brings the class
-static int obstacle_class(imgenv* h, int shape, const float* size4, const double2** pts, int* n_pts) {
-    for (const auto& c : h->ocls)
-        if (c.shape == shape && !memcmp(c.size, size4, 16)) {
-            *pts = c.pts;
-            *n_pts = c.n;
-            return 0;
-        }
-    double sizes[4];
-    for (int j = 0; j < 4; j++) sizes[j] = (double)size4[j];
-    const Pts bb = shape == IMGENV_SHAPE_CIRCLE ? shape_circle(sizes[0], sizes[1], sizes[2]) : shape_rectangle(sizes);
-    std::vector<double2> v(bb.n() > 0 ? bb.n() : 1);
-    for (int q = 0; q < bb.n(); q++) v[q] = make_double2(bb.x[q], bb.y[q]);
-    imgenv::ObstClass c;
-    c.shape = shape;
-    memcpy(c.size, size4, 16);
-    c.n = bb.n();
-    if (int rc = dev_upload(h, &c.pts, v)) return rc;
-    h->ocls.push_back(c);
-    *pts = c.pts;
-    *n_pts = c.n;
-    return 0;
 }
 
 // the obstacle list of one world's reset batch: instances for k_reset_obstacles, the RVO polygons with their BSP
@@ -1225,10 +1248,22 @@ static int world_obstacles(imgenv* h, int k, const imgenv_reset_batch* b, std::v
         for (int j = 0; j < 4; j++) sizes[j] = (double)b->obs_size[4 * q + j];
         const double* p = b->obs_pose + 4 * q;
         const double yaw = tf_yaw_from_quaternion_zw(p[2], p[3]);
+        if (shape != IMGENV_SHAPE_CIRCLE && shape != IMGENV_SHAPE_RECTANGLE) FAIL(IMGENV_EINVAL, "obstacle %d: unsupported shape %d", q, shape);
         imgenv::ObstInstHost oi;
         oi.x = p[0]; oi.y = p[1]; oi.sh = sin(yaw * 0.5); oi.ch = cos(yaw * 0.5);
         oi.world = k;
-        if (int rc = obstacle_class(h, shape, b->obs_size + 4 * q, (const double2**)&oi.pts, &oi.n_pts)) return rc;
+        oi.shape = shape;
+        oi.cx = sizes[0]; oi.cy = sizes[1]; oi.r = sizes[2];
+        if (shape == IMGENV_SHAPE_CIRCLE) {  // init_shape_circle (agent.cpp:18-30)
+            const int bb = (int)ceil(sizes[2] / 0.01);
+            oi.m0 = oi.n0 = -bb;
+            oi.m1 = oi.n1 = bb;
+        } else {                             // init_shape_rectangle (agent.cpp:51-62)
+            oi.m0 = (int)floor(sizes[0] / 0.01); oi.m1 = (int)ceil(sizes[1] / 0.01);
+            oi.n0 = (int)floor(sizes[2] / 0.01); oi.n1 = (int)ceil(sizes[3] / 0.01);
+        }
+        if ((long long)(oi.m1 - oi.m0 + 1) * (long long)(oi.n1 - oi.n0 + 1) > (1ll << 26) || oi.m1 < oi.m0 || oi.n1 < oi.n0)
+            FAIL(IMGENV_EINVAL, "obstacle %d: degenerate or oversized footprint", q);
         h->oinst.push_back(oi);
         const Tf2 bw = tf_from_pose_sc(p[0], p[1], oi.sh, oi.ch);
         double pax, pay, pbx, pby;
@@ -1398,11 +1433,27 @@ static int stage_world(imgenv* h, int k, int q_list, const imgenv_reset_batch* b
     return 0;
 }
 
-static int reset_checks(imgenv* h, int n, const imgenv_reset_batch* b) {
+// everything that can be wrong with the batches is found here, BEFORE any of them touches the handle's state: a reset
+// that fails part-way would leave host and device copies of the earlier worlds out of step
+static int reset_checks(imgenv* h, int n, const imgenv_reset_batch* b, int peds_per_batch) {
     if (!h || !b) FAIL(IMGENV_EINVAL, "null argument");
     for (int q = 0; q < n; q++) {
         if (b[q].struct_size != (int32_t)sizeof(imgenv_reset_batch)) FAIL(IMGENV_EINVAL, "reset batch ABI mismatch");
         if (b[q].n_obstacles < 0 || (h->P > 0 && b[q].ped_traj_cap < 1)) FAIL(IMGENV_EINVAL, "bad reset batch");
+        if (b[q].n_obstacles > 0 && (!b[q].obs_shape || !b[q].obs_size || !b[q].obs_pose)) FAIL(IMGENV_EINVAL, "reset batch %d: null obstacle arrays", q);
+        if (!b[q].robot_pose || !b[q].robot_goal) FAIL(IMGENV_EINVAL, "reset batch %d: null robot arrays", q);
+        for (int o = 0; o < b[q].n_obstacles; o++)
+            if (b[q].obs_shape[o] != IMGENV_SHAPE_CIRCLE && b[q].obs_shape[o] != IMGENV_SHAPE_RECTANGLE)
+                FAIL(IMGENV_EINVAL, "reset batch %d, obstacle %d: unsupported shape %d", q, o, b[q].obs_shape[o]);
+        if (peds_per_batch > 0) {
+            if (!b[q].ped_pose || !b[q].ped_traj_len || !b[q].ped_traj) FAIL(IMGENV_EINVAL, "reset batch %d: null pedestrian arrays", q);
+            if (h->cfg.ped_scene_type == IMGENV_SCENE_DATASET && !b[q].ped_traj_v)
+                FAIL(IMGENV_EINVAL, "dataset scene: ped_traj_v is missing from the reset batch");
+            if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && !b[q].ped_goal) FAIL(IMGENV_EINVAL, "pedscene: ped_goal is missing from the reset batch");
+            for (int j = 0; j < peds_per_batch; j++)
+                if (b[q].ped_traj_len[j] < 1 || b[q].ped_traj_len[j] > b[q].ped_traj_cap)
+                    FAIL(IMGENV_EINVAL, "reset batch %d, ped %d: bad trajectory length %d", q, j, b[q].ped_traj_len[j]);
+        }
     }
     if (h->obs_forked) FAIL(IMGENV_ESTATE, "reset between imgenv_step_begin and imgenv_step_end");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1483,12 +1534,13 @@ static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int w
     h->launches = 2;
     const int rc = launch_views(h, st, 1);
     set_active(h, nullptr, 0);
-    if (rc) return rc;
-    return stage_end(h, st);
+    // k_reset_apply is in flight and reads this generation's page-locked chunks: mark them pending whatever came after
+    const int rc_end = stage_end(h, st);
+    return rc ? rc : rc_end;
 }
 
 extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stream) {
-    if (int rc = reset_checks(h, 1, b)) return rc;
+    if (int rc = reset_checks(h, 1, b, h ? h->P : 0)) return rc;
     hipStream_t st = (hipStream_t)stream;
     RTRY(stage_begin(h));
     RTRY(reset_blocks(h, h->W, nullptr));
@@ -1521,7 +1573,7 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
 extern "C" int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_reset_batch* batches, void* stream) {
     if (n <= 0) return h ? IMGENV_OK : IMGENV_EINVAL;
     if (!worlds) FAIL(IMGENV_EINVAL, "null argument");
-    if (int rc = reset_checks(h, n, batches)) return rc;
+    if (int rc = reset_checks(h, n, batches, h ? h->Pw : 0)) return rc;
     if (h->W == 1) {
         if (n != 1 || worlds[0] != 0) FAIL(IMGENV_EINVAL, "world out of range (n_worlds 1)");
         return imgenv_reset(h, batches, stream);
@@ -1632,6 +1684,11 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
         TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), 0, st>>>(d)));
         h->launches += 1;
+    }
+    if (d.beep_on) {  // beep lottery + ERVO's evacuation term on top of the velocities the solve left (img_env.cpp:323-343)
+        k_beep<<<dim3(h->W), dim3(BEEP_T), 0, st>>>(d, actions);
+        k_evac<<<dim3(h->P), dim3(WAVE), 0, st>>>(d);
+        h->launches += 2;
     }
     // _step_robot (img_env.cpp:388-410)
     {   // ... and the pedestrians' move (img_env.cpp:343-358) in the same launch

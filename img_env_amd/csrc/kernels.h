@@ -246,8 +246,84 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
             query_obstacle_tree(w, s, pos, obst_range_sq);
         }
         const f2 nv = compute_new_velocity(w, s, j, pref);
-        // ERVO: every beep source is ((0,0), 0) through the Python API (yaml_env.py:183-200 never
-        // forwards beep_r / ped_ca_p), for which addEvacVelocity (Agent.cpp:63-69) returns early.
+        // ERVO's evacuation term (Agent.cpp:63-69, 430-432) is added by k_evac once the step's actions -- and with them the
+        // beep sources -- exist; through the reference's Python API there never are any (yaml_env.py:183-200).
+        w.anvx[j] = nv.x;
+        w.anvy[j] = nv.y;
+    }
+}
+
+// Beep lottery (img_env.cpp:323-342), one workgroup per world: `rand() / double(RAND_MAX) < ped_ca_p` once per robot in
+// robot order, then "v_y > 0" of this step's request (the action's beep; 0 for dead robots, yaml_env.py:328-331) makes the
+// robot a source at its pose as the previous step left it (_step_ped runs before _step_robot, img_env.cpp:423-424).
+//
+// rand() is glibc's TYPE_3 additive-feedback generator: r[i] = r[i-3] + r[i-31] mod 2^32, output r[i] >> 1.  The recurrence
+// is linear over Z / 2^32, so word k of the next BEEP_T words is a fixed combination (beep_coef[k][0..30], built on the host
+// by running the recurrence on unit vectors) of the last 31 words: every thread produces one rand() value per round with 31
+// multiply-adds instead of one lane walking a chain of thousands of dependent additions.
+__global__ __launch_bounds__(BEEP_T) void k_beep(DevWorld w, const float* __restrict__ actions) {
+    __shared__ uint32_t comb[31 + BEEP_T];
+    const int wld = blockIdx.x, t = threadIdx.x;
+    const int n_rob = w.W > 1 ? w.Rw : w.R, rob_lo = wld * n_rob;
+    uint32_t* st = w.beep_state + 31 * wld;
+    if (t < 31) comb[t] = st[t];
+    __syncthreads();
+    const uint32_t* c = w.beep_coef + 31 * t;
+    for (int base = 0; base < n_rob; base += BEEP_T) {
+        const int n = min(BEEP_T, n_rob - base);
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 31; j++) v += c[j] * comb[j];
+        comb[31 + t] = v;
+        if (t < n) {
+            const int i = rob_lo + base + t, l = i - w.r0;  // (never sharded: l is the robot's row of `actions`)
+            const int rnd = (int)(v >> 1);
+            const bool lottery = rnd / double(2147483647) < w.ped_ca_p;
+            const double beep_radius = w.py_done[l] ? 0.0 : (double)actions[3 * l + 2];
+            w.beep_flag[i] = (lottery && beep_radius > 0) ? 1 : 0;
+            const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+            w.beep_xy[i] = make_float2((float)r[0], (float)r[1]);
+        }
+        __syncthreads();
+        const uint32_t keep = t < 31 ? comb[n + t] : 0u;  // the stream has advanced by n words
+        __syncthreads();
+        if (t < 31) comb[t] = keep;
+        __syncthreads();
+    }
+    if (t < 31) st[t] = comb[t];
+}
+
+// addEvacVelocity for every source, after the LP (ervo_ros Agent.cpp:63-69, 430-432): newVelocity_ += normalize(pa - ps) for
+// each source within rs (and farther than 1e-4) of the agent, in robot order -- float32 sums, so the order is kept: 64 lanes
+// test 64 robots, the (few) hits are added in index order.  One wavefront per pedestrian; the solve itself ran a step ahead
+// on the side stream (k_orca), the sources only exist once this step's actions do.  Unclamped, as in the reference.
+__global__ __launch_bounds__(WAVE) void k_evac(DevWorld w) {
+    const int j = blockIdx.x, lane = lane_id();
+    const int wld = world_of_ped(w, j);
+    const int n_rob = w.W > 1 ? w.Rw : w.R, rob_lo = wld * n_rob;
+    const f2 pa = F2(w.apx[j], w.apy[j]);
+    f2 nv = F2(w.anvx[j], w.anvy[j]);
+    const float rs = w.beep_r;
+    bool changed = false;
+    for (int base = 0; base < n_rob; base += WAVE) {
+        const int i = rob_lo + base + lane;
+        f2 evac = F2(0.0f, 0.0f);
+        bool hit = false;
+        if (base + lane < n_rob && w.beep_flag[i]) {
+            const float2 ps = w.beep_xy[i];
+            evac = pa - F2(ps.x, ps.y);
+            const float a = vabs(evac);
+            hit = !(a > rs || (double)a < 1e-4);
+        }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            nv = nv + normalize(F2(__shfl(evac.x, src), __shfl(evac.y, src)));
+            changed = true;
+        }
+    }
+    if (lane == 0 && changed) {
         w.anvx[j] = nv.x;
         w.anvy[j] = nv.y;
     }
@@ -1768,9 +1844,10 @@ __global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
     const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
     const unsigned long long fmask = __ballot(frozen);  // counters[2] since the last reset, counters[3] since create
-    if (fmask != 0 && lane_id() == 0) {  // (both counters with one 64-bit add: neither gets anywhere near 2^31 between resets)
-        const unsigned long long n = (unsigned long long)__popcll(fmask);
-        atomicAdd((unsigned long long*)(w.counters + 2), n | (n << 32));
+    if (fmask != 0 && lane_id() == 0) {  // two 32-bit adds: a handle that only ever resets single worlds never clears counters[2],
+        const int n = __popcll(fmask);   // and a carry out of it must not leak into counters[3]
+        atomicAdd(&w.counters[2], n);
+        atomicAdd(&w.counters[3], n);
     }
 }
 

@@ -10,6 +10,7 @@
 #define OWNER_MULTI 0xFFFFFEu  // 24-bit owner field of the composed layer: several robots cover the cell
 #define RC_INLINE 6           // distinct robot classes (shape, size, sensor) per world, carried in the kernel arguments
 #define PC_INLINE 4           // distinct pedestrian classes per world
+#define BEEP_T 256            // rand() values one round of k_beep produces
 #define ORCA_NEAR_CAP 64       // robot agents a pedestrian can have within its 0.5 m neighbour range before k_orca falls back to the full scan
 
 // composed class layer byte (k_compose): low 3 bits = base class, bit 3 = "some robot covers it"
@@ -149,6 +150,14 @@ struct DevWorld {
     int n_obst, n_onodes, oroot;
     int* near_n;     // [P] robot agents within neighborDist of pedestrian j this step (from k_side_robots) ...
     int* near_list;  // [P][ORCA_NEAR_CAP] ... their agent indices, in arrival order
+    // ERVO beep lottery (img_env.cpp:323-342) and evacuation term (ervo_ros Agent.cpp:63-69, 430-432)
+    int beep_on;                 // scene is ERVO, beep_r > 0 and ped_ca_p > 0: the lottery can fire
+    float beep_r;                // rs_ of a source
+    double ped_ca_p;
+    uint32_t* beep_state;        // [W][31] the last 31 words of each world's rand() stream (glibc TYPE_3)
+    const uint32_t* beep_coef;   // [BEEP_T][31] word k of the next BEEP_T as a combination of those 31 (the recurrence is linear)
+    uint8_t* beep_flag;          // [R] robot is a beep source this step
+    float2* beep_xy;             // [R] its position (float32, as RVO::Vector2) before this step's integrate
     SfmDev sfm;  // social-force crowd (pedscene)
     // robot-sharded worlds: this rank only needs the rasters under its own robots' views.  bbox = ordered-uint32 encoded
     // float min x, min y, max x, max y of the local robots' centres, accumulated by k_integrate / k_reset_robots

@@ -179,7 +179,9 @@ class ImageEnv(Env):
         self.dones = o["base_dones"]
         if self._zeros_info is None:
             self._zeros_info = torch.zeros_like(o["dones_info"])
-        return self._state(), o["base_rewards"], o["base_dones"], {"dones_info": self._zeros_info}
+        # copies, like the reference's `deepcopy(self.dones)`: the library's buffers are rewritten in place by the next
+        # step -- or by the reset NeverStopWrapper issues inside this very step() call
+        return self._state(), o["base_rewards"].clone(), o["base_dones"].clone(), {"dones_info": self._zeros_info}
 
     def end_ep(self, robot_res=None):
         """yaml_env.py:379-390: episode recording is out of scope; kept for API compatibility"""
@@ -280,8 +282,8 @@ class InfoLogWrapper(Wrapper):
     def step(self, action):
         import torch
         state, reward, done, info = self.env.step(action)
-        info["arrive"] = state.is_arrives
-        info["collision"] = state.is_collisions
+        info["arrive"] = state.is_arrives.clone()      # (the state tensors are views of buffers a reset rewrites in place)
+        info["collision"] = state.is_collisions.clone()
         di = info["dones_info"]
         di = torch.where(state.is_collisions > 0, state.is_collisions.to(di.dtype), di)
         di = torch.where(state.is_arrives == 1, torch.full_like(di, 5), di)

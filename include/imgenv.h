@@ -93,7 +93,12 @@ typedef struct imgenv_cfg {
     int32_t range_total;          /* number of beams */
     float view_angle_begin, view_angle_end;
     float view_min_dist, view_max_dist;
-    float beep_r, ped_ca_p;       /* never forwarded by yaml_env.py:183-200 => 0 */
+    float beep_r, ped_ca_p;       /* beep lottery (img_env.cpp:323-342): a robot whose action has beep (v_y) > 0 becomes, with
+                                   * probability ped_ca_p, a source of radius beep_r that ERVO pedestrians move away from
+                                   * (ervo_ros Agent.cpp:63-69).  The reference's Python never forwards either
+                                   * (yaml_env.py:183-200 => 0 at the node, the lottery never fires); C-ABI callers may set
+                                   * them.  One glibc rand() stream per world, as a fresh node process starts it.  Not
+                                   * available in a robot shard (every rank would need every robot's action). */
     int32_t relation_ped_robo;    /* 1: robots are agents of the pedestrian simulator */
 
     /* ---- Env.msg ---- */

@@ -69,6 +69,51 @@ typedef struct pclass { /* ped class = (shape, size) */
     pts left, right; /* leg */
 } pclass;
 
+/* ------------------------------------------------------------------ glibc rand() (third-party: glibc 2.31+ stdlib/random.c,
+ * random_r.c -- TYPE_3, degree 31, separation 3, default seed 1), restated in the library's own front / rear pointer form.
+ * img_env.cpp:327 draws rand() once per robot per step for the beep lottery.  One world = one node process = one stream.
+ * Pinned against the container's real libc in tests/test_oracle_known_answers.py. */
+typedef struct glibc_rand_state {
+    int32_t tbl[31];
+    int f, r; /* fptr, rptr as indices */
+} glibc_rand_state;
+
+static int32_t glibc_rand_next(glibc_rand_state* g) { /* __random_r, TYPE_3 branch */
+    uint32_t val = (uint32_t)g->tbl[g->f] + (uint32_t)g->tbl[g->r];
+    g->tbl[g->f] = (int32_t)val;
+    int32_t result = (int32_t)(val >> 1);
+    if (++g->f >= 31) {
+        g->f = 0;
+        ++g->r;
+    } else if (++g->r >= 31) {
+        g->r = 0;
+    }
+    return result;
+}
+
+static void glibc_srand(glibc_rand_state* g, unsigned int seed) { /* __srandom_r */
+    if (seed == 0) seed = 1;
+    g->tbl[0] = (int32_t)seed;
+    int32_t word = (int32_t)seed;
+    for (int i = 1; i < 31; i++) { /* 16807 * word % 2147483647 without overflow (Schrage) */
+        long hi = word / 127773, lo = word % 127773;
+        long t = 16807 * lo - 2836 * hi;
+        if (t < 0) t += 2147483647;
+        word = (int32_t)t;
+        g->tbl[i] = word;
+    }
+    g->f = 3; /* fptr = &state[rand_sep], rptr = &state[0] */
+    g->r = 0;
+    for (int k = 0; k < 310; k++) (void)glibc_rand_next(g); /* kc = rand_deg * 10 discarded draws */
+}
+
+/* unit-test hook: the first n values of rand() after srand(seed) */
+void oracle_test_glibc_rand(unsigned int seed, int n, int32_t* out) {
+    glibc_rand_state g;
+    glibc_srand(&g, seed);
+    for (int i = 0; i < n; i++) out[i] = glibc_rand_next(&g);
+}
+
 struct oracle_world {
     imgenv_cfg cfg;
     int R, P, r0, r1, RL;
@@ -101,6 +146,7 @@ struct oracle_world {
     float* pmax_speed;
     rvo_sim* rvo;
     sfm_scene* sfm;
+    glibc_rand_state lottery; /* the node process's rand() stream as far as the beep lottery consumes it (img_env.cpp:327) */
     int has_reset;
     /* python-side state */
     double* tmp_dist;
@@ -394,6 +440,10 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
         FAIL(IMGENV_EINVAL, "bad robot shard [%d,%d)", cfg->robot_begin, cfg->robot_end);
     }
     w->RL = w->r1 - w->r0;
+    if (cfg->ped_scene_type == IMGENV_SCENE_ERVO && cfg->beep_r > 0 && cfg->ped_ca_p > 0 && w->RL != w->R) {
+        free(w);
+        FAIL(IMGENV_EINVAL, "the beep lottery needs every robot's action: not available in a robot shard");
+    }
     w->Hg = Hg;
     w->Wg = Wg;
     /* img_env.cpp:58-81: float32 request fields read into doubles */
@@ -481,6 +531,7 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     /* ImgEnv::_init (img_env.cpp:83-103): scene + addPed + addRobot */
     if (cfg->ped_scene_type == IMGENV_SCENE_RVO || cfg->ped_scene_type == IMGENV_SCENE_ERVO) {
         w->rvo = rvo_create((float)w->step_hz); /* setTimeStep(step_hz_) rvoscene.h:13-16 */
+        glibc_srand(&w->lottery, 1); /* a fresh node process: rand() was never seeded */
         for (int j = 0; j < P; j++) /* rvoscene.h:53-58 */
             rvo_add_agent(w->rvo, 0.f, 0.f, 0.5f, 10, 5.f, 5.f, 0.5f, (float)(double)w->pmax_speed[j]);
         if (cfg->relation_ped_robo == 1)
@@ -647,6 +698,7 @@ int oracle_grids(oracle_world* w, const uint8_t** obs_map, const uint8_t** peds_
     if (peds_map) *peds_map = w->peds_map;
     return IMGENV_OK;
 }
+
 
 /* ------------------------------------------------------------------ Agent::view */
 
@@ -1117,8 +1169,8 @@ static void step_ped_dataset(oracle_world* w) {
     }
 }
 
-/* ImgEnv::_step_ped_normal (img_env.cpp:304-359) */
-static void step_ped(oracle_world* w) {
+/* ImgEnv::_step_ped_normal (img_env.cpp:304-359); actions = this step's request (local robots) */
+static void step_ped(oracle_world* w, const float* actions) {
     const int P = w->P;
     if (w->cfg.ped_scene_type == IMGENV_SCENE_DATASET) { /* ImgEnv::_step_ped (img_env.cpp:294-302) */
         step_ped_dataset(w);
@@ -1146,11 +1198,26 @@ static void step_ped(oracle_world* w) {
             w->rvo->prefx[j] = gvx;
             w->rvo->prefy[j] = gvy;
         }
-        /* beep lottery (img_env.cpp:323-342): ped_ca_p is 0 through the Python API, so every robot
-         * contributes the source ((0,0), 0) and ERVO's evacuation term is a no-op. */
+        /* beep lottery (img_env.cpp:323-342), one rand() per robot of the request: with probability ped_ca_p a robot whose
+         * v_y (the action's `beep`, yaml_env.py:326; 0 for dead robots, 328-331) is positive becomes a source at its pose --
+         * robot_pose_ as the PREVIOUS step left it, _step_ped runs before _step_robot (img_env.cpp:423-424) -- with radius
+         * beep_r; everybody else contributes ((0,0), 0), for which addEvacVelocity returns early.  Through the reference's Python
+         * API both parameters arrive as 0 (yaml_env.py:183-200 never forwards them) and the lottery never fires. */
         if (w->cfg.ped_scene_type == IMGENV_SCENE_ERVO) {
             float* ps = (float*)calloc((size_t)w->R * 2, sizeof(float));
             float* rs = (float*)calloc((size_t)w->R, sizeof(float));
+            const double ped_ca_p = (double)w->cfg.ped_ca_p, beep_r = (double)w->cfg.beep_r;
+            for (int j = 0; j < w->R; j++) {
+                if (glibc_rand_next(&w->lottery) / (double)2147483647 < ped_ca_p) {
+                    const int l = j - w->r0;
+                    const double beep_radius = (l >= 0 && l < w->RL && w->py_done[l] == 0) ? (double)actions[3 * l + 2] : 0.0;
+                    if (beep_radius > 0) {
+                        ps[2 * j] = (float)REC(w, j)[0]; /* RVO::Vector2(rpose.x, rpose.y) */
+                        ps[2 * j + 1] = (float)REC(w, j)[1];
+                        rs[j] = (float)beep_r;
+                    }
+                }
+            }
             rvo_do_step(w->rvo, w->rvo->n_agents, ps, rs, w->R);
             free(ps);
             free(rs);
@@ -1250,7 +1317,7 @@ int oracle_step_begin(oracle_world* w, const float* actions) {
     if (!w || !actions) FAIL(IMGENV_EINVAL, "null argument");
     if (!w->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
     /* ImgEnv::_step (img_env.cpp:421-425) */
-    step_ped(w);
+    step_ped(w, actions);
     /* _step_req (yaml_env.py:319-331) + _step_robot (img_env.cpp:388-419) */
     for (int l = 0; l < w->RL; l++) {
         if (w->py_done[l] == 0) {

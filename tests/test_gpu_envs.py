@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from scenarios import golden_scenario
+from scenarios import golden_cfg, golden_scenario
 
 pytestmark = pytest.mark.gpu
 FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "python_post_*.npz")))
@@ -20,8 +20,7 @@ def test_make_env_stack_matches_reference(path):
     z = np.load(path)
     meta = ast.literal_eval(str(z["meta"]))
     grid, params, layout = golden_scenario(meta)
-    cfg = worldgen.make_yaml_cfg(meta["n_robots"], meta["n_peds"], grid, time_max=meta["time_max"],
-                                 ped_shape=meta["ped_shape"], state_dim=meta["state_dim"], n_obstacles=meta["n_obstacles"])
+    cfg = golden_cfg(meta, grid)
     env = make_env(cfg)   # VelAction, TimeLimit, SensorsPaperReward, InfoLog, MultiRobotClean
     try:
         st = env.reset(layout=layout)
@@ -64,6 +63,41 @@ def test_reference_action_objects_and_random_spawn():
             resets += int(bool(info["all_down"][0]))
         assert resets == 2            # time_max 5 -> every 6th step ends the episode
         assert cfg["node_id"] == 1    # make_env post-increments node_id (envs/__init__.py:32)
+    finally:
+        env.close()
+
+
+def test_terminal_step_survives_the_auto_reset():
+    """an episode that ends by COLLISION and one that ends by ARRIVAL (not by the time limit): NeverStopWrapper resets the
+    env inside the same step() call (base.py:198-211), and the reset rewrites the library's done / collision / arrive buffers
+    in place.  What step() returned for the terminal step must still be the terminal step's values, as with the reference's
+    `deepcopy(self.dones)` (yaml_env.py:377)."""
+    import torch
+    from img_env_amd import make_env, worldgen
+    from test_oracle_known_answers import _layout
+    grid = worldgen.make_grid(200, 1)
+    stack = ["VelActionWrapper", "TimeLimitWrapper", "SensorsPaperRewardWrapper", "InfoLogWrapper", "MultiRobotCleanWrapper",
+             "NeverStopWrapper"]
+    cfg = worldgen.make_yaml_cfg(1, 0, grid, time_max=50, n_obstacles=0, seed=3, wrappers=stack)
+    env = make_env(cfg)
+    try:
+        # 0.45 m in front of the border wall (8 cells = 1.0 m thick), driving at it: collides within a few steps
+        env.reset(layout=_layout([(1.62, 12.0, 3.14159)], [(20.0, 12.0)]))
+        for s in range(10):
+            st, rew, done, info = env.step(torch.tensor([[0.6, 0.0]], device="cuda"))
+            if bool(info["all_down"][0]):
+                break
+        assert s < 9, "the robot never reached the wall"
+        assert done.cpu().tolist() == [1] and info["collision"].cpu().tolist() == [1] and info["arrive"].cpu().tolist() == [0]
+        assert info["dones_info"].cpu().tolist() == [1] and rew.cpu().tolist() == [-500.0]
+        assert st.is_collisions.cpu().tolist() == [0]    # the state IS the new episode's first observation
+        # arrival: the goal 0.4 m ahead
+        env.reset(layout=_layout([(12.0, 12.0, 0.0)], [(12.4, 12.0)]))
+        st, rew, done, info = env.step(torch.tensor([[0.6, 0.0]], device="cuda"))
+        assert bool(info["all_down"][0])
+        assert done.cpu().tolist() == [1] and info["arrive"].cpu().tolist() == [1] and info["collision"].cpu().tolist() == [0]
+        assert info["dones_info"].cpu().tolist() == [5] and rew.cpu().tolist() == [500.0]
+        assert st.is_arrives.cpu().tolist() == [0]
     finally:
         env.close()
 

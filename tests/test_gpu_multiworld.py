@@ -51,8 +51,8 @@ def _compare_all(gpu, cpus, Rw, Pw, where, fails):
             fails.append((where, k, bad))
 
 
-def _run(World, OracleWorld, W, Rw, Pw, steps, resets, seed, whole_reset=False, **kw):
-    """``resets``: {step: [worlds reset after that step]}"""
+def _run(World, OracleWorld, W, Rw, Pw, steps, resets, seed, whole_reset=False, beep=False, **kw):
+    """``resets``: {step: [worlds reset after that step]}; ``beep``: half of the actions carry a positive beep (v_y)"""
     grid, params, lay0 = small_world(Rw, Pw, seed=seed, **kw)
     layouts = [lay0] + [small_world(Rw, Pw, seed=seed + 100 * k, **kw)[2] for k in range(1, W)]
     gpu = World(_stack_params(params, W), grid)
@@ -76,6 +76,8 @@ def _run(World, OracleWorld, W, Rw, Pw, steps, resets, seed, whole_reset=False, 
         n_reset = 0
         for s in range(steps):
             a = random_actions(rng, W * Rw)
+            if beep:
+                a[:, 2] = np.where(rng.random(W * Rw) < 0.5, 0.2, 0.0).astype(np.float32)
             gpu.step(a)
             for k, cpu in enumerate(cpus):
                 cpu.step(a[k * Rw:(k + 1) * Rw])
@@ -127,6 +129,15 @@ def test_worlds_with_legs_ervo_and_odd_sizes(worlds):
     World, OracleWorld = worlds
     fails, _, _ = _run(World, OracleWorld, 5, 9, 11, 12, {5: [4], 6: [0]}, seed=34, n_obstacles=2, ped_shape="leg",
                        scene="ervoscene", res=0.1, view_cells=37, view_width=3.75, view_height=3.75, grid_size=150)
+    assert not fails, fails[:3]
+
+
+def test_worlds_with_their_own_beep_lotteries(worlds):
+    """every world of a handle is one node process of the reference: its own rand() stream for the beep lottery
+    (img_env.cpp:327), which a reset of that world does not restart"""
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, 4, 10, 12, 16, {5: [3], 8: [0, 2]}, seed=35, n_obstacles=2, scene="ervoscene",
+                       grid_size=80, clearance=0.6, beep=True, beep_r=1.5, ped_ca_p=0.7)
     assert not fails, fails[:3]
 
 

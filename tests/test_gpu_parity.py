@@ -246,6 +246,47 @@ def test_hip_matches_oracle_variants(worlds, name):
         cpu.close()
 
 
+@pytest.mark.parametrize("ped_ca_p, ktype", [(1.0, "diff"), (0.6, "diff"), (0.35, "omni")])
+def test_beep_lottery_and_ervo_evacuation_match_oracle(worlds, ped_ca_p, ktype):
+    """the beep lottery (img_env.cpp:323-342: one glibc rand() per robot per step, `< ped_ca_p`, action beep > 0)
+    and ERVO's evacuation term (ervo_ros Agent.cpp:63-69) through the C ABI.  The crowd must really have been pushed around:
+    the same episode with ped_ca_p = 0 ends elsewhere."""
+    World, OracleWorld = worlds
+    n, P, steps = 40, 30, 25
+    kw = dict(seed=91, grid_size=120, clearance=0.6, n_obstacles=2, scene="ervoscene", robot_ktype=ktype)
+    grid, params, layout = small_world(n, P, beep_r=1.5, ped_ca_p=ped_ca_p, **kw)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    quiet = OracleWorld(dict(params, ped_ca_p=0.0), grid)
+    try:
+        rng = np.random.default_rng(17)
+        acts = []
+        for _ in range(steps):
+            a = random_actions(rng, n)
+            a[:, 2] = np.where(rng.random(n) < 0.5, rng.uniform(0.05, 0.3, n), rng.uniform(-0.3, 0.0, n)).astype(np.float32)
+            acts.append(a)
+        fails = run_pair(gpu, cpu, layout, acts)
+        assert not fails, fails[:3]
+        quiet.reset(layout)
+        for a in acts:
+            quiet.step(a)
+        moved = np.abs(cpu.snapshot()["ped_state"] - quiet.snapshot()["ped_state"]).max()
+        assert moved > 0.05, moved
+        # a second episode on the same handles: the rand() stream carries on, it is not restarted by a reset
+        fails = run_pair(gpu, cpu, layout, acts[:8])
+        assert not fails, ("second episode", fails[:3])
+    finally:
+        gpu.close()
+        cpu.close()
+        quiet.close()
+
+
+def test_beep_lottery_is_rejected_in_a_robot_shard(worlds):
+    World, _ = worlds
+    grid, params, layout = small_world(8, 4, seed=5, scene="ervoscene", beep_r=1.0, ped_ca_p=0.5)
+    with pytest.raises(ValueError, match="beep"):
+        World(dict(params, robot_begin=0, robot_end=4), grid)
+
+
 def _dataset_world(n_robots, n_peds, steps, seed, ped_shape="circle"):
     """pedestrians replay a recorded random walk: rows (x, y, yaw, vx, vy) per step (reset_helper.py:417-432)"""
     from img_env_amd import spawn

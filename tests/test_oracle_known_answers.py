@@ -322,3 +322,35 @@ def test_substep_loop_runs_six_times_for_a_quarter_second(oracle_lib):
             assert s["robot_pose"][0, 0] == pytest.approx(10.0 + float(np.float32(0.6)) * 0.25, abs=1e-15)
         finally:
             w.close()
+
+
+def test_lottery_stream_is_glibc_rand(oracle_lib):
+    """the oracle's restatement of glibc's TYPE_3 rand() (the beep lottery's stream, img_env.cpp:327) against the real
+    libc of this container, default seed and another one"""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    for seed in (1, 20240611):
+        out = (C.c_int32 * 4000)()
+        oracle_lib.oracle_test_glibc_rand(C.c_uint(seed), 4000, out)
+        libc.srand(seed)
+        assert list(out) == [libc.rand() for _ in range(4000)], seed
+    assert out[0] >= 0 and max(out) <= 2147483647
+
+
+def test_beep_pushes_an_ervo_pedestrian_away(oracle_lib):
+    """one robot, one standing ERVO pedestrian 0.8 m to its left (its goal is where it stands): a beep of radius 1.5 with
+    ped_ca_p = 1 adds the unit vector robot -> pedestrian to its new velocity (ervo_ros Agent.cpp:63-69, unclamped), the
+    same request without beep (v_y = 0), with ped_ca_p = 0 or out of range leaves it standing"""
+    for beep_r, p, v_y, pushed in ((1.5, 1.0, 0.2, True), (1.5, 1.0, 0.0, False), (1.5, 0.0, 0.2, False), (0.5, 1.0, 0.2, False)):
+        grid, params = _open_world(n_robots=1, n_peds=1, scene="ervoscene", relation_ped_robo=0, beep_r=beep_r, ped_ca_p=p)
+        w = OracleWorld(params, grid)
+        try:
+            w.reset(_layout([(10.0, 10.0, 0.0)], [(20.0, 10.0)], ped_xy=[(10.0, 10.8)]))
+            w.step(np.array([[0.0, 0.0, v_y]], np.float32))
+            ps = w.snapshot()["ped_state"][0]
+            if pushed:  # velocity (0, 1) for one step of 0.25 s; float32 arithmetic
+                assert abs(ps[2]) < 1e-6 and abs(ps[3] - 1.0) < 1e-6 and abs(ps[1] - 11.05) < 1e-5
+            else:
+                assert abs(ps[2]) < 1e-6 and abs(ps[3]) < 1e-6 and abs(ps[1] - 10.8) < 1e-6
+        finally:
+            w.close()
