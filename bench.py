@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- robot-steps/sec of the img_env step() path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ...` (RANK / WORLD_SIZE in the
+environment), or plainly as above -- the parent process then starts one child per GPU itself (it never touches a GPU) and
+relays rank 0's JSON line.
 
 Workload (BASELINE.json metric, configs[2] = SURVEY "cfg-3"): ONE world with 8192 robots per GPU and
 200 ORCA pedestrians (rvoscene) on a 400x400 occupancy grid, 48x48 sensor_map + 3-channel ped_map,
@@ -59,28 +63,122 @@ def algorithmic_bytes(P, hv=48, wv=48, beams=360, max_ped=N_PEDS):
     return dict(k_view=view, k_obs=obs, k_tail=state, total=view + obs + state)
 
 
-def cpu_baseline(params, grid, layout, seconds=12.0):
-    """the CPU oracle (literal single-thread C restatement of the reference) on the same world"""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle_world(n_robots, n_peds, grid_cells, res, clearance, seed):
+    """an oracle world of the benchmark's geometry (TEST / BASELINE infrastructure: bench.py's cpu_baseline leg only)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from img_env_amd import worldgen
     from oracle_binding import OracleWorld
-    p = dict(params)
-    p["robot_begin"], p["robot_end"] = 0, p["n_robots"]
-    w = OracleWorld(p, grid)
+    grid = worldgen.make_grid(grid_cells, 0)
+    params = worldgen.make_params(n_robots, n_peds, res=res, view_cells=48, beams=360, scene="rvoscene", time_max=TIME_MAX)
+    layout = worldgen.make_layout(grid, res, n_robots, n_peds, seed=seed, clearance=clearance)
+    w = OracleWorld(params, grid)
     w.reset(layout)
+    return w
+
+
+def _oracle_run(w, n_robots, seconds, max_steps, start_at=None):
     rng = np.random.default_rng(1)
-    R = p["n_robots"]
+    if start_at is not None:  # all workers start together
+        while time.time() < start_at:
+            time.sleep(0.005)
     steps, t0 = 0, time.perf_counter()
     while True:
-        a = np.stack([np.zeros(R), rng.uniform(-0.9, 0.9, R), np.zeros(R)], 1).astype(np.float32)
+        a = np.stack([np.zeros(n_robots), rng.uniform(-0.9, 0.9, n_robots), np.zeros(n_robots)], 1).astype(np.float32)
         w.step(a)
         steps += 1
-        if time.perf_counter() - t0 > seconds or steps >= 50:
+        if time.perf_counter() - t0 > seconds or steps >= max_steps:
             break
-    dt = time.perf_counter() - t0
+    return steps, time.perf_counter() - t0
+
+
+def cpu_worker(args):
+    """one process of the all-core CPU baseline (`bench.py --cpu-worker ...`, started by cpu_baseline): its own world of
+    R / k robots beside the benchmark's 200 pedestrians on the benchmark's map -- the reference's env_num idiom (one
+    single-threaded node per env, create_launch.py:57-66).  Never imports torch, never touches a GPU."""
+    n = args.cpu_worker_robots
+    w = _oracle_world(n, args.peds, GRID, RES, CLEARANCE, seed=1000 + args.cpu_worker)
+    steps, dt = _oracle_run(w, n, args.cpu_worker_seconds, 10 ** 9, start_at=args.cpu_worker_start)
     w.close()
-    return dict(value=R * steps / dt, unit="robot-steps/s", cores=1, kind="port",
-                sample="%d steps of the same %d-robot / %d-ped world, v=0 policy, single thread, %.1f s"
-                       % (steps, R, p["n_peds"], dt))
+    print(json.dumps(dict(worker=args.cpu_worker, robots=n, steps=steps, seconds=dt)))
+
+
+def cpu_baseline(params, grid, layout, peds, seconds=6.0, all_core_seconds=8.0):
+    """The CPU oracle (literal single-thread C restatement of the reference, `kind: "port"`) on this box's host cores:
+    (a) ONE thread on the very world the GPU timed (8192 robots in one shared world), and
+    (b) ALL cores the way the reference itself scales on a CPU -- one single-threaded process per core, each its own world of
+        R / cores robots with the same 200 pedestrians and map (env_num independent nodes); `value` is (b)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleWorld
+    import subprocess
+    p = dict(params)
+    p["robot_begin"], p["robot_end"] = 0, p["n_robots"]
+    R = p["n_robots"]
+    w = OracleWorld(p, grid)
+    w.reset(layout)
+    steps, dt = _oracle_run(w, R, seconds, 50)
+    w.close()
+    single = R * steps / dt
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    per = max(1, R // cores)
+    start = time.time() + 6.0 + 0.02 * cores  # imports + world set-up of every worker fit in here
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(k), "--cpu-worker-robots", str(per),
+                               "--cpu-worker-seconds", str(all_core_seconds), "--cpu-worker-start", repr(start), "--peds", str(peds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(cores)]
+    total, slowest, ok = 0.0, 0.0, 0
+    for pr in procs:
+        out, _ = pr.communicate()
+        try:
+            r = json.loads(out.decode().strip().splitlines()[-1])
+        except Exception:
+            continue
+        total += r["robots"] * r["steps"] / r["seconds"]
+        slowest = max(slowest, r["seconds"])
+        ok += 1
+    return dict(value=total if ok else None, unit="robot-steps/s", cores=ok, kind="port", cpu_model=_cpu_model(), nproc=cores,
+                single_thread_value=single,
+                sample="all cores: %d single-threaded oracle processes (one per hardware thread, the reference's env_num idiom), each "
+                       "its own world of %d robots + %d ORCA peds on the 400x400 map @%.2f m, v=0 policy, %.1f s of steps side by side; "
+                       "single_thread_value: 1 thread, %d steps of the same %d-robot shared world the GPU ran, %.1f s"
+                       % (ok, per, peds, RES, slowest, steps, R, dt))
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this parent (which makes no GPU call at all -- children are started
+    as child processes, nothing is exec'ed over a GPU context) starts one rank per GPU and relays rank 0's line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
+    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])
+    rc = max(abs(c) for c in rcs)
+    if rc or not lines:
+        raise SystemExit("bench.py: ranks exited with %s%s" % (rcs, "" if lines else " and rank 0 printed no result line"))
 
 
 def main():
@@ -98,7 +196,15 @@ def main():
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
                     "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)  # internal: one process of the all-core CPU baseline
+    ap.add_argument("--cpu-worker-robots", type=int, default=32, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-seconds", type=float, default=8.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-start", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        return cpu_worker(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -110,14 +216,6 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world_size))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world_size > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
-
     RL = args.robots_per_gpu
     R = RL * world_size
     P = args.peds
@@ -135,7 +233,28 @@ def main():
             lay.robot_goal = lay.robot_goal[order].copy()
     params = worldgen.make_params(R, P, res=res, view_cells=48, beams=360, scene="rvoscene", time_max=TIME_MAX,
                                   robot_begin=rank * RL, robot_end=(rank + 1) * RL)
+
+    # The CPU baseline runs FIRST, before this process makes its first GPU call: its all-core leg starts worker processes,
+    # and nothing may be started from a process that holds a GPU context on this pool.
+    cpu_base = None
+    if world_size == 1 and not args.no_cpu_baseline and not args.force_dist:
+        try:
+            cpu_base = cpu_baseline(dict(params), grid, layouts[0], P)
+        except Exception as e:
+            cpu_base = {"value": None, "unit": "robot-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world_size > 1 or args.force_dist
+    comm_ranks = 0
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+
     world = World(params, grid, device=local_rank)
+    if world.lib.imgenv_backend() != b"hip-gfx950":
+        raise SystemExit("bench.py: %r is not the product library (experiment / profile build)" % world.lib.imgenv_backend())
     r0, r1 = rank * RL, (rank + 1) * RL
     native = False
     if use_dist:
@@ -148,6 +267,7 @@ def main():
         flags = [None] * world_size
         dist.all_gather_object(flags, native)
         native = all(flags)
+        comm_ranks = world.comm_info()[0] if native else 0
 
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     n_act = 16
@@ -161,12 +281,13 @@ def main():
         a[:, :, 1] = torch.rand(n_act, RL, generator=g, device=dev) * 1.8 - 0.9
         return a
 
-    state = dict(elapsed=0, episode=0)
+    state = dict(elapsed=0, episode=0, resets=0)
 
     def do_reset():
         world.reset(layouts[state["episode"] % len(layouts)])
         state["episode"] += 1
         state["elapsed"] = 0
+        state["resets"] += 1
 
     def do_step(a):
         if use_dist and not native:
@@ -186,6 +307,7 @@ def main():
         for s in range(warmup):
             do_step(acts[s % n_act])
         frozen0 = int(world.out["counters"][3].item())
+        resets0 = state["resets"]
         world.timing(timing_mode, which)
         if use_dist:
             dist.barrier()
@@ -227,6 +349,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         frozen = int(world.out["counters"][3].item()) - frozen0
+        state["resets_timed"] = state["resets"] - resets0
         return dt, tm, frozen / float(steps * RL)
 
     # pass 1 (not the headline): per-kernel breakdown, HIP events around every kernel, one sync per step;
@@ -261,6 +384,7 @@ def main():
     # pass 2: THE timed region; HIP events only around the dominant kernel
     dt, tm, frozen_active = run("active", args.steps, args.warmup, timing_mode=args.timing_mode, which=dom_id)
     dom_ms, dom_n = tm[dominant]
+    resets_timed = state["resets_timed"]
     value = R * args.steps / dt
     for q in range(args.repeat):
         for mode in (0, 2):
@@ -294,11 +418,18 @@ def main():
         kernel_bytes = ab.get(dominant, ab["total"]) * RL
         dur_s = (dom_ms / dom_n) * 1e-3 if dom_n else float("nan")
         achieved = kernel_bytes / dur_s / 1e9
-        traffic = None
+        traffic, path_traffic, traffic_source = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
             try:
-                traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
+                counters = json.load(open(pmc))
+                traffic = counters.get(dominant, {}).get("hbm_bytes_per_launch")
+                # every kernel of a step once (k_reset_apply is not part of a step)
+                path_traffic = sum(v["hbm_bytes_per_launch"] for k, v in counters.items()
+                                   if k.startswith("k_") and not k.startswith("k_reset") and k != "k_cell_base")
+                traffic_source = ("profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, "
+                                  "gfx950 corrections) over this same bench command, committed with the build -- NOT collected "
+                                  "during this run")
             except Exception:
                 traffic = None
         out = {
@@ -307,32 +438,38 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg-3: one world, %d robots/GPU x %d GPUs, %d ORCA peds (rvoscene), %dx%d grid "
-                                   "@%.3f m, 48x48 sensor_map + 3ch ped_map, 360-beam laser, time_max %d, reset included"
-                                   % (RL, world_size, P, side, side, res, TIME_MAX),
+                                   "@%.3f m%s, 48x48 sensor_map + 3ch ped_map, 360-beam laser, time_max %d, full reset whenever the time limit "
+                                   "runs out (%d inside the %d timed steps)"
+                                   % (RL, world_size, P, side, side, res,
+                                      "" if world_size == 1 else " (weak scaling: BASELINE's 400x400 grown to %dx%d cells so that %d robots "
+                                      "can be placed without overlapping)" % (side, side, R),
+                                      TIME_MAX, resets_timed, args.steps),
                        "robots": R, "peds": P, "grid": side, "resolution": res, "view": 48, "beams": 360,
                        "policy": "active: v=0, w~U(-0.9,0.9): every robot-step runs the full view path",
                        "parallelism": ("robot-sharded x%d, RCCL all-gather of robot records (%s)" % (
-                           world_size, "ncclAllGather inside imgenv_step" if native else "torch.distributed between step_begin/step_end"))
+                           world_size, ("ncclAllGather inside imgenv_step, communicator of %d ranks as reported by RCCL" % comm_ranks)
+                           if native else "torch.distributed between step_begin/step_end"))
                        if use_dist else "single GPU"},
+            "resets_in_timed_region": resets_timed,
             "frozen_fraction": frozen_active,
             "multi_world": multi_world,
             "episode_policy": episode,
             "kernel_us": per_kernel_us,
             "launches_per_step": launches_per_step,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                         # HBM bytes of ALL kernels of one step (same counters) and what that is per second at the measured rate
+                         "path_traffic_bytes_per_step": path_traffic,
+                         "path_traffic_frac": (path_traffic / (dt / args.steps) / 1e9 / 8000.0) if path_traffic else None,
                          "algorithmic_bytes_per_robot_step": ab, "kernel_avg_us": dur_s * 1e6,
                          "units_per_launch": RL,
-                         # the whole path against the same peak: all algorithmic bytes of a step over the whole step time
-                         "path_achieved": ab["total"] * value / world_size / 1e9,
-                         "path_frac": ab["total"] * value / world_size / 1e9 / 8000.0},
+                         # SURVEY 8(d)'s algorithmic bytes of the whole path over the whole step time.  NOT evidence of HBM use:
+                         # k_obs updates the ped_map sparsely and writes ~6 KB per robot, not the 37 KB the formula counts --
+                         # path_traffic_frac above is the counter-based figure
+                         "path_algorithmic_gbps": ab["total"] * value / world_size / 1e9},
         }
-        if world_size == 1 and not args.no_cpu_baseline:
-            p1 = dict(params)
-            try:
-                out["cpu_baseline"] = cpu_baseline(p1, grid, layouts[0])
-            except Exception as e:
-                out["cpu_baseline"] = {"value": None, "unit": "robot-steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     world.close()
     if use_dist:

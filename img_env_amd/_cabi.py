@@ -231,7 +231,7 @@ def make_reset_batch(b, n_robots, n_peds):
 SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_create", "imgenv_arena_bytes",
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
-           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
+           "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
            "imgenv_reset_worlds_spawn")
 K_COUNT = 8
 
@@ -269,6 +269,7 @@ def bind(lib):
     lib.imgenv_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.imgenv_comm_unique_id.argtypes = [C.c_void_p]
     lib.imgenv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.imgenv_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.imgenv_kernel_name.argtypes = [C.c_int]
     lib.imgenv_kernel_name.restype = C.c_char_p
     return lib

@@ -126,6 +126,8 @@ struct RcclApi {
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclCommDestroy) destroy = nullptr;
     decltype(&ncclGetErrorString) err = nullptr;
+    decltype(&ncclCommCount) count = nullptr;
+    decltype(&ncclCommUserRank) user_rank = nullptr;
 };
 static RcclApi* rccl_api() {
     static RcclApi api;
@@ -141,7 +143,9 @@ static RcclApi* rccl_api() {
             api.all_gather = (decltype(api.all_gather))dlsym(lib, "ncclAllGather");
             api.destroy = (decltype(api.destroy))dlsym(lib, "ncclCommDestroy");
             api.err = (decltype(api.err))dlsym(lib, "ncclGetErrorString");
-            if (api.get_id && api.init_rank && api.all_gather && api.destroy && api.err) api.lib = lib;
+            api.count = (decltype(api.count))dlsym(lib, "ncclCommCount");
+            api.user_rank = (decltype(api.user_rank))dlsym(lib, "ncclCommUserRank");
+            if (api.count && api.user_rank && api.get_id && api.init_rank && api.all_gather && api.destroy && api.err) api.lib = lib;
         }
     }
     return api.lib ? &api : nullptr;
@@ -1756,6 +1760,18 @@ extern "C" int imgenv_comm_init(imgenv_t* h, const void* id128, int32_t rank, in
         FAIL(IMGENV_EDEVICE, "ncclCommInitRank: %s", a->err(e));
     }
     h->comm_ranks = n_ranks;
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_comm_info(imgenv_t* h, int32_t* n_ranks, int32_t* rank) {
+    if (!h) FAIL(IMGENV_EINVAL, "null argument");
+    if (!h->comm) FAIL(IMGENV_ESTATE, "the handle has no communicator (imgenv_comm_init was not called)");
+    int n = 0, r = 0;
+    ncclResult_t e = rccl_api()->count(h->comm, &n);
+    if (e == ncclSuccess) e = rccl_api()->user_rank(h->comm, &r);
+    if (e != ncclSuccess) FAIL(IMGENV_EDEVICE, "ncclCommCount / ncclCommUserRank: %s", rccl_api()->err(e));
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
     return IMGENV_OK;
 }
 

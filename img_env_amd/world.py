@@ -178,6 +178,12 @@ class World:
         self._check(self.lib.imgenv_comm_init(self.h, buf2, rank, n_ranks), "imgenv_comm_init")
         self.native_comm = True
 
+    def comm_info(self):
+        """(ranks, rank) as RCCL reports them for the library's own communicator"""
+        n, r = C.c_int32(), C.c_int32()
+        self._check(self.lib.imgenv_comm_info(self.h, C.byref(n), C.byref(r)), "imgenv_comm_info")
+        return n.value, r.value
+
     def launches(self):
         return self.lib.imgenv_step_launches(self.h)
 

@@ -263,6 +263,8 @@ int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_robot);
 #define IMGENV_COMM_ID_BYTES 128
 int imgenv_comm_unique_id(void* id128);
 int imgenv_comm_init(imgenv_t* h, const void* id128, int32_t rank, int32_t n_ranks);
+/* what RCCL itself reports for the handle's communicator (ncclCommCount / ncclCommUserRank); IMGENV_ESTATE without one */
+int imgenv_comm_info(imgenv_t* h, int32_t* n_ranks, int32_t* rank);
 
 int imgenv_outputs(imgenv_t* h, imgenv_out* out);
 

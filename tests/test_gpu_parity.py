@@ -180,6 +180,31 @@ def test_two_sharded_handles_match_single_world(worlds, by_x):
             w.close()
 
 
+def test_in_library_rccl_exchange_matches_plain_step(worlds):
+    """imgenv_comm_init + imgenv_step on one rank: the library's own ncclAllGather (RCCL, in place, on the step's stream) sits
+    between the integrate and raster stages and must change nothing; RCCL itself reports the communicator's size and rank"""
+    World, _ = worlds
+    n = 24
+    grid, params, layout = small_world(n, 10, seed=31, grid_size=320, clearance=0.8)
+    plain, comm = World(params, grid), World(params, grid)
+    try:
+        comm.init_comm(0, 1)
+        assert comm.comm_info() == (1, 0)
+        plain.reset(layout)
+        comm.reset(layout)
+        rng = np.random.default_rng(6)
+        for s in range(20):
+            a = random_actions(rng, n)
+            plain.step(a)
+            comm.step(a)
+            want, got = plain.snapshot(), comm.snapshot()
+            for k in want:
+                assert np.array_equal(got[k], want[k], equal_nan=True) if want[k].dtype.kind == "f" else np.array_equal(got[k], want[k]), (s, k)
+    finally:
+        plain.close()
+        comm.close()
+
+
 def _rect(params, n):
     from img_env_amd import _cabi
     params["robot_shape"] = np.full(n, _cabi.SHAPE_RECTANGLE, np.int32)
