@@ -1283,12 +1283,12 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     const uint32_t h0 = w.f16_lut[0], h1 = w.f16_lut[100], h2 = w.f16_lut[200], h3 = w.f16_lut[255];
     const uint32_t lut_lo = (h0 & 0xFFu) | ((h1 & 0xFFu) << 8) | ((h2 & 0xFFu) << 16) | ((h3 & 0xFFu) << 24);
     const uint32_t lut_hi = (h0 >> 8) | ((h1 >> 8) << 8) | ((h2 >> 8) << 16) | ((h3 >> 8) << 24);
-#ifdef IMGENV_EXP_SKIP_FINAL
-    if (false)
-#endif
     uint16_t* skip_list = (uint16_t*)src;  // the crop is dead once the beams have their hits
     const int skip_cap = laser ? NC / 2 : 0;
     int n_skip = 0;
+#ifdef IMGENV_EXP_SKIP_FINAL
+    if (false)
+#endif
     for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
         uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
         if (laser) {
