@@ -66,11 +66,13 @@ class ResetBatch(C.Structure):
 
 
 POSE_FIX, POSE_RAND_ANGLE, POSE_RANGE, POSE_RANGE_YAW, POSE_RANGE_VIEW = 0, 1, 2, 3, 4
+POSE_RANGE_CIRCLE, POSE_RANGE_CIRCLE_FIX, POSE_CIRCLE_FIX, POSE_RANGE_MULTI = 5, 6, 7, 8
 
 
 class SpawnAgent(C.Structure):
     _fields_ = [("begin_type", _i32), ("target_type", _i32), ("begin", C.c_double * 6), ("target", C.c_double * 6),
-                ("module_size", C.c_double)]
+                ("module_size", C.c_double), ("begin_multi", C.POINTER(C.c_double)), ("target_multi", C.POINTER(C.c_double)),
+                ("n_begin_multi", _i32), ("n_target_multi", _i32)]
 
 
 class SpawnObstacle(C.Structure):
@@ -80,7 +82,8 @@ class SpawnObstacle(C.Structure):
 class SpawnCfg(C.Structure):
     _fields_ = [("struct_size", _i32), ("n_robots", _i32), ("n_peds", _i32), ("n_obstacles", _i32),
                 ("agents", C.POINTER(SpawnAgent)), ("obstacles", C.POINTER(SpawnObstacle)),
-                ("clearance", C.c_double), ("target_min_dist", C.c_double), ("go_back", _i32), ("ignore_obstacle", _i32)]
+                ("clearance", C.c_double), ("target_min_dist", C.c_double), ("circle_ranges", C.c_double * 2),
+                ("go_back", _i32), ("ignore_obstacle", _i32)]
 
 
 class Out(C.Structure):

@@ -1628,8 +1628,11 @@ static int spawn_cfg_check(const imgenv_spawn_cfg* c) {
         FAIL(IMGENV_EINVAL, "bad spawn cfg");
     for (int i = 0; i < c->n_robots + c->n_peds; i++) {
         const imgenv_spawn_agent& a = c->agents[i];
-        if (a.begin_type < IMGENV_POSE_FIX || a.begin_type > IMGENV_POSE_RANGE_YAW || a.target_type < IMGENV_POSE_FIX ||
-            a.target_type > IMGENV_POSE_RANGE_VIEW)
+        const bool begin_ok = (a.begin_type >= IMGENV_POSE_FIX && a.begin_type <= IMGENV_POSE_RANGE_YAW) ||
+                              a.begin_type == IMGENV_POSE_RANGE_CIRCLE || a.begin_type == IMGENV_POSE_RANGE_CIRCLE_FIX ||
+                              a.begin_type == IMGENV_POSE_RANGE_MULTI;
+        const bool target_ok = a.target_type >= IMGENV_POSE_FIX && a.target_type <= IMGENV_POSE_RANGE_MULTI;
+        if (!begin_ok || !target_ok)
             FAIL(IMGENV_EINVAL, "agent %d: unsupported pose type (%d, %d)", i, a.begin_type, a.target_type);
     }
     return 0;

@@ -289,11 +289,19 @@ int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds, const img
 #define IMGENV_POSE_RANGE 2       /* [x_lo, x_hi, y_lo, y_hi], yaw uniform in +-3.14 */
 #define IMGENV_POSE_RANGE_YAW 3   /* [x_lo, x_hi, y_lo, y_hi, yaw_lo, yaw_hi] */
 #define IMGENV_POSE_RANGE_VIEW 4  /* targets only: [x_lo, x_hi, y_lo, y_hi], drawn around the start (random_view, 62-82) */
+#define IMGENV_POSE_RANGE_CIRCLE 5      /* [cx, cy]: on the episode's circle around (cx, cy) at a random angle + noise, facing the
+                                         * centre (starts, 223-230); opposite the start (targets, 263-268) */
+#define IMGENV_POSE_RANGE_CIRCLE_FIX 6  /* the same at the agent's own share of the circle: angle -3.14 + 6.28 i / n (226-227) */
+#define IMGENV_POSE_CIRCLE_FIX 7        /* targets only: exactly opposite the start, no noise, no checks (258-262) */
+#define IMGENV_POSE_RANGE_MULTI 8       /* one of several boxes, picked per draw (231-232, 269-270): *_multi / n_*_multi */
 
 typedef struct imgenv_spawn_agent {   /* a robot or a pedestrian */
     int32_t begin_type, target_type;  /* IMGENV_POSE_* */
     double begin[6], target[6];
     double module_size;               /* 2 x the footprint's radius (reset_helper.py:167-186): what must clear the obstacles */
+    const double* begin_multi;        /* IMGENV_POSE_RANGE_MULTI: [n_begin_multi][6] boxes x_lo, x_hi, y_lo, y_hi, yaw_lo, yaw_hi */
+    const double* target_multi;       /* (a 4-number box of the YAML carries yaw -3.14 .. 3.14) */
+    int32_t n_begin_multi, n_target_multi;
 } imgenv_spawn_agent;
 
 typedef struct imgenv_spawn_obstacle {
@@ -310,6 +318,7 @@ typedef struct imgenv_spawn_cfg {     /* ONE world's cast */
     const imgenv_spawn_obstacle* obstacles;  /* [n_obstacles] */
     double clearance;                 /* free_check_robo_ped distance (1.0) */
     double target_min_dist;
+    double circle_ranges[2];          /* the episode's circle radius is uniform in here (YAML circle_ranges) */
     int32_t go_back;                  /* pedestrians return to their start: 0 no, 1 yes, 2 a coin per pedestrian */
     int32_t ignore_obstacle;
 } imgenv_spawn_cfg;

@@ -66,9 +66,9 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
                              "robot_size_last", "time_max", "out_arena", "out_arena_bytes"],
               "imgenv_reset_batch": ["n_obstacles", "obs_pose", "ped_traj", "ped_traj_cap", "ignore_obstacle", "ped_traj_v"],
               "imgenv_out": ["n_local", "vector_states", "lasers", "paper_rewards", "counters"],
-              "imgenv_spawn_agent": ["target_type", "begin", "target", "module_size"],
+              "imgenv_spawn_agent": ["target_type", "begin", "target", "module_size", "begin_multi", "target_multi", "n_target_multi"],
               "imgenv_spawn_obstacle": ["pose_type", "size_range", "pose"],
-              "imgenv_spawn_cfg": ["n_obstacles", "agents", "obstacles", "clearance", "target_min_dist", "go_back", "ignore_obstacle"]}
+              "imgenv_spawn_cfg": ["n_obstacles", "agents", "obstacles", "clearance", "target_min_dist", "circle_ranges", "go_back", "ignore_obstacle"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "imgenv.h"', "int main(void) {"]
     for st, fs in fields.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))

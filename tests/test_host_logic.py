@@ -101,11 +101,51 @@ def test_init_ped_dataset_shapes():
     assert b.ped_traj_cap == 5 and bool(b.ped_traj_v) and keep["ped_traj_v"].shape == (3, 5, 2)
 
 
+def _spawn_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "spawn_ref.npz"))
+    return z, sorted(k[:-5] for k in z.files if k.endswith("/seed"))
+
+
+@pytest.mark.parametrize("case", _spawn_cases()[1])
+def test_envpos_reproduces_the_reference_episodes(case):
+    """`spawn.EnvPos(cfg, seed)` against episodes the REFERENCE's own EnvPos placed after `random.seed(seed)`
+    (tests/golden/gen_spawn_golden.py): obstacles, starts, targets, trajectories -- bit for bit.  Covers the spawn sections of
+    the shipped circle.yaml / test.yaml / 10obs_5ped_baseline.yaml (range_circle starts and targets), a synthetic cast with
+    every other pose type, and a circle too small for its cast (the "50 failed circle starts" path)."""
+    import json
+    z, _ = _spawn_cases()
+    g = lambda k: z["%s/%s" % (case, k)]  # noqa: E731
+    cfg = json.loads(str(g("cfg")))
+    ep = spawn.EnvPos(cfg, seed=int(g("seed")))
+    lay = ep.reset()
+    nr = cfg["robot"]["total"]
+    assert ep.circle_range == float(g("circle_range"))
+    assert np.array_equal(np.array(ep.obs_range, float).reshape(-1, 4), g("obs_range"))
+    assert np.array_equal(np.array([p[:3] for p in ep.init_poses], float).reshape(-1, 3), g("init"))
+    assert np.array_equal(np.array([p[:3] for p in ep.target_poses], float).reshape(-1, 3), g("target"))
+    # ... and what becomes of them in the reset batch (ResetEnv.srv: poses as quaternions, goals, trajectories)
+    assert np.array_equal(lay.obs_shape, g("obs_shape"))
+    assert np.array_equal(lay.obs_size, g("obs_size").astype(np.float32))
+    assert np.array_equal(lay.obs_pose[:, :2], g("obs_range")[:, :2]) and np.array_equal(lay.obs_pose[:, 2:], g("obs_quat"))
+    assert np.array_equal(lay.robot_pose[:, :2], g("init")[:nr, :2]) and np.array_equal(lay.robot_pose[:, 2:], g("robot_quat"))
+    assert np.array_equal(lay.robot_goal, g("robot_goal"))
+    assert np.array_equal(lay.ped_pose[:, :2], g("init")[nr:, :2])
+    assert np.array_equal(lay.ped_traj_len, g("ped_traj_len"))
+    for j, n in enumerate(lay.ped_traj_len):
+        assert np.array_equal(lay.ped_traj[j, :n, :2], g("ped_traj")[j, :n])
+
+
 def test_unsupported_spawn_layouts_fail_loudly():
     grid = worldgen.make_grid(200, 0)
     cfg = worldgen.make_yaml_cfg(2, 0, grid)
-    cfg["robot"]["begin_poses_type"] = ["circle", "circle"]
+    cfg["robot"]["target_poses_type"] = ["range_view_plus", "range_view_plus"]  # random_view_plus does not exist in the reference
     with pytest.raises(NotImplementedError):
+        spawn.EnvPos(cfg, seed=0).reset(25.0)
+    cfg = worldgen.make_yaml_cfg(2, 0, grid)
+    cfg["robot"]["begin_poses_type"] = ["fix", "range"]  # fixed start + random target: the reference loops forever
+    cfg["robot"]["begin_poses"] = [[3.0, 3.0, 0.0], cfg["robot"]["begin_poses"][1]]
+    with pytest.raises(ValueError, match="never leaves"):
         spawn.EnvPos(cfg, seed=0).reset(25.0)
 
 
@@ -153,6 +193,53 @@ def test_native_spawn_follows_the_envpos_rules():
     lay = spawn.native_spawn(cfg, 3)
     d = np.abs(lay.robot_goal - lay.robot_pose[:, :2])
     assert (d.max(axis=1) <= 4.0 + 1e-9).all() and (d.max(axis=1) > 2.5).all()
-    cfg["robot"]["begin_poses_type"] = ["circle"] * 16
+    cfg["robot"]["target_poses_type"] = ["range_view_plus"] * 16
     with pytest.raises(NotImplementedError):
         spawn.make_spawn_cfg(cfg)
+
+
+@pytest.mark.parametrize("case", ["circle@1", "test@2", "10obs_5ped_baseline@7", "synthetic@3", "synthetic@5"])
+def test_native_spawn_places_the_reference_casts(case):
+    """the library's own placement on the spawn sections of the reference's shipped configs (range_circle starts / targets) and
+    on the synthetic cast with every pose type: the rules of reset_helper.py, checked on the result"""
+    import json
+    z, _ = _spawn_cases()
+    cfg = json.loads(str(z[case + "/cfg"]))
+    nr, npd = cfg["robot"]["total"], cfg["ped_sim"]["total"]
+    btype = cfg["robot"]["begin_poses_type"][:nr] + cfg["ped_sim"]["begin_poses_type"][:npd]
+    ttype = cfg["robot"]["target_poses_type"][:nr] + cfg["ped_sim"]["target_poses_type"][:npd]
+    bpose = cfg["robot"]["begin_poses"][:nr] + cfg["ped_sim"]["begin_poses"][:npd]
+    tpose = cfg["robot"]["target_poses"][:nr] + cfg["ped_sim"]["target_poses"][:npd]
+    sc = spawn.make_spawn_cfg(cfg)
+    for seed in range(20):
+        lay = spawn.native_spawn(cfg, 100 + seed, sc)
+        starts = np.vstack([lay.robot_pose[:, :2], lay.ped_pose[:, :2]])
+        goals = np.vstack([lay.robot_goal, lay.ped_goal])
+        yaw = 2.0 * np.arctan2(np.concatenate([lay.robot_pose[:, 2], lay.ped_pose[:, 2]]), np.concatenate([lay.robot_pose[:, 3], lay.ped_pose[:, 3]]))
+        drawn = [i for i in range(nr + npd) if btype[i] not in ("fix", "rand_angle")]
+        if len(drawn) > 1:
+            assert _pairwise_min(starts[drawn]) > 1.0 - 1e-9
+        for i in range(nr + npd):
+            if ttype[i] not in ("fix", "rand_angle", "circle_fix"):
+                assert np.linalg.norm(goals[i] - starts[i]) > cfg["target_min_dist"] - 1e-9
+            if "circle" in btype[i]:  # on the episode's circle (1.8 .. 3.2 m) give or take the noise (sigma 0.5), facing the centre
+                r = np.linalg.norm(starts[i] - np.array(bpose[i][:2]))
+                assert 0.0 < r < cfg["circle_ranges"][1] + 3.5
+            if "circle" in ttype[i] and "circle" in btype[i]:
+                # the target lies where the start looks: on the far side of the centre
+                to_goal = goals[i] - np.array(tpose[i][:2])
+                assert np.dot(to_goal, [np.cos(yaw[i]), np.sin(yaw[i])]) > -2.5
+            if btype[i] == "range_multi":
+                assert any(b[0] <= starts[i, 0] <= b[1] and b[2] <= starts[i, 1] <= b[3] for b in bpose[i])
+            if btype[i] == "range":
+                b = bpose[i]
+                assert b[0] <= starts[i, 0] <= b[1] and b[2] <= starts[i, 1] <= b[3]
+            if ttype[i] == "range_view":
+                d = np.abs(goals[i] - starts[i])
+                assert d.max() <= 4.0 + 1e-9 and d.max() > 2.5
+        for q in range(len(lay.obs_shape)):
+            radius = lay.obs_size[q, 2] if lay.obs_shape[q] == _cabi.SHAPE_CIRCLE else np.hypot(lay.obs_size[q, 0], lay.obs_size[q, 2])
+            if len(drawn):
+                assert (np.linalg.norm(starts[drawn] - lay.obs_pose[q, :2], axis=1) > radius).all()
+    a, b = spawn.native_spawn(cfg, 5, sc), spawn.native_spawn(cfg, 5, sc)
+    assert np.array_equal(a.robot_pose, b.robot_pose) and np.array_equal(a.ped_goal, b.ped_goal)
