@@ -156,7 +156,9 @@ class ImageEnv(Env):
                           o["ped_vector_states"], o["ped_maps"], o["step_ds"], o["ped_min_dists"])
 
     def reset(self, layout=None, **kwargs):
-        """yaml_env.py:296-317.  ``layout`` (a worldgen.ResetLayout) overrides the random spawn."""
+        """yaml_env.py:296-317.  ``layout`` (a worldgen.ResetLayout) overrides the random spawn; other keyword arguments
+        (NeverStopWrapper passes the last step's whole info dict) are ignored as in the reference, except
+        ``cur_ped_pos_v_datas``."""
         if layout is None:
             layout = self.env_pose.reset(self._extent)
         data = kwargs.get("cur_ped_pos_v_datas")
@@ -368,7 +370,7 @@ class NeverStopWrapper(Wrapper):
     def step(self, action):
         states, reward, done, info = self.env.step(action)
         if bool(info["all_down"][0]):
-            states = self.env.reset(**{k: v for k, v in info.items() if k == "layout"})
+            states = self.env.reset(**info)  # the reference hands the whole info dict down (TestEpisodeWrapper reads dones_info)
         return states, reward, done, info
 
 

@@ -174,6 +174,75 @@ def run(name, n_robots, n_peds, steps, seed, time_max, ped_shape="circle", state
     world.close()
 
 
+def run_stack(name, n_robots, n_peds, steps, seed, time_max, wrappers, cfg_over, obs_names, n_layouts=3):
+    """The wrappers `run` does not reach: StatePedVectorWrapper, StateBatchWrapper (frame stacks), the discrete VelActionWrapper
+    table, ObsStateTmp / ObsLaserStateTmp and NeverStopWrapper (base.py:19-66, 97-150, 198-211; filter_states.py) -- the
+    reference's own stack, auto-resets included (every reset service call gets the next of `n_layouts` fixed layouts)."""
+    envs = ref_import.import_reference_envs()
+    grid = worldgen.make_grid(200, seed)
+    meta = dict(n_robots=n_robots, n_peds=n_peds, steps=steps, seed=seed, time_max=time_max, ped_shape="circle", state_dim=3,
+                n_obstacles=2, near_goals=False, cfg_over=dict(cfg_over, wrapper=list(wrappers)), n_layouts=n_layouts,
+                obs_names=list(obs_names))
+    cfg = golden_cfg(meta, grid)
+    world = OracleWorld(config.params_from_cfg(cfg), grid)
+    layouts = [worldgen.make_layout(grid, 0.125, n_robots, n_peds, seed=seed + 100 + k, n_obstacles=2) for k in range(n_layouts)]
+    n_resets = [0]
+
+    def init_srv(req):
+        return ref_import.Msg()
+
+    def reset_srv(req):
+        world.reset(layouts[n_resets[0] % n_layouts])
+        n_resets[0] += 1
+        return ref_import.Msg(robot_states=agent_states(world))
+
+    def step_srv(req):
+        a = np.array([[np.float32(r.v), np.float32(r.w), np.float32(r.v_y)] for r in req.robots], np.float32)
+        world.step(a)
+        return ref_import.Msg(robot_states=agent_states(world))
+
+    ref_import.SERVICES.update(init_image_env=init_srv, reset_image_env=reset_srv, step_image_env=step_srv)
+    ref_cfg = dict(cfg)
+    ref_cfg["global_map"] = dict(cfg["global_map"], map_array=None)
+    env = envs.make_env(ref_cfg)
+    out = {}
+    obs = env.reset()
+    rec = {"obs%d" % k: [np.array(o)] for k, o in enumerate(obs)}
+    for k in ("rewards", "dones", "dones_info", "is_clean", "all_down", "speeds", "arrive", "collision", "close"):
+        rec[k] = []
+    rng = np.random.default_rng(seed + 7)
+    acts = []
+    discrete = bool(cfg["discrete_action"])
+    for s in range(steps):
+        if discrete:
+            act = rng.integers(0, len(cfg["discrete_actions"]), n_robots)
+        else:
+            act = np.stack([rng.uniform(-0.1, 0.7, n_robots), rng.uniform(-1.0, 1.0, n_robots)], 1)
+        acts.append(act)
+        obs, rew, done, info = env.step(act)
+        for k, o in enumerate(obs):
+            rec["obs%d" % k].append(np.array(o))
+        rec["rewards"].append(np.array(rew, np.float64))
+        rec["dones"].append(np.array(done))
+        rec["dones_info"].append(np.array(info["dones_info"]))
+        rec["is_clean"].append(np.array(info["is_clean"]))
+        rec["all_down"].append(np.array(info["all_down"]))
+        rec["speeds"].append(np.array(info["speeds"], np.float64))
+        rec["arrive"].append(np.array(info["arrive"]))
+        rec["collision"].append(np.array(info["collision"]))
+        rec["close"].append(np.array(info.get("bool_get_close_to_human", np.zeros(n_robots))))
+    for k, v in rec.items():
+        out["exp_" + k] = np.stack(v)
+    out["actions"] = np.stack(acts)
+    out["n_resets"] = np.array(n_resets[0])
+    out["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, "python_stack_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KiB): %d service resets, obs shapes %s" % (path, os.path.getsize(path) / 1024, n_resets[0],
+                                                                   [out["exp_obs%d" % k].shape for k in range(len(obs))]))
+    world.close()
+
+
 if __name__ == "__main__":
     run("a", n_robots=6, n_peds=5, steps=30, seed=3, time_max=24)
     run("b", n_robots=4, n_peds=7, steps=16, seed=11, time_max=100, ped_shape="leg", state_dim=5)
@@ -191,3 +260,14 @@ if __name__ == "__main__":
         "speed_limiter_w": {"has_velocity_limits": True, "has_jerk_limits": True, "min_velocity": -0.7, "max_velocity": 0.7,
                             "min_jerk": -1.5},
         "ped_sim.type": "ervoscene", "ped_sim.max_speed": [0.4, 0.5, 0.6, 0.3]})
+    table = [[0.0, -0.9], [0.0, 0.3], [0.2, -0.6], [0.2, 0.0], [0.4, 0.6], [0.6, -0.3], [0.6, 0.0, 1], [0.6, 0.9]]
+    base = ["VelActionWrapper", "TimeLimitWrapper", "SensorsPaperRewardWrapper", "InfoLogWrapper", "MultiRobotCleanWrapper"]
+    # frame stacks of 2 images / 3 vector states / 2 laser scans, discrete action table, laser observation, auto-reset by time limit
+    run_stack("a", n_robots=3, n_peds=4, steps=20, seed=41, time_max=6,
+              wrappers=base + ["StatePedVectorWrapper", "StateBatchWrapper", "ObsLaserStateTmp", "NeverStopWrapper"],
+              cfg_over=dict(discrete_action=True, discrete_actions=table, image_batch=2, state_batch=3, laser_batch=2),
+              obs_names=["lasers", "vector_states", "ped_maps"])
+    # image observation, continuous actions, single frames, laser_batch 0 (a stack of one)
+    run_stack("b", n_robots=2, n_peds=3, steps=14, seed=43, time_max=5,
+              wrappers=base + ["StateBatchWrapper", "ObsStateTmp", "NeverStopWrapper"],
+              cfg_over=dict(image_batch=1, state_batch=1, laser_batch=0), obs_names=["sensor_maps", "vector_states", "ped_maps"])

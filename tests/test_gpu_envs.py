@@ -45,6 +45,69 @@ def test_make_env_stack_matches_reference(path):
         env.close()
 
 
+STACKS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "python_stack_*.npz")))
+
+
+@pytest.mark.parametrize("path", STACKS, ids=[os.path.basename(p) for p in STACKS])
+def test_full_wrapper_stack_matches_reference(path):
+    """StatePedVectorWrapper, StateBatchWrapper (frame stacks), the discrete VelActionWrapper table, ObsStateTmp /
+    ObsLaserStateTmp and NeverStopWrapper against what the reference's own stack returned (gen_python_golden.py::run_stack),
+    through its time-limit auto-resets"""
+    import torch
+    from img_env_amd import make_env, worldgen
+    from img_env_amd.envs import ImageEnv
+    z = np.load(path)
+    meta = ast.literal_eval(str(z["meta"]))
+    grid = worldgen.make_grid(200, meta["seed"])
+    cfg = golden_cfg(meta, grid)
+    layouts = [worldgen.make_layout(grid, 0.125, meta["n_robots"], meta["n_peds"], seed=meta["seed"] + 100 + k, n_obstacles=2)
+               for k in range(meta["n_layouts"])]
+    env = make_env(cfg)
+    inner = env
+    while not isinstance(inner, ImageEnv):
+        inner = inner.env
+
+    class Seq:  # every reset takes the next fixed layout, as the generator's reset service did
+        n = 0
+
+        def reset(self, extent=None):
+            lay = layouts[Seq.n % len(layouts)]
+            Seq.n += 1
+            return lay
+    inner.env_pose = Seq()
+
+    def same_obs(obs, t):
+        assert len(obs) == 3
+        for k, o in enumerate(obs):
+            want = z["exp_obs%d" % k][t]
+            got = o.cpu().numpy()
+            assert got.shape == want.shape, (t, k, got.shape, want.shape)
+            if meta["obs_names"][k] == "sensor_maps":
+                assert np.array_equal(got, want), (t, k)
+            else:
+                assert np.abs(got.astype(np.float64) - want).max() <= 1e-4, (t, k)
+    try:
+        same_obs(env.reset(), 0)
+        for s in range(meta["steps"]):
+            a = z["actions"][s]
+            act = torch.as_tensor(a, device="cuda") if a.ndim == 1 else torch.as_tensor(a, dtype=torch.float32, device="cuda")
+            obs, rew, done, info = env.step(act)
+            same_obs(obs, s + 1)
+            assert np.abs(rew.cpu().numpy() - z["exp_rewards"][s]).max() <= 1e-4, s
+            assert np.array_equal(done.cpu().numpy(), z["exp_dones"][s]), s
+            assert np.array_equal(info["dones_info"].cpu().numpy(), z["exp_dones_info"][s]), s
+            assert np.array_equal(info["is_clean"].cpu().numpy(), z["exp_is_clean"][s]), s
+            assert np.array_equal(info["all_down"].cpu().numpy(), z["exp_all_down"][s]), s
+            assert np.abs(info["speeds"].cpu().numpy() - z["exp_speeds"][s]).max() <= 1e-6, s
+            assert np.array_equal(info["arrive"].cpu().numpy().astype(bool), z["exp_arrive"][s].astype(bool)), s
+            assert np.array_equal(info["collision"].cpu().numpy(), z["exp_collision"][s]), s
+            if meta["n_peds"]:
+                assert np.array_equal(info["bool_get_close_to_human"].cpu().numpy(), z["exp_close"][s]), s
+        assert Seq.n == int(z["n_resets"]) >= 2
+    finally:
+        env.close()
+
+
 def test_reference_action_objects_and_random_spawn():
     """List[ContinuousAction] in, random EnvPos-style spawn, NeverStopWrapper auto-reset"""
     from img_env_amd import ContinuousAction, make_env, worldgen
