@@ -89,7 +89,7 @@ class SpawnCfg(C.Structure):
 class Out(C.Structure):
     _fields_ = [
         ("struct_size", _i32), ("n_local", _i32), ("view_h", _i32), ("view_w", _i32), ("n_beams", _i32),
-        ("state_dim", _i32), ("ped_vec_len", _i32),
+        ("state_dim", _i32), ("ped_vec_len", _i32), ("image_h", _i32), ("image_w", _i32), ("grid_h", _i32), ("grid_w", _i32),
         ("vector_states", C.c_void_p), ("view_maps", C.c_void_p), ("sensor_maps", C.c_void_p),
         ("lasers_raw", C.c_void_p), ("lasers", C.c_void_p), ("ped_vector_states", C.c_void_p),
         ("ped_maps", C.c_void_p), ("is_collisions", C.c_void_p), ("is_arrives", C.c_void_p),
@@ -106,7 +106,7 @@ def out_layout(o, n_peds, hp, wp):
     return {
         "vector_states": (np.float32, (R, o.state_dim)),
         "view_maps": (np.uint8, (R, o.view_h, o.view_w)),
-        "sensor_maps": (np.float16, (R, o.view_h, o.view_w)),
+        "sensor_maps": (np.float16, (R, o.image_h, o.image_w)),
         "lasers_raw": (np.float32, (R, B)),
         "lasers": (np.float64, (R, B)),
         "ped_vector_states": (np.float32, (R, o.ped_vec_len)),
@@ -235,7 +235,7 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
-           "imgenv_reset_worlds_spawn")
+           "imgenv_reset_worlds_spawn", "imgenv_cv_resize_u8")
 K_COUNT = 8
 
 
@@ -273,6 +273,7 @@ def bind(lib):
     lib.imgenv_comm_unique_id.argtypes = [C.c_void_p]
     lib.imgenv_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.imgenv_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.imgenv_cv_resize_u8.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
     lib.imgenv_kernel_name.argtypes = [C.c_int]
     lib.imgenv_kernel_name.restype = C.c_char_p
     return lib

@@ -19,8 +19,9 @@ def read_yaml(file):
 
 
 def load_map(cfg):
-    """GridMap::read_image (grid_map.cpp:28-38) for the identity-resize case, or an in-memory grid
-    given as ``cfg['global_map']['map_array']`` (extension used by the synthetic worlds)."""
+    """The map image in its own pixels: ``imread(map_file, IMREAD_GRAYSCALE)`` of GridMap::read_image (grid_map.cpp:28-38),
+    or an in-memory grid given as ``cfg['global_map']['map_array']`` (extension used by the synthetic worlds).  The resize to
+    the view resolution (cv::resize INTER_LINEAR) happens inside ``imgenv_create``."""
     gm = cfg["global_map"]
     if gm.get("map_array") is not None:
         return np.ascontiguousarray(gm["map_array"], np.uint8)
@@ -31,11 +32,13 @@ def load_map(cfg):
             if base and os.path.exists(os.path.join(base, path)):
                 path = os.path.join(base, path)
                 break
-    img = np.array(Image.open(path).convert("L"), np.uint8)
-    if np.float32(gm["resolution"]) != np.float32(cfg["view_map"]["resolution"]):
-        raise ValueError("global_map.resolution != view_map.resolution: the load-time cv::resize "
-                         "(grid_map.cpp:28-38) is not implemented yet (SURVEY section 8 row f2)")
-    return img
+    im = Image.open(path)
+    if im.mode in ("L", "1"):
+        return np.array(im.convert("L"), np.uint8)
+    # cv::imread(IMREAD_GRAYSCALE) of a colour file: Y = 0.299 R + 0.587 G + 0.114 B in OpenCV's fixed point
+    # ((R * 4899 + G * 9617 + B * 1868 + 8192) >> 14); equal to the channel value for the grey-in-RGB maps the reference ships
+    rgb = np.array(im.convert("RGB"), np.int64)
+    return ((rgb[..., 0] * 4899 + rgb[..., 1] * 9617 + rgb[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
 
 
 def _limiter(cfg, key, defaults):

@@ -90,12 +90,15 @@ struct RobotClassHost {
     std::vector<uint32_t> fov_bits, stamp_bits;
     int ray_maxlen = 0, ray_stride = 0, ray_kpad = 8, box_rad = 0;
     bool ok = true;  // false: a table field overflowed its packing
+    bool big = false;  // the view is beyond what k_view packs into 16 / 8 bits: k_view_big and its 32-bit path table instead
+    int sensor_x = 0, sensor_y = 0;  // view cell of the laser
+    std::vector<uint32_t> big_cells;  // [ray_maxlen][ray_stride] view cell of step k of beam b, 0xFFFFFFFF past the ray's end
     std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
     std::vector<uint32_t> inv_pack, inv_ent, top_ent;
 };
 
-static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
+static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_big = false) {
     for (int j = 0; j < 4; j++) k.sizes[j] = (double)k.size[j];
     k.sx = (double)k.sensor[0];
     k.sy = (double)k.sensor[1];
@@ -132,12 +135,14 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
     k.ray_stride = ((B + WAVE_SZ - 1) / WAVE_SZ) * WAVE_SZ;
     if (k.ray_stride == 0) k.ray_stride = WAVE_SZ;
     k.ray_len.assign(k.ray_stride, 0);
-    std::vector<std::vector<uint16_t>> cells(B);
+    std::vector<std::vector<uint32_t>> cells(B);
     std::vector<std::vector<float>> dists(B);
     if (B > 0) {
         double sxv, syv;
         tf_apply(g.base_view, k.sx, k.sy, sxv, syv);
         const int x1 = w2m(sxv, res), y1 = w2m(syv, res);
+        k.sensor_x = x1;
+        k.sensor_y = y1;
         const double x0w = x1 * res, y0w = y1 * res;
         const double map_width = g.base_view.ox, map_height = g.base_view.oy;
         const double max_range = sqrt(map_width * map_width + map_height * map_height);
@@ -162,7 +167,7 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
             int xx = x1, yy = y1;
             while (steep ? (yy != y2) : (xx != x2)) {
                 if (!(xx >= 0 && xx < Hv && yy >= 0 && yy < Wv)) break;  // "else return hit"
-                cells[b].push_back((uint16_t)(xx * Wv + yy));
+                cells[b].push_back((uint32_t)(xx * Wv + yy));
                 const double cx = xx * res, cy = yy * res;
                 dists[b].push_back((float)sqrt((x0w - cx) * (x0w - cx) + (y0w - cy) * (y0w - cy)));
                 if (f < 0) {
@@ -179,14 +184,28 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
     }
     if (k.ray_maxlen == 0) k.ray_maxlen = 1;
     k.ray_kpad = ((k.ray_maxlen + 7) / 8) * 8;
-    // chunk-major: the 8 steps 8c..8c+7 of beam b sit at ((c * ray_stride) + b) * 8; padding = a free dummy cell behind the view
-    k.ray_rows.assign((size_t)(k.ray_kpad / 8) * k.ray_stride * 8, (uint16_t)NC);
-    k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
+    // k_view packs a view cell into 16 bits and (step, row, col) of a hit into 8 bits each; beyond that the class is "big"
+    k.big = force_big || NC + 16 > 0xFFFF || k.ray_maxlen > 255 || Hv > 256 || Wv > 256;
+    if (k.ray_maxlen > 0xFFFF || B > 0xFFFF) k.ok = false;  // (beam << 16 | step) entries of the per-cell ray lists
     std::vector<std::vector<uint32_t>> inv(NC);
+    if (k.big) {
+        k.big_cells.assign((size_t)k.ray_maxlen * k.ray_stride, 0xFFFFFFFFu);
+        k.ray_rows.assign(8, 0);
+        k.ray_dist.assign(1, 6.0f);
+    } else {
+        // chunk-major: the 8 steps 8c..8c+7 of beam b sit at ((c * ray_stride) + b) * 8; padding = a free dummy cell behind the view
+        k.ray_rows.assign((size_t)(k.ray_kpad / 8) * k.ray_stride * 8, (uint16_t)NC);
+        k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
+        k.big_cells.assign(1, 0xFFFFFFFFu);
+    }
     for (int b = 0; b < B; b++)
         for (size_t q = 0; q < cells[b].size(); q++) {
-            k.ray_rows[((q / 8) * (size_t)k.ray_stride + b) * 8 + (q % 8)] = cells[b][q];
-            k.ray_dist[q * k.ray_stride + b] = dists[b][q];
+            if (k.big) {
+                k.big_cells[q * k.ray_stride + b] = cells[b][q];
+            } else {
+                k.ray_rows[((q / 8) * (size_t)k.ray_stride + b) * 8 + (q % 8)] = (uint16_t)cells[b][q];
+                k.ray_dist[q * k.ray_stride + b] = dists[b][q];
+            }
             inv[cells[b][q]].push_back(((uint32_t)b << 16) | (uint32_t)q);
         }
     k.inv_pack.assign(NC, 0);
@@ -204,8 +223,6 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g) {
         if (!inv[c].empty()) {
             k.top_ent[c] = inv[c][0];
         }
-    if (NC + 16 > 0xFFFF) k.ok = false;
-    if (k.ray_maxlen > 255 || Hv > 256 || Wv > 256) k.ok = false;  // k_view packs (step, row, col) of a hit into 8 bits each
     if (k.inv_ent.empty()) k.inv_ent.push_back(0);
 }
 

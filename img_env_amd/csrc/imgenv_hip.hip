@@ -15,6 +15,7 @@
 #define WAVE_SZ 64
 #include "../../include/imgenv.h"
 #include "host_tables.h"
+#include "cv_resize.h"
 #include "spawn_host.h"
 #include "kernels.h"
 #include "world.h"
@@ -81,6 +82,8 @@ struct imgenv {
     void* d_oinst = nullptr;
     size_t cap_oinst = 0;
     int* d_act_list = nullptr;
+    bool big_view = false;   // the view is beyond k_view's packing, or shrunk by cv2.resize: k_view_big
+    size_t lds_view_big = 0;
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
     std::vector<double> tmp_d1;  // scratch of stage_world
@@ -268,7 +271,7 @@ static void plan_arena(const imgenv_cfg& c, const ViewGeom& g, int RL, ArenaPlan
     const size_t P = (size_t)(c.n_peds > 0 ? c.n_peds : 1);
     p.add(R * c.state_dim * 4);  // 0 vector_states
     p.add(R * NC);               // 1 view_maps
-    p.add(R * NC * 2);           // 2 sensor_maps
+    p.add(R * (size_t)c.image_size[0] * (size_t)c.image_size[1] * 2);  // 2 sensor_maps [image_h][image_w] f16
     p.add(R * B * 4);            // 3 lasers_raw
     p.add(R * B * 8);            // 4 lasers
     p.add(R * PV * 4);           // 5 ped_vector_states
@@ -390,8 +393,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (W > 1 && (((size_t)Hg * Wg + 15) & ~(size_t)15) * (size_t)W >= ((size_t)1 << 32))
         FAIL(IMGENV_EINVAL, "n_worlds x map cells must stay below 2^32");
     if (cfg->n_robots >= (int)OWNER_MULTI) FAIL(IMGENV_EINVAL, "more than 2^24 - 3 robots unsupported");
-    if (cfg->global_resolution != cfg->view_resolution)
-        FAIL(IMGENV_EINVAL, "global_resolution != view_resolution: load-time cv::resize not supported");
+    if (cfg->image_size[0] < 1 || cfg->image_size[1] < 1) FAIL(IMGENV_EINVAL, "bad image_size");
     if (cfg->state_dim < 3 || cfg->state_dim > 5) FAIL(IMGENV_EINVAL, "state_dim must be 3, 4 or 5");
     if (cfg->ped_vec_dim != 7) FAIL(IMGENV_EINVAL, "ped_vec_dim must be 7");
     if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM) {
@@ -410,11 +412,22 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (W > 1 && r1 - r0 != cfg->n_robots)
         FAIL(IMGENV_EINVAL, "n_worlds > 1 cannot be combined with a robot shard: give each rank whole worlds (its own handle)");
     const ViewGeom g = make_view_geom(*cfg);
-    if (cfg->image_size[0] != g.Wv || cfg->image_size[1] != g.Hv)
-        FAIL(IMGENV_EINVAL, "image_size (%d,%d) != native view (%d,%d): cv2.resize INTER_CUBIC not supported",
-             cfg->image_size[0], cfg->image_size[1], g.Wv, g.Hv);
-    if ((size_t)g.Hv * g.Wv > 32767) FAIL(IMGENV_EINVAL, "view larger than 32767 cells unsupported");
+    if (g.Hv < 1 || g.Wv < 1 || g.Hv > 4096 || g.Wv > 4096) FAIL(IMGENV_EINVAL, "view of %d x %d cells unsupported", g.Hv, g.Wv);
     if (g.B > 65535) FAIL(IMGENV_EINVAL, "more than 65535 beams unsupported");
+    // cv2.resize(view, (image_size[0], image_size[1]), INTER_CUBIC) (yaml_env.py:431-438): dsize = (width, height)
+    const bool view_resize = cfg->image_size[0] != g.Wv || cfg->image_size[1] != g.Hv;
+    // GridMap::read_image (grid_map.cpp:28-38): the image is resized (INTER_LINEAR) to the view resolution
+    std::vector<uint8_t> resized_map;
+    if (cfg->global_resolution != cfg->view_resolution) {
+        const double resolution_ = (double)cfg->global_resolution, view_res = (double)cfg->view_resolution;
+        const int w2 = (int)(Wg * resolution_ / view_res), h2 = (int)(Hg * resolution_ / view_res);
+        if (w2 < 1 || h2 < 1 || (size_t)w2 * h2 >= ((size_t)1 << 31)) FAIL(IMGENV_EINVAL, "the map would be resized to %d x %d cells", h2, w2);
+        resized_map.resize((size_t)w2 * h2);
+        cv_resize_u8(false, static_map, Hg, Wg, resized_map.data(), h2, w2);
+        static_map = resized_map.data();
+        Hg = h2;
+        Wg = w2;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(IMGENV_EDEVICE, "no HIP device available");
     if (cfg->device < 0 || cfg->device >= ndev) FAIL(IMGENV_EDEVICE, "device %d out of range (%d)", cfg->device, ndev);
@@ -461,7 +474,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             k.shape = shape;
             memcpy(k.size, cfg->robot_size + 4 * i, 16);
             memcpy(k.sensor, cfg->robot_sensor_cfg + 2 * i, 8);
-            build_robot_class(k, g);
+            build_robot_class(k, g, view_resize);
             h->rcls.push_back(std::move(k));
             found = (int)h->rcls.size() - 1;
         }
@@ -597,6 +610,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.inv_pack, k.inv_pack));
             TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
             TRY(dev_upload(h, &o.top_ent, k.top_ent));
+            TRY(dev_upload(h, &o.big_cells, k.big_cells));
+            o.big = k.big ? 1 : 0;
+            o.sensor_x = k.sensor_x;
+            o.sensor_y = k.sensor_y;
+            h->big_view = h->big_view || k.big;
             o.box_rad = k.box_rad;
             max_stride = std::max(max_stride, (size_t)k.ray_stride);
         }
@@ -636,6 +654,16 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         std::vector<uint16_t> lut(256);
         for (int v = 0; v < 256; v++) lut[v] = f32_to_f16((float)v / 255.0f);  // numpy: f16(f32(v)/255)
         TRY(dev_upload(h, &d.f16_lut, lut));
+    }
+    d.resize = view_resize ? 1 : 0;
+    d.img_w = cfg->image_size[0];
+    d.img_h = cfg->image_size[1];
+    if (view_resize) {  // axis tables of the bicubic shrink (csrc/cv_resize.h)
+        const CvAxis ax = cv_axis(g.Wv, d.img_w, true, true), ay = cv_axis(g.Hv, d.img_h, true, false);
+        TRY(dev_upload(h, &d.rs_xofs, ax.ofs));
+        TRY(dev_upload(h, &d.rs_alpha, ax.coef));
+        TRY(dev_upload(h, &d.rs_yofs, ay.ofs));
+        TRY(dev_upload(h, &d.rs_beta, ay.coef));
     }
 
     // robot / ped state
@@ -772,6 +800,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     imgenv_out& o = h->out;
     o.struct_size = (int32_t)sizeof(imgenv_out);
     o.n_local = RL; o.view_h = g.Hv; o.view_w = g.Wv; o.n_beams = g.B; o.state_dim = cfg->state_dim; o.ped_vec_len = d.PV;
+    o.image_h = d.img_h; o.image_w = d.img_w; o.grid_h = Hg; o.grid_w = Wg;
     o.vector_states = (float*)(A + plan.off[0]);
     o.view_maps = (uint8_t*)(A + plan.off[1]);
     o.sensor_maps = (uint16_t*)(A + plan.off[2]);
@@ -815,6 +844,19 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16;  // src u8 (+ dummy cells) | hit u32 | column terms | skip count
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
     h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
+    if (h->big_view) {  // k_view_big: the view at 2 bits a cell | first hit (step, cell) per beam (+ the dummy beam)
+        h->lds_view_big = ((((NC + 3) / 4) + 15) & ~(size_t)15) + 8 * ((size_t)g.B + 1) + 16;
+        h->lds_view = 16;
+    }
+    if (h->lds_view_big > 160 * 1024) {
+        imgenv_destroy(h);
+        FAIL(IMGENV_EINVAL, "a view of %d x %d cells with %d beams does not fit the 160 KiB LDS (%zu B)", g.Hv, g.Wv, g.B, h->lds_view_big);
+    }
+    if (h->lds_view_big > 64 * 1024) {
+        for (const void* f : {(const void*)k_view_big<true, true>, (const void*)k_view_big<true, false>, (const void*)k_view_big<false, true>,
+                              (const void*)k_view_big<false, false>})
+            HIPCHK_H(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view_big));
+    }
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
         imgenv_destroy(h);
         FAIL(IMGENV_EINVAL, "view (%zu B) or pedestrian list (%zu B) does not fit the 160 KiB LDS", h->lds_view, h->lds_obs);
@@ -1002,7 +1044,16 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
 #undef RASTER_CASE
     }
     if (!h->stamp) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
-    {
+    if (h->big_view) {
+        const dim3 gv(n_l), bv(VB_T);
+        const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
+        switch (variant) {
+            case 3: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<true, true><<<gv, bv, h->lds_view_big, st>>>(d))); break;
+            case 2: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<true, false><<<gv, bv, h->lds_view_big, st>>>(d))); break;
+            case 1: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<false, true><<<gv, bv, h->lds_view_big, st>>>(d))); break;
+            default: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<false, false><<<gv, bv, h->lds_view_big, st>>>(d))); break;
+        }
+    } else {
         // one wavefront per robot when the launch fills the machine, four when it is small (a reset of a few worlds): then
         // the single wavefront's latency is all there is
         const bool small = n_l <= 1024;
@@ -1788,6 +1839,12 @@ extern "C" int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_
 extern "C" int imgenv_outputs(imgenv_t* h, imgenv_out* out) {
     if (!h || !out) FAIL(IMGENV_EINVAL, "null argument");
     *out = h->out;
+    return IMGENV_OK;
+}
+
+extern "C" int imgenv_cv_resize_u8(int kind, const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh, int32_t dw) {
+    if (!src || !dst || sh < 1 || sw < 1 || dh < 1 || dw < 1 || (kind != 0 && kind != 1)) FAIL(IMGENV_EINVAL, "bad argument");
+    cv_resize_u8(kind == 1, src, sh, sw, dst, dh, dw);
     return IMGENV_OK;
 }
 

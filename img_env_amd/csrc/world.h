@@ -56,6 +56,9 @@ struct RobotClassDev {
     const uint32_t* inv_ent;     // ... entries (beam << 16 | k), beam descending
     const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or 0xFFFFFFFF
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
+    // views beyond k_view's 16 / 8-bit packing (the shipped configs: 400 x 400 cells, 1000 beams): k_view_big
+    int big, sensor_x, sensor_y; // the laser's view cell
+    const uint32_t* big_cells;   // [ray_maxlen][ray_stride] view cell of step k of beam b, 0xFFFFFFFF past the ray's end
 };
 
 struct PedClassDev {
@@ -121,6 +124,10 @@ struct DevWorld {
     const double* ped_r_round;      // [P] round(PedInfo.r_, 2)
     const float* ped_r32;           // [P] PedInfo.r_
     const uint16_t* f16_lut;        // [256] float16(v / 255)
+    // cv2.resize(view, image_size, INTER_CUBIC) (yaml_env.py:431-438): axis tables built on the host (csrc/cv_resize.h)
+    int resize, img_h, img_w;       // resize: image_size differs from the view size
+    const int *rs_xofs, *rs_yofs;   // [img_w], [img_h] source index of tap 1
+    const short *rs_alpha, *rs_beta;  // [img_w][4], [img_h][4] 11-bit coefficients
     // robots
     double* rec;  // [R][6] x y theta vx vy pad
     double *gx, *gy, *l0v, *l0w, *l1v, *l1w;  // [RL]

@@ -146,7 +146,7 @@ class ImageEnv(Env):
         self.ped_image_size = tuple(cfg["ped_image_size"])
         self.world = World(self.params, self.grid, device=cfg.get("device", 0))
         self.env_pose = spawn.EnvPos(cfg, seed=cfg.get("seed"))
-        self._extent = max(self.grid.shape) * float(cfg["view_map"]["resolution"])
+        self._extent = max(self.grid.shape) * float(cfg["global_map"]["resolution"])
         self.dones = None
         self._zeros_info = None
 

@@ -52,7 +52,7 @@ class VecImageEnv:
         self._spawn_cfg = spawn.make_spawn_cfg(cfg) if native_spawn else None
         self._spawn_seed = (0x9E3779B97F4A7C15 * (1 + (seed or 0))) & 0xFFFFFFFFFFFFFFFF
         self._episodes = 0
-        self._extent = max(self.grid.shape) * float(cfg["view_map"]["resolution"])
+        self._extent = max(self.grid.shape) * float(cfg["global_map"]["resolution"])
         self.world = World(stack_params(self.params, self.env_num), self.grid, device=cfg.get("device", 0))
 
     def __len__(self):

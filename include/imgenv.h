@@ -102,7 +102,9 @@ typedef struct imgenv_cfg {
     int32_t relation_ped_robo;    /* 1: robots are agents of the pedestrian simulator */
 
     /* ---- Env.msg ---- */
-    float global_resolution;      /* must equal view_resolution (identity load resize) */
+    float global_resolution;      /* metres / pixel of the map handed to imgenv_create; when it differs from view_resolution the
+                                   * library resizes the map as GridMap::read_image does (cv::resize INTER_LINEAR to
+                                   * int(px * global_resolution / view_resolution), grid_map.cpp:28-38) */
     int32_t ped_scene_type;       /* IMGENV_SCENE_* */
     int32_t n_robots;             /* robots of the WORLD (all shards) */
     int32_t n_peds;
@@ -116,7 +118,7 @@ typedef struct imgenv_cfg {
     const float* ped_max_speed;   /* [n_peds] */
 
     /* ---- Python-side ImageEnv parameters (yaml_env.py:133-181) ---- */
-    int32_t image_size[2];        /* must equal the native view size (identity cv2.resize) */
+    int32_t image_size[2];        /* sensor_map size (width, height) cv2.resize INTER_CUBIC shrinks the view to (yaml_env.py:433) */
     int32_t ped_image_size[2];
     int32_t max_ped;              /* ped vector has 1 + ped_vec_dim*max_ped entries; n_peds <= max_ped */
     int32_t ped_vec_dim;          /* 7 */
@@ -187,9 +189,12 @@ typedef struct imgenv_out {
     int32_t n_beams;              /* B (0 when !use_laser) */
     int32_t state_dim;
     int32_t ped_vec_len;          /* 1 + ped_vec_dim*max_ped */
+    int32_t image_h, image_w;     /* sensor_maps size: imgenv_cfg.image_size (= the view size unless cv2.resize shrinks it) */
+    int32_t grid_h, grid_w;       /* the occupancy grid after the load-time resize (grid_map.cpp:28-38) */
     float* vector_states;         /* [R][state_dim]      AgentState.state (float32 wire) */
     uint8_t* view_maps;           /* [R][Hv][Wv]         AgentState.view_map (8UC1) */
-    uint16_t* sensor_maps;        /* [R][Hv][Wv] float16 bits = view/255 (yaml_env.py:431-438) */
+    uint16_t* sensor_maps;        /* [R][image_h][image_w] float16 bits = cv2.resize(view, image_size, INTER_CUBIC) / 255
+                                   * (yaml_env.py:431-438; OpenCV copies when the sizes are equal) */
     float* lasers_raw;            /* [R][B]              AgentState.laser */
     double* lasers;               /* [R][B]              _norm_lasers (yaml_env.py:440-444) */
     float* ped_vector_states;     /* [R][ped_vec_len] */
@@ -223,7 +228,8 @@ const char* imgenv_last_error(void);
 
 /* init_image_env: builds all per-class static tables (footprints, FOV mask, ray tables) and
  * uploads the static occupancy grid (uint8, row-major [Hg][Wg], rows <-> world x;
- * grid_map.cpp:40-55). */
+ * grid_map.cpp:40-55).  Hg x Wg is the size of `static_map` as given: the map image in its own pixels when
+ * global_resolution != view_resolution (the grid the handle works on is then the resized one, imgenv_out.grid_h / grid_w). */
 int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, int32_t Wg,
                   imgenv_t** out);
 /* bytes of output arena a handle created from `cfg` needs (256-byte aligned carve-outs) */
@@ -331,6 +337,10 @@ int imgenv_spawn(const imgenv_spawn_cfg* cfg, uint64_t seed, double* robot_pose,
 /* imgenv_reset_worlds() with a fresh placement for each listed world, world worlds[q] from seeds[q]. */
 int imgenv_reset_worlds_spawn(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_spawn_cfg* cfg, const uint64_t* seeds,
                               void* stream);
+
+/* The two OpenCV resizes of the path for one-channel 8-bit images, as the library performs them (OpenCV 4.2.0's generic
+ * fixed-point CPU path restated, csrc/cv_resize.h): host buffers, no device needed.  kind 0: INTER_LINEAR, 1: INTER_CUBIC. */
+int imgenv_cv_resize_u8(int kind, const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh, int32_t dw);
 
 /* number of kernels launched by the last step (bench / profiling aid) */
 int imgenv_step_launches(imgenv_t* h);

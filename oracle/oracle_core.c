@@ -29,6 +29,7 @@
  */
 #define _GNU_SOURCE
 #include "oracle.h"
+#include "oracle_resize.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -118,6 +119,7 @@ struct oracle_world {
     imgenv_cfg cfg;
     int R, P, r0, r1, RL;
     int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;
+    int img_h, img_w; /* sensor_map size after cv2.resize (yaml_env.py:431-438) */
     double res, step_hz, view_w, view_h, a_begin, a_end, min_d, max_d;
     uint8_t *static_map, *obs_map, *peds_map, *priv;
     uint32_t *own_lo, *own_hi;
@@ -424,8 +426,6 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     if (cfg->n_worlds > 1) FAIL(IMGENV_EINVAL, "the oracle is one world: check a batched handle against n_worlds oracles");
     if (cfg->n_peds > cfg->max_ped)
         FAIL(IMGENV_EINVAL, "n_peds %d > max_ped %d (IndexError in yaml_env.py:401)", cfg->n_peds, cfg->max_ped);
-    if (cfg->global_resolution != cfg->view_resolution)
-        FAIL(IMGENV_EINVAL, "global_resolution != view_resolution: load-time cv::resize not supported");
     if (cfg->state_dim < 3 || cfg->state_dim > 5) FAIL(IMGENV_EINVAL, "state_dim must be 3, 4 or 5");
     if (cfg->ped_vec_dim != 7) FAIL(IMGENV_EINVAL, "ped_vec_dim must be 7");
     oracle_world* w = (oracle_world*)calloc(1, sizeof(oracle_world));
@@ -444,10 +444,20 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
         free(w);
         FAIL(IMGENV_EINVAL, "the beep lottery needs every robot's action: not available in a robot shard");
     }
-    w->Hg = Hg;
-    w->Wg = Wg;
     /* img_env.cpp:58-81: float32 request fields read into doubles */
     w->res = (double)cfg->view_resolution;
+    /* GridMap::read_image (grid_map.cpp:28-38): the image is resized (INTER_LINEAR) to the view resolution */
+    w->Hg = Hg;
+    w->Wg = Wg;
+    if (cfg->global_resolution != cfg->view_resolution) {
+        const double resolution_ = (double)cfg->global_resolution;
+        w->Wg = (int)(Wg * resolution_ / w->res);
+        w->Hg = (int)(Hg * resolution_ / w->res);
+        if (w->Hg < 1 || w->Wg < 1) {
+            free(w);
+            FAIL(IMGENV_EINVAL, "the map would be resized to %d x %d cells", w->Hg, w->Wg);
+        }
+    }
     w->view_w = (double)cfg->view_width;
     w->view_h = (double)cfg->view_height;
     w->step_hz = (double)cfg->step_hz;
@@ -462,10 +472,11 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     w->view_base.oy = w->view_w / 2;
     tf_set_yaw(&w->view_base, 3.14159);
     w->base_view = tf_inverse(&w->view_base);
-    if (cfg->image_size[0] != w->Wv || cfg->image_size[1] != w->Hv) {
+    w->img_w = cfg->image_size[0]; /* cv2.resize(view, (image_size[0], image_size[1])): dsize = (width, height) */
+    w->img_h = cfg->image_size[1];
+    if (w->img_w < 1 || w->img_h < 1) {
         free(w);
-        FAIL(IMGENV_EINVAL, "image_size (%d,%d) != native view (%d,%d): cv2.resize INTER_CUBIC not supported",
-             cfg->image_size[0], cfg->image_size[1], w->Wv, w->Hv);
+        FAIL(IMGENV_EINVAL, "bad image_size");
     }
     w->B = cfg->use_laser ? cfg->range_total : 0;
     w->Hp = cfg->ped_image_size[0];
@@ -473,9 +484,14 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     w->SD = cfg->state_dim;
     w->PV = 1 + cfg->ped_vec_dim * cfg->max_ped;
 
-    size_t G = (size_t)Hg * Wg;
+    size_t G = (size_t)w->Hg * w->Wg;
     w->static_map = (uint8_t*)malloc(G);
-    memcpy(w->static_map, static_map, G);
+    if (w->Hg == Hg && w->Wg == Wg)
+        memcpy(w->static_map, static_map, G);
+    else
+        oracle_resize_linear_u8(static_map, Hg, Wg, w->static_map, w->Hg, w->Wg);
+    Hg = w->Hg;
+    Wg = w->Wg;
     w->obs_map = (uint8_t*)malloc(G);
     memcpy(w->obs_map, static_map, G);
     w->peds_map = (uint8_t*)malloc(G);
@@ -547,10 +563,11 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     o->struct_size = (int32_t)sizeof(imgenv_out);
     o->n_local = RL; o->view_h = w->Hv; o->view_w = w->Wv; o->n_beams = w->B; o->state_dim = w->SD;
     o->ped_vec_len = w->PV;
+    o->image_h = w->img_h; o->image_w = w->img_w; o->grid_h = w->Hg; o->grid_w = w->Wg;
     size_t VW = (size_t)w->Hv * w->Wv;
     ALLOC(o->vector_states, float, (size_t)RL * w->SD);
     ALLOC(o->view_maps, uint8_t, RL * VW);
-    ALLOC(o->sensor_maps, uint16_t, RL * VW);
+    ALLOC(o->sensor_maps, uint16_t, (size_t)RL * w->img_h * w->img_w);
     ALLOC(o->lasers_raw, float, (size_t)RL * (w->B > 0 ? w->B : 1));
     ALLOC(o->lasers, double, (size_t)RL * (w->B > 0 ? w->B : 1));
     ALLOC(o->ped_vector_states, float, (size_t)RL * w->PV);
@@ -928,7 +945,14 @@ static void get_states(oracle_world* w) {
         }
         const uint8_t* view = w->view + (size_t)l * Hv * Wv;
         memcpy(o->view_maps + (size_t)l * Hv * Wv, view, (size_t)Hv * Wv);
-        for (int q = 0; q < Hv * Wv; q++) o->sensor_maps[(size_t)l * Hv * Wv + q] = w->f16_lut[view[q]];
+        /* _trans_cv2_sensor_map (yaml_env.py:431-438): cv2.resize INTER_CUBIC (a copy for equal sizes), float16, / 255 */
+        {
+            const size_t IS = (size_t)w->img_h * w->img_w;
+            uint8_t* img = (uint8_t*)malloc(IS);
+            oracle_resize_cubic_u8(view, Hv, Wv, img, w->img_h, w->img_w);
+            for (size_t q = 0; q < IS; q++) o->sensor_maps[(size_t)l * IS + q] = w->f16_lut[img[q]];
+            free(img);
+        }
         o->robot_pose[3 * l] = r[0];
         o->robot_pose[3 * l + 1] = r[1];
         o->robot_pose[3 * l + 2] = r[2];

@@ -73,6 +73,7 @@ class OracleWorld:
         buf = (C.c_double * (self.n_robots * _cabi.RECORD_DOUBLES)).from_address(rec.value)
         self.records = np.frombuffer(buf, dtype=np.float64).reshape(self.n_robots, _cabi.RECORD_DOUBLES)
         self.n_local = o.n_local
+        self.grid_shape = (o.grid_h, o.grid_w)  # after the load-time resize (grid_map.cpp:28-38)
 
     def _check(self, rc, what):
         if rc != 0:
@@ -106,16 +107,16 @@ class OracleWorld:
         return np.frombuffer((C.c_float * n).from_address(p.value), np.float32).reshape(self.n_local, self.n_peds, 5).copy()
 
     def private_grid(self, robot):
-        g = np.zeros_like(self.grid)
+        g = np.zeros(self.grid_shape, np.uint8)
         self._check(self.lib.oracle_private_grid(self.h, robot, g.ctypes.data), "oracle_private_grid")
         return g
 
     def grids(self):
         a, b = C.c_void_p(), C.c_void_p()
         self.lib.oracle_grids(self.h, C.byref(a), C.byref(b))
-        n = self.grid.size
-        obs = np.frombuffer((C.c_uint8 * n).from_address(a.value), np.uint8).reshape(self.grid.shape)
-        ped = np.frombuffer((C.c_uint8 * n).from_address(b.value), np.uint8).reshape(self.grid.shape)
+        n = self.grid_shape[0] * self.grid_shape[1]
+        obs = np.frombuffer((C.c_uint8 * n).from_address(a.value), np.uint8).reshape(self.grid_shape)
+        ped = np.frombuffer((C.c_uint8 * n).from_address(b.value), np.uint8).reshape(self.grid_shape)
         return obs, ped
 
     def snapshot(self):

@@ -74,6 +74,65 @@ def test_hip_matches_oracle(worlds, case):
         cpu.close()
 
 
+def _room_map(px, seed):
+    """a room like the reference's room_10.png: white floor, black walls, a few black blocks"""
+    rng = np.random.default_rng(seed)
+    m = np.full((px, px), 255, np.uint8)
+    m[:5] = m[-5:] = 0
+    m[:, :5] = m[:, -5:] = 0
+    for _ in range(3):
+        a, b = rng.integers(15, px - 25, 2)
+        m[a:a + rng.integers(3, 9), b:b + rng.integers(3, 9)] = 0
+    return m
+
+
+RESAMPLED = {
+    # the geometry of the reference's envs/cfg/test.yaml: a 110 x 110 pixel map at 0.1 m resized (INTER_LINEAR) to 733 x 733
+    # cells of 0.015 m, a 6 m = 400 x 400 cell view shrunk (INTER_CUBIC) to 48 x 48, 1000 beams, 4 leg pedestrians, 4 obstacles
+    "test_yaml_geometry": dict(n_robots=1, n_peds=4, seed=61, map_px=110, global_res=0.1, res=0.015, view_m=6.0, beams=1000,
+                               image=48, ped_shape="leg", dt=0.4, n_obstacles=4, steps=12),
+    # the same with several robots that see each other (circle.yaml has two), pedestrians as discs, ERVO
+    "shipped_view_three_robots": dict(n_robots=3, n_peds=5, seed=62, map_px=110, global_res=0.1, res=0.015, view_m=6.0, beams=1000,
+                                      image=48, scene="ervoscene", dt=0.1, n_obstacles=3, steps=10, clearance=1.2),
+    # only the sensor_map is shrunk (96 -> 48), power-of-two cells; and only the map is resized (0.25 m pixels -> 0.125 m cells)
+    "shrink_96_to_48": dict(n_robots=10, n_peds=6, seed=63, map_px=200, global_res=0.125, res=0.125, view_m=12.0, beams=360,
+                            image=48, n_obstacles=2, steps=15),
+    "map_upscaled_twice": dict(n_robots=12, n_peds=6, seed=64, map_px=120, global_res=0.25, res=0.125, view_m=6.0, beams=360,
+                               image=48, n_obstacles=2, steps=15),
+    # a view that is not square in cells after the shrink target, odd sizes, no laser
+    "shrink_to_84_no_laser": dict(n_robots=4, n_peds=3, seed=65, map_px=150, global_res=0.1, res=0.05, view_m=10.0, beams=0,
+                                  image=84, use_laser=False, n_obstacles=2, steps=10),
+}
+
+
+@pytest.mark.parametrize("case", list(RESAMPLED))
+def test_resampled_maps_and_large_views_match_oracle(worlds, case):
+    """SURVEY f2: cv::resize INTER_LINEAR at map load (grid_map.cpp:28-38), views of up to 400 x 400 cells, and the
+    cv2.resize INTER_CUBIC shrink of the sensor_map (yaml_env.py:431-438) -- k_view_big and the host resize against the oracle"""
+    World, OracleWorld = worlds
+    from img_env_amd import worldgen
+    kw = dict(RESAMPLED[case])
+    n, P, steps = kw.pop("n_robots"), kw.pop("n_peds"), kw.pop("steps")
+    src = _room_map(kw.pop("map_px"), kw["seed"])
+    gres, res, view_m, image = kw.pop("global_res"), kw.pop("res"), kw.pop("view_m"), kw.pop("image")
+    seed, n_obs, clearance = kw.pop("seed"), kw.pop("n_obstacles"), kw.pop("clearance", 1.0)
+    params = worldgen.make_params(n, P, res=res, view_cells=1, **kw)
+    params.update(global_resolution=gres, view_width=view_m, view_height=view_m, image_size=(image, image))
+    layout = worldgen.make_layout(src, gres, n, P, seed=seed, n_obstacles=n_obs, clearance=clearance)
+    gpu, cpu = World(params, src), OracleWorld(params, src)
+    try:
+        o = cpu.out
+        assert o["sensor_maps"].shape == (n, image, image) and o["view_maps"].shape[1] == int(float(np.float32(view_m)) / float(np.float32(res)))  # agent.cpp:81-83, doubles
+        rng = np.random.default_rng(seed)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(steps)])
+        assert not fails, fails[:3]
+        sm = cpu.snapshot()["sensor_maps"].astype(np.float32)
+        assert sm.min() >= 0.0 and sm.max() <= 1.0 and len(np.unique(sm)) > 3  # the shrink really interpolated
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def test_second_reset_reuses_handle(worlds):
     World, OracleWorld = worlds
     grid, params, layout = small_world(10, 5, seed=11)
