@@ -374,6 +374,122 @@ class NeverStopWrapper(Wrapper):
         return states, reward, done, info
 
 
+class TrajectoryPathHelper:
+    """envs/wrapper/evaluation_wrapper/utils.py:5-129: path statistics of one episode's (v, w) commands"""
+
+    def __init__(self, dt):
+        self.dt = dt
+        self.v_array, self.w_array = [], []
+        self.w_zero = self.v_jerk = self.w_jerk = self.w_variance = self.w_avg = self.v_avg = self.w_acc = self.v_acc = 0
+
+    def add_vw(self, v, w):
+        self.v_array.append(v)
+        self.w_array.append(w)
+
+    def reset(self):
+        """cal_w_variance, cal_w_zero, cal_jerk, cal_v_avg, cal_w_avg (utils.py:60-101, 123-129)"""
+        self.w_variance = np.var(self.w_array)
+        tmp = w_zero = 0
+        for w in self.w_array:  # sign changes of w, a zero in between counts once
+            if w == 0:
+                if tmp != 0:
+                    w_zero += 1
+            elif (w > 0 and tmp < 0) or (w < 0 and tmp > 0):
+                w_zero += 1
+            tmp = w
+        self.w_zero = w_zero
+        v_acc = np.diff(self.v_array, axis=0) / self.dt
+        self.v_jerk = np.average(np.abs(np.diff(v_acc, axis=0) / self.dt))
+        self.v_acc = np.average(np.abs(v_acc))
+        w_acc = np.diff(self.w_array, axis=0) / self.dt
+        self.w_jerk = np.average(np.abs(np.diff(w_acc, axis=0) / self.dt))
+        self.w_acc = np.average(np.abs(w_acc))
+        self.v_avg = np.average(self.v_array)
+        self.w_avg = np.average(np.abs(self.w_array))
+
+    def clear_vw_array(self):
+        self.v_array.clear()
+        self.w_array.clear()
+        self.w_zero = self.w_variance = self.w_avg = self.v_avg = self.w_jerk = self.v_jerk = self.v_acc = self.w_acc = 0
+
+
+class TestEpisodeWrapper(Wrapper):
+    """envs/wrapper/evaluation_wrapper/TestEpisodeWrapper.py:8-119: episode statistics of ONE robot (the first), printed after
+    ``init_pose_bag_episodes`` episodes -- upon which the reference exits the process, and so does this."""
+    __test__ = False  # (not a pytest class)
+
+    def __init__(self, env, cfg):
+        super().__init__(env)
+        self.cur_episode = 0
+        self.max_episodes = cfg["init_pose_bag_episodes"]
+        self.dt = cfg["control_hz"]
+        self.arrive_num = self.static_coll_num = self.ped_coll_num = self.other_coll_num = 0
+        self.steps = self.tmp_steps = self.stuck_num = 0
+        self.v_sum = self.w_sum = 0
+        self.speed_step = 0
+        self.w_variance_array, self.v_jerk_array, self.w_jerk_array, self.w_zero_array = [], [], [], []
+        self.traj_helper = TrajectoryPathHelper(dt=self.dt)
+
+    def step(self, action):
+        states, reward, done, info = self.env.step(action)
+        self.tmp_steps += 1
+        speeds = [float(x) for x in info["speeds"][0][:2]]  # "suppose only one agent here"
+        self.v_sum += speeds[0]
+        self.w_sum += abs(speeds[1])
+        self.traj_helper.add_vw(*speeds)
+        return states, reward, done, info
+
+    def reset(self, **kwargs):
+        if self.tmp_steps > 3:  # two or three steps: too short to count
+            self.cur_episode += 1
+            self.dones_statistics(kwargs.get("dones_info"))
+        if self.cur_episode == self.max_episodes:
+            self.screen_out()
+        self.tmp_steps = 0
+        return self.env.reset(**kwargs)
+
+    def dones_statistics(self, t):
+        if t is None:
+            return
+        t = int(t[0])
+        self.speed_step += self.tmp_steps
+        if t == 5:
+            self.arrive_num += 1
+            self.steps += self.tmp_steps
+        elif t == 10:
+            self.stuck_num += 1
+        elif t == 1:
+            self.static_coll_num += 1
+        elif t == 2:
+            self.ped_coll_num += 1
+        elif t == 3:
+            self.other_coll_num += 1
+        else:
+            raise ValueError("[TestEpisodeWrapper]: No dones info: %r" % t)
+        self.traj_helper.reset()  # path_statistics
+        self.v_jerk_array.append(round(self.traj_helper.v_jerk, 4))
+        self.w_jerk_array.append(round(self.traj_helper.w_jerk, 4))
+        self.w_zero_array.append(self.traj_helper.w_zero)
+        self.w_variance_array.append(round(self.traj_helper.w_variance, 4))
+        self.traj_helper.clear_vw_array()
+
+    def statistics(self):
+        n = self.max_episodes
+        return dict(arrive_rate=self.arrive_num / n, static_coll_rate=self.static_coll_num / n, ped_coll_rate=self.ped_coll_num / n,
+                    other_coll_rate=self.other_coll_num / n, avg_arrive_steps=self.steps / max(1, self.arrive_num),
+                    stuck_rate=self.stuck_num / n, avg_v=self.v_sum / self.speed_step, avg_w=self.w_sum / self.speed_step,
+                    avg_w_variance=sum(self.w_variance_array) / n, avg_v_jerk=sum(self.v_jerk_array) / n,
+                    avg_w_jerk=sum(self.w_jerk_array) / n, avg_w_zero=sum(self.w_zero_array) / n)
+
+    def screen_out(self):
+        import sys
+        print("[TestEpisodeWrapper]: Have run max episodes %d, statistics number are in the following:" % self.max_episodes)
+        for k, v in self.statistics().items():
+            print("    %s: %s," % (k, v))
+        print("[TestEpisodeWrapper]: Exit Progress!", flush=True)
+        sys.exit()
+
+
 class StatePedVectorWrapper(ObservationWrapper):
     """envs/wrapper/base.py:19-34"""
     avg = (0.0, 0.0, 0.0, 0.0, 0.25, 0.25, 0.0)
@@ -425,6 +541,7 @@ wrapper_dict = {
     "MultiRobotCleanWrapper": MultiRobotCleanWrapper,
     "InfoLogWrapper": InfoLogWrapper,
     "ObsLaserStateTmp": ObsLaserStateTmp,
+    "TestEpisodeWrapper": TestEpisodeWrapper,
 }
 
 

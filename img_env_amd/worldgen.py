@@ -244,3 +244,30 @@ def make_yaml_cfg(n_robots, n_peds, grid, res=0.125, view_cells=48, beams=360, s
     )
     cfg.update(over)
     return cfg
+
+
+def shipped_test_yaml_cfg(map_file, spawn_sections, env_num=1, wrappers=None):
+    """A config dict with the numbers of the reference's shipped ``envs/cfg/test.yaml`` (lines 7-160): a 110 x 110 pixel map at
+    0.1 m, grid and view cells of 0.015 m, a 6 m x 6 m view (400 x 400 cells) shrunk to 48 x 48, 1000 beams over +-90 degrees,
+    dt 0.4 s, discrete actions, the wrapper list with TestEpisodeWrapper.  ``spawn_sections``: the ``robot`` / ``ped_sim`` /
+    ``object`` / ``circle_ranges`` / ``target_min_dist`` keys (tests/golden/spawn_ref.npz carries the shipped file's)."""
+    table = [[0.0, -0.9], [0.0, -0.6], [0.0, -0.3], [0.0, 0.05], [0.0, 0.3], [0.0, 0.6], [0.0, 0.9],
+             [0.2, -0.9], [0.2, -0.6], [0.2, -0.3], [0.2, 0], [0.2, 0.3], [0.2, 0.6], [0.2, 0.9],
+             [0.4, -0.9], [0.4, -0.6], [0.4, -0.3], [0.4, 0], [0.4, 0.3], [0.4, 0.6], [0.4, 0.9],
+             [0.6, -0.9], [0.6, -0.6], [0.6, -0.3], [0.6, 0], [0.6, 0.3], [0.6, 0.6], [0.6, 0.9]]
+    if wrappers is None:
+        wrappers = ["VelActionWrapper", "TimeLimitWrapper", "SensorsPaperRewardWrapper", "InfoLogWrapper", "MultiRobotCleanWrapper",
+                    "TestEpisodeWrapper", "StateBatchWrapper", "ObsLaserStateTmp", "NeverStopWrapper"]
+    cfg = dict(
+        test=False, env_type="robot_nav", robot_type="diff", env_num=env_num, agent_num_per_env=1, batch_num_per_env=1, env_id=0,
+        env_name="image_ped_circle", cfg_name="test", cfg_type="yaml", control_hz=0.4, time_max=200, robot_radius=0.17,
+        ped_leg_radius=0.1, ped_safety_space=0.7, laser_max=6.0, image_batch=1, image_size=[48, 48], ped_image_size=[48, 48],
+        state_batch=3, state_dim=3, state_normalize=False, laser_batch=0, act_dim=2, discrete_action=True, discrete_actions=table,
+        continuous_actions=[[0, 0.6], [-0.9, 0.9]], max_ped=10, ped_vec_dim=7, ped_image_r=0.3, show_gui=False, sleep_t=0.0,
+        window_height=500, show_image_height=125, is_draw_step=False, step_draw=3, use_laser=True, range_total=1000,
+        view_angle_begin=-1.570795, view_angle_end=1.570795, view_min_dist=0.0, view_max_dist=10.0, beep_r=1.0, ped_ca_p=1.0,
+        relation_ped_robo=1, init_pose_bag_episodes=100, wrapper=list(wrappers),
+        global_map=dict(resolution=0.1, map_file=map_file), view_map=dict(resolution=0.015, width=6, height=6), node_id=0,
+    )
+    cfg.update(spawn_sections)
+    return cfg

@@ -233,6 +233,14 @@ def run_stack(name, n_robots, n_peds, steps, seed, time_max, wrappers, cfg_over,
         rec["close"].append(np.array(info.get("bool_get_close_to_human", np.zeros(n_robots))))
     for k, v in rec.items():
         out["exp_" + k] = np.stack(v)
+    te = env
+    while te is not None and type(te).__name__ != "TestEpisodeWrapper":
+        te = getattr(te, "env", None)
+    if te is not None:  # what the reference's episode statistics had counted by the end of the run
+        out["te_counts"] = np.array([te.cur_episode, te.arrive_num, te.static_coll_num, te.ped_coll_num, te.other_coll_num, te.steps,
+                                     te.stuck_num, te.speed_step], np.int64)
+        out["te_sums"] = np.array([te.v_sum, te.w_sum], np.float64)
+        out["te_arrays"] = np.array([te.w_variance_array, te.v_jerk_array, te.w_jerk_array, te.w_zero_array], np.float64)
     out["actions"] = np.stack(acts)
     out["n_resets"] = np.array(n_resets[0])
     out["meta"] = np.array(repr(meta))
@@ -271,3 +279,8 @@ if __name__ == "__main__":
     run_stack("b", n_robots=2, n_peds=3, steps=14, seed=43, time_max=5,
               wrappers=base + ["StateBatchWrapper", "ObsStateTmp", "NeverStopWrapper"],
               cfg_over=dict(image_batch=1, state_batch=1, laser_batch=0), obs_names=["sensor_maps", "vector_states", "ped_maps"])
+    # the wrapper list of the shipped test.yaml (one robot): TestEpisodeWrapper's statistics over a handful of short episodes
+    run_stack("c", n_robots=1, n_peds=3, steps=44, seed=45, time_max=7,
+              wrappers=base + ["TestEpisodeWrapper", "StateBatchWrapper", "ObsLaserStateTmp", "NeverStopWrapper"],
+              cfg_over=dict(discrete_action=True, discrete_actions=table, image_batch=1, state_batch=3, laser_batch=0,
+                            init_pose_bag_episodes=100), obs_names=["lasers", "vector_states", "ped_maps"], n_layouts=4)

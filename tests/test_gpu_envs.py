@@ -104,6 +104,58 @@ def test_full_wrapper_stack_matches_reference(path):
             if meta["n_peds"]:
                 assert np.array_equal(info["bool_get_close_to_human"].cpu().numpy(), z["exp_close"][s]), s
         assert Seq.n == int(z["n_resets"]) >= 2
+        if "te_counts" in z.files:  # TestEpisodeWrapper's statistics (TestEpisodeWrapper.py:36-80)
+            te = env
+            while type(te).__name__ != "TestEpisodeWrapper":
+                te = te.env
+            got = [te.cur_episode, te.arrive_num, te.static_coll_num, te.ped_coll_num, te.other_coll_num, te.steps, te.stuck_num,
+                   te.speed_step]
+            assert got == z["te_counts"].tolist() and te.cur_episode >= 3
+            assert np.allclose([te.v_sum, te.w_sum], z["te_sums"], atol=1e-6)
+            assert np.allclose(np.array([te.w_variance_array, te.v_jerk_array, te.w_jerk_array, te.w_zero_array], np.float64),
+                               z["te_arrays"], atol=1e-4)
+    finally:
+        env.close()
+
+
+def test_shipped_test_yaml_geometry_loads_through_make_env(tmp_path):
+    """the numbers of the reference's envs/cfg/test.yaml through make_env: a 110 x 110 pixel PNG at 0.1 m (a synthetic room in
+    place of the reference's room_10.png) resized to 733 x 733 cells, 400 x 400 cell views shrunk to 48 x 48, 1000 beams, the
+    shipped cast (1 robot on a circle, 4 leg pedestrians, 4 obstacles: the spawn sections as the fixture carries them) and
+    the shipped wrapper list, TestEpisodeWrapper included"""
+    import json
+    import torch
+    from PIL import Image
+    from img_env_amd import make_env, worldgen
+    m = np.full((110, 110), 255, np.uint8)
+    m[:5] = m[-5:] = 0
+    m[:, :5] = m[:, -5:] = 0
+    Image.fromarray(np.stack([m] * 3, -1)).save(str(tmp_path / "room.png"))  # grey in RGB, as the reference's maps are
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "spawn_ref.npz"))
+    sections = json.loads(str(z["test@1/cfg"]))
+    cfg = worldgen.shipped_test_yaml_cfg("room.png", sections)
+    cfg.update(map_dir=str(tmp_path), seed=5, time_max=12, init_pose_bag_episodes=1000)
+    env = make_env(cfg)
+    try:
+        w = env.world
+        assert (w.n_robots, w.n_peds) == (1, 4)
+        assert w.out["view_maps"].shape == (1, 400, 400) and w.out["sensor_maps"].shape == (1, 48, 48)
+        assert w.out["lasers"].shape == (1, 1000)
+        obs = env.reset()
+        assert obs[0].shape == (1, 1, 1000) and obs[1].shape == (1, 9) and obs[2].shape == (1, 3, 48, 48)
+        vm = w.out["view_maps"][0].cpu().numpy()
+        assert set(np.unique(vm)) <= {0, 100, 200, 255} and (vm == 100).sum() > 300 and (vm == 255).sum() > 10000
+        resets = 0
+        rng = np.random.default_rng(1)
+        for s in range(40):
+            obs, rew, done, info = env.step(torch.as_tensor(rng.integers(0, 28, 1), device="cuda"))
+            resets += int(bool(info["all_down"][0]))
+            assert torch.isfinite(obs[0]).all() and float(obs[0].max()) <= 1.0
+        assert resets >= 2
+        te = env
+        while type(te).__name__ != "TestEpisodeWrapper":
+            te = te.env
+        assert te.cur_episode == resets and te.speed_step > 0
     finally:
         env.close()
 
