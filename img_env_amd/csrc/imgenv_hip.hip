@@ -767,6 +767,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_alloc(h, &f.dest, n, 0xFF)); TRY(dev_alloc(h, &f.last, n, 0xFF));  // -1
         TRY(dev_alloc(h, &f.nodes, f.cap_nodes)); TRY(dev_alloc(h, &f.n_nodes, 1)); TRY(dev_alloc(h, &f.treehash, n));
         TRY(dev_alloc(h, &f.pair_f, (size_t)(n ? n : 1) * (n ? n : 1) * 3)); TRY(dev_alloc(h, &f.pair_code, (size_t)(n ? n : 1) * (n ? n : 1)));
+        TRY(dev_alloc(h, &f.g_nb, (size_t)SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32))); TRY(dev_alloc(h, &f.g_sh, (size_t)4 * SFM_MAX_AGENTS));
         HIPCHK_H(hipMemcpy(f.p, p0.data(), sizeof(double) * 3 * (n ? n : 1), hipMemcpyHostToDevice));
         HIPCHK_H(hipMemcpy(f.vmax, vmax.data(), sizeof(double) * (n ? n : 1), hipMemcpyHostToDevice));
         HIPCHK_H(hipMemcpy(f.nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
@@ -872,6 +873,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
                               (const void*)k_view<false, true, true, 4>, (const void*)k_view<false, false, true, 4>})
             HIPCHK_H(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view));
     }
+    if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM)
+        HIPCHK_H(hipFuncSetAttribute((const void*)k_sfm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(SfmNode) * SFM_LDS_NODES)));
     if (h->lds_obs > 64 * 1024)
         HIPCHK_H(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     h->serial = getenv("IMGENV_SERIAL") && getenv("IMGENV_SERIAL")[0] == '1';
@@ -1740,8 +1743,19 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
     // step's views and was joined before that step's k_tail; its velocities are applied by k_integrate's pedestrian blocks
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
-        TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), 0, st>>>(d)));
-        h->launches += 1;
+        const int n_sfm = h->d.sfm.n, n_pairs = n_sfm * n_sfm;
+        if (n_pairs <= 4096) {  // small crowd: one launch
+            TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 0)));
+            h->launches += 1;
+        } else {  // the n^2 pair terms (three correctly rounded atan2 each) spread over the chip between two one-workgroup launches
+            const bool on = timing_on(h, IMGENV_K_ORCA);
+            if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, st, 0)) return rc_; }
+            k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 1);
+            k_sfm<<<dim3((n_pairs + SFM_MAX_AGENTS - 1) / SFM_MAX_AGENTS), dim3(SFM_MAX_AGENTS), 0, st>>>(d, 2);
+            k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 3);
+            if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, st, 1)) return rc_; }
+            h->launches += 3;
+        }
     }
     if (d.beep_on) {  // beep lottery + ERVO's evacuation term on top of the velocities the solve left (img_env.cpp:323-343)
         k_beep<<<dim3(h->W), dim3(BEEP_T), 0, st>>>(d, actions);

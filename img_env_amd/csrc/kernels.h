@@ -390,18 +390,20 @@ __device__ __forceinline__ void ped_update_one(const DevWorld& w, int j) {
 
 // PedScene::step (pedscene.h:48-50) = Tscene::moveAgents(step_hz) for the whole social-force crowd, then the
 // write-back of img_env.cpp:344-358 (getNewPosAndVel pedscene.h:82-91, set_position, update_bbox)
-__global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w) {
+__global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w, int phase) {
     __shared__ uint32_t nb_bits[SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32)];
     __shared__ double sfm_sh[4 * SFM_MAX_AGENTS];
     __shared__ unsigned short sfm_stk[SFM_WALK_CAP * SFM_MAX_AGENTS];
-    __shared__ SfmNode sfm_nodes[SFM_LDS_NODES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sfm_dyn[];  // [SFM_LDS_NODES] nodes (phases 0, 1, 3; none in phase 2)
+    SfmNode* sfm_nodes = (SfmNode*)sfm_dyn;
     __shared__ int sfm_hash[SFM_MAX_AGENTS];
     __shared__ int sfm_nn;
 #ifdef IMGENV_PHASE_PROFILE
-    sfm_step(w.sfm, w.step_hz, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn, w.dbg);
+    sfm_step(w.sfm, w.step_hz, phase, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn, w.dbg);
 #else
-    sfm_step(w.sfm, w.step_hz, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn);
+    sfm_step(w.sfm, w.step_hz, phase, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn);
 #endif
+    if (phase == 1 || phase == 2) return;
     const int j = threadIdx.x;
     if (j >= w.P) return;
     const double ox = w.ppx[j], oy = w.ppy[j];

@@ -33,7 +33,7 @@
 #define SFM_LEAF_CAP 12
 #define SFM_MAX_DEPTH 64
 #define SFM_WALK_CAP 24  // LDS stack entries per agent of the neighbour walk
-#define SFM_LDS_NODES 192  // quadtree nodes mirrored in LDS for a step (larger trees are walked in HBM)
+#define SFM_LDS_NODES 1024  // quadtree nodes mirrored in (dynamic) LDS for a step: 104 KB (larger trees are walked in HBM)
 
 struct SfmNode {  // Ped::Ttree
     double x, y, w, h;
@@ -56,6 +56,8 @@ struct SfmDev {
     int* err;       // [1] overflow flag (node pool / leaf capacity / depth)
     double* pair_f;            // [n][n][3] social-force term of (agent, neighbour)
     unsigned char* pair_code;  // [n][n] lookahead vote + 1 | has-term << 2
+    uint32_t* g_nb;            // [SFM_MAX_AGENTS][SFM_MAX_AGENTS / 32] neighbour sets, phase 1 -> 2 of a split step
+    double* g_sh;              // [4][SFM_MAX_AGENTS] desired direction x / y and two angles per agent, phase 1 -> 2, 3
 };
 
 // ---- Ttree (ped_tree.cpp:18-137) on flat arrays, shared by the host (initial tree) and the device ----
@@ -201,9 +203,14 @@ __device__ double sfm_angle_to(d3 a, d3 b) {  // Tvector::angleTo
     return diff;
 }
 
-// one Tscene::moveAgents(h) for the whole crowd: thread i = agent i, one workgroup
-__device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SFM_MAX_AGENTS][SFM_MAX_AGENTS/32] */,
-                         double* sh /* LDS [4][SFM_MAX_AGENTS]: desired direction x / y and two angles per agent */,
+// one Tscene::moveAgents(h) for the whole crowd: thread i = agent i, one workgroup -- or, for crowds whose n^2 pair terms (three
+// correctly rounded atan2 each) would keep that one workgroup busy for a millisecond, three launches:
+//   phase 1 (one workgroup)     neighbour sets from the quadtree, desired force, the per-agent angles   -> s.g_nb, s.g_sh
+//   phase 2 (n^2 / 256 workgroups) the pair terms of socialForce / lookaheadForce                      -> s.pair_f, s.pair_code
+//   phase 3 (one workgroup)     sums in neighbour order, obstacle force, move, the serial quadtree surgery
+// phase 0 = everything in one launch (small crowds).
+__device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds /* LDS [SFM_MAX_AGENTS][SFM_MAX_AGENTS/32] */,
+                         double* sh_lds /* LDS [4][SFM_MAX_AGENTS]: desired direction x / y and two angles per agent */,
                          unsigned short* stk /* LDS [SFM_WALK_CAP][blockDim.x]: walk stacks; later one "left its leaf" flag per agent */,
                          SfmNode* lnodes /* LDS [SFM_LDS_NODES] */, int* lhash /* LDS [SFM_MAX_AGENTS] */, int* ln_nodes /* LDS [1] */,
                          unsigned long long* stamp = nullptr /* debug: wall-clock marks of thread 0 */) {
@@ -214,9 +221,11 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
     const int n_cap = SFM_MAX_AGENTS;
     // The tree is pointer-chased many times per step and then edited agent by agent: for the step it lives in LDS (when it
     // fits with room for a few splits), so a dependent access costs ~100 ns instead of ~1 us.
-    double* lp = (double*)nb_bits;  // [n][3] new positions; the neighbour bit sets (8 KB) are dead once the pair terms exist
+    uint32_t* nb_bits = phase == 0 ? nb_lds : s.g_nb;  // split: what one launch hands the next lives in HBM
+    double* sh = phase == 0 ? sh_lds : s.g_sh;
+    double* lp = (double*)nb_lds;  // [n][3] new positions; the LDS neighbour bit sets (8 KB) are dead once the pair terms exist
     const int n_nodes0 = *s.n_nodes;
-    const bool in_lds = n_nodes0 + 32 <= SFM_LDS_NODES;
+    const bool in_lds = phase != 2 && n_nodes0 + 32 <= SFM_LDS_NODES;
     SfmNode* nodes = in_lds ? lnodes : s.nodes;
     int* treehash = in_lds ? lhash : s.treehash;
     int* n_nodes = in_lds ? ln_nodes : s.n_nodes;
@@ -231,7 +240,12 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
     d3 desiredforce = D3(0, 0, 0), socialforce = D3(0, 0, 0), obstacleforce = D3(0, 0, 0), lookaheadforce = D3(0, 0, 0);
     d3 me_p = D3(0, 0, 0), me_v = D3(0, 0, 0);
     uint32_t* mine = nb_bits + (size_t)i * (SFM_MAX_AGENTS / 32);
-    if (i < n) {
+    if (i < n && phase == 3) {  // what phase 1 had in registers
+        me_p = ld3(s.p, i);
+        me_v = ld3(s.v, i);
+        desiredforce = scaled(normalized(D3(sh[i], sh[n_cap + i], 0)), s.vmax[i]);
+    }
+    if (i < n && phase <= 1) {
         me_p = ld3(s.p, i);
         me_v = ld3(s.v, i);
         // Tscene::getNeighbors(p.x, p.y, 20) (ped_scene.cpp:217-252): agents of the leaves the square touches
@@ -287,12 +301,14 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         sh[2 * n_cap + i] = cr_atan2(-desired_direction.x, -desired_direction.y);
         sh[3 * n_cap + i] = cr_atan2(-me_v.x, -me_v.y);
     }
+    if (phase == 1) return;
     __syncthreads();
     // Pair terms of lookaheadForce and socialForce (ped_agent.cpp:316-404, 439-480), one (agent, neighbour) pair per
     // thread and round: the three correctly rounded atan2 of a pair are ~1500 serial instructions, and an agent has up to
     // n - 1 neighbours.  Each term is evaluated exactly as the reference does and parked in HBM; the agents then add
     // their terms in neighbour order, so the sums round as the sequential loops do.
-    for (int pq = threadIdx.x; pq < n * n; pq += blockDim.x) {
+    for (int pq = (phase == 2 ? blockIdx.x * blockDim.x : 0) + threadIdx.x; phase != 3 && pq < n * n;
+         pq += (phase == 2 ? gridDim.x : 1) * blockDim.x) {
         const int pi = pq / n, o = pq - pi * n;
         unsigned char code = 0;  // bits 0-1: lookahead vote + 1, bit 2: has a social term
         d3 term = D3(0, 0, 0);
@@ -351,6 +367,7 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
             s.pair_f[3 * (size_t)pq + 2] = term.z;
         }
     }
+    if (phase == 2) return;
     __threadfence_block();
     __syncthreads();
     SFM_STAMP(3);
@@ -358,10 +375,24 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         {
             int count = 0;
             const d3 e = D3(sh[i], sh[n_cap + i], 0);
-            for (int o = 0; o < n; o++) {
-                const unsigned char code = s.pair_code[(size_t)i * n + o];
-                count += (int)(code & 3) - 1;
-                if (code & 4) socialforce = socialforce + ld3(s.pair_f, i * n + o);
+            // the terms are added in neighbour order (the sums round as the reference's loop does), but their loads do not
+            // depend on each other: eight neighbours' codes and terms are fetched at once, then added one by one
+            const unsigned char* codes = s.pair_code + (size_t)i * n;
+            const double* terms = s.pair_f + 3 * (size_t)i * n;
+            for (int o0 = 0; o0 < n; o0 += 8) {
+                unsigned char cd[8];
+                d3 tm[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int o = min(o0 + u, n - 1);
+                    cd[u] = o0 + u < n ? codes[o] : (unsigned char)1;  // 1: no vote, no term
+                    tm[u] = D3(terms[3 * o], terms[3 * o + 1], terms[3 * o + 2]);  // (garbage where the code has no term: unused)
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    count += (int)(cd[u] & 3) - 1;
+                    if (cd[u] & 4) socialforce = socialforce + tm[u];
+                }
             }
             if (count < 0) {
                 lookaheadforce.x = 0.5f * e.y;
@@ -443,7 +474,7 @@ __device__ void sfm_step(const SfmDev& s, double h, uint32_t* nb_bits /* LDS [SF
         bool split = false;
         for (int a = 0; a < n && lerr == 0; a++) {
             if (!split && !stk[a]) continue;
-            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh);  // sh (8 KB) is free by now
+            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds);  // the LDS angle table (8 KB) is free by now
             split = *n_nodes != nodes_before;
         }
         if (lerr) *s.err = lerr;

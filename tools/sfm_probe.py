@@ -22,6 +22,10 @@ from img_env_amd.world import World  # noqa: E402
 R, P = 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 200
 grid = worldgen.make_grid(400, 0)
 layout = worldgen.make_layout(grid, 0.25, R, P, seed=100, clearance=0.7)
+rng = np.random.default_rng(13)  # the crowd stays inside libpedsim's 10 m x 10 m quadtree root (pedscene.h:17-20)
+layout.ped_pose[:, :2] = rng.uniform(0.5, 9.5, (P, 2))
+layout.ped_traj[:, :, :2] = rng.uniform(0.5, 9.5, layout.ped_traj[:, :, :2].shape)
+layout.ped_goal[:] = rng.uniform(0.5, 9.5, (P, 2))
 w = World(worldgen.make_params(R, P, res=0.25, scene="pedscene", relation_ped_robo=0), grid)
 w.lib.imgenv_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 w.reset(layout)
