@@ -212,8 +212,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker is not None:
         return cpu_worker(args)
-    if args.gpus > 1 and "RANK" not in os.environ:
-        return launch_ranks(args)
+    if "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("IMGENV_BENCH_FORCE_LAUNCHER")):
+        return launch_ranks(args)  # (the env switch lets a one-GPU box exercise the parent / child relay with --gpus 1)
 
     import torch
     import torch.distributed as dist
