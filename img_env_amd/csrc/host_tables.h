@@ -95,6 +95,7 @@ struct RobotClassHost {
     std::vector<uint32_t> big_cells;  // [ray_maxlen][ray_stride] view cell of step k of beam b, 0xFFFFFFFF past the ray's end
     std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
+    std::vector<uint8_t> ray_run;  // [ray_maxlen][ray_stride] steps behind step k of beam b that share a row or column with it
     std::vector<uint32_t> inv_pack, inv_ent, top_ent;
 };
 
@@ -197,6 +198,25 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
         k.ray_rows.assign((size_t)(k.ray_kpad / 8) * k.ray_stride * 8, (uint16_t)NC);
         k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
         k.big_cells.assign(1, 0xFFFFFFFFu);
+        // bresenhamLine leaves a cell behind the hit alone when it shares its row or column with the hit cell (agent.cpp:555-560).
+        // A path moves one cell along its major axis every step and never back along the minor one, so those cells are the
+        // run of steps right behind the hit until the minor coordinate moves: its length per (step, beam), checked here
+        k.ray_run.assign((size_t)k.ray_maxlen * k.ray_stride, 0);
+        for (int b = 0; b < B; b++) {
+            const size_t n = cells[b].size();
+            for (size_t q = 0; q < n; q++) {
+                const uint32_t xq = cells[b][q] / (uint32_t)Wv, yq = cells[b][q] % (uint32_t)Wv;
+                size_t run = 0;
+                bool in_run = true;
+                for (size_t t = q + 1; t < n; t++) {
+                    const bool same = cells[b][t] / (uint32_t)Wv == xq || cells[b][t] % (uint32_t)Wv == yq;
+                    if (same && !in_run) k.ok = false;  // not one run: the packing of k_view's hit word would be wrong
+                    if (same && in_run) run++;
+                    if (!same) in_run = false;
+                }
+                k.ray_run[q * k.ray_stride + b] = (uint8_t)run;  // ray_maxlen <= 255 here
+            }
+        }
     }
     for (int b = 0; b < B; b++)
         for (size_t q = 0; q < cells[b].size(); q++) {
@@ -218,7 +238,7 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     }
     k.inv_ent.reserve(off + 1);
     for (int c = 0; c < NC; c++) k.inv_ent.insert(k.inv_ent.end(), inv[c].begin(), inv[c].end());
-    k.top_ent.assign(NC, 0xFFFFFFFFu);
+    k.top_ent.assign(NC, ((uint32_t)B << 16) | 0xFFFFu);  // no beam: the dummy beam B at a step behind every hit
     for (int c = 0; c < NC; c++)
         if (!inv[c].empty()) {
             k.top_ent[c] = inv[c][0];

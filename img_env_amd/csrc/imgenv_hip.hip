@@ -238,7 +238,7 @@ extern "C" int imgenv_timing_read(imgenv_t* h, double* total_ms, int64_t* launch
 
 // "hip-gfx950" is the product build only: a library compiled with any work-skipping experiment switch or with the
 // profiling instrumentation says so, so that a number measured on it can never pass for the product's
-#if defined(IMGENV_EXP_SKIP_CROP) || defined(IMGENV_EXP_SKIP_HITS) || defined(IMGENV_EXP_SKIP_FINAL) || defined(IMGENV_EXP_CROP_U8)
+#if defined(IMGENV_EXP_STOP_AFTER) || defined(IMGENV_EXP_SKIP_RESOLVE) || defined(IMGENV_EXP_SKIP_CROP) || defined(IMGENV_EXP_SKIP_HITS) || defined(IMGENV_EXP_SKIP_FINAL) || defined(IMGENV_EXP_CROP_U8)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-EXPERIMENT-work-skipped"; }
 #elif defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-profile-instrumented"; }
@@ -607,6 +607,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.ray_rows, k.ray_rows));
             TRY(dev_upload(h, &o.ray_len, k.ray_len));
             TRY(dev_upload(h, &o.ray_dist, k.ray_dist));
+            TRY(dev_upload(h, &o.ray_run, k.ray_run));
             TRY(dev_upload(h, &o.inv_pack, k.inv_pack));
             TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
             TRY(dev_upload(h, &o.top_ent, k.top_ent));

@@ -1074,8 +1074,10 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 
-// laser_map value of a cell its top beam leaves alone: the next lower beam through the cell that writes decides
-__device__ __forceinline__ uint32_t resolve_skipped_cell(const RobotClassDev& k, const uint32_t* hit, uint32_t c, uint32_t cx, uint32_t cy) {
+// laser_map value of a cell its top beam leaves alone: the next lower beam through the cell that writes decides.
+// hit word of a beam: first-hit step << 16 | last step behind the hit that still shares a row or column with the hit cell
+// (the beam leaves the steps in between alone, agent.cpp:555-560); a beam without a hit holds 0xFFFFFFFF
+__device__ __forceinline__ uint32_t resolve_skipped_cell(const RobotClassDev& k, const uint32_t* hit, uint32_t c) {
     const uint32_t pk = k.inv_pack[c];
     const uint32_t e0 = pk & 0xFFFFFu, cnt = pk >> 20;
     for (uint32_t e = 1; e < cnt; e++) {  // entry 0 is the top beam
@@ -1083,9 +1085,19 @@ __device__ __forceinline__ uint32_t resolve_skipped_cell(const RobotClassDev& k,
         const uint32_t kk = ent & 0xFFFFu, hp = hit[ent >> 16], hk = hp >> 16;
         if (kk < hk) return 3u;   // 255
         if (kk == hk) return 0u;  // 0
-        if (cx != ((hp >> 8) & 0xFFu) && cy != (hp & 0xFFu)) break;  // this beam writes 200
+        if (kk > (hp & 0xFFFFu)) break;  // this beam writes 200
     }
     return 2u;
+}
+
+// the resolved class of such a cell into the two output planes, unless it is the provisional 200 (class 2) they already hold
+__device__ __forceinline__ void patch_resolved(const uint32_t* stamp_bits, uint8_t* out_u8, uint16_t* out_f16, uint32_t h01, uint32_t h3,
+                                               uint32_t c, uint32_t v) {
+    if (v == 2u) return;
+    const bool st = ((stamp_bits[c >> 5] >> (c & 31)) & 1u) != 0;  // own footprint: 100 over anything but 0
+    v = (st && v != 0u) ? 1u : v;
+    out_u8[c] = (uint8_t)(v == 0u ? 0u : (v == 1u ? 100u : 255u));
+    out_f16[c] = (uint16_t)(v == 0u ? (h01 & 0xFFFFu) : (v == 1u ? (h01 >> 16) : h3));
 }
 
 // NW: wavefronts per robot.  1 when a launch fills the machine (instruction issue bounds it); 4 for small launches (a reset of
@@ -1121,7 +1133,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     uint8_t* src = smem;
     uint32_t* hit = (uint32_t*)(smem + NCp);
     double2* colt = (double2*)(smem + NCp + 4 * (size_t)w.hit_stride);
-    int* skip_cnt = (int*)(colt + Wv);  // NW > 1: the wavefronts' common count of skipped cells
+    int* skip_cnt = (int*)(colt + Wv);  // [0] list entries (NW > 1), [1] chunk descriptors, [2] result slots of the final pass
     PHASE_BEGIN();
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
@@ -1152,7 +1164,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
         colt[b] = make_double2(vw.m01 * y, vw.m11 * y);
     }
     if (tid < 16) src[NC + tid] = 255;  // dummy free cells behind the view (padded path entries)
-    if (NW > 1 && tid == 0) *skip_cnt = 0;
+    if (tid < 3) skip_cnt[tid] = 0;
     __syncthreads();
 #ifdef IMGENV_EXP_SKIP_CROP
     for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) *(uint32_t*)(src + c4) = 0xFFFFFFFFu;
@@ -1225,11 +1237,14 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     }
     __syncthreads();
     PHASE_MARK(1);
+#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 1
+    return;  // instruction accounting: collision + crop only
+#endif
 
     // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
 #ifdef IMGENV_EXP_SKIP_HITS
     for (int b = tid; b < w.B; b += NT) hit[b] = 0xFFFFFFFFu;
-    if (tid == 0) hit[w.B] = 0x0000FFFFu;
+    if (tid == 0) hit[w.B] = 0u;
     __syncthreads();
     if (false) {
 #else
@@ -1263,19 +1278,21 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
                 const uint32_t first = min(found2 & 0xFFFFu, found2 >> 16);
                 const bool has = first < 0x0100u;  // value 0 in the key's top byte
                 const uint32_t hk = first & 0xFFu;
-                // the cell of that step comes back out of the path table (one more load per beam, beside the distance's)
-                const uint32_t hc = has ? ((const uint16_t*)rows)[((size_t)(hk >> 3) * k.ray_stride + b) * 8 + (hk & 7u)] : 0u;
+                // how far behind the hit the beam stays in the hit cell's row or column: static per (step, beam)
+                const uint32_t run = has ? k.ray_run[(size_t)hk * k.ray_stride + b] : 0u;
                 const float hd = has ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
-                const uint32_t hx = __umulhi(hc, wv_magic), hy = hc - hx * (uint32_t)Wv;
-                hit[b] = has ? ((hk << 16) | (hx << 8) | hy) : 0xFFFFFFFFu;
+                hit[b] = has ? ((hk << 16) | (hk + run)) : 0xFFFFFFFFu;
                 w.lasers_raw[(size_t)l * w.B + b] = hd;
                 w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
             }
         }
-        if (tid == 0) hit[w.B] = 0x0000FFFFu;  // the dummy beam of cells without any (see the final pass)
+        if (tid == 0) hit[w.B] = 0u;  // the dummy beam of cells without any (see the final pass)
         __syncthreads();
     }
     PHASE_MARK(2);
+#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 2
+    return;  // instruction accounting: collision + crop + first hits
+#endif
 
     // (4) laser_map (agent.cpp:437) per cell from its top beam, the own footprint stamped 100 (agent.cpp:503),
     //     stored as uint8 and as float16(v / 255) (yaml_env.py:431-438).  Class index: 0 -> 0, 1 -> 100, 2 -> 200, 3 -> 255
@@ -1285,8 +1302,8 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     const uint32_t h0 = w.f16_lut[0], h1 = w.f16_lut[100], h2 = w.f16_lut[200], h3 = w.f16_lut[255];
     const uint32_t lut_lo = (h0 & 0xFFu) | ((h1 & 0xFFu) << 8) | ((h2 & 0xFFu) << 16) | ((h3 & 0xFFu) << 24);
     const uint32_t lut_hi = (h0 >> 8) | ((h1 >> 8) << 8) | ((h2 >> 8) << 16) | ((h3 >> 8) << 24);
-    uint16_t* skip_list = (uint16_t*)src;  // the crop is dead once the beams have their hits
-    const int skip_cap = laser ? NC / 2 : 0;
+    uint32_t* skip_list = (uint32_t*)src;  // the crop is dead once the beams have their hits
+    const uint32_t no_beam = ((uint32_t)w.B << 16) | 0xFFFFu;  // top_ent of a cell no beam crosses
     int n_skip = 0;
 #ifdef IMGENV_EXP_SKIP_FINAL
     if (false)
@@ -1294,7 +1311,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
         uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
         if (laser) {
-            uint32_t top[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            uint32_t top[4] = {no_beam, no_beam, no_beam, no_beam};
             if (A4 || c4 + 4 <= NC) {
                 const uint4 t4 = *(const uint4*)(k.top_ent + c4);
                 top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
@@ -1303,49 +1320,32 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
                 for (int q = 0; q < 4; q++)
                     if (c4 + q < NC) top[q] = k.top_ent[c4 + q];
             }
-            if (__any((top[0] & top[1] & top[2] & top[3]) != 0xFFFFFFFFu)) {  // rows behind the sensor see no beam at all
-                const uint32_t cx0 = __umulhi((uint32_t)c4, wv_magic), cy0 = (uint32_t)c4 - cx0 * (uint32_t)Wv;
+            if (__any(min(min(top[0], top[1]), min(top[2], top[3])) < no_beam)) {  // rows behind the sensor see no beam at all
                 uint32_t skips = 0;
                 I = 0;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    uint32_t cx = cx0, cy = cy0 + q;
-                    if (!A4) {
-                        cx = __umulhi((uint32_t)(c4 + q), wv_magic);
-                        cy = (uint32_t)(c4 + q) - cx * (uint32_t)Wv;
-                    }
-                    // a cell no beam crosses (top = 0xFFFFFFFF) looks up the dummy beam B, whose "hit" is step 0 at a
-                    // row / column no cell has: its step 0xFFFF lies behind that, class 200, never "left alone"
-                    const uint32_t bq = min(top[q] >> 16, (uint32_t)w.B), kk = top[q] & 0xFFFFu;
-                    const uint32_t hp = hit[bq], hk = hp >> 16;  // hk = 0xFFFF when the beam never hits
-                    const bool alone = (cx == ((hp >> 8) & 0xFFu)) | (cy == (hp & 0xFFu));
+                    // a cell no beam crosses looks up the dummy beam B at step 0xFFFF: that beam "hits" at step 0 and leaves
+                    // nothing alone, so the cell is class 200
+                    const uint32_t kk = top[q] & 0xFFFFu;
+                    const uint32_t hp = hit[top[q] >> 16], hk = hp >> 16;  // hk = 0xFFFF when the beam never hits
                     const uint32_t v = kk < hk ? 3u : (kk == hk ? 0u : 2u);
-                    skips |= ((kk > hk) & alone) ? (1u << q) : 0u;
+                    skips |= ((kk > hk) & (kk <= (hp & 0xFFFFu))) ? (1u << q) : 0u;
                     I |= v << (8 * q);
                 }
-                if (__any(skips != 0)) {  // left alone by their top beam: provisional 200 now, resolved after the pass
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const bool sk = ((skips >> q) & 1u) != 0;
-                        const unsigned long long mask = __ballot(sk);
-                        int pos = n_skip + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (NW > 1 && mask != 0ull) {  // several wavefronts share the list: one LDS atomic per wavefront and round
-                            int first = 0;
-                            if (lane == 0) first = atomicAdd(skip_cnt, __popcll(mask));
-                            pos = __shfl(first, 0) + __popcll(mask & ((1ull << lane) - 1ull));
-                        }
-                        if (sk) {
-                            if (pos < skip_cap) {
-                                skip_list[pos] = (uint16_t)(c4 + q);
-                            } else {  // list full (never seen): resolve in place
-                                const uint32_t c = (uint32_t)(c4 + q);
-                                const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
-                                const uint32_t v = resolve_skipped_cell(k, hit, c, cx, cy);
-                                I = (I & ~(0xFFu << (8 * q))) | (v << (8 * q));
-                            }
-                        }
-                        n_skip += __popcll(mask);
+                // left alone by their top beam: provisional 200 now, resolved after the pass.  One list entry per lane and
+                // round (c4 << 4 | the four flags): at most NC / 4 entries, which the dead crop always holds
+                const unsigned long long mask = __ballot(skips != 0);
+                if (mask != 0ull) {
+                    int pos = n_skip;
+                    if (NW > 1) {  // several wavefronts share the list: one LDS atomic per wavefront and round
+                        int first = 0;
+                        if (lane == 0) first = atomicAdd(skip_cnt, __popcll(mask));
+                        pos = __shfl(first, 0);
                     }
+                    pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (skips != 0) skip_list[pos] = ((uint32_t)c4 << 4) | skips;
+                    n_skip += __popcll(mask);
                 }
             }
         } else {
@@ -1376,26 +1376,126 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
             }
         }
     }
-    // (5) the cells a top beam left alone, one per lane: the next lower beam through the cell that writes decides
-    //     (agent.cpp:555-560); only values other than the provisional 200 are patched into the two output planes
+    // (5) the cells a top beam left alone: the next lower beam through the cell that writes decides (agent.cpp:555-560), i.e.
+    //     the first entry of the cell's static ray list that is not "left alone" again.  Those lists are long next to the
+    //     sensor (a cell behind an axis-parallel wall is left alone by most of its beams), so they are cut into chunks of 8
+    //     entries and every lane takes one chunk, all 8 loads in flight together:
+    //       A  one list entry per lane: every flagged cell allocates its chunks behind the entry list (LDS atomic cursor) --
+    //          a descriptor each, 1 << 31 | cell for a list of one chunk, else result slot << 9 | chunk -- and, for several
+    //          chunks, a result slot (list position << 18 | class << 16 | cell; starts as "nobody writes": class 200) in
+    //          the dead column table;
+    //       B  one chunk per lane: the first deciding entry of the chunk; patched straight into the two output planes for
+    //          one-chunk cells (only values other than the provisional 200), else LDS atomicMin into the cell's slot;
+    //       C  one slot per lane: patch.
+    //     A cell that finds no room (never seen) walks its list alone.
     if (NW > 1) {
         __syncthreads();
-        n_skip = min(*skip_cnt, skip_cap);
+        n_skip = skip_cnt[0];
     } else {
-        n_skip = min(__builtin_amdgcn_readfirstlane(n_skip), skip_cap);  // lane 0 ran every round of the loop above
+        n_skip = __builtin_amdgcn_readfirstlane(n_skip);  // lane 0 ran every round of the loop above
     }
+#ifdef IMGENV_EXP_SKIP_RESOLVE
+    n_skip = 0;
+#endif
     if (n_skip > 0) {
         __builtin_amdgcn_s_waitcnt(0);  // the provisional stores of this wave have landed
         __syncthreads();
+        uint32_t* desc = skip_list + n_skip;
+        uint32_t* slots = (uint32_t*)colt;
+#ifdef IMGENV_EXP_TINY_RESOLVE  // test build: hardly any room, most cells take the fallbacks
+        const int cap_d = 5, cap_r = 2;
+#else
+        const int cap_d = NCp / 4 - n_skip, cap_r = 4 * Wv;
+#endif
+        const uint32_t NOP = 0xFFFFFFFFu;
+#ifdef IMGENV_EXP_RESOLVE_STATS  // how many cells are left alone, and how long the lists behind them are
+        if (tid == 0) {
+            atomicAdd(&w.dbg[16], 1ull);
+            atomicAdd(&w.dbg[17], (unsigned long long)n_skip);
+        }
         for (int t = tid; t < n_skip; t += NT) {
-            const uint32_t c = skip_list[t];
-            const uint32_t cx = __umulhi(c, wv_magic), cy = c - cx * (uint32_t)Wv;
-            uint32_t v = resolve_skipped_cell(k, hit, c, cx, cy);
-            if (v != 2u) {
-                const bool st = ((k.stamp_bits[c >> 5] >> (c & 31)) & 1u) != 0;
-                v = (st && v != 0u) ? 1u : v;
-                out_u8[c] = (uint8_t)(lut_u8 >> (8 * v));
-                out_f16[c] = (uint16_t)(v == 0u ? h0 : (v == 1u ? h1 : h3));
+            const uint32_t e = skip_list[t];
+            for (uint32_t bits = e & 15u; bits != 0u; bits &= bits - 1u) {
+                const uint32_t c = (e >> 4) + (uint32_t)__builtin_ctz(bits);
+                const uint32_t cnt = k.inv_pack[c] >> 20;
+                atomicAdd(&w.dbg[18], 1ull);
+                atomicAdd(&w.dbg[19], (unsigned long long)cnt);
+                atomicMax(&w.dbg[20], (unsigned long long)cnt);
+                atomicAdd(&w.dbg[21 + min(cnt >> 3, 8u)], 1ull);
+                {  // where the walk ends: entry index of the first deciding beam (bins 1, 2, 3-4, 5-8, 9-16, 17+), or never
+                    const uint32_t pk = k.inv_pack[c], e0 = pk & 0xFFFFFu;
+                    uint32_t at = 0, verdict = 2;
+                    for (uint32_t q = 1; q < cnt && at == 0; q++) {
+                        const uint32_t ent = k.inv_ent[e0 + q], kk = ent & 0xFFFFu, hp = hit[ent >> 16], hk = hp >> 16;
+                        if (kk < hk) { at = q; verdict = 3; }
+                        else if (kk == hk) { at = q; verdict = 0; }
+                        else if (kk > (hp & 0xFFFFu)) at = q;
+                    }
+                    const int bin = at == 0 ? 6 : (at <= 2 ? (int)at - 1 : (at <= 4 ? 2 : (at <= 8 ? 3 : (at <= 16 ? 4 : 5))));
+                    atomicAdd(&w.dbg[8 + bin], 1ull);
+                    if (verdict != 2) atomicAdd(&w.dbg[15], 1ull);
+                    if (at == 0) atomicAdd(&w.dbg[30], (unsigned long long)cnt);  // entries walked for nothing
+                    else atomicAdd(&w.dbg[31], (unsigned long long)at);
+                }
+            }
+        }
+#endif
+        for (int t = tid; t < n_skip; t += NT) {  // A
+            const uint32_t e = skip_list[t];
+            for (uint32_t bits = e & 15u; bits != 0u; bits &= bits - 1u) {
+                const uint32_t c = (e >> 4) + (uint32_t)__builtin_ctz(bits);
+                const uint32_t n = (k.inv_pack[c] >> 20) - 1u;  // entries below the top beam
+                if (n == 0u) continue;                          // nobody else: stays 200
+                const int nch = (int)((n + 7u) >> 3);
+                bool alone = false;
+                if (nch == 1) {
+                    const int pos = atomicAdd(&skip_cnt[1], 1);
+                    if (pos < cap_d) desc[pos] = 0x80000000u | c;
+                    else alone = true;
+                } else {
+                    const int slot = atomicAdd(&skip_cnt[2], 1);
+                    if (slot < cap_r) {
+                        slots[slot] = (0xFFFu << 18) | (2u << 16) | c;
+                        const int pos = atomicAdd(&skip_cnt[1], nch);
+                        alone = pos + nch > cap_d;
+                        for (int j = 0; j < nch && pos + j < cap_d; j++) desc[pos + j] = alone ? NOP : (((uint32_t)slot << 9) | (uint32_t)j);
+                    } else {
+                        alone = true;
+                    }
+                }
+                if (alone) patch_resolved(k.stamp_bits, out_u8, out_f16, h0 | (h1 << 16), h3, c, resolve_skipped_cell(k, hit, c));
+            }
+        }
+        __syncthreads();
+        const int nd = min(skip_cnt[1], cap_d), nr = min(skip_cnt[2], cap_r);
+        for (int t = tid; t < nd; t += NT) {  // B
+            const uint32_t d = desc[t];
+            if (d == NOP) continue;
+            const bool one = (d >> 31) != 0u;
+            const uint32_t c = (one ? d : slots[d >> 9]) & 0xFFFFu;
+            const uint32_t pk = k.inv_pack[c], e0 = pk & 0xFFFFFu, last = (pk >> 20) - 1u;
+            const uint32_t eb = one ? 1u : 1u + 8u * (d & 0x1FFu);
+            uint32_t ent[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) ent[q] = k.inv_ent[e0 + min(eb + q, last)];
+            uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t kk = ent[q] & 0xFFFFu, hp = hit[ent[q] >> 16], hk = hp >> 16;
+                const uint32_t v = kk < hk ? 3u : (kk == hk ? 0u : 2u);
+                const bool decides = !((kk > hk) & (kk <= (hp & 0xFFFFu))) & (eb + q <= last);
+                key = min(key, decides ? (((eb + q) << 18) | (v << 16) | c) : 0xFFFFFFFFu);
+            }
+            if (key != 0xFFFFFFFFu) {
+                if (one) patch_resolved(k.stamp_bits, out_u8, out_f16, h0 | (h1 << 16), h3, c, (key >> 16) & 3u);
+                else atomicMin(&slots[d >> 9], key);
+            }
+        }
+        if (nr > 0) {
+            __syncthreads();
+            for (int t = tid; t < nr; t += NT) {  // C
+                const uint32_t key = slots[t];
+                patch_resolved(k.stamp_bits, out_u8, out_f16, h0 | (h1 << 16), h3, key & 0xFFFFu, (key >> 16) & 3u);
             }
         }
     }

@@ -52,9 +52,10 @@ struct RobotClassDev {
                                  // chunk per lane, consecutive lanes contiguous; padding points at a free dummy cell
     const uint16_t* ray_len;     // [ray_stride] number of in-map steps before the ray leaves / ends
     const float* ray_dist;       // [ray_maxlen][ray_stride] float32(hit distance) if the hit is at step k
+    const uint8_t* ray_run;      // [ray_maxlen][ray_stride] steps right behind step k that share its row or column (left alone by a hit at k)
     const uint32_t* inv_pack;    // [Hv*Wv] rays through a view cell: first entry | count << 20 ...
     const uint32_t* inv_ent;     // ... entries (beam << 16 | k), beam descending
-    const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or 0xFFFFFFFF
+    const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or B << 16 | 0xFFFF
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
     // views beyond k_view's 16 / 8-bit packing (the shipped configs: 400 x 400 cells, 1000 beams): k_view_big
     int big, sensor_x, sensor_y; // the laser's view cell
