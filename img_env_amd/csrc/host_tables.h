@@ -97,6 +97,7 @@ struct RobotClassHost {
     std::vector<float> ray_dist;
     std::vector<uint8_t> ray_run;  // [ray_maxlen][ray_stride] steps behind step k of beam b that share a row or column with it
     std::vector<uint32_t> inv_pack, inv_ent, top_ent;
+    std::vector<uint32_t> inv_cell;  // [NC][2] k_view's step (5): filter word, inv_pack
 };
 
 static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_big = false) {
@@ -244,6 +245,38 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
             k.top_ent[c] = inv[c][0];
         }
     if (k.inv_ent.empty()) k.inv_ent.push_back(0);
+    // k_view's step (5) for the cells a top beam leaves alone.  Such a cell keeps its 200 unless one of the lower beams through
+    // it gets as far as the cell, so the kernel keeps the largest first-hit step of overlapping blocks of beams -- level v:
+    // 16 << v beams starting every 8 << v, v = 0, 1, 2, stored back to back -- and compares the one block around the cell's
+    // lower beams with their smallest step.  Per cell, one 8-byte record: block index | no such block << 13 | own footprint
+    // << 14 | smallest step << 24, then the cell's inv_pack word.
+    k.inv_cell.assign((size_t)NC * 2, 0);
+    if (!k.big) {
+        const uint32_t nb8 = ((uint32_t)B >> 3) + 1;
+        const uint32_t lvl_n[3] = {nb8, (nb8 + 1) >> 1, (nb8 + 3) >> 2};
+        const uint32_t lvl_off[3] = {0, lvl_n[0], lvl_n[0] + lvl_n[1]};
+        for (int c = 0; c < NC; c++) {
+            const uint32_t st = (k.stamp_bits[c >> 5] >> (c & 31)) & 1u;
+            k.inv_cell[2 * (size_t)c] = (1u << 13) | (st << 14);
+            k.inv_cell[2 * (size_t)c + 1] = k.inv_pack[c];
+            if (inv[c].size() < 2) continue;
+            uint32_t bmin = 0xFFFFFFFFu, bmax = 0, kkmin = 0xFFFFu;
+            for (size_t e = 1; e < inv[c].size(); e++) {
+                bmin = std::min(bmin, inv[c][e] >> 16);
+                bmax = std::max(bmax, inv[c][e] >> 16);
+                kkmin = std::min(kkmin, inv[c][e] & 0xFFFFu);
+            }
+            uint32_t idx = 0, none = 1;
+            for (uint32_t v = 0; v < 3 && none; v++) {
+                const uint32_t i = (bmin >> 3) >> v;  // block i of level v covers beams [i * (8 << v), (i + 2) * (8 << v))
+                if (bmax < (i + 2) * (8u << v) && lvl_off[v] + i < (1u << 13)) {
+                    idx = lvl_off[v] + i;
+                    none = 0;
+                }
+            }
+            k.inv_cell[2 * (size_t)c] = idx | (none << 13) | (st << 14) | (std::min(kkmin, 0xFFu) << 24);
+        }
+    }
 }
 
 struct PedClassHost {

@@ -238,7 +238,7 @@ extern "C" int imgenv_timing_read(imgenv_t* h, double* total_ms, int64_t* launch
 
 // "hip-gfx950" is the product build only: a library compiled with any work-skipping experiment switch or with the
 // profiling instrumentation says so, so that a number measured on it can never pass for the product's
-#if defined(IMGENV_EXP_STOP_AFTER) || defined(IMGENV_EXP_SKIP_RESOLVE) || defined(IMGENV_EXP_SKIP_CROP) || defined(IMGENV_EXP_SKIP_HITS) || defined(IMGENV_EXP_SKIP_FINAL) || defined(IMGENV_EXP_CROP_U8)
+#if defined(IMGENV_EXP_STOP_AFTER) || defined(IMGENV_EXP_NO_DRAIN) || defined(IMGENV_EXP_SKIP_RESOLVE) || defined(IMGENV_EXP_SKIP_CROP) || defined(IMGENV_EXP_SKIP_HITS) || defined(IMGENV_EXP_SKIP_FINAL) || defined(IMGENV_EXP_CROP_U8)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-EXPERIMENT-work-skipped"; }
 #elif defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-profile-instrumented"; }
@@ -611,6 +611,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.inv_pack, k.inv_pack));
             TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
             TRY(dev_upload(h, &o.top_ent, k.top_ent));
+            {
+                const uint32_t* cells2 = nullptr;
+                TRY(dev_upload(h, &cells2, k.inv_cell));
+                o.inv_cell = (const uint2*)cells2;
+            }
             TRY(dev_upload(h, &o.big_cells, k.big_cells));
             o.big = k.big ? 1 : 0;
             o.sensor_x = k.sensor_x;
@@ -843,7 +848,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     const size_t NC = (size_t)g.Hv * g.Wv;
     max_stride += 4;  // + the dummy beam of view cells that no beam crosses (kept a multiple of 16 bytes)
     d.hit_stride = (int)max_stride;
-    h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16;  // src u8 (+ dummy cells) | hit u32 | column terms | skip count
+    // src u8 (+ dummy cells) | hit u32 | column terms | cursors of the final pass | largest hit step of blocks of beams (3 levels)
+    h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16 + 4 * (2 * (max_stride / 8 + 1) + 4);
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
     h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
     if (h->big_view) {  // k_view_big: the view at 2 bits a cell | first hit (step, cell) per beam (+ the dummy beam)

@@ -1090,14 +1090,24 @@ __device__ __forceinline__ uint32_t resolve_skipped_cell(const RobotClassDev& k,
     return 2u;
 }
 
-// the resolved class of such a cell into the two output planes, unless it is the provisional 200 (class 2) they already hold
-__device__ __forceinline__ void patch_resolved(const uint32_t* stamp_bits, uint8_t* out_u8, uint16_t* out_f16, uint32_t h01, uint32_t h3,
-                                               uint32_t c, uint32_t v) {
+// the resolved class of such a cell into the two output planes, unless it is the provisional 200 (class 2) they already hold;
+// st: the cell lies under the own footprint (100 over anything but 0)
+__device__ __forceinline__ void patch_stamped(uint8_t* out_u8, uint16_t* out_f16, uint32_t h01, uint32_t h3, uint32_t c, uint32_t v, bool st) {
     if (v == 2u) return;
-    const bool st = ((stamp_bits[c >> 5] >> (c & 31)) & 1u) != 0;  // own footprint: 100 over anything but 0
     v = (st && v != 0u) ? 1u : v;
     out_u8[c] = (uint8_t)(v == 0u ? 0u : (v == 1u ? 100u : 255u));
     out_f16[c] = (uint16_t)(v == 0u ? (h01 & 0xFFFFu) : (v == 1u ? (h01 >> 16) : h3));
+}
+
+// inclusive prefix sum over the 64 lanes of a wavefront (every lane must be active): four row shifts, two row broadcasts
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return x;
 }
 
 // NW: wavefronts per robot.  1 when a launch fills the machine (instruction issue bounds it); 4 for small launches (a reset of
@@ -1134,6 +1144,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     uint32_t* hit = (uint32_t*)(smem + NCp);
     double2* colt = (double2*)(smem + NCp + 4 * (size_t)w.hit_stride);
     int* skip_cnt = (int*)(colt + Wv);  // [0] list entries (NW > 1), [1] chunk descriptors, [2] result slots of the final pass
+    uint32_t* reach_tab = (uint32_t*)(skip_cnt + 4);  // largest hit word of overlapping blocks of 16 / 32 / 64 beams (filter of (5))
     PHASE_BEGIN();
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
@@ -1288,6 +1299,19 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
         }
         if (tid == 0) hit[w.B] = 0u;  // the dummy beam of cells without any (see the final pass)
         __syncthreads();
+        // how far the beams get at most, for the filter of (5): blocks of 16 beams every 8, of 32 every 16, of 64 every 32 (a cell's
+        // beams lie inside one of them unless they are more than 33), largest hit word = largest first-hit step
+        const int nb8 = (w.B >> 3) + 1, n0 = nb8, n1 = (nb8 + 1) >> 1, n2 = (nb8 + 3) >> 2;
+        for (int i = tid; i < n0; i += NT) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) m = max(m, hit[min(8 * i + q, w.B)]);
+            reach_tab[i] = m;
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += NT) reach_tab[n0 + i] = max(reach_tab[2 * i], reach_tab[min(2 * i + 2, n0 - 1)]);
+        __syncthreads();
+        for (int i = tid; i < n2; i += NT) reach_tab[n0 + n1 + i] = max(reach_tab[n0 + 2 * i], reach_tab[n0 + min(2 * i + 2, n1 - 1)]);
     }
     PHASE_MARK(2);
 #if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 2
@@ -1380,10 +1404,11 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     //     the first entry of the cell's static ray list that is not "left alone" again.  Those lists are long next to the
     //     sensor (a cell behind an axis-parallel wall is left alone by most of its beams), so they are cut into chunks of 8
     //     entries and every lane takes one chunk, all 8 loads in flight together:
-    //       A  one list entry per lane: every flagged cell allocates its chunks behind the entry list (LDS atomic cursor) --
-    //          a descriptor each, 1 << 31 | cell for a list of one chunk, else result slot << 9 | chunk -- and, for several
-    //          chunks, a result slot (list position << 18 | class << 16 | cell; starts as "nobody writes": class 200) in
-    //          the dead column table;
+    //       A  one list entry per lane: every flagged cell that passes the filter below allocates its chunks behind the entry
+    //          list (prefix sum over the wavefront) --
+    //          a descriptor each (cell, first entry, chunk number, own-footprint bit) -- and, for several chunks, a result
+    //          slot (stamped << 30 | list position << 18 | class << 16 | cell; starts as "nobody writes": class 200) in the
+    //          dead column table;
     //       B  one chunk per lane: the first deciding entry of the chunk; patched straight into the two output planes for
     //          one-chunk cells (only values other than the provisional 200), else LDS atomicMin into the cell's slot;
     //       C  one slot per lane: patch.
@@ -1398,16 +1423,20 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     n_skip = 0;
 #endif
     if (n_skip > 0) {
+#ifndef IMGENV_EXP_NO_DRAIN
         __builtin_amdgcn_s_waitcnt(0);  // the provisional stores of this wave have landed
         __syncthreads();
-        uint32_t* desc = skip_list + n_skip;
+#endif
+        const int n_even = (n_skip + 1) & ~1;
+        uint2* desc = (uint2*)(skip_list + n_even);
         uint32_t* slots = (uint32_t*)colt;
 #ifdef IMGENV_EXP_TINY_RESOLVE  // test build: hardly any room, most cells take the fallbacks
         const int cap_d = 5, cap_r = 2;
 #else
-        const int cap_d = NCp / 4 - n_skip, cap_r = 4 * Wv;
+        const int cap_d = (NCp / 4 - n_even) / 2, cap_r = 4 * Wv;
 #endif
-        const uint32_t NOP = 0xFFFFFFFFu;
+        const uint2 NOP = make_uint2(0xFFFFFFFFu, 0u);
+        const uint32_t h01 = h0 | (h1 << 16);
 #ifdef IMGENV_EXP_RESOLVE_STATS  // how many cells are left alone, and how long the lists behind them are
         if (tid == 0) {
             atomicAdd(&w.dbg[16], 1ull);
@@ -1440,62 +1469,106 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
             }
         }
 #endif
-        for (int t = tid; t < n_skip; t += NT) {  // A
-            const uint32_t e = skip_list[t];
-            for (uint32_t bits = e & 15u; bits != 0u; bits &= bits - 1u) {
-                const uint32_t c = (e >> 4) + (uint32_t)__builtin_ctz(bits);
-                const uint32_t n = (k.inv_pack[c] >> 20) - 1u;  // entries below the top beam
-                if (n == 0u) continue;                          // nobody else: stays 200
-                const int nch = (int)((n + 7u) >> 3);
-                bool alone = false;
-                if (nch == 1) {
-                    const int pos = atomicAdd(&skip_cnt[1], 1);
-                    if (pos < cap_d) desc[pos] = 0x80000000u | c;
-                    else alone = true;
-                } else {
-                    const int slot = atomicAdd(&skip_cnt[2], 1);
-                    if (slot < cap_r) {
-                        slots[slot] = (0xFFFu << 18) | (2u << 16) | c;
-                        const int pos = atomicAdd(&skip_cnt[1], nch);
-                        alone = pos + nch > cap_d;
-                        for (int j = 0; j < nch && pos + j < cap_d; j++) desc[pos + j] = alone ? NOP : (((uint32_t)slot << 9) | (uint32_t)j);
-                    } else {
-                        alone = true;
-                    }
+        int base_d = 0, base_r = 0;  // NW == 1: the two cursors live in scalar registers
+        const int n_items = 4 * n_skip;
+        for (int tb = 0; tb < n_items; tb += 4 * NT) {  // A: one (list entry, cell of its four) per lane, four rounds' loads in flight
+            uint32_t cell_of[4];
+            uint2 info[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int t = tb + r * NT + tid;
+                cell_of[r] = 0xFFFFFFFFu;
+                if (t < n_items) {
+                    const uint32_t e = skip_list[t >> 2], q = (uint32_t)t & 3u;
+                    if (((e >> q) & 1u) != 0u) cell_of[r] = (e >> 4) + q;
                 }
-                if (alone) patch_resolved(k.stamp_bits, out_u8, out_f16, h0 | (h1 << 16), h3, c, resolve_skipped_cell(k, hit, c));
+                info[r] = k.inv_cell[min(cell_of[r], (uint32_t)NC - 1u)];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (tb + r * NT >= n_items) break;  // uniform
+                const uint32_t c = cell_of[r], f = info[r].x, pk = info[r].y;
+                const uint32_t n = (pk >> 20) - 1u, nch = (n + 7u) >> 3;  // entries below the top beam, in chunks of 8
+                const bool st = ((f >> 14) & 1u) != 0u;
+                // filter: a lower beam decides 255 / 0 only if it gets as far as this cell; when none of the beams of the
+                // block around the cell's beams does, whoever writes the cell writes 200, which is what it holds
+                const bool pass = c != 0xFFFFFFFFu && nch != 0u && (((f >> 13) & 1u) != 0u || (reach_tab[f & 0x1FFFu] >> 16) >= (f >> 24));
+                const uint32_t own = pass ? (nch | (nch > 1u ? 0x10000u : 0u)) : 0u;
+                // room for nch descriptors (low half) and, for several chunks, one result slot (high half): a prefix sum
+                // over the wavefront instead of one LDS atomic per cell
+                const uint32_t incl = wave_prefix_sum(own);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (NW > 1) {
+                    int fd = 0, fr = 0;
+                    if (lane == 63 && total != 0u) {
+                        fd = atomicAdd(&skip_cnt[1], (int)(total & 0xFFFFu));
+                        fr = atomicAdd(&skip_cnt[2], (int)(total >> 16));
+                    }
+                    base_d = __builtin_amdgcn_readlane(fd, 63);
+                    base_r = __builtin_amdgcn_readlane(fr, 63);
+                }
+                if (own != 0u) {
+                    const uint32_t excl = incl - own;
+                    const int pos = base_d + (int)(excl & 0xFFFFu), slot = base_r + (int)(excl >> 16);
+                    const bool multi = nch > 1u;
+                    const bool alone = pos + (int)nch > cap_d || (multi && slot >= cap_r);
+                    const uint32_t e0 = pk & 0xFFFFFu;
+                    if (multi && slot < cap_r) slots[slot] = ((uint32_t)st << 30) | (0xFFFu << 18) | (2u << 16) | c;  // also when it walks alone: C reads every slot
+                    const uint32_t lo = c | ((uint32_t)slot << 19) | ((uint32_t)st << 29) | (multi ? 0u : 0x80000000u);
+                    for (int j = 0; j < (int)nch && pos + j < cap_d; j++)
+                        desc[pos + j] = alone ? NOP : make_uint2(lo | ((min(8u, n - 8u * (uint32_t)j) - 1u) << 16), (e0 + 1u + 8u * (uint32_t)j) | ((uint32_t)j << 20));
+                    if (alone) patch_stamped(out_u8, out_f16, h01, h3, c, resolve_skipped_cell(k, hit, c), st);
+                }
+                if (NW == 1) {
+                    base_d += (int)(total & 0xFFFFu);
+                    base_r += (int)(total >> 16);
+                }
             }
         }
+        if (NW == 1 && tid == 0) {
+            skip_cnt[1] = base_d;
+            skip_cnt[2] = base_r;
+        }
         __syncthreads();
+#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 3
+        return;  // instruction accounting: ... + step A of the resolve
+#endif
         const int nd = min(skip_cnt[1], cap_d), nr = min(skip_cnt[2], cap_r);
-        for (int t = tid; t < nd; t += NT) {  // B
-            const uint32_t d = desc[t];
-            if (d == NOP) continue;
-            const bool one = (d >> 31) != 0u;
-            const uint32_t c = (one ? d : slots[d >> 9]) & 0xFFFFu;
-            const uint32_t pk = k.inv_pack[c], e0 = pk & 0xFFFFFu, last = (pk >> 20) - 1u;
-            const uint32_t eb = one ? 1u : 1u + 8u * (d & 0x1FFu);
+#ifdef IMGENV_EXP_RESOLVE_STATS
+        if (tid == 0) {
+            atomicAdd(&w.dbg[6], (unsigned long long)nd);
+            atomicAdd(&w.dbg[7], (unsigned long long)nr);
+        }
+#endif
+        for (int t = tid; t < nd; t += NT) {  // B: descriptor = cell | entries - 1 << 16 | slot << 19 | stamped << 29 | one chunk << 31,
+            const uint2 d = desc[t];          //                 first entry | chunk << 20
+            const uint32_t c = d.x & 0xFFFFu;
+            if (c == 0xFFFFu) continue;
+            const uint32_t nv = (d.x >> 16) & 7u, first = d.y & 0xFFFFFu, eb = 1u + 8u * (d.y >> 20);
             uint32_t ent[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) ent[q] = k.inv_ent[e0 + min(eb + q, last)];
+            for (int q = 0; q < 8; q++) ent[q] = k.inv_ent[first + min((uint32_t)q, nv)];
             uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const uint32_t kk = ent[q] & 0xFFFFu, hp = hit[ent[q] >> 16], hk = hp >> 16;
                 const uint32_t v = kk < hk ? 3u : (kk == hk ? 0u : 2u);
-                const bool decides = !((kk > hk) & (kk <= (hp & 0xFFFFu))) & (eb + q <= last);
-                key = min(key, decides ? (((eb + q) << 18) | (v << 16) | c) : 0xFFFFFFFFu);
+                const bool decides = !((kk > hk) & (kk <= (hp & 0xFFFFu))) & ((uint32_t)q <= nv);
+                key = min(key, decides ? (((eb + q) << 18) | (v << 16)) : 0xFFFFFFFFu);
             }
             if (key != 0xFFFFFFFFu) {
-                if (one) patch_resolved(k.stamp_bits, out_u8, out_f16, h0 | (h1 << 16), h3, c, (key >> 16) & 3u);
-                else atomicMin(&slots[d >> 9], key);
+                if ((d.x >> 31) != 0u) patch_stamped(out_u8, out_f16, h01, h3, c, (key >> 16) & 3u, ((d.x >> 29) & 1u) != 0u);
+                else atomicMin(&slots[(d.x >> 19) & 0x3FFu], key | c | (((d.x >> 29) & 1u) << 30));
             }
         }
+#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 4
+        return;  // instruction accounting: ... + step B
+#endif
         if (nr > 0) {
             __syncthreads();
             for (int t = tid; t < nr; t += NT) {  // C
                 const uint32_t key = slots[t];
-                patch_resolved(k.stamp_bits, out_u8, out_f16, h0 | (h1 << 16), h3, key & 0xFFFFu, (key >> 16) & 3u);
+                patch_stamped(out_u8, out_f16, h01, h3, key & 0xFFFFu, (key >> 16) & 3u, ((key >> 30) & 1u) != 0u);
             }
         }
     }

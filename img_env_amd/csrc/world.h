@@ -56,6 +56,7 @@ struct RobotClassDev {
     const uint32_t* inv_pack;    // [Hv*Wv] rays through a view cell: first entry | count << 20 ...
     const uint32_t* inv_ent;     // ... entries (beam << 16 | k), beam descending
     const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or B << 16 | 0xFFFF
+    const uint2* inv_cell;       // [Hv*Wv] k_view's step (5): {block of the reach table | none << 13 | own footprint << 14 | smallest step << 24, inv_pack}
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
     // views beyond k_view's 16 / 8-bit packing (the shipped configs: 400 x 400 cells, 1000 beams): k_view_big
     int big, sensor_x, sensor_y; // the laser's view cell

@@ -30,6 +30,13 @@ a = torch.zeros(R, 3, device="cuda")
 a[:, 1] = torch.rand(R, device="cuda") * 1.8 - 0.9
 for s in range(300):
     w.step(a)
+import time  # noqa: E402
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for s in range(300):
+    w.step(a)
+torch.cuda.synchronize()
+print("ms/step %.4f" % ((time.perf_counter() - t0) / 300 * 1e3))
 w.timing(1)
 prev = w.timing_read()
 samples = {k: [] for k in prev}

@@ -35,3 +35,4 @@ print("views %d, with skipped cells %d, entries/view %.1f, cells/view %.1f, mean
 print("cells by list length (bins of 8):", v[21:30])
 print("walk ends at entry 1 / 2 / 3-4 / 5-8 / 9-16 / 17+ / never:", v[8:15], "cells that change value:", v[15])
 print("entries walked: to a deciding beam %d, to the end of the list %d" % (v[31], v[30]))
+print("chunks / view %.1f, result slots / view %.1f (after the filter)" % (v[6] / max(v[16], 1), v[7] / max(v[16], 1)))

@@ -4,13 +4,13 @@
 cd /root/repo
 export IMGENV_SERIAL=1
 i=0
-for f in "" -DIMGENV_EXP_STOP_AFTER=1 -DIMGENV_EXP_STOP_AFTER=2 -DIMGENV_EXP_SKIP_RESOLVE -DIMGENV_EXP_SKIP_FINAL; do
+for f in "" -DIMGENV_EXP_STOP_AFTER=1 -DIMGENV_EXP_STOP_AFTER=2 -DIMGENV_EXP_SKIP_RESOLVE -DIMGENV_EXP_STOP_AFTER=3 -DIMGENV_EXP_STOP_AFTER=4 -DIMGENV_EXP_NO_DRAIN; do
   i=$((i+1))
   python3 tools/experiment.py $f --build-only --out=/tmp/exp_$i.so >/dev/null 2>&1
 done
 cd /tmp && export TMPDIR=/tmp
 rm -f /root/repo/gpurun_out/pmc_exp.txt
-for i in 1 2 3 4 5; do
+for i in ${EXP_BUILDS:-1 2 3 4 5 6 7}; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES -d /root/repo/gpurun_out/pmc_exp_$i -o p --output-format csv -- python3 /root/repo/tools/exp_run.py /tmp/exp_$i.so 8 > /root/repo/gpurun_out/pmc_exp_$i.log 2>&1
   echo "== build $i" >> /root/repo/gpurun_out/pmc_exp.txt
   python3 /root/repo/tools/pmc_summary.py /root/repo/gpurun_out/pmc_exp_$i | grep -A9 "k_view<true, true, false, 1>" >> /root/repo/gpurun_out/pmc_exp.txt
@@ -18,4 +18,4 @@ for i in 1 2 3 4 5; do
   db=$(ls /root/repo/gpurun_out/pmc_expt_$i/*/*.db /root/repo/gpurun_out/pmc_expt_$i/*.db 2>/dev/null | head -1)
   python3 /root/repo/tools/rocpd_stats.py $db | grep "k_view" >> /root/repo/gpurun_out/pmc_exp.txt
 done
-rm -rf /root/repo/gpurun_out/pmc_exp_[12345] /root/repo/gpurun_out/pmc_expt_[12345]
+rm -rf /root/repo/gpurun_out/pmc_exp_[1234567] /root/repo/gpurun_out/pmc_expt_[1234567]

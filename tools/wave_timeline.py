@@ -33,7 +33,7 @@ buf = np.zeros(12 * R, dtype=np.uint64)
 w.lib.imgenv_debug_waves(w.h, buf.ctypes.data_as(C.c_void_p))
 for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 * R].reshape(R, 4)), ("k_raster", buf[8 * R:].reshape(R, 4))):
     t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
-    ok = (t1 > 0) & (t0 > t0.max() - 30000)  # this launch only: frozen robots keep the record of an older step
+    ok = (t1 > 0) & (t0 > t0.max() - 6000)  # this launch only (60 us back from the last start): frozen robots keep an older record
     xc = (rec[:, 3] & 0xF).astype(np.int64)
     print("   per-XCC first start (ticks): " + " ".join(str(int(t0[ok & (xc == x)].min() - t0[ok].min())) for x in sorted(set(xc[ok].tolist()))))
     base = t0[ok].min()
@@ -42,6 +42,7 @@ for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 *
     print("%s: %d waves, span %.1f us; wave life us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (
         name, ok.sum(), e.max(), d.min(), *np.percentile(d, [10, 50, 90, 99]), d.max()))
     print("   starts us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % (*np.percentile(s, [10, 50, 90]), s.max()))
+    print("   starts histogram (5 us bins): " + " ".join(str(int(x)) for x in np.histogram(s, bins=np.arange(0, s.max() + 5, 5))[0]))
     ts = np.linspace(0, e.max(), 11)[1:-1]
     print("   resident waves at " + " ".join("%.0fus:%d" % (t, ((s <= t) & (e > t)).sum()) for t in ts))
     hw = rec[ok, 2]
