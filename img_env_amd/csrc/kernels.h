@@ -1387,9 +1387,9 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
         const uint32_t sel = st & (I | (I >> 1));                   // ... and class != 0
         I = (I & ~(sel | (sel << 1))) | sel;
         const uint32_t packed = __builtin_amdgcn_perm(lut_u8, lut_u8, I);
-        const uint32_t s01 = __builtin_amdgcn_perm(I, I, 0x01010000u), s23 = __builtin_amdgcn_perm(I, I, 0x03030202u);
-        const uint32_t f01 = (__builtin_amdgcn_perm(lut_lo, lut_lo, s01) & 0x00FF00FFu) | (__builtin_amdgcn_perm(lut_hi, lut_hi, s01) & 0xFF00FF00u);
-        const uint32_t f23 = (__builtin_amdgcn_perm(lut_lo, lut_lo, s23) & 0x00FF00FFu) | (__builtin_amdgcn_perm(lut_hi, lut_hi, s23) & 0xFF00FF00u);
+        // two float16 values per v_perm: selector bytes (c, c + 4) pick the low byte out of lut_lo and the high one out of lut_hi
+        const uint32_t s01 = __builtin_amdgcn_perm(I, I, 0x01010000u) | 0x04000400u, s23 = __builtin_amdgcn_perm(I, I, 0x03030202u) | 0x04000400u;
+        const uint32_t f01 = __builtin_amdgcn_perm(lut_hi, lut_lo, s01), f23 = __builtin_amdgcn_perm(lut_hi, lut_lo, s23);
         if (A4 || c4 + 4 <= NC) {
             *(uint32_t*)(out_u8 + c4) = packed;
             *(uint2*)(out_f16 + c4) = make_uint2(f01, f23);
