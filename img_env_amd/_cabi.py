@@ -97,6 +97,8 @@ class Out(C.Structure):
         ("base_rewards", C.c_void_p), ("base_dones", C.c_void_p),
         ("rewards", C.c_void_p), ("paper_rewards", C.c_void_p), ("dones", C.c_void_p), ("dones_info", C.c_void_p), ("is_clean", C.c_void_p),
         ("robot_pose", C.c_void_p), ("ped_state", C.c_void_p), ("counters", C.c_void_p),
+        ("step_rewards", C.c_void_p), ("step_dones", C.c_void_p), ("step_dones_info", C.c_void_p), ("step_is_clean", C.c_void_p),
+        ("step_is_arrives", C.c_void_p), ("step_is_collisions", C.c_void_p),
     ]
 
 
@@ -125,6 +127,12 @@ def out_layout(o, n_peds, hp, wp):
         "robot_pose": (np.float64, (R, 3)),
         "ped_state": (np.float64, (max(n_peds, 1), 4)),
         "counters": (np.int32, (4,)),
+        "step_rewards": (np.float64, (R,)),
+        "step_dones": (np.uint8, (R,)),
+        "step_dones_info": (np.int32, (R,)),
+        "step_is_clean": (np.uint8, (R,)),
+        "step_is_arrives": (np.uint8, (R,)),
+        "step_is_collisions": (np.int8, (R,)),
     }
 
 
@@ -235,7 +243,7 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
-           "imgenv_reset_worlds_spawn", "imgenv_cv_resize_u8")
+           "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_cv_resize_u8")
 K_COUNT = 8
 
 
@@ -263,6 +271,8 @@ def bind(lib):
     lib.imgenv_reset_worlds_spawn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(SpawnCfg),
                                               C.POINTER(C.c_uint64), C.c_void_p]
     lib.imgenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.imgenv_step_autoreset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SpawnCfg), C.c_uint64, C.POINTER(C.c_int32), C.c_int32,
+                                          C.POINTER(C.c_int32), C.c_void_p]
     lib.imgenv_step_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.imgenv_step_end.argtypes = [C.c_void_p, C.c_void_p]
     lib.imgenv_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]

@@ -107,6 +107,7 @@ struct imgenv {
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     bool serial = false;  // IMGENV_SERIAL=1: no side streams (profiling aid)
     volatile int* err_host = nullptr;  // [8] page-locked flags the kernels raise on overflow; checked at every API call
+    volatile int* finished_host = nullptr;  // [1 + W] page-locked: the worlds whose robots are all done (k_finished)
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
     std::vector<RvoObstacles> rvos;  // one obstacle set per world
     int sfm_cap_obs = 0;
@@ -291,6 +292,12 @@ static void plan_arena(const imgenv_cfg& c, const ViewGeom& g, int RL, ArenaPlan
     p.add(16);                   // 19 counters
     p.add((size_t)c.n_robots * IMGENV_RECORD_DOUBLES * 8);  // 20 records
     p.add(R * 8);                // 21 paper_rewards
+    p.add(R * 8);                // 22 step_rewards
+    p.add(R);                    // 23 step_dones
+    p.add(R * 4);                // 24 step_dones_info
+    p.add(R);                    // 25 step_is_clean
+    p.add(R);                    // 26 step_is_arrives
+    p.add(R);                    // 27 step_is_collisions
 }
 
 static int shard_of(const imgenv_cfg& c, int& r0, int& r1) {
@@ -362,6 +369,7 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamDestroy(h->side2);
     }
     if (h->err_host) (void)hipHostFree((void*)h->err_host);
+    if (h->finished_host) (void)hipHostFree((void*)h->finished_host);
     for (int g = 0; g < imgenv::STAGE_GENS; g++) {
         for (auto& c : h->stage_gen[g]) (void)hipHostFree(c.p);
         if (h->ev_gen[g]) (void)hipEventDestroy(h->ev_gen[g]);
@@ -731,6 +739,15 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_alloc(h, &d.beep_flag, R));
         TRY(dev_alloc(h, &d.beep_xy, R));
     }
+    {   // the finished-world list of imgenv_step_autoreset: written by k_finished straight into page-locked host memory
+        int* f = nullptr;
+        HIPCHK_H(hipHostMalloc((void**)&f, (size_t)(1 + W) * sizeof(int), hipHostMallocMapped));
+        memset(f, 0, (size_t)(1 + W) * sizeof(int));
+        h->finished_host = f;
+        int* dev = nullptr;
+        HIPCHK_H(hipHostGetDevicePointer((void**)&dev, f, 0));
+        d.finished = dev;
+    }
     {   // overflow flags live in page-locked host memory the device writes through: no copy, no sync to read them
         int* e = nullptr;
         HIPCHK_H(hipHostMalloc((void**)&e, 8 * sizeof(int), hipHostMallocMapped));
@@ -831,6 +848,14 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     d.rec = (double*)(A + plan.off[20]);
     o.paper_rewards = (double*)(A + plan.off[21]);
     d.paper_rewards = o.paper_rewards;
+    o.step_rewards = (double*)(A + plan.off[22]);
+    o.step_dones = (uint8_t*)(A + plan.off[23]);
+    o.step_dones_info = (int32_t*)(A + plan.off[24]);
+    o.step_is_clean = (uint8_t*)(A + plan.off[25]);
+    o.step_is_arrives = (uint8_t*)(A + plan.off[26]);
+    o.step_is_collisions = (int8_t*)(A + plan.off[27]);
+    d.step_rewards = o.step_rewards; d.step_dones = o.step_dones; d.step_dones_info = o.step_dones_info;
+    d.step_is_clean = o.step_is_clean; d.step_is_arrives = o.step_is_arrives; d.step_is_collisions = o.step_is_collisions;
     d.vector_states = o.vector_states; d.view_maps = o.view_maps; d.sensor_maps = o.sensor_maps;
     d.lasers_raw = o.lasers_raw; d.lasers = o.lasers; d.ped_vector_states = o.ped_vector_states;
     d.ped_maps = o.ped_maps; d.is_collisions = o.is_collisions; d.is_arrives = o.is_arrives;
@@ -1807,6 +1832,33 @@ extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) {
         if (e != ncclSuccess) FAIL(IMGENV_EDEVICE, "ncclAllGather: %s", rccl_api()->err(e));
     }
     return imgenv_step_end(h, stream);
+}
+
+extern "C" int imgenv_step_autoreset(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, int32_t* worlds_out,
+                                     int32_t cap, int32_t* n_out, void* stream) {
+    if (!h || !actions || !n_out) FAIL(IMGENV_EINVAL, "null argument");
+    if (int rc = spawn_cfg_check(cfg)) return rc;
+    if (cfg->n_robots != h->Rw || cfg->n_peds != h->Pw)
+        FAIL(IMGENV_EINVAL, "spawn cfg is for %d robots / %d pedestrians, a world of this handle has %d / %d", cfg->n_robots,
+             cfg->n_peds, h->Rw, h->Pw);
+    if (h->RL != h->R) FAIL(IMGENV_EINVAL, "imgenv_step_autoreset needs all robots of every world on this handle");
+    *n_out = 0;
+    if (int rc = imgenv_step(h, actions, stream)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    k_finished<<<dim3(1), dim3(1024), 0, st>>>(h->d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));  // NeverStopWrapper reads the dones here too (base.py:205)
+    const int n = h->finished_host[0];
+    if (n < 0 || n > h->W) FAIL(IMGENV_EDEVICE, "finished-world list is corrupt (%d)", n);
+    if (n == 0) return IMGENV_OK;
+    std::vector<int32_t> worlds((size_t)n);
+    for (int q = 0; q < n; q++) worlds[q] = h->finished_host[1 + q];
+    std::sort(worlds.begin(), worlds.end());  // the device lists them in no particular order; seeds go by ascending index
+    std::vector<uint64_t> seeds((size_t)n);
+    for (int q = 0; q < n; q++) seeds[q] = seed0 + (uint64_t)q;
+    *n_out = n;
+    for (int q = 0; q < n && worlds_out && q < cap; q++) worlds_out[q] = worlds[q];
+    return imgenv_reset_worlds_spawn(h, n, worlds.data(), cfg, seeds.data(), stream);
 }
 
 extern "C" int imgenv_comm_unique_id(void* id128) {

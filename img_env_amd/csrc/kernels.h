@@ -1870,6 +1870,12 @@ __device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset
     w.dones[l] = (uint8_t)done;
     w.dones_info[l] = dinfo;
     w.is_clean[l] = clean_before;
+    w.step_rewards[l] = reward;  // the same again where a reset behind this step does not reach (imgenv_step_autoreset)
+    w.step_dones[l] = (uint8_t)done;
+    w.step_dones_info[l] = dinfo;
+    w.step_is_clean[l] = clean_before;
+    w.step_is_arrives[l] = (uint8_t)arr;
+    w.step_is_collisions[l] = (int8_t)coll;
     w.clean_state[l] = done > 0 ? 0 : clean_before;
     if (l == 0) w.counters[0] = elapsed;
     return done;
@@ -2185,6 +2191,27 @@ __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, i
     }
     const int l = i - w.r0;
     if (valid && l >= 0 && l < w.RL) state_robot(w, l);
+}
+
+// NeverStopWrapper's question (base.py:198-211): are all robots of a world done?  One workgroup walks the worlds, a thread
+// each; the worlds that are go, unordered, into page-locked host memory: finished[1..] = which, finished[0] = how many.
+__global__ __launch_bounds__(1024) void k_finished(DevWorld w) {
+    __shared__ int n_sh;
+    if (threadIdx.x == 0) n_sh = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < w.W; k0 += blockDim.x) {  // uniform trip count (ballot inside)
+        const int k = k0 + threadIdx.x;
+        bool all_done = k < w.W;
+        if (all_done)
+            for (int q = 0; q < w.Rw && all_done; q++) all_done = w.dones[(size_t)k * w.Rw + q] != 0;
+        const unsigned long long mask = __ballot(all_done);
+        int first = 0;
+        if (mask != 0ull && lane_id() == 0) first = atomicAdd(&n_sh, __popcll(mask));
+        first = __shfl(first, 0);
+        if (all_done) w.finished[1 + first + __popcll(mask & ((1ull << lane_id()) - 1ull))] = k;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) w.finished[0] = n_sh;
 }
 
 // Per-robot scalars, one thread per robot: Agent::get_state (agent.cpp:156-184), the _get_states distances,

@@ -184,6 +184,9 @@ struct DevWorld {
     float* ped_vector_states;
     float* ped_maps;
     int8_t* is_collisions;
+    // the step's own scalars (imgenv_out.step_*): written by a step's tail beside the arrays a reset rewrites
+    double* step_rewards; uint8_t* step_dones; int32_t* step_dones_info; uint8_t* step_is_clean; uint8_t* step_is_arrives; int8_t* step_is_collisions;
+    int* finished;             // page-locked host memory: [0] number of worlds whose robots are all done, [1..] their indices (k_finished)
     uint8_t* is_arrives;
     double* step_ds;
     double* ped_min_dists;

@@ -89,8 +89,22 @@ class VecImageEnv:
             actions = np.array([[a.v, a.w, a.beep] for a in actions], np.float32)  # float32 wire (Agent.msg:8-10)
         return actions
 
+    def _step_native(self, actions):
+        """step + NeverStopWrapper inside the library (``imgenv_step_autoreset``): the finished envs are found on the device,
+        their placements drawn on the host in C++, the per-robot results of the step itself kept in ``out['step_*']`` --
+        no tensor work on the Python side"""
+        o, finished = self.world.step_autoreset(self._actions(actions), self._spawn_cfg, self._spawn_seed + self._episodes)
+        self._episodes += len(finished)
+        all_down = (o["step_dones"].view(self.env_num, self.robot_total) > 0).all(dim=1)
+        info = {"dones_info": o["step_dones_info"], "is_clean": o["step_is_clean"], "arrive": o["step_is_arrives"],
+                "collision": o["step_is_collisions"], "all_down": all_down.repeat_interleave(self.robot_total),
+                "reset_envs": finished}
+        return self._state(), o["step_rewards"], o["step_dones"], info
+
     def step(self, actions):
         import torch
+        if self.native_spawn and self.auto_reset:
+            return self._step_native(actions)
         o = self.world.step(self._actions(actions))
         E, R = self.env_num, self.robot_total
         all_down = (o["dones"].view(E, R) > 0).all(dim=1)

@@ -54,6 +54,7 @@ class World:
         self.n_robots, self.n_peds = cfg.n_robots, cfg.n_peds
         self.n_worlds = max(1, cfg.n_worlds)
         self._trace = [0.0, 0] if os.environ.get("IMGENV_TRACE_RESET") else None  # seconds inside imgenv_reset_worlds, calls
+        self._finished_buf = None
         o = _cabi.Out()
         self._check(self.lib.imgenv_outputs(self.h, C.byref(o)), "imgenv_outputs")
         self.n_local = o.n_local
@@ -150,6 +151,19 @@ class World:
         a = self._actions(actions)
         self._check(self.lib.imgenv_step(self.h, C.c_void_p(a.data_ptr()), self._stream()), "imgenv_step")
         return self.out
+
+    def step_autoreset(self, actions, spawn_cfg, seed0):
+        """``imgenv_step_autoreset``: one step, then every world whose robots are all done starts a new episode from a fresh
+        placement drawn inside the library (the k-th such world, ascending, from ``seed0 + k``).  Returns the outputs and the
+        list of worlds that were reset; ``out['step_*']`` keep what the step itself returned for them."""
+        a = self._actions(actions)
+        if self._finished_buf is None:
+            self._finished_buf = (C.c_int32 * self.n_worlds)()
+        n = C.c_int32(0)
+        self._check(self.lib.imgenv_step_autoreset(self.h, C.c_void_p(a.data_ptr()), C.byref(spawn_cfg[0]),
+                                                   C.c_uint64(int(seed0) & 0xFFFFFFFFFFFFFFFF), self._finished_buf,
+                                                   self.n_worlds, C.byref(n), self._stream()), "imgenv_step_autoreset")
+        return self.out, list(self._finished_buf[:n.value])
 
     def step_begin(self, actions):
         a = self._actions(actions)

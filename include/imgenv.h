@@ -217,6 +217,15 @@ typedef struct imgenv_out {
     double* ped_state;            /* [n_peds][4] x, y, vx, vy (world copy) */
     int32_t* counters;            /* [4]: steps since reset (n_worlds > 1: of world 0), #done robots of the last step (local),
                                    * #frozen views since the last imgenv_reset (local), #frozen views since create */
+    /* The last STEP's own per-robot scalars: every imgenv_step writes them beside the arrays above, a reset never touches
+     * them.  After imgenv_step_autoreset() the rows of the worlds it reset hold, above, the new episode's first observation
+     * (NeverStopWrapper, base.py:198-211) and, here, what that step itself returned for them. */
+    double* step_rewards;         /* [R] */
+    uint8_t* step_dones;          /* [R] */
+    int32_t* step_dones_info;     /* [R] */
+    uint8_t* step_is_clean;       /* [R] */
+    uint8_t* step_is_arrives;     /* [R] */
+    int8_t* step_is_collisions;   /* [R] */
 } imgenv_out;
 
 typedef struct imgenv imgenv_t;
@@ -337,6 +346,14 @@ int imgenv_spawn(const imgenv_spawn_cfg* cfg, uint64_t seed, double* robot_pose,
 /* imgenv_reset_worlds() with a fresh placement for each listed world, world worlds[q] from seeds[q]. */
 int imgenv_reset_worlds_spawn(imgenv_t* h, int32_t n, const int32_t* worlds, const imgenv_spawn_cfg* cfg, const uint64_t* seeds,
                               void* stream);
+/* One env step of a handle of n_worlds reference envs the way the trainer runs them (NeverStopWrapper over the default
+ * wrapper stack, base.py:198-211, one env process per world): imgenv_step(), then every world whose robots are ALL done
+ * (imgenv_out.dones) starts a new episode from a fresh placement, as imgenv_reset_worlds_spawn() would, the k-th such world
+ * (ascending world index) from seed seed0 + k.  The list of finished worlds is made on the device and read by the host
+ * from page-locked memory, so the call returns with the step complete on `stream` (one host synchronisation, no copy).
+ * worlds_out (may be NULL) receives up to cap world indices, *n_out their number. */
+int imgenv_step_autoreset(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, int32_t* worlds_out,
+                          int32_t cap, int32_t* n_out, void* stream);
 
 /* The two OpenCV resizes of the path for one-channel 8-bit images, as the library performs them (OpenCV 4.2.0's generic
  * fixed-point CPU path restated, csrc/cv_resize.h): host buffers, no device needed.  kind 0: INTER_LINEAR, 1: INTER_CUBIC. */

@@ -64,6 +64,8 @@ class OracleWorld:
         self.out = {}
         for name, (dt, shape) in _cabi.out_layout(o, self.n_peds, cfg.ped_image_size[0], cfg.ped_image_size[1]).items():
             ptr = getattr(o, name)
+            if not ptr:  # a field only the library has (imgenv_out.step_*: the oracle knows no auto-reset)
+                continue
             n = int(np.prod(shape))
             buf = (C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr)
             self.out[name] = np.frombuffer(buf, dtype=dt).reshape(shape)

@@ -32,7 +32,7 @@ def hip_lib():
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ("imgenv_create", "imgenv_reset", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_reset_worlds_spawn",
-                 "imgenv_spawn", "imgenv_step", "imgenv_step_begin",
+                 "imgenv_spawn", "imgenv_step", "imgenv_step_autoreset", "imgenv_step_begin",
                  "imgenv_step_end", "imgenv_outputs", "imgenv_destroy", "imgenv_comm_init"):
         assert must in names
 
@@ -65,7 +65,7 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     fields = {"imgenv_cfg": ["abi_version", "view_resolution", "robot_shape", "limiter_w", "image_size", "ped_image_r",
                              "robot_size_last", "time_max", "out_arena", "out_arena_bytes"],
               "imgenv_reset_batch": ["n_obstacles", "obs_pose", "ped_traj", "ped_traj_cap", "ignore_obstacle", "ped_traj_v"],
-              "imgenv_out": ["n_local", "vector_states", "lasers", "paper_rewards", "counters"],
+              "imgenv_out": ["n_local", "vector_states", "lasers", "paper_rewards", "counters", "step_rewards", "step_is_collisions"],
               "imgenv_spawn_agent": ["target_type", "begin", "target", "module_size", "begin_multi", "target_multi", "n_target_multi"],
               "imgenv_spawn_obstacle": ["pose_type", "size_range", "pose"],
               "imgenv_spawn_cfg": ["n_obstacles", "agents", "obstacles", "clearance", "target_min_dist", "circle_ranges", "go_back", "ignore_obstacle"]}

@@ -316,8 +316,13 @@ def test_vec_env_with_native_spawn_matches_oracles_fed_the_same_placements():
             a = np.zeros((E * R, 3), np.float32)
             a[:, 0], a[:, 1] = rng.uniform(0, 0.6, E * R), rng.uniform(-0.9, 0.9, E * R)
             _, rew, done, info = vec.step(torch.as_tensor(a, device="cuda"))
+            rew, done, dinfo = rew.cpu().numpy(), done.cpu().numpy(), info["dones_info"].cpu().numpy()
             for k, c in enumerate(cpus):
                 c.step(a[k * R:(k + 1) * R])
+                ref = c.snapshot()  # what the step itself returned, also for the envs the library has already reset
+                assert np.array_equal(rew[k * R:(k + 1) * R], ref["rewards"]), (s, k)
+                assert np.array_equal(done[k * R:(k + 1) * R], ref["dones"]), (s, k)
+                assert np.array_equal(dinfo[k * R:(k + 1) * R], ref["dones_info"]), (s, k)
             for q, k in enumerate(info["reset_envs"]):  # the envs that ended: the same placements for their oracles
                 cpus[k].reset(spawn.native_spawn(cfg, seed0 + n_eps + q))
             n_eps += len(info["reset_envs"])
