@@ -98,7 +98,7 @@ class Out(C.Structure):
         ("rewards", C.c_void_p), ("paper_rewards", C.c_void_p), ("dones", C.c_void_p), ("dones_info", C.c_void_p), ("is_clean", C.c_void_p),
         ("robot_pose", C.c_void_p), ("ped_state", C.c_void_p), ("counters", C.c_void_p),
         ("step_rewards", C.c_void_p), ("step_dones", C.c_void_p), ("step_dones_info", C.c_void_p), ("step_is_clean", C.c_void_p),
-        ("step_is_arrives", C.c_void_p), ("step_is_collisions", C.c_void_p),
+        ("step_is_arrives", C.c_void_p), ("step_is_collisions", C.c_void_p), ("step_all_down", C.c_void_p),
     ]
 
 
@@ -133,6 +133,7 @@ def out_layout(o, n_peds, hp, wp):
         "step_is_clean": (np.uint8, (R,)),
         "step_is_arrives": (np.uint8, (R,)),
         "step_is_collisions": (np.int8, (R,)),
+        "step_all_down": (np.uint8, (R,)),
     }
 
 

@@ -10,6 +10,8 @@
 
 #include <string>
 #include <chrono>
+#include <memory>
+#include <unordered_map>
 #include <vector>
 
 #define WAVE_SZ 64
@@ -108,6 +110,10 @@ struct imgenv {
     bool serial = false;  // IMGENV_SERIAL=1: no side streams (profiling aid)
     volatile int* err_host = nullptr;  // [8] page-locked flags the kernels raise on overflow; checked at every API call
     volatile int* finished_host = nullptr;  // [1 + W] page-locked: the worlds whose robots are all done (k_finished)
+    // imgenv_step_autoreset draws the placements of the next few seeds while the device is still busy with the step
+    std::unordered_map<uint64_t, std::unique_ptr<SpawnOut>> spawn_ahead;
+    uint64_t spawn_ahead_cfg = 0;  // fingerprint of the spawn cfg the placements were drawn from
+    int spawn_ahead_n = 8;
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
     std::vector<RvoObstacles> rvos;  // one obstacle set per world
     int sfm_cap_obs = 0;
@@ -298,6 +304,7 @@ static void plan_arena(const imgenv_cfg& c, const ViewGeom& g, int RL, ArenaPlan
     p.add(R);                    // 25 step_is_clean
     p.add(R);                    // 26 step_is_arrives
     p.add(R);                    // 27 step_is_collisions
+    p.add(R);                    // 28 step_all_down
 }
 
 static int shard_of(const imgenv_cfg& c, int& r0, int& r1) {
@@ -854,6 +861,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     o.step_is_clean = (uint8_t*)(A + plan.off[25]);
     o.step_is_arrives = (uint8_t*)(A + plan.off[26]);
     o.step_is_collisions = (int8_t*)(A + plan.off[27]);
+    o.step_all_down = (uint8_t*)(A + plan.off[28]);
+    d.step_all_down = o.step_all_down;
     d.step_rewards = o.step_rewards; d.step_dones = o.step_dones; d.step_dones_info = o.step_dones_info;
     d.step_is_clean = o.step_is_clean; d.step_is_arrives = o.step_is_arrives; d.step_is_collisions = o.step_is_collisions;
     d.vector_states = o.vector_states; d.view_maps = o.view_maps; d.sensor_maps = o.sensor_maps;
@@ -1834,6 +1843,36 @@ extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) {
     return imgenv_step_end(h, stream);
 }
 
+// FNV-1a over everything spawn_world reads of a spawn cfg
+static uint64_t spawn_cfg_fingerprint(const imgenv_spawn_cfg& c) {
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t q = 0; q < n; q++) hsh = (hsh ^ b[q]) * 1099511628211ull;
+    };
+    mix(&c.n_robots, sizeof(int32_t) * 3);
+    mix(&c.clearance, sizeof(double));
+    mix(&c.target_min_dist, sizeof(double));
+    mix(c.circle_ranges, sizeof(c.circle_ranges));
+    mix(&c.go_back, sizeof(int32_t) * 2);
+    for (int a = 0; a < c.n_robots + c.n_peds; a++) {
+        const imgenv_spawn_agent& g = c.agents[a];
+        mix(&g.begin_type, sizeof(int32_t) * 2);
+        mix(g.begin, sizeof(g.begin));
+        mix(g.target, sizeof(g.target));
+        mix(&g.module_size, sizeof(double));
+        mix(&g.n_begin_multi, sizeof(int32_t) * 2);
+        if (g.begin_multi) mix(g.begin_multi, sizeof(double) * 6 * (size_t)g.n_begin_multi);
+        if (g.target_multi) mix(g.target_multi, sizeof(double) * 6 * (size_t)g.n_target_multi);
+    }
+    for (int q = 0; q < c.n_obstacles; q++) {
+        mix(&c.obstacles[q].shape, sizeof(int32_t) * 2);
+        mix(c.obstacles[q].size_range, sizeof(c.obstacles[q].size_range));
+        mix(c.obstacles[q].pose, sizeof(c.obstacles[q].pose));
+    }
+    return hsh;
+}
+
 extern "C" int imgenv_step_autoreset(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, int32_t* worlds_out,
                                      int32_t cap, int32_t* n_out, void* stream) {
     if (!h || !actions || !n_out) FAIL(IMGENV_EINVAL, "null argument");
@@ -1843,22 +1882,70 @@ extern "C" int imgenv_step_autoreset(imgenv_t* h, const float* actions, const im
              cfg->n_peds, h->Rw, h->Pw);
     if (h->RL != h->R) FAIL(IMGENV_EINVAL, "imgenv_step_autoreset needs all robots of every world on this handle");
     *n_out = 0;
+    static const bool trace = getenv("IMGENV_TRACE_RESET") != nullptr;  // where the host's time goes, every 200 calls
+    static double acc[4] = {0, 0, 0, 0};
+    static long calls = 0, resets = 0;
+    std::chrono::steady_clock::time_point tp[5];
+    if (trace) tp[0] = std::chrono::steady_clock::now();
     if (int rc = imgenv_step(h, actions, stream)) return rc;
     hipStream_t st = (hipStream_t)stream;
     k_finished<<<dim3(1), dim3(1024), 0, st>>>(h->d);
     HIPCHK(hipGetLastError());
+    {   // while the device works: the placements of the next seeds (a placement depends on its seed alone, not on the world)
+        const uint64_t fp = spawn_cfg_fingerprint(*cfg);
+        if (fp != h->spawn_ahead_cfg) h->spawn_ahead.clear();
+        h->spawn_ahead_cfg = fp;
+        for (auto it = h->spawn_ahead.begin(); it != h->spawn_ahead.end();)  // seeds the caller has moved past
+            it = (it->first - seed0 >= (uint64_t)h->spawn_ahead_n) ? h->spawn_ahead.erase(it) : std::next(it);
+        for (int q = 0; q < h->spawn_ahead_n; q++) {
+            std::unique_ptr<SpawnOut>& slot = h->spawn_ahead[seed0 + (uint64_t)q];
+            if (slot) continue;
+            slot.reset(new SpawnOut);
+            if (spawn_world(*cfg, seed0 + (uint64_t)q, *slot)) slot->batch.struct_size = 0;  // could not be placed: reported if used
+        }
+    }
+    if (trace) tp[1] = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(st));  // NeverStopWrapper reads the dones here too (base.py:205)
+    if (trace) tp[2] = std::chrono::steady_clock::now();
     const int n = h->finished_host[0];
     if (n < 0 || n > h->W) FAIL(IMGENV_EDEVICE, "finished-world list is corrupt (%d)", n);
-    if (n == 0) return IMGENV_OK;
-    std::vector<int32_t> worlds((size_t)n);
-    for (int q = 0; q < n; q++) worlds[q] = h->finished_host[1 + q];
-    std::sort(worlds.begin(), worlds.end());  // the device lists them in no particular order; seeds go by ascending index
-    std::vector<uint64_t> seeds((size_t)n);
-    for (int q = 0; q < n; q++) seeds[q] = seed0 + (uint64_t)q;
-    *n_out = n;
-    for (int q = 0; q < n && worlds_out && q < cap; q++) worlds_out[q] = worlds[q];
-    return imgenv_reset_worlds_spawn(h, n, worlds.data(), cfg, seeds.data(), stream);
+    int rc = IMGENV_OK;
+    if (n > 0) {
+        std::vector<int32_t> worlds((size_t)n);
+        for (int q = 0; q < n; q++) worlds[q] = h->finished_host[1 + q];
+        std::sort(worlds.begin(), worlds.end());  // the device lists them in no particular order; seeds go by ascending index
+        *n_out = n;
+        for (int q = 0; q < n && worlds_out && q < cap; q++) worlds_out[q] = worlds[q];
+        std::vector<std::unique_ptr<SpawnOut>> outs((size_t)n);
+        std::vector<imgenv_reset_batch> batches((size_t)n);
+        for (int q = 0; q < n; q++) {
+            auto it = h->spawn_ahead.find(seed0 + (uint64_t)q);
+            if (it != h->spawn_ahead.end() && it->second->batch.struct_size != 0) {
+                outs[q] = std::move(it->second);
+                h->spawn_ahead.erase(it);
+            } else {
+                outs[q].reset(new SpawnOut);
+                if (const char* why = spawn_world(*cfg, seed0 + (uint64_t)q, *outs[q])) FAIL(IMGENV_EINVAL, "spawn of world %d: %s", worlds[q], why);
+            }
+            batches[q] = outs[q]->batch;
+        }
+        h->spawn_ahead_n = std::min(256, std::max(8, 2 * n));  // twice what this step needed
+        if (trace) tp[3] = std::chrono::steady_clock::now();
+        rc = imgenv_reset_worlds(h, n, worlds.data(), batches.data(), stream);
+    } else if (trace) {
+        tp[3] = std::chrono::steady_clock::now();
+    }
+    if (trace) {
+        tp[4] = std::chrono::steady_clock::now();
+        for (int q = 0; q < 4; q++) acc[q] += std::chrono::duration<double, std::micro>(tp[q + 1] - tp[q]).count();
+        resets += n;
+        if (++calls % 200 == 0) {
+            fprintf(stderr, "[imgenv_step_autoreset] %ld calls, %.1f worlds reset/call: step launches + placements ahead %.1f us, wait for the device %.1f us, "
+                            "finished list %.1f us, reset launches %.1f us per call\n", calls, (double)resets / calls, acc[0] / calls, acc[1] / calls,
+                    acc[2] / calls, acc[3] / calls);
+        }
+    }
+    return rc;
 }
 
 extern "C" int imgenv_comm_unique_id(void* id128) {

@@ -2204,6 +2204,8 @@ __global__ __launch_bounds__(1024) void k_finished(DevWorld w) {
         bool all_done = k < w.W;
         if (all_done)
             for (int q = 0; q < w.Rw && all_done; q++) all_done = w.dones[(size_t)k * w.Rw + q] != 0;
+        if (k < w.W)
+            for (int q = 0; q < w.Rw; q++) w.step_all_down[(size_t)k * w.Rw + q] = all_done ? 1 : 0;
         const unsigned long long mask = __ballot(all_done);
         int first = 0;
         if (mask != 0ull && lane_id() == 0) first = atomicAdd(&n_sh, __popcll(mask));

@@ -185,7 +185,7 @@ struct DevWorld {
     float* ped_maps;
     int8_t* is_collisions;
     // the step's own scalars (imgenv_out.step_*): written by a step's tail beside the arrays a reset rewrites
-    double* step_rewards; uint8_t* step_dones; int32_t* step_dones_info; uint8_t* step_is_clean; uint8_t* step_is_arrives; int8_t* step_is_collisions;
+    double* step_rewards; uint8_t* step_dones; int32_t* step_dones_info; uint8_t* step_is_clean; uint8_t* step_is_arrives; int8_t* step_is_collisions; uint8_t* step_all_down;
     int* finished;             // page-locked host memory: [0] number of worlds whose robots are all done, [1..] their indices (k_finished)
     uint8_t* is_arrives;
     double* step_ds;

@@ -36,6 +36,7 @@ class VecImageEnv:
     """
 
     def __init__(self, cfg, env_num=None, seed=None, auto_reset=True, native_spawn=False):
+        import torch
         from .world import World
         self.cfg = cfg
         self.env_num = int(env_num if env_num is not None else cfg.get("env_num", 1))
@@ -54,6 +55,7 @@ class VecImageEnv:
         self._episodes = 0
         self._extent = max(self.grid.shape) * float(cfg["global_map"]["resolution"])
         self.world = World(stack_params(self.params, self.env_num), self.grid, device=cfg.get("device", 0))
+        self._all_down = self.world.out["step_all_down"].view(torch.bool) if native_spawn else None
 
     def __len__(self):
         return self.env_num * self.robot_total
@@ -95,10 +97,8 @@ class VecImageEnv:
         no tensor work on the Python side"""
         o, finished = self.world.step_autoreset(self._actions(actions), self._spawn_cfg, self._spawn_seed + self._episodes)
         self._episodes += len(finished)
-        all_down = (o["step_dones"].view(self.env_num, self.robot_total) > 0).all(dim=1)
         info = {"dones_info": o["step_dones_info"], "is_clean": o["step_is_clean"], "arrive": o["step_is_arrives"],
-                "collision": o["step_is_collisions"], "all_down": all_down.repeat_interleave(self.robot_total),
-                "reset_envs": finished}
+                "collision": o["step_is_collisions"], "all_down": self._all_down, "reset_envs": finished}
         return self._state(), o["step_rewards"], o["step_dones"], info
 
     def step(self, actions):

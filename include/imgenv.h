@@ -226,6 +226,8 @@ typedef struct imgenv_out {
     uint8_t* step_is_clean;       /* [R] */
     uint8_t* step_is_arrives;     /* [R] */
     int8_t* step_is_collisions;   /* [R] */
+    uint8_t* step_all_down;       /* [R] 1 where all robots of the robot's world were done after that step (written by
+                                   * imgenv_step_autoreset only) */
 } imgenv_out;
 
 typedef struct imgenv imgenv_t;

@@ -65,7 +65,7 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     fields = {"imgenv_cfg": ["abi_version", "view_resolution", "robot_shape", "limiter_w", "image_size", "ped_image_r",
                              "robot_size_last", "time_max", "out_arena", "out_arena_bytes"],
               "imgenv_reset_batch": ["n_obstacles", "obs_pose", "ped_traj", "ped_traj_cap", "ignore_obstacle", "ped_traj_v"],
-              "imgenv_out": ["n_local", "vector_states", "lasers", "paper_rewards", "counters", "step_rewards", "step_is_collisions"],
+              "imgenv_out": ["n_local", "vector_states", "lasers", "paper_rewards", "counters", "step_rewards", "step_is_collisions", "step_all_down"],
               "imgenv_spawn_agent": ["target_type", "begin", "target", "module_size", "begin_multi", "target_multi", "n_target_multi"],
               "imgenv_spawn_obstacle": ["pose_type", "size_range", "pose"],
               "imgenv_spawn_cfg": ["n_obstacles", "agents", "obstacles", "clearance", "target_min_dist", "circle_ranges", "go_back", "ignore_obstacle"]}

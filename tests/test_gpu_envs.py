@@ -317,6 +317,9 @@ def test_vec_env_with_native_spawn_matches_oracles_fed_the_same_placements():
             a[:, 0], a[:, 1] = rng.uniform(0, 0.6, E * R), rng.uniform(-0.9, 0.9, E * R)
             _, rew, done, info = vec.step(torch.as_tensor(a, device="cuda"))
             rew, done, dinfo = rew.cpu().numpy(), done.cpu().numpy(), info["dones_info"].cpu().numpy()
+            down = info["all_down"].cpu().numpy()
+            assert [k for k in range(E) if down[k * R:(k + 1) * R].all()] == list(info["reset_envs"]), s
+            assert all(down[k * R:(k + 1) * R].all() or not down[k * R:(k + 1) * R].any() for k in range(E)), s
             for k, c in enumerate(cpus):
                 c.step(a[k * R:(k + 1) * R])
                 ref = c.snapshot()  # what the step itself returned, also for the envs the library has already reset

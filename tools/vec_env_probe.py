@@ -48,9 +48,17 @@ def main():
             resets += len(info["reset_envs"])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out["native_spawn" if native else "python_spawn"] = dict(
-            robot_steps_per_s=n * args.steps / dt, us_per_step=1e6 * dt / args.steps, env_resets_per_step=resets / args.steps,
-            first_reset_ms=1e3 * t_reset)
+        res = dict(robot_steps_per_s=n * args.steps / dt, us_per_step=1e6 * dt / args.steps, env_resets_per_step=resets / args.steps,
+                   first_reset_ms=1e3 * t_reset)
+        if native:  # the same steps without the reset half: what NeverStopWrapper costs on top of the step
+            env.auto_reset = False
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in range(args.steps):
+                env.step(acts[s % 16])
+            torch.cuda.synchronize()
+            res["us_per_step_without_resets"] = 1e6 * (time.perf_counter() - t0) / args.steps
+        out["native_spawn" if native else "python_spawn"] = res
         env.close()
     print(json.dumps(dict(envs=args.envs, robots_per_env=args.robots, peds_per_env=args.peds, **out)))
 
