@@ -422,6 +422,19 @@ def main():
         except Exception as e:  # a secondary number must never cost the headline line
             multi_world = {"error": repr(e)}
 
+    vec_env = None
+    if world_size == 1 and not args.no_multi_world and not args.force_dist:
+        # secondary: the trainer's end-to-end loop -- 1024 reference envs of 4 robots behind VecImageEnv (the wrapper stack's
+        # outputs, NeverStopWrapper-style resets inside the library: imgenv_step_autoreset), Python call to Python return
+        try:
+            from vec_env_probe import measure as measure_vec
+            v = measure_vec(1024, 4, 3, 2, steps=args.steps, natives=(True,))
+            vec_env = dict(value=v["native_spawn"]["robot_steps_per_s"], unit="robot-steps/s", envs=1024, robots_per_env=4,
+                           peds_per_env=3, **{k: v["native_spawn"][k] for k in ("us_per_step", "env_resets_per_step",
+                                                                                "us_per_step_without_resets")})
+        except Exception as e:
+            vec_env = {"error": repr(e)}
+
     if rank == 0:
         ab = algorithmic_bytes(P)
         kernel_bytes = ab.get(dominant, ab["total"]) * RL
@@ -462,6 +475,7 @@ def main():
             "resets_in_timed_region": resets_timed,
             "frozen_fraction": frozen_active,
             "multi_world": multi_world,
+            "vec_env": vec_env,
             "episode_policy": episode,
             "kernel_us": per_kernel_us,
             "launches_per_step": launches_per_step,
