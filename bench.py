@@ -430,8 +430,7 @@ def main():
             from vec_env_probe import measure as measure_vec
             v = measure_vec(1024, 4, 3, 2, steps=args.steps, natives=(True,))
             vec_env = dict(value=v["native_spawn"]["robot_steps_per_s"], unit="robot-steps/s", envs=1024, robots_per_env=4,
-                           peds_per_env=3, **{k: v["native_spawn"][k] for k in ("us_per_step", "env_resets_per_step",
-                                                                                "us_per_step_without_resets")})
+                           peds_per_env=3, **{k: v["native_spawn"][k] for k in ("us_per_step", "env_resets_per_step")})
         except Exception as e:
             vec_env = {"error": repr(e)}
 
