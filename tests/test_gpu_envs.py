@@ -278,7 +278,8 @@ def test_vec_env_matches_one_make_env_per_env():
             e.close()
 
 
-def test_vec_env_with_native_spawn_matches_oracles_fed_the_same_placements():
+@pytest.mark.parametrize("E,R,P", [(5, 3, 4), (6, 1, 0), (3, 2, 1)])
+def test_vec_env_with_native_spawn_matches_oracles_fed_the_same_placements(E, R, P):
     """VecImageEnv(native_spawn=True): every episode's placement is drawn inside the library (imgenv_reset_worlds_spawn).
     The same placements, re-drawn through imgenv_spawn with the seeds the env used, go to one oracle per env."""
     import copy
@@ -288,7 +289,6 @@ def test_vec_env_with_native_spawn_matches_oracles_fed_the_same_placements():
     from oracle_binding import OracleWorld, build_oracle
     from parity import compare
     build_oracle()
-    E, R, P = 5, 3, 4
     grid = worldgen.make_grid(200, 3)
     cfg = worldgen.make_yaml_cfg(R, P, grid, time_max=5, n_obstacles=3, seed=9)
     vec = VecImageEnv(copy.deepcopy(cfg), env_num=E, seed=9, native_spawn=True)
