@@ -805,6 +805,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK_H(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
     }
     TRY(dev_alloc(h, &d.prof, 16 + 12 * (size_t)RL));
+    TRY(dev_alloc(h, &d.tail_sig, RL));
+    TRY(dev_alloc(h, &d.tail_cnt, (size_t)(RL + WAVE - 1) / WAVE * TAIL_CNT_STRIDE));
     TRY(dev_alloc(h, &d.dbg, 32));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
 
     // output arena
@@ -1005,6 +1007,14 @@ static int check_device_flags(imgenv* h) {
 
 // fork: the pedestrian half of the observation needs the local robots' new poses only, so it starts right behind
 // k_integrate (in a sharded world: underneath the record exchange) on its own stream
+// what the tails need, whichever kernel ends up running them (tail_group)
+static void set_tail_fields(imgenv* h, int is_reset, int tail_elapsed) {
+    DevWorld& d = h->d;
+    d.tail_fused = h->P > 0 ? 1 : 0;
+    d.tail_is_reset = is_reset;
+    d.tail_elapsed = tail_elapsed;
+}
+
 static int launch_obs(imgenv* h, hipStream_t st) {
     DevWorld& d = h->d;
     const bool overlap = !h->serial;
@@ -1031,6 +1041,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const int n_g = d.act_ng, n_p = d.act_np, n_l = d.act_nl;
     // k_compose: 4 cells per thread over everything, or a fixed number of 256-thread blocks per listed world
+    set_tail_fields(h, is_reset, h->elapsed);
     const unsigned compose_blocks = d.act_list ? (unsigned)(((h->Gs / 4 + 255) / 256) * d.act_nw) : (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
     if (h->P > 0) {
         // One fork and one join per step on the caller's stream (every event operation costs it a ~6 us dependency
@@ -1063,6 +1074,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             HIPCHK(hipStreamWaitEvent(s_obs, h->ev_join, 0));
             HIPCHK(hipEventRecord(h->ev_join2, s_obs));
         }
+    }
+    if (h->P == 0) {  // no side streams: Agent::get_state of the robots gets its own small launch (k_side_robots does it otherwise)
+        k_state<<<dim3((n_l + 127) / 128), dim3(128), 0, st>>>(d);
+        h->launches += 1;
     }
     // STAMP mode: no compose.  A reset has given the worlds it covers their base classes together with their obstacle maps
     // (k_reset_apply, k_reset_obstacles); every STAMP_TAGS steps one sweep drops all stamps before their tags come round again.
@@ -1120,9 +1135,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         }
 #undef VIEW_CASE
     }
+    // no launch for the per-robot scalars: the k_view / k_obs wavefront that completes a group of 64 robots runs them
+    // (tail_group).  The caller's stream ends the step behind both side streams
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
-    TIMED(h, IMGENV_K_TAIL, st, (k_tail<<<dim3((n_l + 127) / 128), dim3(128), 0, st>>>(d, is_reset, h->elapsed, h->P > 0 ? 0 : 1)));
-    h->launches += 4;
+    h->launches += 3;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1815,6 +1831,7 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         }
     }
     h->launches += 1;
+    set_tail_fields(h, 0, h->elapsed + 1);  // imgenv_step_end counts the step; k_obs goes out before that
     if (h->P > 0)
         if (int rc = launch_obs(h, st)) return rc;
     HIPCHK(hipGetLastError());

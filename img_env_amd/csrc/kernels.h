@@ -135,6 +135,39 @@ __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls)
     return w.rc[cls];
 }
 
+// The per-robot scalars of a step (tail_group, what k_tail used to be) have no launch of their own.  k_view and k_obs each make
+// ONE 64-bit exchange on their robot's word -- k_view brings the collision code, k_obs the pedestrian distance, all the tail
+// needs from them, so no store has to be waited for -- and whichever comes second counts the robot in its group of 64; the
+// wavefront that completes a group runs the group's tails, one lane per robot.  The exchange and the 64-way counter cost the
+// step about 1 us (tools/experiment.py -DIMGENV_EXP_END_RMW on round 2's kernels); the launch + join bubble they replace, 10.
+// Call tail_arrive_* with all 64 lanes of the first (or only) wavefront of the workgroup at active-list position t.
+#define TAIL_CNT_STRIDE 32  // one group counter per 128-byte line: 32 of them in one line queue up behind each other like one (k_view 62 -> 88 us)
+__device__ __forceinline__ void tail_group(const DevWorld& w, int g);
+__device__ __forceinline__ void tail_count(const DevWorld& w, int t, bool later) {
+    int run = 0;
+    if (lane_id() == 0 && later) {
+        const int g = t >> 6, members = min(WAVE, w.act_nl - (g << 6));
+        run = atomicAdd(&w.tail_cnt[g * TAIL_CNT_STRIDE], 1) + 1 == members;
+    }
+    if (__builtin_amdgcn_readfirstlane(run)) tail_group(w, t >> 6);
+}
+__device__ __forceinline__ void tail_arrive_view(const DevWorld& w, int t, int l, int code) {
+    bool later = false;
+    if (lane_id() == 0) {
+        const unsigned long long prev = atomicOr(&w.tail_sig[l], ((unsigned long long)(uint32_t)code << 8) | 2ull);
+        later = !w.tail_fused || (prev & 1ull) != 0ull;  // no pedestrians, no k_obs: the view is all there is
+    }
+    tail_count(w, t, later);
+}
+__device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l, double min_dist) {  // min_dist holds a float32 value
+    bool later = false;
+    if (lane_id() == 0) {
+        const unsigned long long prev = atomicOr(&w.tail_sig[l], ((unsigned long long)__float_as_uint((float)min_dist) << 32) | 1ull);
+        later = (prev & 2ull) != 0ull;
+    }
+    tail_count(w, t, later);
+}
+
 // Optional per-phase cycle accounting (build with -DIMGENV_PHASE_PROFILE): lane 0 of every wave adds
 // the shader-clock cycles of each phase to w.prof[slot]; tools/phase_profile.py prints the split.
 #if defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE)
@@ -1120,7 +1153,10 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int l = act_member(w, w.Rw, blockIdx.x);
     const int lane = lane_id();
-    if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: every per-robot output keeps its last value (counted in k_tail)
+    if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value (counted in tail_group)
+        if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, w.is_coll[l]);
+        return;
+    }
     const int i = w.r0 + l;
     const RobotClassDev k = robot_class(w, w.robot_cls[i]);
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
@@ -1575,6 +1611,9 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     if (tid == 0) w.is_coll[l] = code;
     PHASE_MARK(4);
     WAVE_DONE(0);
+    // hand the collision code over at the END: the wavefronts of a launch start together but finish spread over tens of
+    // microseconds, and 64 same-address atomics in one burst (at the start: k_view 62 -> 89 us) queue up behind each other
+    if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, code);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1598,7 +1637,10 @@ __global__ __launch_bounds__(VB_T) void k_view_big(DevWorld w) {
     __shared__ uint32_t best_sh;
     const int tid = threadIdx.x;
     const int l = act_member(w, w.Rw, blockIdx.x);
-    if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: every per-robot output keeps its last value
+    if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value
+        if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, w.is_coll[l]);
+        return;
+    }
     const int i = w.r0 + l;
     const RobotClassDev& k = w.rc_mem[w.robot_cls[i]];
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
@@ -1727,6 +1769,7 @@ __global__ __launch_bounds__(VB_T) void k_view_big(DevWorld w) {
         if (!w.resize) out_f16[c] = w.f16_lut[v];
     }
     if (tid == 0) w.is_coll[l] = code;
+    if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, code);
     if (!w.resize) return;
     // (5) cv2.resize(view, image_size, INTER_CUBIC).astype(float16) / 255 (yaml_env.py:431-438)
     __threadfence_block();
@@ -1809,12 +1852,14 @@ __device__ __forceinline__ void state_robot(const DevWorld& w, int l) {
     w.robot_pose[3 * l + 2] = r[2];
 }
 
-__device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset, int elapsed, int do_state) {
-    if (do_state) state_robot(w, l);  // otherwise k_side_robots has written it on the side stream
-    const float* vs01 = w.vector_states + (size_t)l * w.SD;
-    const float s0 = vs01[0], s1 = vs01[1];
-    const double min_dist = w.ped_min_dists[l];
-    const int coll = w.is_coll[l];
+__device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset, int elapsed, int coll, double min_dist) {
+    float s0, s1;  // vector_states[0:2], recomputed: whoever writes the state (k_side_robots / k_state) may not have got there yet
+    {
+        const double* r = w.rec + (size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES;
+        const Tf2 target_base = tf_inverse(tf_mul(w.world_target[l], tf_from_pose_sc(r[0], r[1], r[5], r[6])));
+        s0 = (float)target_base.ox;
+        s1 = (float)target_base.oy;
+    }
     const int arr = w.is_arr[l];
     w.is_collisions[l] = (int8_t)coll;
     w.is_arrives[l] = (uint8_t)arr;
@@ -2138,6 +2183,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     PHASE_MARK(11);
     WAVE_DONE(1);
     if (lane == 0) w.ped_min_dists[l] = min_dist;
+    tail_arrive_obs(w, blockIdx.x, l, min_dist);
+}
+
+// Agent::get_state of the local robots in a world without pedestrians (with pedestrians k_side_robots does it on the side
+// stream): its correctly rounded atan2 is a long serial chain and needs many registers, so it stays out of the kernels that
+// run the tails.
+__global__ void k_state(DevWorld w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < w.act_nl) state_robot(w, act_member(w, w.Rw, t));
 }
 
 // Per-robot work that needs the new poses only, on the side stream beside the rasters and the view:
@@ -2216,21 +2270,30 @@ __global__ __launch_bounds__(1024) void k_finished(DevWorld w) {
     if (threadIdx.x == 0) w.finished[0] = n_sh;
 }
 
-// Per-robot scalars, one thread per robot: Agent::get_state (agent.cpp:156-184), the _get_states distances,
-// ImageEnv.step and the wrapper stack (reward / done).  Runs after k_view (collision code) and k_obs (ped distance).
-__global__ void k_tail(DevWorld w, int is_reset, int elapsed, int do_state) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// Per-robot scalars, one lane per robot of a group of 64 consecutive active-list positions: Agent::get_state's first two
+// components (agent.cpp:156-184), the _get_states distances, ImageEnv.step and the wrapper stack (reward / done).  Run by the
+// k_view / k_obs wavefront that completes the group (tail_count).  The collision code and the pedestrian distance of each robot
+// are in its exchange word, read at device scope (the wavefronts that wrote them ran on other compute units).
+__device__ __forceinline__ void tail_group(const DevWorld& w, int g) {
+    const int t = (g << 6) + lane_id();
     const bool valid = t < w.act_nl;
     const int l = act_member(w, w.Rw, valid ? t : 0);
+    const int is_reset = w.tail_is_reset;
     int done = 0;
     // robots whose view was frozen this step (agent.cpp:358-360: collided before this step, or arrived): the collision code
     // the previous step published, the arrive flag this step's integrate left
     const bool frozen = valid && !is_reset && (w.is_collisions[l] != 0 || w.is_arr[l] != 0);
-    // TimeLimitWrapper counts per world: steps since that world's last reset
-    if (valid) done = tail_robot(w, l, is_reset, elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], do_state);
-    if (w.sharded && blockIdx.x == 0 && threadIdx.x < 4)  // the rasters of this step are done with the box: re-arm it
-        w.bbox[threadIdx.x] = threadIdx.x < 2 ? BBOX_INIT_MIN : BBOX_INIT_MAX;
-    const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per wavefront
+    if (valid) {
+        const unsigned long long sig = __hip_atomic_load(&w.tail_sig[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double min_dist = w.tail_fused ? (double)__uint_as_float((uint32_t)(sig >> 32)) : w.ped_min_dists[l];
+        // TimeLimitWrapper counts per world: steps since that world's last reset
+        done = tail_robot(w, l, is_reset, w.tail_elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], (int)((sig >> 8) & 0xFFull), min_dist);
+        w.tail_sig[l] = 0ull;  // for the next chain of launches
+    }
+    if (lane_id() == 0) w.tail_cnt[g * TAIL_CNT_STRIDE] = 0;
+    if (w.sharded && g == 0 && lane_id() < 4)  // the rasters and k_compose of this step (its only readers) are long done with the box: re-arm it
+        w.bbox[lane_id()] = lane_id() < 2 ? BBOX_INIT_MIN : BBOX_INIT_MAX;
+    const unsigned long long mask = __ballot(done > 0);  // counters[1] = robots done this step, one atomic per group
     if (mask != 0 && lane_id() == 0) atomicAdd(&w.counters[1], __popcll(mask));
     const unsigned long long fmask = __ballot(frozen);  // counters[2] since the last reset, counters[3] since create
     if (fmask != 0 && lane_id() == 0) {  // two 32-bit adds: a handle that only ever resets single worlds never clears counters[2],

@@ -92,6 +92,11 @@ struct DevWorld {
     const int* act_list;  // [act_nw] worlds of this launch
     int act_nw;
     int act_nl, act_ng, act_np;  // local robots, world-wide robots (rasters, RVO records) and pedestrians of this launch
+    // the step's per-robot scalars (tail_group in kernels.h) are run by k_view / k_obs wavefronts themselves
+    unsigned long long* tail_sig;  // [RL] exchange word: k_obs' min_dist (float bits) << 32 | k_view's collision code << 8 | who has been here (2 view, 1 obs)
+    int* tail_cnt;                 // [ceil(RL / 64)][32] (one per 128-byte line) robots of the group whose two wavefronts have both been here
+    int tail_fused;                // k_obs runs in this chain of launches (pedestrians exist); otherwise k_view alone hands over
+    int tail_is_reset, tail_elapsed;
     uint32_t Gs;
     size_t act_cells;  // grid cells of an everything-launch (k_compose, k_cell_base)
     const int* world_epoch;                              // [W] global step count at the world's last reset
