@@ -962,7 +962,7 @@ __device__ __forceinline__ void reset_robot(const DevWorld& w, const int* list, 
     if (t == 0 && whole) w.counters[2] = 0;  // frozen robot-steps since this reset (of every world)
 }
 
-// reset of a robot-sharded world: bounding box of the local robots' new positions (k_tail re-arms it every step)
+// reset of a robot-sharded world: bounding box of the local robots' new positions (tail_group re-arms it every step)
 __global__ void k_reset_bbox(DevWorld w, const double* __restrict__ pose3) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = l < w.RL;
@@ -1798,7 +1798,7 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     DevWorld& d = h->d;
     h->launches = 0;
     // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
-    // step's views and was joined before that step's k_tail; its velocities are applied by k_integrate's pedestrian blocks
+    // step's views and was joined at the end of that step; its velocities are applied by k_integrate's pedestrian blocks
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
         const int n_sfm = h->d.sfm.n, n_pairs = n_sfm * n_sfm;
         if (n_pairs <= 4096) {  // small crowd: one launch

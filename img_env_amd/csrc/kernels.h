@@ -10,7 +10,9 @@
 //   k_obs<E>       1 wave / robot        PedInfo, sorted ped vector, ped_map (img_env.cpp:568-584, yaml_env.py:392-456)
 //   k_side_robots  1 thread / robot      RVO robot records + Agent::get_state (agent.cpp:156-184), on a side stream
 //   k_orca         1 wave / pedestrian   waypoint logic + ORCA half-planes + LP (img_env.cpp:304-343), on a side stream
-//   k_tail         1 thread / robot      step_ds, reward / done wrappers (yaml_env.py:446-481, base.py:153-254)
+//   tail_group     1 lane / robot        step_ds, reward / done wrappers (yaml_env.py:446-481, base.py:153-254): no launch of its
+//                                        own, run inside k_view / k_obs by the wavefront that completes a group of 64 robots
+//   k_state        1 thread / robot      Agent::get_state in worlds without pedestrians (no side streams there)
 // A handle may hold several independent worlds (DevWorld::W): robots and pedestrians are numbered world-major, every grid
 // layer exists once per world, and a launch covers everything or the worlds listed in DevWorld::act_list (a reset).
 //
@@ -954,7 +956,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel) 
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
     const int b = blockIdx.x;
     WAVE_T0();
-    if (STAMP && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_tail tallies this step's dones (k_compose does this otherwise)
+    if (STAMP && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // tail_group tallies this step's dones (k_compose does this otherwise)
     const Region g = grid_region(w);
     if (b < w.act_ng) {
         const int i = act_member(w, w.Rw, b);
@@ -1027,7 +1029,7 @@ __global__ void k_compose(DevWorld w) {
         c0 = base + ((size_t)(blockIdx.x - q * per_world) * blockDim.x + threadIdx.x) * 4;
         G = base + w.Gs;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // k_tail tallies this step's dones
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[1] = 0;  // tail_group tallies this step's dones
     if (c0 >= G) return;
     if (w.sharded) {  // only the region this rank's rasters were clipped to (everything else is clean and unread)
         const Region g = grid_region(w);
@@ -2197,7 +2199,7 @@ __global__ void k_state(DevWorld w) {
 // Per-robot work that needs the new poses only, on the side stream beside the rasters and the view:
 //  * _step_robot tail for the RVO scenes: setRobotPos for every robot (img_env.cpp:411-417, rvoscene.h:47-51), straight
 //    from the gathered robot records, so that the solve does not have to wait for the raster;
-//  * Agent::get_state of the local robots (its correctly rounded atan2 is a long serial chain that k_tail, on the
+//  * Agent::get_state of the local robots (its correctly rounded atan2 is a long serial chain that the tails, on the
 //    critical path, would otherwise run).
 #define SIDE_PED_TILE 1024
 __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
