@@ -1202,6 +1202,10 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
     const int code = (int)(best & 3);
+    // the collision code is all the step's tail needs from this kernel: hand it over NOW, with no store of this wavefront in
+    // flight -- if this wavefront completes its group, the tails' loads do not queue up behind 7 KB of view stores (in-order
+    // vmcnt), and they run underneath the other wavefronts instead of behind the last one
+    if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, code);
     PHASE_MARK(0);
 
     // (2) egocentric crop (agent.cpp:373-404): 4 view cells per lane per round -> one LDS dword.
@@ -1613,9 +1617,6 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     if (tid == 0) w.is_coll[l] = code;
     PHASE_MARK(4);
     WAVE_DONE(0);
-    // hand the collision code over at the END: the wavefronts of a launch start together but finish spread over tens of
-    // microseconds, and 64 same-address atomics in one burst (at the start: k_view 62 -> 89 us) queue up behind each other
-    if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, code);
 }
 
 // ------------------------------------------------------------------------------------------------
