@@ -141,7 +141,8 @@ __device__ __forceinline__ RobotClassDev robot_class(const DevWorld& w, int cls)
 // ONE 64-bit exchange on their robot's word -- k_view brings the collision code, k_obs the pedestrian distance, all the tail
 // needs from them, so no store has to be waited for -- and whichever comes second counts the robot in its group of 64; the
 // wavefront that completes a group runs the group's tails, one lane per robot.  The exchange and the 64-way counter cost the
-// step about 1 us (tools/experiment.py -DIMGENV_EXP_END_RMW on round 2's kernels); the launch + join bubble they replace, 10.
+// step about 1 us; the launch + join bubble they replace, 10.  k_view arrives right after its collision phase (no store in
+// flight yet), k_obs at its end.
 // Call tail_arrive_* with all 64 lanes of the first (or only) wavefront of the workgroup at active-list position t.
 #define TAIL_CNT_STRIDE 32  // one group counter per 128-byte line: 32 of them in one line queue up behind each other like one (k_view 62 -> 88 us)
 __device__ __forceinline__ void tail_group(const DevWorld& w, int g);
