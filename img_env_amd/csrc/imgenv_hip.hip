@@ -805,6 +805,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK_H(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
     }
     TRY(dev_alloc(h, &d.prof, 16 + 12 * (size_t)RL));
+    d.state_in_integrate = P == 0 ? 1 : 0;
     TRY(dev_alloc(h, &d.tail_sig, RL));
     TRY(dev_alloc(h, &d.tail_cnt, (size_t)(RL + WAVE - 1) / WAVE * TAIL_CNT_STRIDE));
     TRY(dev_alloc(h, &d.dbg, 32));  // phase sums | per-wave (start, end, hw id, -) of k_view and k_obs
@@ -1075,7 +1076,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             HIPCHK(hipEventRecord(h->ev_join2, s_obs));
         }
     }
-    if (h->P == 0) {  // no side streams: Agent::get_state of the robots gets its own small launch (k_side_robots does it otherwise)
+    if (h->P == 0 && is_reset) {  // no side streams: after a reset Agent::get_state gets its own small launch (in a step k_integrate does it, with pedestrians k_side_robots)
         k_state<<<dim3((n_l + 127) / 128), dim3(128), 0, st>>>(d);
         h->launches += 1;
     }

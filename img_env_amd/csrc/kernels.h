@@ -12,7 +12,8 @@
 //   k_orca         1 wave / pedestrian   waypoint logic + ORCA half-planes + LP (img_env.cpp:304-343), on a side stream
 //   tail_group     1 lane / robot        step_ds, reward / done wrappers (yaml_env.py:446-481, base.py:153-254): no launch of its
 //                                        own, run inside k_view / k_obs by the wavefront that completes a group of 64 robots
-//   k_state        1 thread / robot      Agent::get_state in worlds without pedestrians (no side streams there)
+//   k_state        1 thread / robot      Agent::get_state after a reset of worlds without pedestrians (no side streams there;
+//                                        in their steps k_integrate does it)
 // A handle may hold several independent worlds (DevWorld::W): robots and pedestrians are numbered world-major, every grid
 // layer exists once per world, and a launch covers everything or the worlds listed in DevWorld::act_list (a reset).
 //
@@ -596,6 +597,8 @@ __device__ __forceinline__ void ped_dataset_one(const DevWorld& w, int j, int st
     ped_leg_gait(w, j, x, y, ox, oy);
 }
 
+__device__ __forceinline__ void state_robot(const DevWorld& w, int l);  // Agent::get_state, below
+
 // Serial fallback of the robot update (more sub-steps than INT_ITEMS - 2): one thread per robot.
 __global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions, int nb_robot, int step) {
     if ((int)blockIdx.x >= nb_robot) {
@@ -609,6 +612,7 @@ __global__ void k_integrate_serial(DevWorld w, const float* __restrict__ actions
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = l < w.RL;
     if (valid && !w.py_done[l]) integrate_robot(w, actions, l);
+    if (w.state_in_integrate && valid) state_robot(w, l);  // no pedestrians, no side stream: get_state right behind the move
     if (w.sharded) {
         const double* r = w.rec + (size_t)(w.r0 + (valid ? l : 0)) * IMGENV_RECORD_DOUBLES;
         bbox_accumulate(w, valid, r[0], r[1]);
@@ -737,6 +741,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
     }
     __syncthreads();
     if (alive && g == 0) integrate_finish(w, l, r, v, wv, v_y, theta, trig[rb], n_sub);
+    if (w.state_in_integrate && valid && g == 0) state_robot(w, l);  // no pedestrians, no side stream: get_state right behind the move
     if (w.sharded) bbox_accumulate(w, valid && g == 0, r[0], r[1]);
 }
 
@@ -2190,9 +2195,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     tail_arrive_obs(w, blockIdx.x, l, min_dist);
 }
 
-// Agent::get_state of the local robots in a world without pedestrians (with pedestrians k_side_robots does it on the side
-// stream): its correctly rounded atan2 is a long serial chain and needs many registers, so it stays out of the kernels that
-// run the tails.
+// Agent::get_state of the local robots after a reset of worlds without pedestrians (with pedestrians k_side_robots does it on
+// the side stream; in the steps of pedestrian-free worlds k_integrate does): its correctly rounded atan2 is a long serial chain
+// and needs many registers, so it stays out of the kernels that run the tails.
 __global__ void k_state(DevWorld w) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < w.act_nl) state_robot(w, act_member(w, w.Rw, t));

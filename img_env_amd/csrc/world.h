@@ -97,6 +97,7 @@ struct DevWorld {
     int* tail_cnt;                 // [ceil(RL / 64)][32] (one per 128-byte line) robots of the group whose two wavefronts have both been here
     int tail_fused;                // k_obs runs in this chain of launches (pedestrians exist); otherwise k_view alone hands over
     int tail_is_reset, tail_elapsed;
+    int state_in_integrate;        // no pedestrians (no k_side_robots): k_integrate ends with Agent::get_state
     uint32_t Gs;
     size_t act_cells;  // grid cells of an everything-launch (k_compose, k_cell_base)
     const int* world_epoch;                              // [W] global step count at the world's last reset
