@@ -60,7 +60,7 @@ def algorithmic_bytes(P, hv=48, wv=48, beams=360, max_ped=N_PEDS):
     view = hv * wv + hv * wv + 2 * hv * wv + 4 * beams   # grid window gather + sensor_map u8 + f16 copy + lasers f32
     obs = (20 * P + 3 * 48 * 48 * 4 + 4 * (1 + 7 * max_ped)) if P > 0 else 0
     state = 128
-    return dict(k_view=view, k_obs=obs, k_tail=state, total=view + obs + state)
+    return dict(k_view=view, k_obs=obs, tail=state, total=view + obs + state)  # tail: the per-robot scalars, run inside k_view / k_obs
 
 
 def _cpu_model():
