@@ -15,6 +15,9 @@ SHAPE_CIRCLE, SHAPE_RECTANGLE, SHAPE_LEG = 0, 1, 2
 SCENE_EMPTY, SCENE_RVO, SCENE_ERVO, SCENE_PEDSIM, SCENE_DATASET = 0, 1, 2, 3, 4
 KTYPE_DIFF, KTYPE_OMNI = 0, 1
 FLAG_PRIVATE_GRIDS = 1
+FLAG_COMPOSE_DENSE = 2
+FLAG_COMPOSE_SPARSE = 4
+FLAG_NO_VIEW_MAPS = 8  # imgenv_out.view_maps not wanted (include/imgenv.h)
 
 SHAPES = {"circle": SHAPE_CIRCLE, "rectangle": SHAPE_RECTANGLE, "leg": SHAPE_LEG}
 # Env.msg ped_scene_type strings (scenefactory.h:8-24): anything else is the EmptyScene
@@ -245,7 +248,7 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
            "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_cv_resize_u8")
-K_COUNT = 8
+K_COUNT = 10
 
 
 def library_path():

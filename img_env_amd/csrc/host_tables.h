@@ -92,7 +92,15 @@ struct RobotClassHost {
     bool ok = true;  // false: a table field overflowed its packing
     bool big = false;  // the view is beyond what k_view packs into 16 / 8 bits: k_view_big and its 32-bit path table instead
     int sensor_x = 0, sensor_y = 0;  // view cell of the laser
-    std::vector<uint32_t> big_cells;  // [ray_maxlen][ray_stride] view cell of step k of beam b, 0xFFFFFFFF past the ray's end
+    // big views (csrc/view_big.h).  The cropped view lives as a bitmap in 8 x 8 tiles: bit address of view cell (a, b) =
+    // ((a / 8) * big_tb + b / 8) * 64 + (a % 8) * 8 + b % 8, so that one wavefront crops one tile and stores one 64-bit ballot
+    int big_ta = 0, big_tb = 0;       // tiles per column / per row
+    std::vector<uint32_t> big_cells;  // [ray_kpad][ray_stride] bit address of step k of beam b; past the ray's end: the always-free bit behind the bitmap
+    std::vector<uint16_t> ray_end;    // [ray_maxlen][ray_stride] last step behind step k of beam b that shares its row or column (k itself if none)
+    std::vector<uint32_t> big_inv;    // [NC][2] rays through a view cell: first entry of inv_ent, count
+    std::vector<uint32_t> crop_tiles; // tiles with at least one cell inside the field of view: ta << 16 | tb ...
+    std::vector<uint64_t> crop_masks; // ... and their cells inside it (bit = (a % 8) * 8 + b % 8)
+    std::vector<uint32_t> tap_rec;    // [16][image_h * image_w][4] the 4 x 4 source cells of every pixel of the shrunk sensor_map (build_big_taps)
     std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
     std::vector<uint8_t> ray_run;  // [ray_maxlen][ray_stride] steps behind step k of beam b that share a row or column with it
@@ -190,10 +198,48 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     k.big = force_big || NC + 16 > 0xFFFF || k.ray_maxlen > 255 || Hv > 256 || Wv > 256;
     if (k.ray_maxlen > 0xFFFF || B > 0xFFFF) k.ok = false;  // (beam << 16 | step) entries of the per-cell ray lists
     std::vector<std::vector<uint32_t>> inv(NC);
+    k.big_ta = (Hv + 7) / 8;
+    k.big_tb = (Wv + 7) / 8;
     if (k.big) {
-        k.big_cells.assign((size_t)k.ray_maxlen * k.ray_stride, 0xFFFFFFFFu);
+        const uint32_t free_bit = (uint32_t)k.big_ta * (uint32_t)k.big_tb * 64u;  // the word behind the bitmap stays zero
+        k.big_cells.assign((size_t)k.ray_kpad * k.ray_stride, free_bit);  // k_beams_big walks 8 steps at a time
         k.ray_rows.assign(8, 0);
-        k.ray_dist.assign(1, 6.0f);
+        k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
+        k.ray_end.assign((size_t)k.ray_maxlen * k.ray_stride, 0);
+        k.ray_run.assign(1, 0);
+        // the cells a hit leaves alone (agent.cpp:555-560) are one run of steps right behind it (see below): its last step
+        for (int b = 0; b < B; b++) {
+            const size_t n = cells[b].size();
+            for (size_t q = 0; q < n; q++) {
+                const uint32_t xq = cells[b][q] / (uint32_t)Wv, yq = cells[b][q] % (uint32_t)Wv;
+                // (a path moves along its major axis every step and never back along the minor one: once off the hit's row and
+                // column it stays off; tests/test_k_view_tables.py checks that on whole paths)
+                size_t run = 0;
+                for (size_t t = q + 1; t < n; t++) {
+                    if (!(cells[b][t] / (uint32_t)Wv == xq || cells[b][t] % (uint32_t)Wv == yq)) break;
+                    run++;
+                }
+                k.ray_end[q * k.ray_stride + b] = (uint16_t)(q + run);
+            }
+        }
+        for (int ta = 0; ta < k.big_ta; ta++)
+            for (int tb = 0; tb < k.big_tb; tb++) {
+                uint64_t mask = 0;
+                for (int q = 0; q < 64; q++) {
+                    const int a = ta * 8 + (q >> 3), b = tb * 8 + (q & 7);
+                    if (a >= Hv || b >= Wv) continue;
+                    const int c = a * Wv + b;
+                    if ((k.fov_bits[c >> 5] >> (c & 31)) & 1u) mask |= 1ull << q;
+                }
+                if (mask) {
+                    k.crop_tiles.push_back(((uint32_t)ta << 16) | (uint32_t)tb);
+                    k.crop_masks.push_back(mask);
+                }
+            }
+        if (k.crop_tiles.empty()) {
+            k.crop_tiles.push_back(0);
+            k.crop_masks.push_back(0);
+        }
     } else {
         // chunk-major: the 8 steps 8c..8c+7 of beam b sit at ((c * ray_stride) + b) * 8; padding = a free dummy cell behind the view
         k.ray_rows.assign((size_t)(k.ray_kpad / 8) * k.ray_stride * 8, (uint16_t)NC);
@@ -222,7 +268,9 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     for (int b = 0; b < B; b++)
         for (size_t q = 0; q < cells[b].size(); q++) {
             if (k.big) {
-                k.big_cells[q * k.ray_stride + b] = cells[b][q];
+                const uint32_t a = cells[b][q] / (uint32_t)Wv, bb = cells[b][q] % (uint32_t)Wv;
+                k.big_cells[q * k.ray_stride + b] = ((a >> 3) * (uint32_t)k.big_tb + (bb >> 3)) * 64u + (a & 7u) * 8u + (bb & 7u);
+                k.ray_dist[q * k.ray_stride + b] = dists[b][q];
             } else {
                 k.ray_rows[((q / 8) * (size_t)k.ray_stride + b) * 8 + (q % 8)] = (uint16_t)cells[b][q];
                 k.ray_dist[q * k.ray_stride + b] = dists[b][q];
@@ -233,10 +281,15 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     uint32_t off = 0;
     for (int c = 0; c < NC; c++) {
         std::sort(inv[c].begin(), inv[c].end(), [](uint32_t a, uint32_t b) { return a > b; });  // beam descending
-        if (off >= (1u << 20) || inv[c].size() >= (1u << 12)) k.ok = false;
+        if (!k.big && (off >= (1u << 20) || inv[c].size() >= (1u << 12))) k.ok = false;
         k.inv_pack[c] = off | ((uint32_t)inv[c].size() << 20);
+        if (k.big) {
+            k.big_inv.push_back(off);
+            k.big_inv.push_back((uint32_t)inv[c].size());
+        }
         off += (uint32_t)inv[c].size();
     }
+    if (k.big_inv.empty()) k.big_inv.assign(2, 0);
     k.inv_ent.reserve(off + 1);
     for (int c = 0; c < NC; c++) k.inv_ent.insert(k.inv_ent.end(), inv[c].begin(), inv[c].end());
     k.top_ent.assign(NC, ((uint32_t)B << 16) | 0xFFFFu);  // no beam: the dummy beam B at a step behind every hit
@@ -277,6 +330,28 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
             k.inv_cell[2 * (size_t)c] = idx | (none << 13) | (st << 14) | (std::min(kkmin, 0xFFu) << 24);
         }
     }
+}
+
+// cv2.resize(view, image_size, INTER_CUBIC) (yaml_env.py:431-438) reads 4 x 4 view cells per pixel of the sensor_map (no
+// anti-aliasing): k_beams_big evaluates exactly those cells.  One 16-byte record per (tap, pixel), tap-major so that the
+// pixels of a wavefront read consecutive records: view cell | own footprint << 31, the cell's top beam entry, the bit
+// address of the cell in the tiled crop bitmap, 0.  xofs / yofs: source index of tap 1 per destination column / row
+// (csrc/cv_resize.h), borders replicated as OpenCV does.
+static void build_big_taps(RobotClassHost& k, const ViewGeom& g, const std::vector<int>& xofs, const std::vector<int>& yofs) {
+    const int IW = (int)xofs.size(), IH = (int)yofs.size(), NP = IW * IH;
+    k.tap_rec.assign((size_t)16 * NP * 4, 0);
+    for (int dy = 0; dy < IH; dy++)
+        for (int dx = 0; dx < IW; dx++)
+            for (int kr = 0; kr < 4; kr++)
+                for (int j = 0; j < 4; j++) {
+                    const int a = std::min(std::max(yofs[dy] - 1 + kr, 0), g.Hv - 1), b = std::min(std::max(xofs[dx] - 1 + j, 0), g.Wv - 1);
+                    const uint32_t c = (uint32_t)a * (uint32_t)g.Wv + (uint32_t)b;
+                    const uint32_t st = (k.stamp_bits[c >> 5] >> (c & 31)) & 1u;
+                    uint32_t* r = &k.tap_rec[((size_t)(kr * 4 + j) * NP + (size_t)dy * IW + dx) * 4];
+                    r[0] = c | (st << 31);
+                    r[1] = k.top_ent[c];
+                    r[2] = (((uint32_t)a >> 3) * (uint32_t)k.big_tb + ((uint32_t)b >> 3)) * 64u + ((uint32_t)a & 7u) * 8u + ((uint32_t)b & 7u);
+                }
 }
 
 struct PedClassHost {

@@ -84,8 +84,10 @@ struct imgenv {
     void* d_oinst = nullptr;
     size_t cap_oinst = 0;
     int* d_act_list = nullptr;
-    bool big_view = false;   // the view is beyond k_view's packing, or shrunk by cv2.resize: k_view_big
+    bool big_view = false;   // the view is beyond k_view's packing, or shrunk by cv2.resize: the kernels of view_big.h
     size_t lds_view_big = 0;
+    bool big_bits_in_lds = true;  // the crop bitmap of one robot fits the LDS next to the hit words
+    int big_crop_chunks = 1, big_full_chunks = 1;
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
     std::vector<double> tmp_d1;  // scratch of stage_world
@@ -161,8 +163,8 @@ static RcclApi* rccl_api() {
     return api.lib ? &api : nullptr;
 }
 
-static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster",
-                                                         "k_compose", "k_view", "k_obs", "k_tail"};
+static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster", "k_compose",
+                                                         "k_view", "k_obs", "k_tail", "k_crop_big", "k_fullview_big"};
 extern "C" const char* imgenv_kernel_name(int id) { return (id >= 0 && id < IMGENV_K_COUNT) ? KERNEL_NAMES[id] : ""; }
 
 static int timing_flush(imgenv* h) {
@@ -631,10 +633,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
                 TRY(dev_upload(h, &cells2, k.inv_cell));
                 o.inv_cell = (const uint2*)cells2;
             }
-            TRY(dev_upload(h, &o.big_cells, k.big_cells));
             o.big = k.big ? 1 : 0;
-            o.sensor_x = k.sensor_x;
-            o.sensor_y = k.sensor_y;
             h->big_view = h->big_view || k.big;
             o.box_rad = k.box_rad;
             max_stride = std::max(max_stride, (size_t)k.ray_stride);
@@ -679,12 +678,59 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     d.resize = view_resize ? 1 : 0;
     d.img_w = cfg->image_size[0];
     d.img_h = cfg->image_size[1];
+    CvAxis ax, ay;
     if (view_resize) {  // axis tables of the bicubic shrink (csrc/cv_resize.h)
-        const CvAxis ax = cv_axis(g.Wv, d.img_w, true, true), ay = cv_axis(g.Hv, d.img_h, true, false);
+        ax = cv_axis(g.Wv, d.img_w, true, true);
+        ay = cv_axis(g.Hv, d.img_h, true, false);
         TRY(dev_upload(h, &d.rs_xofs, ax.ofs));
         TRY(dev_upload(h, &d.rs_alpha, ax.coef));
         TRY(dev_upload(h, &d.rs_yofs, ay.ofs));
         TRY(dev_upload(h, &d.rs_beta, ay.coef));
+    }
+    d.keep_view_maps = (cfg->flags & IMGENV_FLAG_NO_VIEW_MAPS) ? 0 : 1;
+    if (h->big_view) {  // view_big.h: tiled crop bitmap + hit words per local robot, static tables per class
+        std::vector<BigClassDev> bc(h->rcls.size());
+        int max_crop = 1;
+        for (size_t c = 0; c < h->rcls.size(); c++) {
+            RobotClassHost& k = h->rcls[c];
+            BigClassDev& o = bc[c];
+            memset(&o, 0, sizeof(o));
+            if (!k.big) {
+                imgenv_destroy(h);
+                FAIL(IMGENV_EINVAL, "robot classes with and without big views in one world");
+            }
+            o.ta = k.big_ta;
+            o.tb = k.big_tb;
+            o.n_crop = (int)k.crop_tiles.size();
+            max_crop = std::max(max_crop, o.n_crop);
+            TRY(dev_upload(h, &o.crop_tiles, k.crop_tiles));
+            TRY(dev_upload(h, &o.crop_masks, k.crop_masks));
+            TRY(dev_upload(h, &o.cells, k.big_cells));
+            TRY(dev_upload(h, &o.ray_end, k.ray_end));
+            {
+                const uint32_t* p2 = nullptr;
+                TRY(dev_upload(h, &p2, k.big_inv));
+                o.inv = (const uint2*)p2;
+            }
+            if (view_resize) {
+                build_big_taps(k, g, ax.ofs, ay.ofs);
+                const uint32_t* p4 = nullptr;
+                TRY(dev_upload(h, &p4, k.tap_rec));
+                o.taps = (const uint4*)p4;
+                std::vector<uint32_t>().swap(k.tap_rec);
+            }
+        }
+        TRY(dev_upload(h, &d.big_mem, bc));
+        const size_t tiles = (size_t)h->rcls[0].big_ta * h->rcls[0].big_tb;
+        d.big_words = (int)((tiles * 2 + 1 + 3) & ~(size_t)3);  // + the always-free word the padded path entries point at
+        d.big_hit_stride = (g.B + 2 + 3) & ~3;
+        TRY(dev_alloc(h, &d.big_bits, (size_t)RL * 2 * d.big_words));
+        TRY(dev_alloc(h, &d.big_hit, (size_t)RL * d.big_hit_stride));
+        // cells no crop tile covers lie outside the field of view for good: "unknown" in plane 1 (read without the laser only)
+        if (!cfg->use_laser)
+            HIPCHK_H(hipMemset2D(d.big_bits + d.big_words, (size_t)8 * d.big_words, 0xFF, (size_t)4 * d.big_words, (size_t)RL));
+        h->big_crop_chunks = (max_crop + (VBC_T / WAVE) * VBC_TPW - 1) / ((VBC_T / WAVE) * VBC_TPW);
+        h->big_full_chunks = (int)(((size_t)g.Hv * g.Wv + VBF_T * 4 - 1) / (VBF_T * 4));
     }
 
     // robot / ped state
@@ -889,17 +935,22 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16 + 4 * (2 * (max_stride / 8 + 1) + 4);
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
     h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
-    if (h->big_view) {  // k_view_big: the view at 2 bits a cell | first hit (step, cell) per beam (+ the dummy beam)
-        h->lds_view_big = ((((NC + 3) / 4) + 15) & ~(size_t)15) + 8 * ((size_t)g.B + 1) + 16;
+    if (h->big_view) {  // k_beams_big: hit words (+ the dummy beam, + the flag word) | the occupied plane of the crop bitmap
+        const size_t lds_hit = 4 * (size_t)d.big_hit_stride, lds_bits = 4 * (size_t)d.big_words;
+        h->big_bits_in_lds = lds_hit + lds_bits <= 150 * 1024;  // beyond that (views above ~1000 x 1000 cells) the beams read the bitmap from HBM
+        h->lds_view_big = lds_hit + (h->big_bits_in_lds ? lds_bits : 0) + 16;
         h->lds_view = 16;
+        d.big_bits_in_lds = h->big_bits_in_lds ? 1 : 0;
     }
     if (h->lds_view_big > 160 * 1024) {
         imgenv_destroy(h);
-        FAIL(IMGENV_EINVAL, "a view of %d x %d cells with %d beams does not fit the 160 KiB LDS (%zu B)", g.Hv, g.Wv, g.B, h->lds_view_big);
+        FAIL(IMGENV_EINVAL, "the hit words of %d beams do not fit the 160 KiB LDS (%zu B)", g.B, h->lds_view_big);
     }
     if (h->lds_view_big > 64 * 1024) {
-        for (const void* f : {(const void*)k_view_big<true, true>, (const void*)k_view_big<true, false>, (const void*)k_view_big<false, true>,
-                              (const void*)k_view_big<false, false>})
+        for (const void* f : {(const void*)k_beams_big<true, true, true>, (const void*)k_beams_big<true, false, true>,
+                              (const void*)k_beams_big<false, true, true>, (const void*)k_beams_big<false, false, true>,
+                              (const void*)k_beams_big<true, true, false>, (const void*)k_beams_big<true, false, false>,
+                              (const void*)k_beams_big<false, true, false>, (const void*)k_beams_big<false, false, false>})
             HIPCHK_H(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view_big));
     }
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
@@ -1104,15 +1155,27 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
 #undef RASTER_CASE
     }
     if (!h->stamp) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
-    if (h->big_view) {
-        const dim3 gv(n_l), bv(VB_T);
-        const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
+    if (h->big_view) {  // view_big.h: crop (tiles of every robot spread over the chip) -> beams + shrunk sensor_map (a workgroup
+                        // per robot) -> the full view, only where it is an output
+        const dim3 gc((unsigned)n_l * (unsigned)h->big_crop_chunks), gv(n_l), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
+        if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true><<<gc, dim3(VBC_T), 0, st>>>(d, h->big_crop_chunks)));
+        else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false><<<gc, dim3(VBC_T), 0, st>>>(d, h->big_crop_chunks)));
+        const int variant = (h->pow2 ? 4 : 0) | (h->stamp ? 2 : 0) | (h->big_bits_in_lds ? 1 : 0);
+#define BEAMS_CASE(N, P2, ST, LB) \
+    case N: TIMED(h, IMGENV_K_VIEW, st, (k_beams_big<P2, ST, LB><<<gv, dim3(VBB_T), h->lds_view_big, st>>>(d))); break;
         switch (variant) {
-            case 3: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<true, true><<<gv, bv, h->lds_view_big, st>>>(d))); break;
-            case 2: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<true, false><<<gv, bv, h->lds_view_big, st>>>(d))); break;
-            case 1: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<false, true><<<gv, bv, h->lds_view_big, st>>>(d))); break;
-            default: TIMED(h, IMGENV_K_VIEW, st, (k_view_big<false, false><<<gv, bv, h->lds_view_big, st>>>(d))); break;
+            BEAMS_CASE(7, true, true, true)
+            BEAMS_CASE(6, true, true, false)
+            BEAMS_CASE(5, true, false, true)
+            BEAMS_CASE(4, true, false, false)
+            BEAMS_CASE(3, false, true, true)
+            BEAMS_CASE(2, false, true, false)
+            BEAMS_CASE(1, false, false, true)
+            BEAMS_CASE(0, false, false, false)
         }
+#undef BEAMS_CASE
+        if (d.keep_view_maps || !d.resize) TIMED(h, IMGENV_K_FULLVIEW, st, (k_fullview_big<<<gf, dim3(VBF_T), 0, st>>>(d, h->big_full_chunks)));
+        h->launches += (d.keep_view_maps || !d.resize) ? 2 : 1;
     } else {
         // one wavefront per robot when the launch fills the machine, four when it is small (a reset of a few worlds): then
         // the single wavefront's latency is all there is

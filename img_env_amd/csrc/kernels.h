@@ -1625,194 +1625,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     WAVE_DONE(0);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Agent::view (agent.cpp:356-509) for views beyond k_view's packing -- the reference's shipped configs crop 400 x 400 cells at
-// 0.015 m and cast 1000 beams of up to 283 steps (envs/cfg/test.yaml) -- and the cv2.resize INTER_CUBIC of the result down to
-// image_size (yaml_env.py:431-438).  One workgroup of 256 threads per robot:
-//   LDS: src2[NC / 4]   the cropped view at 2 bits a cell (0 occupied, 1 free, 2 unknown): 40 KB for 400 x 400
-//        hit_k[B + 1], hit_c[B + 1]   first hit of each beam (step, view cell); entry B is the dummy beam of cells no beam crosses
-//   (1) collision as in k_view (the (cell, last sample) list of k_raster);  (2) crop: the reference's fp64 chain per cell, four
-//   cells (one LDS byte) per thread;  (3) one beam per thread walks its path (32-bit cell table, one coalesced load per step for
-//   64 consecutive beams) to its first occupied cell, the hit distance comes from the two cells as in bresenhamLine;  (4) every
-//   cell takes the verdict of the highest beam through it, falling back on the per-cell ray list where that beam leaves the cell
-//   alone (agent.cpp:555-560), then the own footprint; view_maps (and sensor_maps when nothing is resized) are written;
-//   (5) the workgroup reads its own view back and shrinks it: OpenCV's fixed-point bicubic (csrc/cv_resize.h), one output
-//   pixel per thread and round.
-// This kernel is about running the shipped geometry at all, bit for bit; it has not been tuned.
-#define VB_T 256
-template <bool POW2, bool STAMP>
-__global__ __launch_bounds__(VB_T) void k_view_big(DevWorld w) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t best_sh;
-    const int tid = threadIdx.x;
-    const int l = act_member(w, w.Rw, blockIdx.x);
-    if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value
-        if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, w.is_coll[l]);
-        return;
-    }
-    const int i = w.r0 + l;
-    const RobotClassDev& k = w.rc_mem[w.robot_cls[i]];
-    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
-    const Tf2 vw = tf_mul(bw, w.view_base);
-    const int Hv = w.Hv, Wv = w.Wv, NC = Hv * Wv, B = w.B;
-    const int Hg = w.Hg, Wg = w.Wg;
-    const double res = w.res, inv = w.inv_res;
-    const uint32_t self = (uint32_t)i;
-    const size_t cell0 = (size_t)world_of_robot(w, i) * w.Gs;
-    uint8_t* src2 = smem;
-    uint32_t* hit_k = (uint32_t*)(smem + (((size_t)(NC + 3) / 4 + 15) & ~(size_t)15));
-    uint32_t* hit_c = hit_k + (B + 1);
-    if (tid == 0) best_sh = 0;
-    __syncthreads();
-    // (1) collision: the last footprint sample on an occupied cell decides (agent.cpp:294-326)
-    {
-        uint32_t best = 0;
-        const int n_cov = w.fp_n[l];
-        if (n_cov >= 0) {
-            const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
-            for (int e = tid; e < n_cov; e += VB_T) {
-                const uint2 ce = list[e];
-                const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, w.stamp_tag);
-                best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
-            }
-        } else {
-            for (int q = tid; q < k.n_fp; q += VB_T) {
-                const double2 fp = k.fp[q];
-                double wx, wy;
-                tf_apply(bw, fp.x, fp.y, wx, wy);
-                int m, n;
-                w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                if (m >= 0 && m < Hg && n >= 0 && n < Wg) {
-                    const uint32_t cc = cell_seen_class<STAMP>(w.cell[cell0 + (size_t)m * Wg + n], self, w.stamp_tag);
-                    if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
-                }
-            }
-        }
-        if (best) atomicMax(&best_sh, best);
-    }
-    // (2) egocentric crop (agent.cpp:373-404)
-    for (int c4 = tid * 4; c4 < NC; c4 += VB_T * 4) {
-        uint32_t byte = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = c4 + q;
-            uint32_t code = 2u;  // 200: outside the field of view / the map (or past the end of the view)
-            if (c < NC && ((k.fov_bits[c >> 5] >> (c & 31)) & 1u)) {
-                const int a = c / Wv, b = c - a * Wv;
-                const double x = a * res, y = b * res;
-                const double wx = (vw.m00 * x + vw.m01 * y) + vw.ox, wy = (vw.m10 * x + vw.m11 * y) + vw.oy;
-                int m, n;
-                w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                if (m >= 0 && m < Hg && n >= 0 && n < Wg)  // < 250 -> 0, else 255 (agent.cpp:394-401)
-                    code = cell_seen_class<STAMP>(w.cell[cell0 + (size_t)m * Wg + n], self, w.stamp_tag) == CLS_HIGH ? 1u : 0u;
-            }
-            byte |= code << (2 * q);
-        }
-        src2[c4 >> 2] = (uint8_t)byte;
-    }
-    __syncthreads();
-    const int code = (int)(best_sh & 3u);
-    // (3) laser (agent.cpp:405-438, 511-624)
-    const bool laser = w.use_laser != 0;
-    if (laser) {
-        const double x0w = k.sensor_x * res, y0w = k.sensor_y * res;  // map2world of the start cell
-        for (int b = tid; b < B; b += VB_T) {
-            const int len = k.ray_len[b];
-            uint32_t hk = 0xFFFFFFFFu, hc = 0xFFFFFFFFu;
-            for (int kk = 0; kk < len; kk++) {
-                const uint32_t c = k.big_cells[(size_t)kk * k.ray_stride + b];
-                if (((src2[c >> 2] >> (2 * (c & 3u))) & 3u) == 0u) {
-                    hk = (uint32_t)kk;
-                    hc = c;
-                    break;
-                }
-            }
-            float hd = 6.0f;  // agent.cpp:513
-            if (hk != 0xFFFFFFFFu) {
-                const int hx = (int)(hc / (uint32_t)Wv), hy = (int)(hc - (uint32_t)hx * (uint32_t)Wv);
-                const double cx = hx * res, cy = hy * res;
-                hd = (float)sqrt((x0w - cx) * (x0w - cx) + (y0w - cy) * (y0w - cy));
-            }
-            hit_k[b] = hk;
-            hit_c[b] = hc;
-            w.lasers_raw[(size_t)l * B + b] = hd;
-            w.lasers[(size_t)l * B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
-        }
-        if (tid == 0) {  // the dummy beam: "hit" at step 0 in a cell no cell shares a row or column with
-            hit_k[B] = 0u;
-            hit_c[B] = 0xFFFFFFFFu;
-        }
-    }
-    __syncthreads();
-    // (4) laser_map per cell + own footprint (agent.cpp:419-437, 503)
-    uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
-    uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;  // only when nothing is resized
-    for (int c = tid; c < NC; c += VB_T) {
-        uint32_t v;  // 0 / 255 / 200
-        if (laser) {
-            const uint32_t cx = (uint32_t)c / (uint32_t)Wv, cy = (uint32_t)c - cx * (uint32_t)Wv;
-            const uint32_t pk = k.inv_pack[c], e0 = pk & 0xFFFFFu, cnt = pk >> 20;
-            v = 200u;  // no beam writes the cell: laser_map keeps its initial 200
-            for (uint32_t e = 0; e < cnt; e++) {  // beams through the cell, highest first: the last writer wins
-                const uint32_t ent = k.inv_ent[e0 + e];
-                const uint32_t kk = ent & 0xFFFFu, hk = hit_k[ent >> 16];
-                if (kk < hk) {
-                    v = 255u;
-                    break;
-                }
-                if (kk == hk) {
-                    v = 0u;
-                    break;
-                }
-                const uint32_t hc = hit_c[ent >> 16];
-                const uint32_t hx = hc / (uint32_t)Wv, hy = hc - hx * (uint32_t)Wv;
-                if (cx != hx && cy != hy) break;  // behind the hit, in another row and column: 200; else left alone
-            }
-        } else {
-            const uint32_t cd = (src2[c >> 2] >> (2 * (c & 3))) & 3u;
-            v = cd == 1u ? 255u : (cd == 0u ? 0u : 200u);
-        }
-        if (((k.stamp_bits[c >> 5] >> (c & 31)) & 1u) && v != 0u) v = 100u;  // draw(view_map_, 100) skips 0 / 1 / 2
-        out_u8[c] = (uint8_t)v;
-        if (!w.resize) out_f16[c] = w.f16_lut[v];
-    }
-    if (tid == 0) w.is_coll[l] = code;
-    if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, code);
-    if (!w.resize) return;
-    // (5) cv2.resize(view, image_size, INTER_CUBIC).astype(float16) / 255 (yaml_env.py:431-438)
-    __threadfence_block();
-    __syncthreads();
-    const int IW = w.img_w, IH = w.img_h, vec_end = (IW / 8) * 8;
-    uint16_t* img = w.sensor_maps + (size_t)l * IW * IH;
-    for (int p = tid; p < IW * IH; p += VB_T) {
-        const int dy = p / IW, dx = p - dy * IW;
-        const short* al = w.rs_alpha + 4 * dx;
-        const short* be = w.rs_beta + 4 * dy;
-        const int sx = w.rs_xofs[dx], sy = w.rs_yofs[dy];
-        int s[4];
-#pragma unroll
-        for (int kr = 0; kr < 4; kr++) {  // HResizeCubic of the four source rows, replicated borders
-            const uint8_t* S = out_u8 + (size_t)min(max(sy - 1 + kr, 0), Hv - 1) * Wv;
-            int acc = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc += (int)S[min(max(sx - 1 + j, 0), Wv - 1)] * (int)al[j];
-            s[kr] = acc;
-        }
-        int o;
-        if (dx < vec_end) {  // VResizeCubicVec_32s8u: float32, separately rounded multiply and add, nearest-even
-            const float scale = 1.f / (2048 * 2048);
-            float t = (float)s[3] * ((float)be[3] * scale);
-            t = (float)s[2] * ((float)be[2] * scale) + t;
-            t = (float)s[1] * ((float)be[1] * scale) + t;
-            t = (float)s[0] * ((float)be[0] * scale) + t;
-            o = (int)rintf(t);
-        } else {             // VResizeCubic tail: FixedPtCast<int, uchar, 22>
-            o = (s[0] * be[0] + s[1] * be[1] + s[2] * be[2] + s[3] * be[3] + (1 << 21)) >> 22;
-        }
-        img[p] = w.f16_lut[min(max(o, 0), 255)];
-    }
-}
+#include "view_big.h"  // views beyond k_view's packing or shrunk by cv2.resize: k_crop_big, k_beams_big, k_fullview_big
 
 // ------------------------------------------------------------------------------------------------
 // Observation + reward / done for local robot l = blockIdx.x, one wavefront.

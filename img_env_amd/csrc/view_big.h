@@ -1,0 +1,356 @@
+// view_big.h -- Agent::view (agent.cpp:356-509) for views beyond k_view's 16 / 8-bit packing, and for views that
+// cv2.resize INTER_CUBIC shrinks (yaml_env.py:431-438).  Every shipped config of the reference is one: 400 x 400 cells of
+// 0.015 m, 1000 beams of up to 283 steps, a 48 x 48 sensor_map (envs/cfg/test.yaml:54, 126-132).
+//
+// A view of 160 000 cells is far too much for one wavefront, and a launch of a few hundred robots (one robot per env,
+// a few hundred envs) has to fill 256 compute units, so the work of ONE robot is spread over the chip:
+//
+//   k_crop_big     1 wavefront / 8 x 8 tile of view cells inside the field of view (static list per class), any number of
+//                  tiles per robot in flight.  The view -> grid transform of a cell is two fused multiply-adds per axis on the
+//                  cell's integer coordinates (the reference's chain of roundings only matters within 1e-6 of a rounding
+//                  boundary; those lanes redo it literally), one gather of the class layer, and the tile's 64 verdicts leave
+//                  as ONE ballot: the cropped view is a bitmap of 20 KB per robot in HBM instead of 160 KB of bytes.
+//   k_beams_big    1 workgroup of 1024 / robot: collision code; the bitmap into LDS; one beam per thread walks its static path
+//                  (coalesced 32-bit bit addresses, 8 steps in flight) to its first occupied cell -> hit word
+//                  (first-hit step << 16 | last step behind it in the hit cell's row or column, as in k_view) and lasers;
+//                  then, for a shrunk sensor_map, ONLY the 4 x 4 source cells of each of its pixels are evaluated (static
+//                  tap records) and run through OpenCV's fixed-point bicubic -- the full view is never written unless asked for.
+//   k_fullview_big 1 thread / 4 cells, only when the full view is an output (imgenv_out.view_maps, or a big view that is not
+//                  shrunk): laser_map + own footprint of every cell from the hit words.
+//
+// laser_map semantics as in k_view: a cell ends with the verdict of the HIGHEST beam through it that writes it (static
+// top entry per cell; where that beam leaves the cell alone, agent.cpp:555-560, the cell's static ray list is walked).  A cell
+// under the own footprint becomes 100 unless it is 0 (agent.cpp:307-312), and it can only be 0 if the crop found it
+// occupied: such cells skip the beams altogether, which also keeps the walks away from the long ray lists around the sensor.
+#pragma once
+
+#define VBC_T 256    // k_crop_big: 4 wavefronts
+#define VBC_TPW 8    // tiles per wavefront
+#define VBC_U 4      // tiles a wavefront keeps in flight
+#define VBB_T 1024   // k_beams_big
+#define VBF_T 256    // k_fullview_big
+
+// ------------------------------------------------------------------------------------------------
+// (2) egocentric crop (agent.cpp:373-404), tiled
+template <bool STAMP>
+__global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks) {
+    const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
+    const int l = act_member(w, w.Rw, t);
+    if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: the view keeps its last value (agent.cpp:358-360)
+    const int i = w.r0 + l;
+    const BigClassDev& k = w.big_mem[w.robot_cls[i]];
+    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
+    const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
+    const double res = w.res;
+    // cell index = round(((m00 (a res) + m01 (b res)) + ox) / res): in cells that is m00 a + m01 b + ox / res up to a few ulps
+    const double oxs = vw.ox * w.inv_res, oys = vw.oy * w.inv_res;
+    const int Hg = w.Hg, Wg = w.Wg;
+    const uint32_t self = (uint32_t)i, tag = STAMP ? w.stamp_tag : 0u;
+    const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
+                                    : (CLS_HIGH | CLS_ROBOT | (self << 8));
+    const uint32_t base_tag_mask = 7u | (0xFFu << STAMP_TAG_SHIFT), base_tag_ours = CLS_HIGH | (tag << STAMP_TAG_SHIFT);
+    const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int da = lane >> 3, db = lane & 7;
+    unsigned long long* plane0 = (unsigned long long*)(w.big_bits + (size_t)l * 2 * w.big_words);
+    unsigned long long* plane1 = (unsigned long long*)(w.big_bits + ((size_t)l * 2 + 1) * w.big_words);
+    const bool want_unknown = w.use_laser == 0;  // with the laser on only "occupied or not" survives into the outputs
+    const int n_crop = k.n_crop, tb_n = k.tb;
+    const int first = chunk * ((VBC_T / WAVE) * VBC_TPW);
+    for (int it = 0; it < VBC_TPW; it += VBC_U) {
+        if (first + it * (VBC_T / WAVE) + wave >= n_crop) break;  // uniform
+        uint32_t idx[VBC_U], tile_w[VBC_U];
+        bool look[VBC_U], risky = false;
+        int a_[VBC_U], b_[VBC_U];
+#pragma unroll
+        for (int u = 0; u < VBC_U; u++) {
+            const int ti = first + (it + u) * (VBC_T / WAVE) + wave;  // consecutive wavefronts take consecutive tiles
+            const bool valid = ti < n_crop;
+            const uint32_t tile = k.crop_tiles[valid ? ti : 0];
+            const unsigned long long mask = valid ? k.crop_masks[ti] : 0ull;
+            const int a = (int)(tile >> 16) * 8 + da, b = (int)(tile & 0xFFFFu) * 8 + db;
+            tile_w[u] = valid ? (tile >> 16) * (uint32_t)tb_n + (tile & 0xFFFFu) : 0xFFFFFFFFu;
+            const double fa = (double)a, fb = (double)b;
+            const double tx = __fma_rn(vw.m00, fa, __fma_rn(vw.m01, fb, oxs)), ty = __fma_rn(vw.m10, fa, __fma_rn(vw.m11, fb, oys));
+            const double rx = rint(tx), ry = rint(ty);
+            const bool fov = ((mask >> lane) & 1ull) != 0ull;
+            risky |= fov & ((fabs(tx - rx) > 0.499999) | (fabs(ty - ry) > 0.499999));
+            a_[u] = a;
+            b_[u] = b;
+            const int m = (int)rx, n = (int)ry;
+            look[u] = fov & ((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg);
+            idx[u] = look[u] ? cell0 + (uint32_t)(m * Wg + n) : cell0;
+        }
+        if (__builtin_expect(__any(risky), 0)) {  // somebody within 1e-6 of a rounding boundary: the reference's own chain
+#pragma unroll
+            for (int u = 0; u < VBC_U; u++) {
+                const int ti = first + (it + u) * (VBC_T / WAVE) + wave;
+                const bool fov = ti < n_crop && ((k.crop_masks[ti < n_crop ? ti : 0] >> lane) & 1ull) != 0ull;
+                double wx, wy;
+                tf_apply(vw, a_[u] * res, b_[u] * res, wx, wy);
+                const int m = w2m(wx, res), n = w2m(wy, res);
+                look[u] = fov & ((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg);
+                idx[u] = look[u] ? cell0 + (uint32_t)(m * Wg + n) : cell0;
+            }
+        }
+        uint32_t v[VBC_U];
+#pragma unroll
+        for (int u = 0; u < VBC_U; u++) v[u] = w.cell[idx[u]];
+#pragma unroll
+        for (int u = 0; u < VBC_U; u++) {
+            // free = >= 250 in this robot's private grid (agent.cpp:394-401): class HIGH with nobody else's stamp on it
+            bool free_cell;
+            if (STAMP) {
+                const uint32_t x = (v[u] & base_tag_mask) ^ base_tag_ours;
+                free_cell = (v[u] == free_own) | (((x & 7u) == 0u) & (x != 0u));
+            } else {
+                free_cell = (v[u] == (uint32_t)CLS_HIGH) | (v[u] == free_own);
+            }
+            const unsigned long long occ = __ballot(look[u] & !free_cell);
+            const unsigned long long unk = __ballot(!look[u]);
+            if (lane == 0 && tile_w[u] != 0xFFFFFFFFu) {
+                plane0[tile_w[u]] = occ;
+                if (want_unknown) plane1[tile_w[u]] = unk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// laser_map value of view cell c (agent.cpp:419-437, 555-560) from the beams' hit words: the cell's top beam decides, unless
+// it leaves the cell alone; then the next lower beam through the cell that writes it does (static list, beam descending)
+__device__ __forceinline__ uint32_t big_laser_value(const RobotClassDev& rc, const BigClassDev& k, const uint32_t* hit, uint32_t c, uint32_t top) {
+    const uint32_t kk = top & 0xFFFFu, hp = hit[top >> 16], hk = hp >> 16;  // hk = 0xFFFF: the beam never hits
+    if (kk < hk) return 255u;
+    if (kk == hk) return 0u;
+    if (kk > (hp & 0xFFFFu)) return 200u;
+    const uint2 pk = k.inv[c];
+    for (uint32_t e = 1; e < pk.y; e += 4) {  // entry 0 is the top beam; four entries in flight
+        uint32_t ent[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) ent[q] = rc.inv_ent[pk.x + min(e + (uint32_t)q, pk.y - 1u)];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (e + (uint32_t)q >= pk.y) break;
+            const uint32_t k2 = ent[q] & 0xFFFFu, h2 = hit[ent[q] >> 16], hk2 = h2 >> 16;
+            if (k2 < hk2) return 255u;
+            if (k2 == hk2) return 0u;
+            if (k2 > (h2 & 0xFFFFu)) return 200u;
+        }
+    }
+    return 200u;  // nobody writes the cell: laser_map keeps its initial 200
+}
+
+// view_map value (0 / 100 / 200 / 255) of a cell: bits = the robot's crop bitmap (plane 0 occupied, plane 1 unknown, `words`
+// 32-bit words apart), addr = the cell's bit address, st = the own footprint covers it
+__device__ __forceinline__ uint32_t big_cell_value(const RobotClassDev& rc, const BigClassDev& k, const uint32_t* hit, const uint32_t* plane0,
+                                                   const uint32_t* plane1, bool laser, uint32_t c, uint32_t top, uint32_t addr, bool st) {
+    const bool occ = ((plane0[addr >> 5] >> (addr & 31u)) & 1u) != 0u;
+    uint32_t v;
+    if (!laser) {
+        const bool unk = ((plane1[addr >> 5] >> (addr & 31u)) & 1u) != 0u;
+        v = occ ? 0u : (unk ? 200u : 255u);
+    } else if (st && !occ) {
+        return 100u;  // a beam can only write 0 where the crop is occupied
+    } else {
+        v = big_laser_value(rc, k, hit, c, top);
+    }
+    return (st && v != 0u) ? 100u : v;  // draw(view_map_, 100) skips 0 / 1 / 2 (agent.cpp:307-312)
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1) collision, (3) laser, and the shrunk sensor_map.  LDS: hit[B + 2] | the occupied plane of the crop (LDSBM)
+template <bool POW2, bool STAMP, bool LDSBM>
+__global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t best_sh;
+    const int tid = threadIdx.x;
+    const int l = act_member(w, w.Rw, blockIdx.x);
+    const int B = w.B;
+    uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
+    if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value
+        if (tid == 0) hit_g[B + 1] = 0u;
+        if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, w.is_coll[l]);
+        return;
+    }
+    const int i = w.r0 + l;
+    const int cls = w.robot_cls[i];
+    const RobotClassDev& rc = w.rc_mem[cls];
+    const BigClassDev& k = w.big_mem[cls];
+    const uint32_t self = (uint32_t)i;
+    uint32_t* hit = (uint32_t*)smem;
+    uint32_t* bm = hit + ((B + 2 + 3) & ~3);
+    const uint32_t* plane0_g = w.big_bits + (size_t)l * 2 * w.big_words;
+    const uint32_t* plane1_g = plane0_g + w.big_words;
+    if (tid == 0) best_sh = 0;
+    __syncthreads();
+    // (1) collision: the last footprint sample on an occupied cell decides (agent.cpp:294-326)
+    {
+        uint32_t best = 0;
+        const int n_cov = w.fp_n[l];
+        if (n_cov >= 0) {
+            const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
+            for (int e = tid; e < n_cov; e += VBB_T) {
+                const uint2 ce = list[e];
+                const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, w.stamp_tag);
+                best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
+            }
+        } else {
+            const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+            const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
+            const size_t cell0 = (size_t)world_of_robot(w, i) * w.Gs;
+            for (int q = tid; q < rc.n_fp; q += VBB_T) {
+                const double2 fp = rc.fp[q];
+                double wx, wy;
+                tf_apply(bw, fp.x, fp.y, wx, wy);
+                int m, n;
+                w2m_pair<POW2>(wx, wy, w.res, w.inv_res, m, n);
+                if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+                    const uint32_t cc = cell_seen_class<STAMP>(w.cell[cell0 + (size_t)m * w.Wg + n], self, w.stamp_tag);
+                    if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
+                }
+            }
+        }
+        if (best) atomicMax(&best_sh, best);
+    }
+    if (LDSBM) {
+        const uint4* src = (const uint4*)plane0_g;
+        for (int q = tid; q < w.big_words / 4; q += VBB_T) ((uint4*)bm)[q] = src[q];
+    }
+    __syncthreads();
+    const int code = (int)(best_sh & 3u);
+    // the collision code is all the step's tail needs from the view: hand it over now (see k_view)
+    if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, code);
+    const uint32_t* plane0 = LDSBM ? (const uint32_t*)bm : plane0_g;
+    // (3) laser (agent.cpp:405-438, 511-624): first occupied cell on each beam's precomputed path
+    const bool laser = w.use_laser != 0;
+    if (laser) {
+        const int stride = rc.ray_stride, kpad = rc.ray_kpad;
+        for (int b0 = 0; b0 < B; b0 += VBB_T) {
+            const int b = b0 + tid, bb = min(b, B - 1);
+            const int len = b < B ? (int)rc.ray_len[bb] : 0;
+            uint32_t hk = 0xFFFFFFFFu;
+            const uint32_t* col = k.cells + bb;
+            for (int k0 = 0; k0 < kpad; k0 += 8) {
+                uint32_t addr[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) addr[j] = col[(size_t)(k0 + j) * stride];  // padded rows point at the free bit
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) m |= ((plane0[addr[j] >> 5] >> (addr[j] & 31u)) & 1u) << j;
+                if (m != 0u && hk == 0xFFFFFFFFu) hk = (uint32_t)k0 + (uint32_t)__builtin_ctz(m);
+                if (__all((hk != 0xFFFFFFFFu) | (k0 + 8 >= len))) break;
+            }
+            if (b < B) {
+                const bool has = hk != 0xFFFFFFFFu;
+                const size_t at = (size_t)(has ? hk : 0u) * stride + b;
+                const uint32_t end = has ? (uint32_t)k.ray_end[at] : 0u;
+                const float hd = has ? rc.ray_dist[at] : 6.0f;  // agent.cpp:513
+                const uint32_t word = has ? ((hk << 16) | end) : 0xFFFFFFFFu;
+                hit[b] = word;
+                hit_g[b] = word;
+                w.lasers_raw[(size_t)l * B + b] = hd;
+                w.lasers[(size_t)l * B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
+            }
+        }
+    }
+    if (tid == 0) {
+        hit[B] = 0u;  // the dummy beam of cells no beam crosses: "hits" at step 0 and leaves nothing alone -> 200
+        hit_g[B] = 0u;
+        hit_g[B + 1] = 1u;  // this robot's view is being redone (k_fullview_big)
+        w.is_coll[l] = code;
+    }
+    if (!w.resize) return;
+    __syncthreads();
+    // cv2.resize(view, image_size, INTER_CUBIC).astype(float16) / 255 (yaml_env.py:431-438): HResizeCubic of the four
+    // source rows, then the vertical pass (csrc/cv_resize.h), on the 16 view cells each pixel reads
+    const int IW = w.img_w, IH = w.img_h, NP = IW * IH, vec_end = (IW / 8) * 8;
+    uint16_t* img = w.sensor_maps + (size_t)l * NP;
+    for (int p = tid; p < NP; p += VBB_T) {
+        const int dy = p / IW, dx = p - dy * IW;
+        const short* al = w.rs_alpha + 4 * dx;
+        const short* be = w.rs_beta + 4 * dy;
+        int s[4];
+#pragma unroll
+        for (int kr = 0; kr < 4; kr++) {
+            uint4 rec[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) rec[j] = k.taps[(size_t)(kr * 4 + j) * NP + p];
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc += (int)big_cell_value(rc, k, hit, plane0, plane1_g, laser, rec[j].x & 0x7FFFFFFFu, rec[j].y, rec[j].z, (rec[j].x >> 31) != 0u) * (int)al[j];
+            s[kr] = acc;
+        }
+        int o;
+        if (dx < vec_end) {  // VResizeCubicVec_32s8u: float32, separately rounded multiply and add, nearest-even
+            const float scale = 1.f / (2048 * 2048);
+            float t = (float)s[3] * ((float)be[3] * scale);
+            t = (float)s[2] * ((float)be[2] * scale) + t;
+            t = (float)s[1] * ((float)be[1] * scale) + t;
+            t = (float)s[0] * ((float)be[0] * scale) + t;
+            o = (int)rintf(t);
+        } else {             // VResizeCubic tail: FixedPtCast<int, uchar, 22>
+            o = (s[0] * be[0] + s[1] * be[1] + s[2] * be[2] + s[3] * be[3] + (1 << 21)) >> 22;
+        }
+        img[p] = w.f16_lut[min(max(o, 0), 255)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (4) the full view: laser_map per cell + own footprint (agent.cpp:419-437, 503), 4 cells per thread; view_maps when it is
+// an output, sensor_maps (float16) when nothing is shrunk
+__global__ __launch_bounds__(VBF_T) void k_fullview_big(DevWorld w, int chunks) {
+    const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
+    const int l = act_member(w, w.Rw, t);
+    const int B = w.B;
+    const uint32_t* hit = w.big_hit + (size_t)l * w.big_hit_stride;
+    if (hit[B + 1] == 0u) return;  // frozen
+    const int NC = w.Hv * w.Wv, c4 = (chunk * VBF_T + (int)threadIdx.x) * 4;
+    if (c4 >= NC) return;
+    const int cls = w.robot_cls[w.r0 + l];
+    const RobotClassDev& rc = w.rc_mem[cls];
+    const BigClassDev& k = w.big_mem[cls];
+    const uint32_t* plane0 = w.big_bits + (size_t)l * 2 * w.big_words;
+    const uint32_t* plane1 = plane0 + w.big_words;
+    const bool laser = w.use_laser != 0;
+    const uint32_t Wv = (uint32_t)w.Wv, tb_n = (uint32_t)k.tb;
+    const uint32_t stamp = (rc.stamp_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;
+    uint32_t top[4] = {0u, 0u, 0u, 0u};
+    if (laser) {
+        if (c4 + 4 <= NC) {
+            const uint4 t4 = *(const uint4*)(rc.top_ent + c4);
+            top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
+        } else {
+            for (int q = 0; q < 4 && c4 + q < NC; q++) top[q] = rc.top_ent[c4 + q];
+        }
+    }
+    uint32_t val[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t c = (uint32_t)min(c4 + q, NC - 1);
+        const bool st = ((stamp >> q) & 1u) != 0u;
+        uint32_t addr = 0;
+        if (!laser || st) {  // the crop bit itself is only needed without the laser or under the own footprint
+            const uint32_t a = c / Wv, b = c - a * Wv;
+            addr = ((a >> 3) * tb_n + (b >> 3)) * 64u + (a & 7u) * 8u + (b & 7u);
+        }
+        val[q] = (laser && !st) ? big_laser_value(rc, k, hit, c, top[q]) : big_cell_value(rc, k, hit, plane0, plane1, laser, c, top[q], addr, st);
+    }
+    uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
+    uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;  // only when nothing is shrunk
+    const bool vec = (NC & 3) == 0;  // then every robot's rows start on a 4-cell boundary
+    if (w.keep_view_maps) {
+        if (vec) *(uint32_t*)(out_u8 + c4) = val[0] | (val[1] << 8) | (val[2] << 16) | (val[3] << 24);
+        else for (int q = 0; q < 4 && c4 + q < NC; q++) out_u8[c4 + q] = (uint8_t)val[q];
+    }
+    if (!w.resize) {
+        const uint32_t f0 = w.f16_lut[val[0]], f1 = w.f16_lut[val[1]], f2 = w.f16_lut[val[2]], f3 = w.f16_lut[val[3]];
+        if (vec) *(uint2*)(out_f16 + c4) = make_uint2(f0 | (f1 << 16), f2 | (f3 << 16));
+        else {
+            const uint32_t f[4] = {f0, f1, f2, f3};
+            for (int q = 0; q < 4 && c4 + q < NC; q++) out_f16[c4 + q] = (uint16_t)f[q];
+        }
+    }
+}

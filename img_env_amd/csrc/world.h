@@ -58,9 +58,21 @@ struct RobotClassDev {
     const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or B << 16 | 0xFFFF
     const uint2* inv_cell;       // [Hv*Wv] k_view's step (5): {block of the reach table | none << 13 | own footprint << 14 | smallest step << 24, inv_pack}
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
-    // views beyond k_view's 16 / 8-bit packing (the shipped configs: 400 x 400 cells, 1000 beams): k_view_big
-    int big, sensor_x, sensor_y; // the laser's view cell
-    const uint32_t* big_cells;   // [ray_maxlen][ray_stride] view cell of step k of beam b, 0xFFFFFFFF past the ray's end
+    int big;                     // views beyond k_view's 16 / 8-bit packing, or shrunk by cv2.resize (the shipped configs: 400 x
+                                 // 400 cells, 1000 beams): the kernels of view_big.h and the tables of BigClassDev
+};
+
+// A robot class whose view goes through view_big.h.  The cropped view is a bitmap in 8 x 8 tiles (one wavefront crops one tile
+// and stores its ballot): bit address of view cell (a, b) = ((a / 8) * tb + b / 8) * 64 + (a % 8) * 8 + b % 8.
+struct BigClassDev {
+    int ta, tb;                  // tiles per column / row
+    int n_crop;                  // tiles that touch the field of view
+    const uint32_t* crop_tiles;  // [n_crop] ta << 16 | tb
+    const uint64_t* crop_masks;  // [n_crop] the tile's cells inside the field of view
+    const uint32_t* cells;       // [ray_kpad][ray_stride] bit address of step k of beam b (past the end: the free bit behind the bitmap)
+    const uint16_t* ray_end;     // [ray_maxlen][ray_stride] last step behind (k, b) in the row or column of its cell
+    const uint2* inv;            // [Hv*Wv] rays through a view cell: {first entry of inv_ent, count}
+    const uint4* taps;           // [16][img_h*img_w] source cells of the shrunk sensor_map (host_tables.h build_big_taps)
 };
 
 struct PedClassDev {
@@ -126,6 +138,13 @@ struct DevWorld {
     PedClassDev pc[PC_INLINE];
     const PedClassDev* pc_mem;  // the same records in HBM, for per-lane (divergent) class lookups
     const RobotClassDev* rc_mem;
+    // big views (view_big.h): class tables, and per local robot the cropped view as a tiled bitmap (plane 0: occupied, plane 1:
+    // outside the map / the field of view; big_words 32-bit words each, the last ones stay zero) and the beams' hit words
+    const BigClassDev* big_mem;
+    uint32_t* big_bits;          // [RL][2][big_words]
+    uint32_t* big_hit;           // [RL][big_hit_stride]: B hit words | the dummy beam | 1 = the view was redone by this chain of launches
+    int big_words, big_hit_stride, big_bits_in_lds;
+    int keep_view_maps;          // view_maps (the full-size view) is an output; otherwise a shrunk view is never materialised
     const int* robot_cls;  // [R]
     const int* ped_cls;    // [P]
     const double* robot_size_last;  // [R]

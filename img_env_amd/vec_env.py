@@ -12,7 +12,7 @@ Robots are numbered env-major: env k owns rows ``[k * robot_total, (k + 1) * rob
 """
 import numpy as np
 
-from . import config, spawn
+from . import _cabi, config, spawn
 from .envs import ContinuousAction, ImageState
 
 _PER_AGENT = ("robot_shape", "robot_size", "robot_sensor_cfg", "robot_size_last", "ped_shape", "ped_size", "ped_max_speed")
@@ -54,6 +54,10 @@ class VecImageEnv:
         self._spawn_seed = (0x9E3779B97F4A7C15 * (1 + (seed or 0))) & 0xFFFFFFFFFFFFFFFF
         self._episodes = 0
         self._extent = max(self.grid.shape) * float(cfg["global_map"]["resolution"])
+        if not cfg.get("keep_view_maps", False):
+            # ImageState has no full-size view: where the view is shrunk into the sensor_map (the shipped 400 x 400 -> 48 x 48)
+            # the library then only evaluates the view cells the shrink reads (IMGENV_FLAG_NO_VIEW_MAPS)
+            self.params["flags"] = int(self.params.get("flags", 0)) | _cabi.FLAG_NO_VIEW_MAPS
         self.world = World(stack_params(self.params, self.env_num), self.grid, device=cfg.get("device", 0))
         self._all_down = self.world.out["step_all_down"].view(torch.bool) if native_spawn else None
 

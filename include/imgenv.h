@@ -159,6 +159,11 @@ typedef struct imgenv_cfg {
  * their step, nothing per cell, best for big or many maps with few agents each.  The result is the same either way. */
 #define IMGENV_FLAG_COMPOSE_DENSE 2
 #define IMGENV_FLAG_COMPOSE_SPARSE 4
+/* imgenv_out.view_maps is not wanted.  It only matters where the view is shrunk into the sensor_map (image_size differs from
+ * the view size, every shipped config of the reference: a 400 x 400 view, 160 KB per robot, behind a 48 x 48 sensor_map):
+ * the library then evaluates only the 4 x 4 view cells each sensor_map pixel reads and never writes the full-size view;
+ * view_maps keeps whatever it held.  ImageState (envs/state/state.py:4-28) has no such field, so img_env_amd's envs set it. */
+#define IMGENV_FLAG_NO_VIEW_MAPS 8
 
 /* ResetEnv.srv:1-6 (img_env.cpp:162-292).  Poses are (x, y, qz, qw): geometry_msgs/Pose with a
  * planar orientation; yaw is recovered with tf::Matrix3x3(q).getRPY as the node does. */
@@ -375,7 +380,9 @@ int imgenv_step_launches(imgenv_t* h);
 #define IMGENV_K_VIEW 5
 #define IMGENV_K_OBS 6
 #define IMGENV_K_TAIL 7
-#define IMGENV_K_COUNT 8
+#define IMGENV_K_CROP 8      /* big views (csrc/view_big.h): k_crop_big; IMGENV_K_VIEW is then k_beams_big */
+#define IMGENV_K_FULLVIEW 9  /* k_fullview_big */
+#define IMGENV_K_COUNT 10
 int imgenv_timing(imgenv_t* h, int mode, int which);
 /* synchronises the recorded events and returns accumulated milliseconds / launch counts per kernel
  * id since the last imgenv_timing() call; arrays of IMGENV_K_COUNT entries */

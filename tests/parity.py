@@ -36,18 +36,18 @@ def compare(g, c, fields=EXACT + CLOSE):
     return bad
 
 
-def run_pair(gpu, cpu, layout, actions_seq, verbose=False):
+def run_pair(gpu, cpu, layout, actions_seq, verbose=False, fields=EXACT + CLOSE):
     """reset + step both worlds; returns list of (step, {field: why})"""
     gpu.reset(layout)
     cpu.reset(layout)
     fails = []
-    b = compare(gpu.snapshot(), cpu.snapshot())
+    b = compare(gpu.snapshot(), cpu.snapshot(), fields)
     if b:
         fails.append((-1, b))
     for s, a in enumerate(actions_seq):
         gpu.step(a)
         cpu.step(a)
-        b = compare(gpu.snapshot(), cpu.snapshot())
+        b = compare(gpu.snapshot(), cpu.snapshot(), fields)
         if b:
             fails.append((s, b))
             if verbose:

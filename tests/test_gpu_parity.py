@@ -105,12 +105,15 @@ RESAMPLED = {
 }
 
 
+@pytest.mark.parametrize("view_maps", [True, False], ids=["full_view", "no_view_maps"])
 @pytest.mark.parametrize("case", list(RESAMPLED))
-def test_resampled_maps_and_large_views_match_oracle(worlds, case):
+def test_resampled_maps_and_large_views_match_oracle(worlds, case, view_maps):
     """SURVEY f2: cv::resize INTER_LINEAR at map load (grid_map.cpp:28-38), views of up to 400 x 400 cells, and the
-    cv2.resize INTER_CUBIC shrink of the sensor_map (yaml_env.py:431-438) -- k_view_big and the host resize against the oracle"""
+    cv2.resize INTER_CUBIC shrink of the sensor_map (yaml_env.py:431-438) -- the kernels of csrc/view_big.h and the host
+    resize against the oracle; once with the full-size view as an output, once without (IMGENV_FLAG_NO_VIEW_MAPS: only the
+    view cells the shrink reads are evaluated)"""
     World, OracleWorld = worlds
-    from img_env_amd import worldgen
+    from img_env_amd import _cabi, worldgen
     kw = dict(RESAMPLED[case])
     n, P, steps = kw.pop("n_robots"), kw.pop("n_peds"), kw.pop("steps")
     src = _room_map(kw.pop("map_px"), kw["seed"])
@@ -119,13 +122,17 @@ def test_resampled_maps_and_large_views_match_oracle(worlds, case):
     params = worldgen.make_params(n, P, res=res, view_cells=1, **kw)
     params.update(global_resolution=gres, view_width=view_m, view_height=view_m, image_size=(image, image))
     layout = worldgen.make_layout(src, gres, n, P, seed=seed, n_obstacles=n_obs, clearance=clearance)
-    gpu, cpu = World(params, src), OracleWorld(params, src)
+    gpu = World(dict(params, flags=int(params.get("flags", 0)) | (0 if view_maps else _cabi.FLAG_NO_VIEW_MAPS)), src)
+    cpu = OracleWorld(params, src)
     try:
         o = cpu.out
         assert o["sensor_maps"].shape == (n, image, image) and o["view_maps"].shape[1] == int(float(np.float32(view_m)) / float(np.float32(res)))  # agent.cpp:81-83, doubles
         rng = np.random.default_rng(seed)
-        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(steps)])
+        fields = tuple(f for f in EXACT + CLOSE if view_maps or f != "view_maps")
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(steps)], fields=fields)
         assert not fails, fails[:3]
+        if not view_maps and image * image != o["view_maps"][0].size:
+            assert not gpu.snapshot()["view_maps"].any()  # never written
         sm = cpu.snapshot()["sensor_maps"].astype(np.float32)
         assert sm.min() >= 0.0 and sm.max() <= 1.0 and len(np.unique(sm)) > 3  # the shrink really interpolated
     finally:
