@@ -248,7 +248,7 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
            "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_cv_resize_u8")
-K_COUNT = 10
+K_COUNT = 11
 
 
 def library_path():

@@ -95,12 +95,12 @@ struct RobotClassHost {
     // big views (csrc/view_big.h).  The cropped view lives as a bitmap in 8 x 8 tiles: bit address of view cell (a, b) =
     // ((a / 8) * big_tb + b / 8) * 64 + (a % 8) * 8 + b % 8, so that one wavefront crops one tile and stores one 64-bit ballot
     int big_ta = 0, big_tb = 0;       // tiles per column / per row
-    std::vector<uint32_t> big_cells;  // [ray_kpad][ray_stride] bit address of step k of beam b; past the ray's end: the always-free bit behind the bitmap
+    std::vector<uint32_t> big_cells;  // [ray_kpad / 4][ray_stride][4] bit address of step k of beam b; past the ray's end: the always-free bit behind the bitmap
     std::vector<uint16_t> ray_end;    // [ray_maxlen][ray_stride] last step behind step k of beam b that shares its row or column (k itself if none)
     std::vector<uint32_t> big_inv;    // [NC][2] rays through a view cell: first entry of inv_ent, count
     std::vector<uint32_t> crop_tiles; // tiles with at least one cell inside the field of view: ta << 16 | tb ...
     std::vector<uint64_t> crop_masks; // ... and their cells inside it (bit = (a % 8) * 8 + b % 8)
-    std::vector<uint32_t> tap_rec;    // [16][image_h * image_w][4] the 4 x 4 source cells of every pixel of the shrunk sensor_map (build_big_taps)
+    std::vector<uint32_t> tap_top, tap_inv, tap_addr;  // [16][image_h * image_w] the 4 x 4 source cells of every pixel of the shrunk sensor_map (build_big_taps)
     std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
     std::vector<uint8_t> ray_run;  // [ray_maxlen][ray_stride] steps behind step k of beam b that share a row or column with it
@@ -194,15 +194,17 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     }
     if (k.ray_maxlen == 0) k.ray_maxlen = 1;
     k.ray_kpad = ((k.ray_maxlen + 7) / 8) * 8;
+    if (force_big || NC + 16 > 0xFFFF || k.ray_maxlen > 255 || Hv > 256 || Wv > 256) k.ray_kpad = ((k.ray_maxlen + 31) / 32) * 32;  // k_beams_big: 32 steps a round
     // k_view packs a view cell into 16 bits and (step, row, col) of a hit into 8 bits each; beyond that the class is "big"
     k.big = force_big || NC + 16 > 0xFFFF || k.ray_maxlen > 255 || Hv > 256 || Wv > 256;
     if (k.ray_maxlen > 0xFFFF || B > 0xFFFF) k.ok = false;  // (beam << 16 | step) entries of the per-cell ray lists
+    if (k.big && B > 0x7FFF) k.ok = false;                   // k_taps_big keeps a flag in bit 31 of a cell's top entry
     std::vector<std::vector<uint32_t>> inv(NC);
     k.big_ta = (Hv + 7) / 8;
     k.big_tb = (Wv + 7) / 8;
     if (k.big) {
         const uint32_t free_bit = (uint32_t)k.big_ta * (uint32_t)k.big_tb * 64u;  // the word behind the bitmap stays zero
-        k.big_cells.assign((size_t)k.ray_kpad * k.ray_stride, free_bit);  // k_beams_big walks 8 steps at a time
+        k.big_cells.assign((size_t)k.ray_kpad * k.ray_stride, free_bit);  // k_beams_big walks 32 steps at a time
         k.ray_rows.assign(8, 0);
         k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
         k.ray_end.assign((size_t)k.ray_maxlen * k.ray_stride, 0);
@@ -269,7 +271,7 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
         for (size_t q = 0; q < cells[b].size(); q++) {
             if (k.big) {
                 const uint32_t a = cells[b][q] / (uint32_t)Wv, bb = cells[b][q] % (uint32_t)Wv;
-                k.big_cells[q * k.ray_stride + b] = ((a >> 3) * (uint32_t)k.big_tb + (bb >> 3)) * 64u + (a & 7u) * 8u + (bb & 7u);
+                k.big_cells[((q / 4) * (size_t)k.ray_stride + b) * 4 + q % 4] = ((a >> 3) * (uint32_t)k.big_tb + (bb >> 3)) * 64u + (a & 7u) * 8u + (bb & 7u);
                 k.ray_dist[q * k.ray_stride + b] = dists[b][q];
             } else {
                 k.ray_rows[((q / 8) * (size_t)k.ray_stride + b) * 8 + (q % 8)] = (uint16_t)cells[b][q];
@@ -333,13 +335,16 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
 }
 
 // cv2.resize(view, image_size, INTER_CUBIC) (yaml_env.py:431-438) reads 4 x 4 view cells per pixel of the sensor_map (no
-// anti-aliasing): k_beams_big evaluates exactly those cells.  One 16-byte record per (tap, pixel), tap-major so that the
-// pixels of a wavefront read consecutive records: view cell | own footprint << 31, the cell's top beam entry, the bit
-// address of the cell in the tiled crop bitmap, 0.  xofs / yofs: source index of tap 1 per destination column / row
+// anti-aliasing): k_taps_big evaluates exactly those cells.  Per (tap, pixel), tap-major so that the pixels of a wavefront
+// read consecutive words: the hot word = the cell's top beam entry | own footprint << 31 (what nearly every tap is decided
+// by), and two cold ones -- the cell's ray list {first entry, count} and its bit address in the tiled crop bitmap -- for the
+// taps a top beam leaves alone or the own footprint covers.  xofs / yofs: source index of tap 1 per destination column / row
 // (csrc/cv_resize.h), borders replicated as OpenCV does.
 static void build_big_taps(RobotClassHost& k, const ViewGeom& g, const std::vector<int>& xofs, const std::vector<int>& yofs) {
     const int IW = (int)xofs.size(), IH = (int)yofs.size(), NP = IW * IH;
-    k.tap_rec.assign((size_t)16 * NP * 4, 0);
+    k.tap_top.assign((size_t)16 * NP, 0);
+    k.tap_inv.assign((size_t)16 * NP * 2, 0);
+    k.tap_addr.assign((size_t)16 * NP, 0);
     for (int dy = 0; dy < IH; dy++)
         for (int dx = 0; dx < IW; dx++)
             for (int kr = 0; kr < 4; kr++)
@@ -347,10 +352,11 @@ static void build_big_taps(RobotClassHost& k, const ViewGeom& g, const std::vect
                     const int a = std::min(std::max(yofs[dy] - 1 + kr, 0), g.Hv - 1), b = std::min(std::max(xofs[dx] - 1 + j, 0), g.Wv - 1);
                     const uint32_t c = (uint32_t)a * (uint32_t)g.Wv + (uint32_t)b;
                     const uint32_t st = (k.stamp_bits[c >> 5] >> (c & 31)) & 1u;
-                    uint32_t* r = &k.tap_rec[((size_t)(kr * 4 + j) * NP + (size_t)dy * IW + dx) * 4];
-                    r[0] = c | (st << 31);
-                    r[1] = k.top_ent[c];
-                    r[2] = (((uint32_t)a >> 3) * (uint32_t)k.big_tb + ((uint32_t)b >> 3)) * 64u + ((uint32_t)a & 7u) * 8u + ((uint32_t)b & 7u);
+                    const size_t at = (size_t)(kr * 4 + j) * NP + (size_t)dy * IW + dx;
+                    k.tap_top[at] = k.top_ent[c] | (st << 31);  // fewer than 32768 beams in a big view
+                    k.tap_inv[2 * at] = k.big_inv[2 * (size_t)c];
+                    k.tap_inv[2 * at + 1] = k.big_inv[2 * (size_t)c + 1];
+                    k.tap_addr[at] = (((uint32_t)a >> 3) * (uint32_t)k.big_tb + ((uint32_t)b >> 3)) * 64u + ((uint32_t)a & 7u) * 8u + ((uint32_t)b & 7u);
                 }
 }
 

@@ -164,7 +164,7 @@ static RcclApi* rccl_api() {
 }
 
 static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster", "k_compose",
-                                                         "k_view", "k_obs", "k_tail", "k_crop_big", "k_fullview_big"};
+                                                         "k_view", "k_obs", "k_tail", "k_crop_big", "k_fullview_big", "k_taps_big"};
 extern "C" const char* imgenv_kernel_name(int id) { return (id >= 0 && id < IMGENV_K_COUNT) ? KERNEL_NAMES[id] : ""; }
 
 static int timing_flush(imgenv* h) {
@@ -262,6 +262,9 @@ struct OutField {
     size_t offset, bytes;
 };
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// LDS of k_taps_big: hit words (+ the dummy beam) | 16 tap values per pixel | list of the taps that need a second look | counter
+static size_t taps_lds_bytes(int B) { return 16 * (size_t)((B + 4) / 4) + 16 * (size_t)VBT_T + 2 * 16 * (size_t)VBT_T + 16; }
+
 
 struct ArenaPlan {
     size_t total = 0;
@@ -714,16 +717,20 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             }
             if (view_resize) {
                 build_big_taps(k, g, ax.ofs, ay.ofs);
-                const uint32_t* p4 = nullptr;
-                TRY(dev_upload(h, &p4, k.tap_rec));
-                o.taps = (const uint4*)p4;
-                std::vector<uint32_t>().swap(k.tap_rec);
+                const uint32_t* p2i = nullptr;
+                TRY(dev_upload(h, &o.tap_top, k.tap_top));
+                TRY(dev_upload(h, &p2i, k.tap_inv));
+                o.tap_inv = (const uint2*)p2i;
+                TRY(dev_upload(h, &o.tap_addr, k.tap_addr));
+                std::vector<uint32_t>().swap(k.tap_top);
+                std::vector<uint32_t>().swap(k.tap_inv);
+                std::vector<uint32_t>().swap(k.tap_addr);
             }
         }
         TRY(dev_upload(h, &d.big_mem, bc));
         const size_t tiles = (size_t)h->rcls[0].big_ta * h->rcls[0].big_tb;
         d.big_words = (int)((tiles * 2 + 1 + 3) & ~(size_t)3);  // + the always-free word the padded path entries point at
-        d.big_hit_stride = (g.B + 2 + 3) & ~3;
+        d.big_hit_stride = (g.B + 3 + 3) & ~3;  // B hit words, the dummy beam, the flag, the collision code
         TRY(dev_alloc(h, &d.big_bits, (size_t)RL * 2 * d.big_words));
         TRY(dev_alloc(h, &d.big_hit, (size_t)RL * d.big_hit_stride));
         // cells no crop tile covers lie outside the field of view for good: "unknown" in plane 1 (read without the laser only)
@@ -935,22 +942,22 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16 + 4 * (2 * (max_stride / 8 + 1) + 4);
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
     h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
-    if (h->big_view) {  // k_beams_big: hit words (+ the dummy beam, + the flag word) | the occupied plane of the crop bitmap
-        const size_t lds_hit = 4 * (size_t)d.big_hit_stride, lds_bits = 4 * (size_t)d.big_words;
-        h->big_bits_in_lds = lds_hit + lds_bits <= 150 * 1024;  // beyond that (views above ~1000 x 1000 cells) the beams read the bitmap from HBM
-        h->lds_view_big = lds_hit + (h->big_bits_in_lds ? lds_bits : 0) + 16;
+    if (h->big_view) {  // k_beams_big: the occupied plane of the crop bitmap; k_taps_big: the hit words
+        const size_t lds_bits = 4 * (size_t)d.big_words;
+        h->big_bits_in_lds = lds_bits <= 150 * 1024;  // beyond that (views above ~1000 x 1000 cells) the beams read the bitmap from HBM
+        h->lds_view_big = (h->big_bits_in_lds ? lds_bits : 0) + 16;
         h->lds_view = 16;
         d.big_bits_in_lds = h->big_bits_in_lds ? 1 : 0;
-    }
-    if (h->lds_view_big > 160 * 1024) {
-        imgenv_destroy(h);
-        FAIL(IMGENV_EINVAL, "the hit words of %d beams do not fit the 160 KiB LDS (%zu B)", g.B, h->lds_view_big);
+        if (taps_lds_bytes(g.B) > 160 * 1024) {
+            imgenv_destroy(h);
+            FAIL(IMGENV_EINVAL, "the hit words of %d beams do not fit the 160 KiB LDS", g.B);
+        }
+        if (taps_lds_bytes(g.B) > 64 * 1024)
+            HIPCHK_H(hipFuncSetAttribute((const void*)k_taps_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)taps_lds_bytes(g.B)));
     }
     if (h->lds_view_big > 64 * 1024) {
         for (const void* f : {(const void*)k_beams_big<true, true, true>, (const void*)k_beams_big<true, false, true>,
-                              (const void*)k_beams_big<false, true, true>, (const void*)k_beams_big<false, false, true>,
-                              (const void*)k_beams_big<true, true, false>, (const void*)k_beams_big<true, false, false>,
-                              (const void*)k_beams_big<false, true, false>, (const void*)k_beams_big<false, false, false>})
+                              (const void*)k_beams_big<false, true, true>, (const void*)k_beams_big<false, false, true>})
             HIPCHK_H(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_view_big));
     }
     if (h->lds_view > 160 * 1024 || h->lds_obs > 160 * 1024) {
@@ -1155,14 +1162,17 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
 #undef RASTER_CASE
     }
     if (!h->stamp) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
-    if (h->big_view) {  // view_big.h: crop (tiles of every robot spread over the chip) -> beams + shrunk sensor_map (a workgroup
-                        // per robot) -> the full view, only where it is an output
-        const dim3 gc((unsigned)n_l * (unsigned)h->big_crop_chunks), gv(n_l), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
+    if (h->big_view) {  // view_big.h: crop (tiles of every robot spread over the chip) -> beams (a workgroup per robot and 256
+                        // beams) -> the shrunk sensor_map (a thread per pixel) -> the full view, only where it is an output
+        const int quarters = std::max(1, (d.B + VBB_T - 1) / VBB_T), tap_chunks = (d.img_w * d.img_h + VBT_T - 1) / VBT_T;
+        const bool full = d.keep_view_maps || !d.resize;
+        const dim3 gc((unsigned)n_l * (unsigned)h->big_crop_chunks), gb((unsigned)n_l * (unsigned)quarters);
+        const dim3 gt((unsigned)n_l * (unsigned)tap_chunks), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
         if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true><<<gc, dim3(VBC_T), 0, st>>>(d, h->big_crop_chunks)));
         else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false><<<gc, dim3(VBC_T), 0, st>>>(d, h->big_crop_chunks)));
         const int variant = (h->pow2 ? 4 : 0) | (h->stamp ? 2 : 0) | (h->big_bits_in_lds ? 1 : 0);
 #define BEAMS_CASE(N, P2, ST, LB) \
-    case N: TIMED(h, IMGENV_K_VIEW, st, (k_beams_big<P2, ST, LB><<<gv, dim3(VBB_T), h->lds_view_big, st>>>(d))); break;
+    case N: TIMED(h, IMGENV_K_VIEW, st, (k_beams_big<P2, ST, LB><<<gb, dim3(VBB_T), h->lds_view_big, st>>>(d, quarters))); break;
         switch (variant) {
             BEAMS_CASE(7, true, true, true)
             BEAMS_CASE(6, true, true, false)
@@ -1174,8 +1184,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             BEAMS_CASE(0, false, false, false)
         }
 #undef BEAMS_CASE
-        if (d.keep_view_maps || !d.resize) TIMED(h, IMGENV_K_FULLVIEW, st, (k_fullview_big<<<gf, dim3(VBF_T), 0, st>>>(d, h->big_full_chunks)));
-        h->launches += (d.keep_view_maps || !d.resize) ? 2 : 1;
+        // the last kernel of the chain commits the robots' new is_collision_
+        if (d.resize) TIMED(h, IMGENV_K_TAPS, st, (k_taps_big<<<gt, dim3(VBT_T), taps_lds_bytes(d.B), st>>>(d, tap_chunks, full ? 0 : 1)));
+        if (full) TIMED(h, IMGENV_K_FULLVIEW, st, (k_fullview_big<<<gf, dim3(VBF_T), 0, st>>>(d, h->big_full_chunks, 1)));
+        h->launches += (d.resize ? 1 : 0) + (full ? 1 : 0);
     } else {
         // one wavefront per robot when the launch fills the machine, four when it is small (a reset of a few worlds): then
         // the single wavefront's latency is all there is

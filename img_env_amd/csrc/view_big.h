@@ -10,10 +10,11 @@
 //                  cell's integer coordinates (the reference's chain of roundings only matters within 1e-6 of a rounding
 //                  boundary; those lanes redo it literally), one gather of the class layer, and the tile's 64 verdicts leave
 //                  as ONE ballot: the cropped view is a bitmap of 20 KB per robot in HBM instead of 160 KB of bytes.
-//   k_beams_big    1 workgroup of 1024 / robot: collision code; the bitmap into LDS; one beam per thread walks its static path
-//                  (coalesced 32-bit bit addresses, 8 steps in flight) to its first occupied cell -> hit word
+//   k_beams_big    1 workgroup of 256 / robot and 256 beams: the bitmap into LDS; one beam per thread walks its static path
+//                  (coalesced 16-byte loads of bit addresses, 32 steps in flight) to its first occupied cell -> hit word
 //                  (first-hit step << 16 | last step behind it in the hit cell's row or column, as in k_view) and lasers;
-//                  then, for a shrunk sensor_map, ONLY the 4 x 4 source cells of each of its pixels are evaluated (static
+//                  the first workgroup of a robot also takes the collision code and hands it to the step's tail.
+//   k_taps_big     1 thread / pixel of a shrunk sensor_map: ONLY the 4 x 4 source cells of the pixel are evaluated (static
 //                  tap records) and run through OpenCV's fixed-point bicubic -- the full view is never written unless asked for.
 //   k_fullview_big 1 thread / 4 cells, only when the full view is an output (imgenv_out.view_maps, or a big view that is not
 //                  shrunk): laser_map + own footprint of every cell from the hit words.
@@ -27,7 +28,8 @@
 #define VBC_T 256    // k_crop_big: 4 wavefronts
 #define VBC_TPW 8    // tiles per wavefront
 #define VBC_U 4      // tiles a wavefront keeps in flight
-#define VBB_T 1024   // k_beams_big
+#define VBB_T 256    // k_beams_big: one beam per thread
+#define VBT_T 256    // k_taps_big: one sensor_map pixel per thread
 #define VBF_T 256    // k_fullview_big
 
 // ------------------------------------------------------------------------------------------------
@@ -36,7 +38,10 @@ template <bool STAMP>
 __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks) {
     const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
     const int l = act_member(w, w.Rw, t);
-    if (w.is_coll[l] || w.is_arr[l]) return;  // frozen: the view keeps its last value (agent.cpp:358-360)
+    const bool frozen = w.is_coll[l] || w.is_arr[l];  // the view keeps its last value (agent.cpp:358-360)
+    // the kernels behind this one go by this word: is_collision_ itself changes underneath them (committed by the last one)
+    if (chunk == 0 && threadIdx.x == 0) w.big_hit[(size_t)l * w.big_hit_stride + w.B + 1] = frozen ? 0u : 1u;
+    if (frozen) return;
     const int i = w.r0 + l;
     const BigClassDev& k = w.big_mem[w.robot_cls[i]];
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
@@ -118,15 +123,11 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// laser_map value of view cell c (agent.cpp:419-437, 555-560) from the beams' hit words: the cell's top beam decides, unless
-// it leaves the cell alone; then the next lower beam through the cell that writes it does (static list, beam descending)
-__device__ __forceinline__ uint32_t big_laser_value(const RobotClassDev& rc, const BigClassDev& k, const uint32_t* hit, uint32_t c, uint32_t top) {
-    const uint32_t kk = top & 0xFFFFu, hp = hit[top >> 16], hk = hp >> 16;  // hk = 0xFFFF: the beam never hits
-    if (kk < hk) return 255u;
-    if (kk == hk) return 0u;
-    if (kk > (hp & 0xFFFFu)) return 200u;
-    const uint2 pk = k.inv[c];
-    for (uint32_t e = 1; e < pk.y; e += 4) {  // entry 0 is the top beam; four entries in flight
+// laser_map value of a view cell (agent.cpp:419-437, 555-560) from the beams' hit words: the cell's top beam decides, unless
+// it leaves the cell alone; then the next lower beam through the cell that writes it does (static list, beam descending).
+// big_walk: the list behind its first entry (the top beam), pk = {first entry, count}
+__device__ __forceinline__ uint32_t big_walk(const RobotClassDev& rc, const uint32_t* hit, uint2 pk) {
+    for (uint32_t e = 1; e < pk.y; e += 4) {  // four entries in flight
         uint32_t ent[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) ent[q] = rc.inv_ent[pk.x + min(e + (uint32_t)q, pk.y - 1u)];
@@ -140,6 +141,13 @@ __device__ __forceinline__ uint32_t big_laser_value(const RobotClassDev& rc, con
         }
     }
     return 200u;  // nobody writes the cell: laser_map keeps its initial 200
+}
+__device__ __forceinline__ uint32_t big_laser_value(const RobotClassDev& rc, const BigClassDev& k, const uint32_t* hit, uint32_t c, uint32_t top) {
+    const uint32_t kk = top & 0xFFFFu, hp = hit[top >> 16], hk = hp >> 16;  // hk = 0xFFFF: the beam never hits
+    if (kk < hk) return 255u;
+    if (kk == hk) return 0u;
+    if (kk > (hp & 0xFFFFu)) return 200u;
+    return big_walk(rc, hit, k.inv[c]);
 }
 
 // view_map value (0 / 100 / 200 / 255) of a cell: bits = the robot's crop bitmap (plane 0 occupied, plane 1 unknown, `words`
@@ -160,18 +168,20 @@ __device__ __forceinline__ uint32_t big_cell_value(const RobotClassDev& rc, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// (1) collision, (3) laser, and the shrunk sensor_map.  LDS: hit[B + 2] | the occupied plane of the crop (LDSBM)
+// (1) collision and (3) laser.  One workgroup of 256 per robot and 256 beams; LDS: the occupied plane of the crop (LDSBM).
+// Every beam walks its static path 32 steps at a time (eight 16-byte loads of bit addresses in flight, consecutive lanes
+// contiguous), one LDS bit lookup per step; a wavefront leaves as soon as all its beams have hit or ended.
 template <bool POW2, bool STAMP, bool LDSBM>
-__global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w) {
+__global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t best_sh;
     const int tid = threadIdx.x;
-    const int l = act_member(w, w.Rw, blockIdx.x);
+    const int t = (int)blockIdx.x / quarters, quarter = (int)blockIdx.x - t * quarters;
+    const int l = act_member(w, w.Rw, t);
     const int B = w.B;
     uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
-    if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value
-        if (tid == 0) hit_g[B + 1] = 0u;
-        if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, w.is_coll[l]);
+    if (hit_g[B + 1] == 0u) {  // frozen (k_crop_big looked): every per-robot output keeps its last value
+        if (quarter == 0 && tid < WAVE) tail_arrive_view(w, t, l, w.is_coll[l]);
         return;
     }
     const int i = w.r0 + l;
@@ -179,14 +189,16 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w) {
     const RobotClassDev& rc = w.rc_mem[cls];
     const BigClassDev& k = w.big_mem[cls];
     const uint32_t self = (uint32_t)i;
-    uint32_t* hit = (uint32_t*)smem;
-    uint32_t* bm = hit + ((B + 2 + 3) & ~3);
+    uint32_t* bm = (uint32_t*)smem;
     const uint32_t* plane0_g = w.big_bits + (size_t)l * 2 * w.big_words;
-    const uint32_t* plane1_g = plane0_g + w.big_words;
-    if (tid == 0) best_sh = 0;
-    __syncthreads();
-    // (1) collision: the last footprint sample on an occupied cell decides (agent.cpp:294-326)
-    {
+    if (LDSBM) {
+        const uint4* src = (const uint4*)plane0_g;
+        for (int q = tid; q < w.big_words / 4; q += VBB_T) ((uint4*)bm)[q] = src[q];
+    }
+    if (quarter == 0) {
+        // (1) collision: the last footprint sample on an occupied cell decides (agent.cpp:294-326)
+        if (tid == 0) best_sh = 0;
+        __syncthreads();
         uint32_t best = 0;
         const int n_cov = w.fp_n[l];
         if (n_cov >= 0) {
@@ -213,100 +225,172 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w) {
             }
         }
         if (best) atomicMax(&best_sh, best);
+        __syncthreads();
+        const int code = (int)(best_sh & 3u);
+        // the collision code is all the step's tail needs from the view: hand it over now (see k_view)
+        if (tid < WAVE) tail_arrive_view(w, t, l, code);
+        if (tid == 0) {
+            hit_g[B] = 0u;  // the dummy beam of cells no beam crosses: "hits" at step 0 and leaves nothing alone -> 200
+            hit_g[B + 2] = (uint32_t)code;  // is_collision_ of this step: committed by the last kernel of the chain
+        }
+    } else {
+        __syncthreads();
     }
-    if (LDSBM) {
-        const uint4* src = (const uint4*)plane0_g;
-        for (int q = tid; q < w.big_words / 4; q += VBB_T) ((uint4*)bm)[q] = src[q];
-    }
-    __syncthreads();
-    const int code = (int)(best_sh & 3u);
-    // the collision code is all the step's tail needs from the view: hand it over now (see k_view)
-    if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, code);
-    const uint32_t* plane0 = LDSBM ? (const uint32_t*)bm : plane0_g;
     // (3) laser (agent.cpp:405-438, 511-624): first occupied cell on each beam's precomputed path
+    if (w.use_laser == 0) return;
+    const uint32_t* plane0 = LDSBM ? (const uint32_t*)bm : plane0_g;
+    const int stride = rc.ray_stride, kpad = rc.ray_kpad;
+    const int b = quarter * VBB_T + tid, bb = min(b, B - 1);
+    const int len = b < B ? (int)rc.ray_len[bb] : 0;
+    uint32_t hk = 0xFFFFFFFFu;
+    const uint4* col = (const uint4*)k.cells + bb;  // [kpad / 4][stride] four steps per entry
+    for (int k0 = 0; k0 < kpad; k0 += 32) {
+        uint4 a4[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) a4[j] = col[(size_t)((k0 >> 2) + j) * stride];  // padded steps point at the free bit
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t ad[4] = {a4[j].x, a4[j].y, a4[j].z, a4[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) m |= ((plane0[ad[q] >> 5] >> (ad[q] & 31u)) & 1u) << (4 * j + q);
+        }
+        if (m != 0u && hk == 0xFFFFFFFFu) hk = (uint32_t)k0 + (uint32_t)__builtin_ctz(m);
+        if (__all((hk != 0xFFFFFFFFu) | (k0 + 32 >= len))) break;
+    }
+    if (b < B) {
+        const bool has = hk != 0xFFFFFFFFu;
+        const size_t at = (size_t)(has ? hk : 0u) * stride + b;
+        const uint32_t end = has ? (uint32_t)k.ray_end[at] : 0u;
+        const float hd = has ? rc.ray_dist[at] : 6.0f;  // agent.cpp:513
+        hit_g[b] = has ? ((hk << 16) | end) : 0xFFFFFFFFu;
+        w.lasers_raw[(size_t)l * B + b] = hd;
+        w.lasers[(size_t)l * B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv2.resize(view, image_size, INTER_CUBIC).astype(float16) / 255 (yaml_env.py:431-438), one pixel of the sensor_map per
+// thread: the 16 view cells the pixel reads (static tap records) are evaluated from the hit words and the crop bitmap, then
+// HResizeCubic of the four source rows and the vertical pass (csrc/cv_resize.h).  The full-size view is not needed.
+//   pass 1  every tap from its top beam (one hot word per tap); the few that need more -- left alone by that beam, under the
+//           own footprint, or no laser at all -- go on a list in LDS (one prefix sum and one LDS atomic per wavefront);
+//   pass 2  the list, spread evenly over the workgroup: crop bit, ray list walk;
+//   pass 3  the two resize passes from the 16 values of the pixel.
+// LDS: hit[B + 1 .. pad] | vals[VBT_T][16] u8 | list[VBT_T * 16] u16 | counter
+__global__ __launch_bounds__(VBT_T) void k_taps_big(DevWorld w, int chunks, int commit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = lane_id();
+    const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
+    const int l = act_member(w, w.Rw, t);
+    const int B = w.B;
+    const uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
+    if (hit_g[B + 1] == 0u) return;  // frozen
+    if (commit && chunk == 0 && tid == 0) w.is_coll[l] = (int)hit_g[B + 2];
+    const int cls = w.robot_cls[w.r0 + l];
+    const RobotClassDev& rc = w.rc_mem[cls];
+    const BigClassDev& k = w.big_mem[cls];
+    const int n_hit4 = (B + 4) / 4;  // B words + the dummy beam, in 16-byte units
+    uint32_t* hit = (uint32_t*)smem;
+    uint32_t* vals = hit + 4 * n_hit4;                  // [VBT_T][4]: the pixel's 16 tap values, one byte each
+    uint16_t* list = (uint16_t*)(vals + 4 * VBT_T);     // pixel of the workgroup << 4 | tap
+    int* n_list = (int*)(list + 16 * VBT_T);
     const bool laser = w.use_laser != 0;
-    if (laser) {
-        const int stride = rc.ray_stride, kpad = rc.ray_kpad;
-        for (int b0 = 0; b0 < B; b0 += VBB_T) {
-            const int b = b0 + tid, bb = min(b, B - 1);
-            const int len = b < B ? (int)rc.ray_len[bb] : 0;
-            uint32_t hk = 0xFFFFFFFFu;
-            const uint32_t* col = k.cells + bb;
-            for (int k0 = 0; k0 < kpad; k0 += 8) {
-                uint32_t addr[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) addr[j] = col[(size_t)(k0 + j) * stride];  // padded rows point at the free bit
-                uint32_t m = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) m |= ((plane0[addr[j] >> 5] >> (addr[j] & 31u)) & 1u) << j;
-                if (m != 0u && hk == 0xFFFFFFFFu) hk = (uint32_t)k0 + (uint32_t)__builtin_ctz(m);
-                if (__all((hk != 0xFFFFFFFFu) | (k0 + 8 >= len))) break;
-            }
-            if (b < B) {
-                const bool has = hk != 0xFFFFFFFFu;
-                const size_t at = (size_t)(has ? hk : 0u) * stride + b;
-                const uint32_t end = has ? (uint32_t)k.ray_end[at] : 0u;
-                const float hd = has ? rc.ray_dist[at] : 6.0f;  // agent.cpp:513
-                const uint32_t word = has ? ((hk << 16) | end) : 0xFFFFFFFFu;
-                hit[b] = word;
-                hit_g[b] = word;
-                w.lasers_raw[(size_t)l * B + b] = hd;
-                w.lasers[(size_t)l * B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
-            }
-        }
-    }
-    if (tid == 0) {
-        hit[B] = 0u;  // the dummy beam of cells no beam crosses: "hits" at step 0 and leaves nothing alone -> 200
-        hit_g[B] = 0u;
-        hit_g[B + 1] = 1u;  // this robot's view is being redone (k_fullview_big)
-        w.is_coll[l] = code;
-    }
-    if (!w.resize) return;
-    __syncthreads();
-    // cv2.resize(view, image_size, INTER_CUBIC).astype(float16) / 255 (yaml_env.py:431-438): HResizeCubic of the four
-    // source rows, then the vertical pass (csrc/cv_resize.h), on the 16 view cells each pixel reads
+    if (laser)
+        for (int q = tid; q < n_hit4; q += VBT_T) ((uint4*)hit)[q] = ((const uint4*)hit_g)[q];
+    if (tid == 0) *n_list = 0;
+    const uint32_t* plane0 = w.big_bits + (size_t)l * 2 * w.big_words;
+    const uint32_t* plane1 = plane0 + w.big_words;
     const int IW = w.img_w, IH = w.img_h, NP = IW * IH, vec_end = (IW / 8) * 8;
-    uint16_t* img = w.sensor_maps + (size_t)l * NP;
-    for (int p = tid; p < NP; p += VBB_T) {
-        const int dy = p / IW, dx = p - dy * IW;
-        const short* al = w.rs_alpha + 4 * dx;
-        const short* be = w.rs_beta + 4 * dy;
-        int s[4];
+    const int p = chunk * VBT_T + tid, pc = min(p, NP - 1);
+    uint32_t top[16];
 #pragma unroll
-        for (int kr = 0; kr < 4; kr++) {
-            uint4 rec[4];
+    for (int j = 0; j < 16; j++) top[j] = k.tap_top[(size_t)j * NP + pc];
+    __syncthreads();
+    // pass 1
+    uint32_t packed[4] = {0u, 0u, 0u, 0u}, more = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) rec[j] = k.taps[(size_t)(kr * 4 + j) * NP + p];
-            int acc = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc += (int)big_cell_value(rc, k, hit, plane0, plane1_g, laser, rec[j].x & 0x7FFFFFFFu, rec[j].y, rec[j].z, (rec[j].x >> 31) != 0u) * (int)al[j];
-            s[kr] = acc;
+    for (int j = 0; j < 16; j++) {
+        if (laser) {
+            const uint32_t kk = top[j] & 0xFFFFu, hp = hit[(top[j] >> 16) & 0x7FFFu], hk = hp >> 16;
+            const uint32_t v = kk < hk ? 255u : (kk == hk ? 0u : 200u);
+            packed[j >> 2] |= v << (8 * (j & 3));
+            more |= (((kk > hk) & (kk <= (hp & 0xFFFFu))) | ((top[j] >> 31) != 0u)) ? (1u << j) : 0u;
+        } else {
+            more |= 1u << j;
         }
-        int o;
-        if (dx < vec_end) {  // VResizeCubicVec_32s8u: float32, separately rounded multiply and add, nearest-even
-            const float scale = 1.f / (2048 * 2048);
-            float t = (float)s[3] * ((float)be[3] * scale);
-            t = (float)s[2] * ((float)be[2] * scale) + t;
-            t = (float)s[1] * ((float)be[1] * scale) + t;
-            t = (float)s[0] * ((float)be[0] * scale) + t;
-            o = (int)rintf(t);
-        } else {             // VResizeCubic tail: FixedPtCast<int, uchar, 22>
-            o = (s[0] * be[0] + s[1] * be[1] + s[2] * be[2] + s[3] * be[3] + (1 << 21)) >> 22;
-        }
-        img[p] = w.f16_lut[min(max(o, 0), 255)];
     }
+    if (p >= NP) more = 0;
+    *(uint4*)(vals + 4 * tid) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    {
+        const uint32_t cnt = (uint32_t)__popc(more), incl = wave_prefix_sum(cnt);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        int base = 0;
+        if (lane == 63 && total != 0u) base = atomicAdd(n_list, (int)total);
+        base = __builtin_amdgcn_readlane(base, 63);
+        int pos = base + (int)(incl - cnt);
+        for (uint32_t m = more; m != 0u; m &= m - 1u) list[pos++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
+    }
+    __syncthreads();
+    // pass 2
+    const int n_items = *n_list;
+    for (int it = tid; it < n_items; it += VBT_T) {
+        const uint32_t item = list[it], px = item >> 4, j = item & 15u;
+        const size_t at = (size_t)j * NP + (size_t)(chunk * VBT_T) + px;
+        const uint32_t tj = k.tap_top[at], addr = k.tap_addr[at];
+        const bool st = (tj >> 31) != 0u;
+        const bool occ = ((plane0[addr >> 5] >> (addr & 31u)) & 1u) != 0u;
+        uint32_t v;
+        if (!laser) {
+            const bool unk = ((plane1[addr >> 5] >> (addr & 31u)) & 1u) != 0u;
+            v = occ ? 0u : (unk ? 200u : 255u);
+        } else if (st && !occ) {
+            v = 100u;  // a beam can only write 0 where the crop is occupied
+        } else {
+            const uint32_t kk = tj & 0xFFFFu, hp = hit[(tj >> 16) & 0x7FFFu], hk = hp >> 16;
+            v = kk < hk ? 255u : (kk == hk ? 0u : 200u);
+            if ((kk > hk) & (kk <= (hp & 0xFFFFu))) v = big_walk(rc, hit, k.tap_inv[at]);
+        }
+        v = (st && v != 0u) ? 100u : v;  // draw(view_map_, 100) skips 0 / 1 / 2 (agent.cpp:307-312)
+        ((uint8_t*)vals)[16 * px + j] = (uint8_t)v;
+    }
+    __syncthreads();
+    // pass 3
+    if (p >= NP) return;
+    const int dy = p / IW, dx = p - dy * IW;
+    const short* al = w.rs_alpha + 4 * dx;
+    const short* be = w.rs_beta + 4 * dy;
+    const uint4 pv = *(const uint4*)(vals + 4 * tid);
+    const uint32_t rows[4] = {pv.x, pv.y, pv.z, pv.w};
+    int s[4];
+#pragma unroll
+    for (int kr = 0; kr < 4; kr++)  // HResizeCubic of the four source rows
+        s[kr] = (int)(rows[kr] & 0xFFu) * (int)al[0] + (int)((rows[kr] >> 8) & 0xFFu) * (int)al[1] + (int)((rows[kr] >> 16) & 0xFFu) * (int)al[2] +
+                (int)(rows[kr] >> 24) * (int)al[3];
+    int o;
+    if (dx < vec_end) {  // VResizeCubicVec_32s8u: float32, separately rounded multiply and add, nearest-even
+        const float scale = 1.f / (2048 * 2048);
+        float v = (float)s[3] * ((float)be[3] * scale);
+        v = (float)s[2] * ((float)be[2] * scale) + v;
+        v = (float)s[1] * ((float)be[1] * scale) + v;
+        v = (float)s[0] * ((float)be[0] * scale) + v;
+        o = (int)rintf(v);
+    } else {             // VResizeCubic tail: FixedPtCast<int, uchar, 22>
+        o = (s[0] * be[0] + s[1] * be[1] + s[2] * be[2] + s[3] * be[3] + (1 << 21)) >> 22;
+    }
+    w.sensor_maps[(size_t)l * NP + p] = w.f16_lut[min(max(o, 0), 255)];
 }
 
 // ------------------------------------------------------------------------------------------------
 // (4) the full view: laser_map per cell + own footprint (agent.cpp:419-437, 503), 4 cells per thread; view_maps when it is
 // an output, sensor_maps (float16) when nothing is shrunk
-__global__ __launch_bounds__(VBF_T) void k_fullview_big(DevWorld w, int chunks) {
+__global__ __launch_bounds__(VBF_T) void k_fullview_big(DevWorld w, int chunks, int commit) {
     const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
     const int l = act_member(w, w.Rw, t);
     const int B = w.B;
     const uint32_t* hit = w.big_hit + (size_t)l * w.big_hit_stride;
     if (hit[B + 1] == 0u) return;  // frozen
+    if (commit && chunk == 0 && threadIdx.x == 0) w.is_coll[l] = (int)hit[B + 2];
     const int NC = w.Hv * w.Wv, c4 = (chunk * VBF_T + (int)threadIdx.x) * 4;
     if (c4 >= NC) return;
     const int cls = w.robot_cls[w.r0 + l];

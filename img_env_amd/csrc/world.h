@@ -69,10 +69,13 @@ struct BigClassDev {
     int n_crop;                  // tiles that touch the field of view
     const uint32_t* crop_tiles;  // [n_crop] ta << 16 | tb
     const uint64_t* crop_masks;  // [n_crop] the tile's cells inside the field of view
-    const uint32_t* cells;       // [ray_kpad][ray_stride] bit address of step k of beam b (past the end: the free bit behind the bitmap)
+    const uint32_t* cells;       // [ray_kpad / 4][ray_stride][4] bit address of steps 4c..4c+3 of beam b (past the end: the free bit behind the bitmap)
     const uint16_t* ray_end;     // [ray_maxlen][ray_stride] last step behind (k, b) in the row or column of its cell
     const uint2* inv;            // [Hv*Wv] rays through a view cell: {first entry of inv_ent, count}
-    const uint4* taps;           // [16][img_h*img_w] source cells of the shrunk sensor_map (host_tables.h build_big_taps)
+    // the 4 x 4 source cells of every pixel of a shrunk sensor_map (host_tables.h build_big_taps), [16][img_h * img_w] each
+    const uint32_t* tap_top;     // the cell's top beam entry | own footprint << 31
+    const uint2* tap_inv;        // its ray list {first entry of inv_ent, count}
+    const uint32_t* tap_addr;    // its bit address in the crop bitmap
 };
 
 struct PedClassDev {
@@ -142,7 +145,7 @@ struct DevWorld {
     // outside the map / the field of view; big_words 32-bit words each, the last ones stay zero) and the beams' hit words
     const BigClassDev* big_mem;
     uint32_t* big_bits;          // [RL][2][big_words]
-    uint32_t* big_hit;           // [RL][big_hit_stride]: B hit words | the dummy beam | 1 = the view was redone by this chain of launches
+    uint32_t* big_hit;           // [RL][big_hit_stride]: B hit words | the dummy beam | 1 = the view is redone by this chain of launches | its collision code
     int big_words, big_hit_stride, big_bits_in_lds;
     int keep_view_maps;          // view_maps (the full-size view) is an output; otherwise a shrunk view is never materialised
     const int* robot_cls;  // [R]

@@ -382,7 +382,8 @@ int imgenv_step_launches(imgenv_t* h);
 #define IMGENV_K_TAIL 7
 #define IMGENV_K_CROP 8      /* big views (csrc/view_big.h): k_crop_big; IMGENV_K_VIEW is then k_beams_big */
 #define IMGENV_K_FULLVIEW 9  /* k_fullview_big */
-#define IMGENV_K_COUNT 10
+#define IMGENV_K_TAPS 10     /* k_taps_big */
+#define IMGENV_K_COUNT 11
 int imgenv_timing(imgenv_t* h, int mode, int which);
 /* synchronises the recorded events and returns accumulated milliseconds / launch counts per kernel
  * id since the last imgenv_timing() call; arrays of IMGENV_K_COUNT entries */

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Kernel trace + stats + timeline of the shipped test.yaml geometry (tools/shipped_probe.py): tools/profile_shipped.sh <tag> [envs]
+tag=${1:-shipped}
+envs=${2:-256}
+out=/root/repo/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t -- python3 /root/repo/tools/shipped_probe.py --envs $envs --steps 60 > $out/${tag}_trace.log 2>&1
+cd /root/repo
+db=$(ls $out/${tag}_trace/*/*.db $out/${tag}_trace/*.db 2>/dev/null | head -1)
+[ -n "$db" ] && python3 tools/rocpd_stats.py $db > $out/${tag}_kernel_stats.txt
+[ -n "$db" ] && python3 tools/timeline.py $db 90 > $out/${tag}_timeline.txt 2>/dev/null
+rm -rf $out/${tag}_trace
