@@ -87,7 +87,7 @@ struct imgenv {
     bool big_view = false;   // the view is beyond k_view's packing, or shrunk by cv2.resize: the kernels of view_big.h
     size_t lds_view_big = 0;
     bool big_bits_in_lds = true;  // the crop bitmap of one robot fits the LDS next to the hit words
-    int big_crop_chunks = 1, big_full_chunks = 1;
+    int big_max_crop = 1, big_full_chunks = 1;
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
     std::vector<double> tmp_d1;  // scratch of stage_world
@@ -601,6 +601,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         TRY(dev_alloc(h, &d.own_hi, Gp));
     }
     TRY(dev_alloc(h, &d.cell, Gp));
+    TRY(dev_alloc(h, &d.seg_tag, Gp / 64 + 2));
 
     // class tables
     size_t max_stride = WAVE;
@@ -727,7 +728,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
                 std::vector<uint32_t>().swap(k.tap_addr);
             }
         }
-        TRY(dev_upload(h, &d.big_mem, bc));
+        for (size_t c = 0; c < bc.size(); c++) d.big[c] = bc[c];
         const size_t tiles = (size_t)h->rcls[0].big_ta * h->rcls[0].big_tb;
         d.big_words = (int)((tiles * 2 + 1 + 3) & ~(size_t)3);  // + the always-free word the padded path entries point at
         d.big_hit_stride = (g.B + 3 + 3) & ~3;  // B hit words, the dummy beam, the flag, the collision code
@@ -736,7 +737,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         // cells no crop tile covers lie outside the field of view for good: "unknown" in plane 1 (read without the laser only)
         if (!cfg->use_laser)
             HIPCHK_H(hipMemset2D(d.big_bits + d.big_words, (size_t)8 * d.big_words, 0xFF, (size_t)4 * d.big_words, (size_t)RL));
-        h->big_crop_chunks = (max_crop + (VBC_T / WAVE) * VBC_TPW - 1) / ((VBC_T / WAVE) * VBC_TPW);
+        h->big_max_crop = max_crop;
         h->big_full_chunks = (int)(((size_t)g.Hv * g.Wv + VBF_T * 4 - 1) / (VBF_T * 4));
     }
 
@@ -1166,10 +1167,13 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
                         // beams) -> the shrunk sensor_map (a thread per pixel) -> the full view, only where it is an output
         const int quarters = std::max(1, (d.B + VBB_T - 1) / VBB_T), tap_chunks = (d.img_w * d.img_h + VBT_T - 1) / VBT_T;
         const bool full = d.keep_view_maps || !d.resize;
-        const dim3 gc((unsigned)n_l * (unsigned)h->big_crop_chunks), gb((unsigned)n_l * (unsigned)quarters);
+        // tiles per wavefront: 8 while the launch is small (a reset of a few worlds: every robot on ~40 workgroups), 32 once
+        // there are enough robots to fill the chip anyway (the dispatcher starts about one workgroup per nanosecond)
+        const int tpw = n_l >= 512 ? 32 : 8, crop_chunks = (h->big_max_crop + (VBC_T / WAVE) * tpw - 1) / ((VBC_T / WAVE) * tpw);
+        const dim3 gc((unsigned)((n_l + 7) / 8 * 8) * (unsigned)crop_chunks), gb((unsigned)n_l * (unsigned)quarters);
         const dim3 gt((unsigned)n_l * (unsigned)tap_chunks), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
-        if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true><<<gc, dim3(VBC_T), 0, st>>>(d, h->big_crop_chunks)));
-        else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false><<<gc, dim3(VBC_T), 0, st>>>(d, h->big_crop_chunks)));
+        if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
+        else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
         const int variant = (h->pow2 ? 4 : 0) | (h->stamp ? 2 : 0) | (h->big_bits_in_lds ? 1 : 0);
 #define BEAMS_CASE(N, P2, ST, LB) \
     case N: TIMED(h, IMGENV_K_VIEW, st, (k_beams_big<P2, ST, LB><<<gb, dim3(VBB_T), h->lds_view_big, st>>>(d, quarters))); break;

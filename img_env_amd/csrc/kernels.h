@@ -90,7 +90,12 @@ __device__ __forceinline__ int world_of_ped(const DevWorld& w, int j) { return w
 // final word does not depend on the order in which the rasters of a step arrive. ----
 __device__ __forceinline__ bool stamp_is_current(uint32_t v, uint32_t tag) { return ((v >> STAMP_TAG_SHIFT) & 0xFFu) == tag; }
 // view_robot (img_env.cpp:620-629): robot i covers the cell
-__device__ __forceinline__ void stamp_robot(uint32_t* cell, uint32_t i, uint32_t tag) {
+// seg_tag: the tag again, once per 64 consecutive cells of the layer: where it is not this step's, no cell of the segment
+// carries a stamp of this step, and the obstacle map alone says what a view sees there (k_crop_big reads a byte per cell
+// instead of this layer's word)
+__device__ __forceinline__ void stamp_robot(const DevWorld& w, size_t c, uint32_t i, uint32_t tag) {
+    uint32_t* cell = w.cell + c;
+    w.seg_tag[c >> 6] = (uint8_t)tag;
     uint32_t old = *cell;
     for (;;) {
         const uint32_t kind = stamp_is_current(old, tag) ? (old >> STAMP_KIND_SHIFT) & 3u : 0u;
@@ -104,7 +109,9 @@ __device__ __forceinline__ void stamp_robot(uint32_t* cell, uint32_t i, uint32_t
     }
 }
 // view_ped (img_env.cpp:594-618): a pedestrian sample lands on the cell
-__device__ __forceinline__ void stamp_ped(uint32_t* cell, uint32_t old /* the word as just read */, uint32_t tag) {
+__device__ __forceinline__ void stamp_ped(const DevWorld& w, size_t c, uint32_t old /* the word as just read */, uint32_t tag) {
+    uint32_t* cell = w.cell + c;
+    w.seg_tag[c >> 6] = (uint8_t)tag;
     for (;;) {
         if (stamp_is_current(old, tag) && ((old >> STAMP_KIND_SHIFT) & 3u) == STAMP_PED) return;
         const uint32_t seen = atomicCAS(cell, old, (old & 7u) | (STAMP_PED << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT));
@@ -771,7 +778,7 @@ __device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t 
     const uint32_t next = (uint32_t)__shfl_down((int)ci, 1);
     if (in && (lane == WAVE - 1 || next != ci)) {
         const uint32_t v = w.cell[c], base = v & 7u;
-        if (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW)) stamp_ped(w.cell + c, v, w.stamp_tag);
+        if (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW)) stamp_ped(w, c, v, w.stamp_tag);
     }
 }
 
@@ -862,7 +869,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             for (int e = tid; e < n_cached; e += NT) {
                 const uint32_t c = list[e].x;
                 if (STAMP) {
-                    stamp_robot(w.cell + c, (uint32_t)i, w.stamp_tag);
+                    stamp_robot(w, c, (uint32_t)i, w.stamp_tag);
                 } else {
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
@@ -903,7 +910,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 } else {
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
                     if (STAMP) {
-                        stamp_robot(w.cell + c, (uint32_t)i, w.stamp_tag);
+                        stamp_robot(w, c, (uint32_t)i, w.stamp_tag);
                     } else {
                         atomicMin(&w.own_lo[c], id);
                         atomicMax(&w.own_hi[c], id);
@@ -933,7 +940,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c = cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
                 if (STAMP) {
-                    stamp_robot(w.cell + c, (uint32_t)i, w.stamp_tag);
+                    stamp_robot(w, c, (uint32_t)i, w.stamp_tag);
                 } else {
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
@@ -1059,6 +1066,7 @@ __global__ void k_compose(DevWorld w) {
 __global__ __launch_bounds__(256) void k_cell_base(DevWorld w) {
     const size_t G = w.act_cells, c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (c0 >= G) return;
+    if ((c0 & 63) == 0) w.seg_tag[c0 >> 6] = 0;
     if (c0 + 4 <= G) {
         const uint4 v = *(const uint4*)(w.cell + c0);
         *(uint4*)(w.cell + c0) = make_uint4(v.x & 7u, v.y & 7u, v.z & 7u, v.w & 7u);

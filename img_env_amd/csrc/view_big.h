@@ -26,24 +26,28 @@
 #pragma once
 
 #define VBC_T 256    // k_crop_big: 4 wavefronts
-#define VBC_TPW 8    // tiles per wavefront
 #define VBC_U 4      // tiles a wavefront keeps in flight
 #define VBB_T 256    // k_beams_big: one beam per thread
 #define VBT_T 256    // k_taps_big: one sensor_map pixel per thread
 #define VBF_T 256    // k_fullview_big
 
 // ------------------------------------------------------------------------------------------------
-// (2) egocentric crop (agent.cpp:373-404), tiled
+// (2) egocentric crop (agent.cpp:373-404), tiled.  All workgroups of one robot run on the same XCD (blockIdx modulo 8), so the
+// robot's window of the map is fetched from HBM once and shared through that XCD's L2.  STAMP mode reads the obstacle map
+// itself (one byte per cell) and the class layer's word only inside 64-cell segments some raster stamped this step (seg_tag).
 template <bool STAMP>
-__global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks) {
-    const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
+__global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int n_robots, int tpw) {
+    // block g: XCD g % 8 takes robots g % 8, g % 8 + 8, ... with all their chunks
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int t = (slot / chunks) * 8 + xcd, chunk = slot % chunks;
+    if (t >= n_robots) return;
     const int l = act_member(w, w.Rw, t);
     const bool frozen = w.is_coll[l] || w.is_arr[l];  // the view keeps its last value (agent.cpp:358-360)
     // the kernels behind this one go by this word: is_collision_ itself changes underneath them (committed by the last one)
     if (chunk == 0 && threadIdx.x == 0) w.big_hit[(size_t)l * w.big_hit_stride + w.B + 1] = frozen ? 0u : 1u;
     if (frozen) return;
     const int i = w.r0 + l;
-    const BigClassDev& k = w.big_mem[w.robot_cls[i]];
+    const BigClassDev k = w.big[__builtin_amdgcn_readfirstlane(w.robot_cls[i])];
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
@@ -62,8 +66,8 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks) {
     unsigned long long* plane1 = (unsigned long long*)(w.big_bits + ((size_t)l * 2 + 1) * w.big_words);
     const bool want_unknown = w.use_laser == 0;  // with the laser on only "occupied or not" survives into the outputs
     const int n_crop = k.n_crop, tb_n = k.tb;
-    const int first = chunk * ((VBC_T / WAVE) * VBC_TPW);
-    for (int it = 0; it < VBC_TPW; it += VBC_U) {
+    const int first = chunk * ((VBC_T / WAVE) * tpw);  // tpw tiles per wavefront: more in big launches (workgroup dispatch has a price)
+    for (int it = 0; it < tpw; it += VBC_U) {
         if (first + it * (VBC_T / WAVE) + wave >= n_crop) break;  // uniform
         uint32_t idx[VBC_U], tile_w[VBC_U];
         bool look[VBC_U], risky = false;
@@ -99,20 +103,41 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks) {
                 idx[u] = look[u] ? cell0 + (uint32_t)(m * Wg + n) : cell0;
             }
         }
-        uint32_t v[VBC_U];
+        // free = >= 250 in this robot's private grid (agent.cpp:394-401)
+        bool free_cell[VBC_U];
+        if (STAMP) {
+            uint32_t o[VBC_U], sg[VBC_U];
+            bool stamped = false;
 #pragma unroll
-        for (int u = 0; u < VBC_U; u++) v[u] = w.cell[idx[u]];
+            for (int u = 0; u < VBC_U; u++) {
+                o[u] = w.obs_map[idx[u]];
+                sg[u] = w.seg_tag[idx[u] >> 6];
+            }
+#pragma unroll
+            for (int u = 0; u < VBC_U; u++) {
+                free_cell[u] = o[u] >= 250u;
+                stamped |= look[u] & (sg[u] == tag);
+            }
+            if (__any(stamped)) {  // near a robot or a pedestrian: class HIGH with nobody else's stamp of this step on it
+#pragma unroll
+                for (int u = 0; u < VBC_U; u++) {
+                    if (look[u] & (sg[u] == tag)) {
+                        const uint32_t v = w.cell[idx[u]];
+                        const uint32_t x = (v & base_tag_mask) ^ base_tag_ours;
+                        free_cell[u] = (v == free_own) | (((x & 7u) == 0u) & (x != 0u));
+                    }
+                }
+            }
+        } else {
+            uint32_t v[VBC_U];
+#pragma unroll
+            for (int u = 0; u < VBC_U; u++) v[u] = w.cell[idx[u]];
+#pragma unroll
+            for (int u = 0; u < VBC_U; u++) free_cell[u] = (v[u] == (uint32_t)CLS_HIGH) | (v[u] == free_own);
+        }
 #pragma unroll
         for (int u = 0; u < VBC_U; u++) {
-            // free = >= 250 in this robot's private grid (agent.cpp:394-401): class HIGH with nobody else's stamp on it
-            bool free_cell;
-            if (STAMP) {
-                const uint32_t x = (v[u] & base_tag_mask) ^ base_tag_ours;
-                free_cell = (v[u] == free_own) | (((x & 7u) == 0u) & (x != 0u));
-            } else {
-                free_cell = (v[u] == (uint32_t)CLS_HIGH) | (v[u] == free_own);
-            }
-            const unsigned long long occ = __ballot(look[u] & !free_cell);
+            const unsigned long long occ = __ballot(look[u] & !free_cell[u]);
             const unsigned long long unk = __ballot(!look[u]);
             if (lane == 0 && tile_w[u] != 0xFFFFFFFFu) {
                 plane0[tile_w[u]] = occ;
@@ -185,9 +210,9 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
         return;
     }
     const int i = w.r0 + l;
-    const int cls = w.robot_cls[i];
-    const RobotClassDev& rc = w.rc_mem[cls];
-    const BigClassDev& k = w.big_mem[cls];
+    const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[i]);
+    const RobotClassDev rc = w.rc[cls];
+    const BigClassDev k = w.big[cls];
     const uint32_t self = (uint32_t)i;
     uint32_t* bm = (uint32_t*)smem;
     const uint32_t* plane0_g = w.big_bits + (size_t)l * 2 * w.big_words;
@@ -287,9 +312,9 @@ __global__ __launch_bounds__(VBT_T) void k_taps_big(DevWorld w, int chunks, int 
     const uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
     if (hit_g[B + 1] == 0u) return;  // frozen
     if (commit && chunk == 0 && tid == 0) w.is_coll[l] = (int)hit_g[B + 2];
-    const int cls = w.robot_cls[w.r0 + l];
-    const RobotClassDev& rc = w.rc_mem[cls];
-    const BigClassDev& k = w.big_mem[cls];
+    const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l]);
+    const RobotClassDev rc = w.rc[cls];
+    const BigClassDev k = w.big[cls];
     const int n_hit4 = (B + 4) / 4;  // B words + the dummy beam, in 16-byte units
     uint32_t* hit = (uint32_t*)smem;
     uint32_t* vals = hit + 4 * n_hit4;                  // [VBT_T][4]: the pixel's 16 tap values, one byte each
@@ -393,9 +418,9 @@ __global__ __launch_bounds__(VBF_T) void k_fullview_big(DevWorld w, int chunks, 
     if (commit && chunk == 0 && threadIdx.x == 0) w.is_coll[l] = (int)hit[B + 2];
     const int NC = w.Hv * w.Wv, c4 = (chunk * VBF_T + (int)threadIdx.x) * 4;
     if (c4 >= NC) return;
-    const int cls = w.robot_cls[w.r0 + l];
-    const RobotClassDev& rc = w.rc_mem[cls];
-    const BigClassDev& k = w.big_mem[cls];
+    const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l]);
+    const RobotClassDev rc = w.rc[cls];
+    const BigClassDev k = w.big[cls];
     const uint32_t* plane0 = w.big_bits + (size_t)l * 2 * w.big_words;
     const uint32_t* plane1 = plane0 + w.big_words;
     const bool laser = w.use_laser != 0;

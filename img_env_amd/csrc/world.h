@@ -135,6 +135,7 @@ struct DevWorld {
     uint32_t* own_hi;        // max (robot index + 1) covering the cell, 0 = none
     uint32_t* cell;          // composed layer: class byte | (owning robot or OWNER_MULTI) << 8, one gather per lookup
                              // (STAMP mode: base class | this step's stamp, and the three layers above do not exist)
+    uint8_t* seg_tag;        // STAMP mode: [cells / 64] tag of the last step that stamped a cell of the segment
     // class records travel by value in the kernel arguments: scalar loads, and their table pointers are known
     // to be global (no flat loads, no reloads after stores)
     RobotClassDev rc[RC_INLINE];
@@ -143,7 +144,7 @@ struct DevWorld {
     const RobotClassDev* rc_mem;
     // big views (view_big.h): class tables, and per local robot the cropped view as a tiled bitmap (plane 0: occupied, plane 1:
     // outside the map / the field of view; big_words 32-bit words each, the last ones stay zero) and the beams' hit words
-    const BigClassDev* big_mem;
+    BigClassDev big[RC_INLINE];  // by value like rc[]: scalar loads, pointers known to be global
     uint32_t* big_bits;          // [RL][2][big_words]
     uint32_t* big_hit;           // [RL][big_hit_stride]: B hit words | the dummy beam | 1 = the view is redone by this chain of launches | its collision code
     int big_words, big_hit_stride, big_bits_in_lds;

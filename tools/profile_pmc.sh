@@ -1,10 +1,11 @@
 #!/bin/bash
 # The counter half of profile_round.sh alone: FETCH_SIZE / WRITE_SIZE passes and the three SQ passes of the headline bench
 # command (separate runs).  tools/profile_pmc.sh <tag>; results under gpurun_out/<tag>_pmc*.
+# PMC_CMD="python3 /root/repo/tools/shipped_probe.py --envs 2048 --steps 6" tools/profile_pmc.sh <tag> profiles another command.
 tag=${1:-pmc}
 out=/root/repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-S="python3 /root/repo/bench.py --steps 6 --warmup 3 --spinup 0 --no-cpu-baseline --no-episode --no-multi-world"
+S=${PMC_CMD:-"python3 /root/repo/bench.py --steps 6 --warmup 3 --spinup 0 --no-cpu-baseline --no-episode --no-multi-world"}
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_fetch -o p --output-format csv -- $S > $out/${tag}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_write -o p --output-format csv -- $S > $out/${tag}_write.log 2>&1
 i=0
