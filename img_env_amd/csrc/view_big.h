@@ -31,6 +31,20 @@
 #define VBT_T 256    // k_taps_big: one sensor_map pixel per thread
 #define VBF_T 256    // k_fullview_big
 
+__device__ __forceinline__ long long uniform_i64(long long v) {  // a value known to be the same in every lane, into scalar registers
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(unsigned long long)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// a (>= 0) times a 64-bit m, both wave-uniform, in 32-bit pieces the scalar unit has instructions for (a 64-bit multiply-add
+// of uniform values would be selected as v_mad_u64_u32, i.e. onto the vector unit)
+__device__ __forceinline__ long long umul_i64(int a, long long m) {
+    const uint32_t mlo = (uint32_t)(unsigned long long)m, mhi = (uint32_t)((unsigned long long)m >> 32);
+    const uint32_t lo = (uint32_t)a * mlo, hi = __umulhi((uint32_t)a, mlo) + (uint32_t)a * mhi;
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------------------------------------
 // (2) egocentric crop (agent.cpp:373-404), tiled.  All workgroups of one robot run on the same XCD (blockIdx modulo 8), so the
 // robot's window of the map is fetched from HBM once and shared through that XCD's L2.  STAMP mode reads the obstacle map
@@ -52,96 +66,122 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
     const double res = w.res;
-    // cell index = round(((m00 (a res) + m01 (b res)) + ox) / res): in cells that is m00 a + m01 b + ox / res up to a few ulps
+    // cell index = round(((m00 (a res) + m01 (b res)) + ox) / res): in cells that is m00 a + m01 b + ox / res up to a few ulps.
+    // Every multiply, shift, convert or fp64 operation costs a SIMD 4 cycles per wavefront, an integer add 2.4
+    // (tools/micro/valu_issue.hip), so the fast path is 32.32 fixed point: the tile's corner term is wave-uniform (scalar unit),
+    // a lane adds its own constant offset -- one 64-bit add per axis, the cell index is the high word (0.5 is folded in), and
+    // the low word says how close to a rounding boundary the value is.  The coefficients carry 2^-33 of rounding error each:
+    // with view coordinates below 4096 the sum is within 2^-20 of the exact value, the reference's own fp64 chain within 1e-11;
+    // lanes within 2^-17 of a boundary take the literal chain.
     const double oxs = vw.ox * w.inv_res, oys = vw.oy * w.inv_res;
+    const double two32 = 4294967296.0;
+    // (wave-uniform values, moved to scalar registers so that the per-tile products run on the scalar unit)
+    const long long M00 = uniform_i64((long long)rint(vw.m00 * two32)), M01 = uniform_i64((long long)rint(vw.m01 * two32));
+    const long long M10 = uniform_i64((long long)rint(vw.m10 * two32)), M11 = uniform_i64((long long)rint(vw.m11 * two32));
+    const long long OX = uniform_i64((long long)rint(oxs * two32) + (1ll << 31)), OY = uniform_i64((long long)rint(oys * two32) + (1ll << 31));
+    const bool fixed_ok = fabs(oxs) < 1048576.0 && fabs(oys) < 1048576.0;  // (always, for a pose anywhere near its map)
     const int Hg = w.Hg, Wg = w.Wg;
     const uint32_t self = (uint32_t)i, tag = STAMP ? w.stamp_tag : 0u;
     const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
                                     : (CLS_HIGH | CLS_ROBOT | (self << 8));
     const uint32_t base_tag_mask = 7u | (0xFFu << STAMP_TAG_SHIFT), base_tag_ours = CLS_HIGH | (tag << STAMP_TAG_SHIFT);
-    const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;
+    const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs, last_cell = (uint32_t)(Hg * Wg - 1);
+    const uint8_t* obs = w.obs_map + cell0;
+    const uint32_t* cls = w.cell + cell0;
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int da = lane >> 3, db = lane & 7;
+    long long Lx = da * M00 + db * M01, Ly = da * M10 + db * M11;  // this lane's offset inside any tile
+    asm volatile("" : "+v"(Lx), "+v"(Ly));  // (opaque: keeps the compiler from folding it back into a per-lane 64-bit multiply per tile)
     unsigned long long* plane0 = (unsigned long long*)(w.big_bits + (size_t)l * 2 * w.big_words);
     unsigned long long* plane1 = (unsigned long long*)(w.big_bits + ((size_t)l * 2 + 1) * w.big_words);
     const bool want_unknown = w.use_laser == 0;  // with the laser on only "occupied or not" survives into the outputs
     const int n_crop = k.n_crop, tb_n = k.tb;
     const int first = chunk * ((VBC_T / WAVE) * tpw);  // tpw tiles per wavefront: more in big launches (workgroup dispatch has a price)
+    // lane q holds the descriptor of this wavefront's q-th tile (tpw <= 64): one load here, a readlane per tile below
+    uint32_t my_tile = 0, my_fov_lo = 0, my_fov_hi = 0;
+    {
+        const int ti = first + lane * (VBC_T / WAVE) + wave;
+        if (lane < tpw && ti < n_crop) {
+            my_tile = k.crop_tiles[ti];
+            const unsigned long long f = k.crop_masks[ti];
+            my_fov_lo = (uint32_t)f;
+            my_fov_hi = (uint32_t)(f >> 32);
+        }
+    }
     for (int it = 0; it < tpw; it += VBC_U) {
         if (first + it * (VBC_T / WAVE) + wave >= n_crop) break;  // uniform
         uint32_t idx[VBC_U], tile_w[VBC_U];
-        bool look[VBC_U], risky = false;
-        int a_[VBC_U], b_[VBC_U];
+        unsigned long long look[VBC_U], risky = 0ull;  // lane masks (scalar registers)
 #pragma unroll
         for (int u = 0; u < VBC_U; u++) {
             const int ti = first + (it + u) * (VBC_T / WAVE) + wave;  // consecutive wavefronts take consecutive tiles
             const bool valid = ti < n_crop;
-            const uint32_t tile = k.crop_tiles[valid ? ti : 0];
-            const unsigned long long mask = valid ? k.crop_masks[ti] : 0ull;
-            const int a = (int)(tile >> 16) * 8 + da, b = (int)(tile & 0xFFFFu) * 8 + db;
+            const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, it + u);
+            const unsigned long long fov = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_fov_hi, it + u) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readlane((int)my_fov_lo, it + u);  // 0 past the end of the list
+            const int ta8 = (int)(tile >> 16) * 8, tb8 = (int)(tile & 0xFFFFu) * 8;
             tile_w[u] = valid ? (tile >> 16) * (uint32_t)tb_n + (tile & 0xFFFFu) : 0xFFFFFFFFu;
-            const double fa = (double)a, fb = (double)b;
-            const double tx = __fma_rn(vw.m00, fa, __fma_rn(vw.m01, fb, oxs)), ty = __fma_rn(vw.m10, fa, __fma_rn(vw.m11, fb, oys));
-            const double rx = rint(tx), ry = rint(ty);
-            const bool fov = ((mask >> lane) & 1ull) != 0ull;
-            risky |= fov & ((fabs(tx - rx) > 0.499999) | (fabs(ty - ry) > 0.499999));
-            a_[u] = a;
-            b_[u] = b;
-            const int m = (int)rx, n = (int)ry;
-            look[u] = fov & ((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg);
-            idx[u] = look[u] ? cell0 + (uint32_t)(m * Wg + n) : cell0;
+            const long long Tx = OX + umul_i64(ta8, M00) + umul_i64(tb8, M01), Ty = OY + umul_i64(ta8, M10) + umul_i64(tb8, M11);  // wave-uniform
+            const unsigned long long Fx = (unsigned long long)(Tx + Lx), Fy = (unsigned long long)(Ty + Ly);
+            const int m = (int)(uint32_t)(Fx >> 32), n = (int)(uint32_t)(Fy >> 32);
+            const uint32_t G = 1u << 15;
+            risky |= fov & __ballot(((uint32_t)Fx + G < 2u * G) | ((uint32_t)Fy + G < 2u * G));
+            look[u] = fov & __ballot(((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg));
+            idx[u] = min((uint32_t)(m * Wg + n), last_cell);  // any valid address for the lanes that do not look
         }
-        if (__builtin_expect(__any(risky), 0)) {  // somebody within 1e-6 of a rounding boundary: the reference's own chain
+        if (__builtin_expect(risky != 0ull || !fixed_ok, 0)) {  // somebody within 2^-17 of a rounding boundary: the reference's own chain
 #pragma unroll
             for (int u = 0; u < VBC_U; u++) {
                 const int ti = first + (it + u) * (VBC_T / WAVE) + wave;
-                const bool fov = ti < n_crop && ((k.crop_masks[ti < n_crop ? ti : 0] >> lane) & 1ull) != 0ull;
+                const bool valid = ti < n_crop;
+                const uint32_t tile = k.crop_tiles[valid ? ti : 0];
+                const unsigned long long fov = valid ? k.crop_masks[ti] : 0ull;
+                const int a = (int)(tile >> 16) * 8 + da, b = (int)(tile & 0xFFFFu) * 8 + db;
                 double wx, wy;
-                tf_apply(vw, a_[u] * res, b_[u] * res, wx, wy);
+                tf_apply(vw, a * res, b * res, wx, wy);
                 const int m = w2m(wx, res), n = w2m(wy, res);
-                look[u] = fov & ((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg);
-                idx[u] = look[u] ? cell0 + (uint32_t)(m * Wg + n) : cell0;
+                look[u] = fov & __ballot(((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg));
+                idx[u] = min((uint32_t)(m * Wg + n), last_cell);
             }
         }
         // free = >= 250 in this robot's private grid (agent.cpp:394-401)
-        bool free_cell[VBC_U];
+        unsigned long long free_cell[VBC_U];
         if (STAMP) {
             uint32_t o[VBC_U], sg[VBC_U];
-            bool stamped = false;
+            unsigned long long stamped[VBC_U], any_stamped = 0ull;
 #pragma unroll
             for (int u = 0; u < VBC_U; u++) {
-                o[u] = w.obs_map[idx[u]];
-                sg[u] = w.seg_tag[idx[u] >> 6];
+                o[u] = obs[idx[u]];
+                sg[u] = w.seg_tag[(cell0 + idx[u]) >> 6];
             }
 #pragma unroll
             for (int u = 0; u < VBC_U; u++) {
-                free_cell[u] = o[u] >= 250u;
-                stamped |= look[u] & (sg[u] == tag);
+                free_cell[u] = __ballot(o[u] >= 250u);
+                stamped[u] = look[u] & __ballot(sg[u] == tag);
+                any_stamped |= stamped[u];
             }
-            if (__any(stamped)) {  // near a robot or a pedestrian: class HIGH with nobody else's stamp of this step on it
+            if (any_stamped != 0ull) {  // near a robot or a pedestrian: class HIGH with nobody else's stamp of this step on it
 #pragma unroll
                 for (int u = 0; u < VBC_U; u++) {
-                    if (look[u] & (sg[u] == tag)) {
-                        const uint32_t v = w.cell[idx[u]];
-                        const uint32_t x = (v & base_tag_mask) ^ base_tag_ours;
-                        free_cell[u] = (v == free_own) | (((x & 7u) == 0u) & (x != 0u));
-                    }
+                    if (stamped[u] == 0ull) continue;
+                    const uint32_t v = cls[idx[u]];
+                    const uint32_t x = (v & base_tag_mask) ^ base_tag_ours;
+                    const unsigned long long f2 = __ballot((v == free_own) | (((x & 7u) == 0u) & (x != 0u)));
+                    free_cell[u] = (free_cell[u] & ~stamped[u]) | (f2 & stamped[u]);
                 }
             }
         } else {
             uint32_t v[VBC_U];
 #pragma unroll
-            for (int u = 0; u < VBC_U; u++) v[u] = w.cell[idx[u]];
+            for (int u = 0; u < VBC_U; u++) v[u] = cls[idx[u]];
 #pragma unroll
-            for (int u = 0; u < VBC_U; u++) free_cell[u] = (v[u] == (uint32_t)CLS_HIGH) | (v[u] == free_own);
+            for (int u = 0; u < VBC_U; u++) free_cell[u] = __ballot((v[u] == (uint32_t)CLS_HIGH) | (v[u] == free_own));
         }
 #pragma unroll
         for (int u = 0; u < VBC_U; u++) {
-            const unsigned long long occ = __ballot(look[u] & !free_cell[u]);
-            const unsigned long long unk = __ballot(!look[u]);
             if (lane == 0 && tile_w[u] != 0xFFFFFFFFu) {
-                plane0[tile_w[u]] = occ;
-                if (want_unknown) plane1[tile_w[u]] = unk;
+                plane0[tile_w[u]] = look[u] & ~free_cell[u];
+                if (want_unknown) plane1[tile_w[u]] = ~look[u];
             }
         }
     }
