@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--spinup", type=int, default=2000, help="untimed steps before the warm-up (clock ramp)")
     ap.add_argument("--timing-mode", type=int, default=2, help="diagnostic: 0 = no HIP events in the timed pass")
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
+    ap.add_argument("--passes", type=int, default=5, help="timed passes of the SAME --steps; value = the median pass")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
                     "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)  # internal: one process of the all-core CPU baseline
@@ -391,10 +392,44 @@ def main():
     if args.spinup > 0:
         run("active", args.spinup, 0)
     # pass 2: THE timed region; HIP events only around the dominant kernel
-    dt, tm, frozen_active = run("active", args.steps, args.warmup, timing_mode=args.timing_mode, which=dom_id)
+    # Several passes of exactly --steps steps each, every one bracketed by barrier + synchronize; the MEDIAN pass is the line's
+    # value (boxes of the pool alternate between two step times from process to process and pass to pass, and the driver's 20-step
+    # region is 2.5 ms long), min / max are reported beside it
+    passes = []
+    for q in range(max(1, args.passes)):
+        d_q, tm_q, fr_q = run("active", args.steps, args.warmup if q == 0 else min(args.warmup, 5), timing_mode=args.timing_mode, which=dom_id)
+        passes.append((d_q, tm_q, fr_q, state["resets_timed"]))
+    order = sorted(range(len(passes)), key=lambda q: passes[q][0])
+    dt, tm, frozen_active, resets_timed = passes[order[len(order) // 2]]
     dom_ms, dom_n = tm[dominant]
-    resets_timed = state["resets_timed"]
     value = R * args.steps / dt
+    pass_values = [R * args.steps / p[0] for p in passes]
+    # SURVEY 8(d) wants the auto-reset inside the timed region; a run shorter than an episode (the driver's 20 steps) never meets
+    # one, so it is timed separately: the same N steps + ONE full imgenv_reset of the world
+    with_reset = None
+    if args.steps <= TIME_MAX:
+        acts_r = make_actions("active")
+        state["episode"] = 0
+        do_reset()
+        for s in range(min(args.warmup, 5)):
+            do_step(acts_r[s % n_act])
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        for s in range(args.steps):
+            do_step(acts_r[s % n_act])
+        do_reset()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dtr = time.perf_counter() - t0r
+        if use_dist:
+            t = torch.tensor([dtr], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtr = float(t.item())
+        with_reset = dict(value=R * args.steps / dtr, ms_per_step=1e3 * dtr / args.steps,
+                          what="%d steps + one full imgenv_reset of the world inside the timed region" % args.steps)
     for q in range(args.repeat):
         for mode in (0, 2):
             d2, _, _ = run("active", args.steps, args.warmup, timing_mode=mode, which=dom_id)
@@ -434,6 +469,16 @@ def main():
         except Exception as e:
             vec_env = {"error": repr(e)}
 
+    shipped = None
+    if world_size == 1 and not args.no_multi_world and not args.force_dist:
+        # secondary: the geometry of the reference's shipped envs/cfg/test.yaml (BASELINE cfg-1): 400 x 400 cell views shrunk to
+        # 48 x 48, 1000 beams, one robot + 4 leg pedestrians + 4 obstacles per env, VecImageEnv end to end with auto-resets
+        try:
+            from shipped_probe import measure as measure_shipped
+            shipped = [measure_shipped(E, steps=max(args.steps, 100), device=local_rank) for E in (256, 2048)]
+        except Exception as e:
+            shipped = {"error": repr(e)}
+
     if rank == 0:
         ab = algorithmic_bytes(P)
         kernel_bytes = ab.get(dominant, ab["total"]) * RL
@@ -453,6 +498,20 @@ def main():
                                   "during this run")
             except Exception:
                 traffic = None
+        # instruction-issue ceiling of the dominant kernel: wavefronts x vector instructions per wavefront (SQ_INSTS_VALU of the
+        # committed counter passes) x cycles per wave64 instruction (tools/micro/valu_issue.hip on this chip: 4.2 for everything
+        # but plain add / and, which take 2.4) over 1024 SIMDs
+        issue = None
+        try:
+            cnt = json.load(open(pmc)).get(dominant, {}) if os.path.exists(pmc) else {}
+            if cnt.get("valu_per_wave") and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
+                waves, vpw = cnt["waves_per_launch"], cnt["valu_per_wave"]
+                lo, hi = (waves * vpw * c / (1024 * 2.4e9) * 1e6 for c in (2.4, 4.2))
+                issue = {"valu_per_wave": vpw, "waves_per_launch": waves, "cycles_model": "4.2 cycles per wave64 VALU instruction per SIMD "
+                         "(2.4 for v_add_u32 / v_and_b32), 1024 SIMDs at 2.4 GHz: profiles/r3_valu_issue.txt", "ceiling_us": hi,
+                         "ceiling_us_if_all_were_adds": lo, "frac": hi / (dur_s * 1e6), "source": "profiles/pmc_latest.json (SQ passes)"}
+        except Exception:
+            issue = None
         out = {
             "metric": "robot-steps/sec (whole node) at 8192 robots, 48x48 maps, 360 lasers",
             "value": value, "unit": "robot-steps/s", "n_gpus": world_size, "steps": args.steps,
@@ -472,6 +531,9 @@ def main():
                            if native else "torch.distributed between step_begin/step_end"))
                        if use_dist else "single GPU"},
             "resets_in_timed_region": resets_timed,
+            "passes": {"n": len(passes), "value_is": "median", "values": pass_values, "min": min(pass_values), "max": max(pass_values)},
+            "with_reset": with_reset,
+            "shipped": shipped,
             "frozen_fraction": frozen_active,
             "multi_world": multi_world,
             "vec_env": vec_env,
@@ -488,7 +550,8 @@ def main():
                          # SURVEY 8(d)'s algorithmic bytes of the whole path over the whole step time.  NOT evidence of HBM use:
                          # k_obs updates the ped_map sparsely and writes ~6 KB per robot, not the 37 KB the formula counts --
                          # path_traffic_frac above is the counter-based figure
-                         "path_algorithmic_gbps": ab["total"] * value / world_size / 1e9},
+                         "path_algorithmic_gbps": ab["total"] * value / world_size / 1e9,
+                         "issue": issue},
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

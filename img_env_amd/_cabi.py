@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 RECORD_DOUBLES = 8
 
 SHAPE_CIRCLE, SHAPE_RECTANGLE, SHAPE_LEG = 0, 1, 2

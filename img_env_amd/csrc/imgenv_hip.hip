@@ -117,6 +117,9 @@ struct imgenv {
     uint64_t spawn_ahead_cfg = 0;  // fingerprint of the spawn cfg the placements were drawn from
     int spawn_ahead_n = 8;
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
+    double trace_acc[4] = {0, 0, 0, 0};  // IMGENV_TRACE_RESET: host time inside imgenv_step_autoreset
+    long trace_calls = 0, trace_resets = 0;
+    bool chain_open = false;  // a chain of launches that hands over through tail_sig / tail_cnt has started and not been completed
     std::vector<RvoObstacles> rvos;  // one obstacle set per world
     int sfm_cap_obs = 0;
     // live timing (imgenv_timing)
@@ -247,9 +250,9 @@ extern "C" int imgenv_timing_read(imgenv_t* h, double* total_ms, int64_t* launch
 
 // "hip-gfx950" is the product build only: a library compiled with any work-skipping experiment switch or with the
 // profiling instrumentation says so, so that a number measured on it can never pass for the product's
-#if defined(IMGENV_EXP_STOP_AFTER) || defined(IMGENV_EXP_NO_DRAIN) || defined(IMGENV_EXP_SKIP_RESOLVE) || defined(IMGENV_EXP_SKIP_CROP) || defined(IMGENV_EXP_SKIP_HITS) || defined(IMGENV_EXP_SKIP_FINAL) || defined(IMGENV_EXP_CROP_U8)
+#if defined(IMGENV_EXP_STOP_AFTER)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-EXPERIMENT-work-skipped"; }
-#elif defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE)
+#elif defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE) || defined(IMGENV_EXP_RESOLVE_STATS) || defined(IMGENV_EXP_TINY_RESOLVE)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-profile-instrumented"; }
 #else
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950"; }
@@ -440,13 +443,17 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     std::vector<uint8_t> resized_map;
     if (cfg->global_resolution != cfg->view_resolution) {
         const double resolution_ = (double)cfg->global_resolution, view_res = (double)cfg->view_resolution;
-        const int w2 = (int)(Wg * resolution_ / view_res), h2 = (int)(Hg * resolution_ / view_res);
-        if (w2 < 1 || h2 < 1 || (size_t)w2 * h2 >= ((size_t)1 << 31)) FAIL(IMGENV_EINVAL, "the map would be resized to %d x %d cells", h2, w2);
+        const double w2d = floor(Wg * resolution_ / view_res), h2d = floor(Hg * resolution_ / view_res);  // (range-checked before the cast)
+        if (!(w2d >= 1 && h2d >= 1 && w2d * h2d < 2147483648.0)) FAIL(IMGENV_EINVAL, "the map would be resized to %.0f x %.0f cells", h2d, w2d);
+        const int w2 = (int)w2d, h2 = (int)h2d;
         resized_map.resize((size_t)w2 * h2);
         cv_resize_u8(false, static_map, Hg, Wg, resized_map.data(), h2, w2);
         static_map = resized_map.data();
         Hg = h2;
         Wg = w2;
+        // the kernels index the worlds' copies of a layer with 32 bits: checked again on the grid the handle really works on
+        if (W > 1 && (((size_t)Hg * Wg + 15) & ~(size_t)15) * (size_t)W >= ((size_t)1 << 32))
+            FAIL(IMGENV_EINVAL, "n_worlds x map cells must stay below 2^32 (the map is resized to %d x %d cells)", Hg, Wg);
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(IMGENV_EDEVICE, "no HIP device available");
@@ -1075,7 +1082,20 @@ static void set_tail_fields(imgenv* h, int is_reset, int tail_elapsed) {
     d.tail_elapsed = tail_elapsed;
 }
 
+// The fused tails (tail_group in kernels.h) rely on tail_sig / tail_cnt being zero when a chain of launches starts; the chain
+// itself re-zeroes them.  A chain that was abandoned half-way (an error between imgenv_step_begin and imgenv_step_end, a failing
+// launch) leaves stale bits behind: the next chain clears the words first.
+static int chain_begin(imgenv* h, hipStream_t st) {
+    if (h->chain_open) {
+        HIPCHK(hipMemsetAsync(h->d.tail_sig, 0, sizeof(unsigned long long) * (size_t)h->RL, st));
+        HIPCHK(hipMemsetAsync(h->d.tail_cnt, 0, sizeof(int) * (size_t)(h->RL + WAVE - 1) / WAVE * TAIL_CNT_STRIDE, st));
+    }
+    h->chain_open = true;
+    return 0;
+}
+
 static int launch_obs(imgenv* h, hipStream_t st) {
+    if (int rc = chain_begin(h, st)) return rc;
     DevWorld& d = h->d;
     const bool overlap = !h->serial;
     hipStream_t s_obs = overlap ? h->side2 : st;
@@ -1102,6 +1122,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     const int n_g = d.act_ng, n_p = d.act_np, n_l = d.act_nl;
     // k_compose: 4 cells per thread over everything, or a fixed number of 256-thread blocks per listed world
     set_tail_fields(h, is_reset, h->elapsed);
+    if (h->P == 0)
+        if (int rc = chain_begin(h, st)) return rc;
     const unsigned compose_blocks = d.act_list ? (unsigned)(((h->Gs / 4 + 255) / 256) * d.act_nw) : (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
     if (h->P > 0) {
         // One fork and one join per step on the caller's stream (every event operation costs it a ~6 us dependency
@@ -1220,6 +1242,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     h->launches += 3;
     HIPCHK(hipGetLastError());
+    h->chain_open = false;
     return 0;
 }
 
@@ -1650,7 +1673,12 @@ static int reset_checks(imgenv* h, int n, const imgenv_reset_batch* b, int peds_
                     FAIL(IMGENV_EINVAL, "reset batch %d, ped %d: bad trajectory length %d", q, j, b[q].ped_traj_len[j]);
         }
     }
-    if (h->obs_forked) FAIL(IMGENV_ESTATE, "reset between imgenv_step_begin and imgenv_step_end");
+    if (h->obs_forked) {
+        // a step that was begun and never ended (the caller's exchange failed in between): its k_obs is in flight on a side
+        // stream and will still arrive at the tails' hand-over words; wait for it, the reset's first chain then clears them
+        if (h->side2) HIPCHK(hipStreamSynchronize(h->side2));
+        h->obs_forked = false;
+    }
     HIPCHK(hipSetDevice(h->cfg.device));
     if (int rc = check_device_flags(h)) {  // report what the abandoned episode raised, then start clean
         for (int q = 0; q < 8; q++) h->err_host[q] = 0;
@@ -1873,6 +1901,7 @@ extern "C" int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset
 extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream) {
     if (!h || !actions) FAIL(IMGENV_EINVAL, "null argument");
     if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
+    if (h->obs_forked) FAIL(IMGENV_ESTATE, "imgenv_step_begin twice without imgenv_step_end (reset the handle to recover from an aborted step)");
     if (int rc = check_device_flags(h)) return rc;
     hipStream_t st = (hipStream_t)stream;
     DevWorld& d = h->d;
@@ -1980,8 +2009,8 @@ extern "C" int imgenv_step_autoreset(imgenv_t* h, const float* actions, const im
     if (h->RL != h->R) FAIL(IMGENV_EINVAL, "imgenv_step_autoreset needs all robots of every world on this handle");
     *n_out = 0;
     static const bool trace = getenv("IMGENV_TRACE_RESET") != nullptr;  // where the host's time goes, every 200 calls
-    static double acc[4] = {0, 0, 0, 0};
-    static long calls = 0, resets = 0;
+    double* acc = h->trace_acc;
+    long &calls = h->trace_calls, &resets = h->trace_resets;
     std::chrono::steady_clock::time_point tp[5];
     if (trace) tp[0] = std::chrono::steady_clock::now();
     if (int rc = imgenv_step(h, actions, stream)) return rc;
@@ -2011,24 +2040,32 @@ extern "C" int imgenv_step_autoreset(imgenv_t* h, const float* actions, const im
         std::vector<int32_t> worlds((size_t)n);
         for (int q = 0; q < n; q++) worlds[q] = h->finished_host[1 + q];
         std::sort(worlds.begin(), worlds.end());  // the device lists them in no particular order; seeds go by ascending index
-        *n_out = n;
-        for (int q = 0; q < n && worlds_out && q < cap; q++) worlds_out[q] = worlds[q];
-        std::vector<std::unique_ptr<SpawnOut>> outs((size_t)n);
-        std::vector<imgenv_reset_batch> batches((size_t)n);
+        // every placement first: a seed that cannot be placed fails the call BEFORE anything is handed out or taken from the
+        // pre-drawn placements (the step itself has been applied; no world has been reset; *n_out stays 0; a repeated call
+        // meets the same seeds)
+        std::vector<SpawnOut*> use((size_t)n, nullptr);
+        std::vector<std::unique_ptr<SpawnOut>> fresh;
         for (int q = 0; q < n; q++) {
             auto it = h->spawn_ahead.find(seed0 + (uint64_t)q);
             if (it != h->spawn_ahead.end() && it->second->batch.struct_size != 0) {
-                outs[q] = std::move(it->second);
-                h->spawn_ahead.erase(it);
+                use[q] = it->second.get();
             } else {
-                outs[q].reset(new SpawnOut);
-                if (const char* why = spawn_world(*cfg, seed0 + (uint64_t)q, *outs[q])) FAIL(IMGENV_EINVAL, "spawn of world %d: %s", worlds[q], why);
+                fresh.emplace_back(new SpawnOut);
+                if (const char* why = spawn_world(*cfg, seed0 + (uint64_t)q, *fresh.back()))
+                    FAIL(IMGENV_EINVAL, "spawn of world %d (seed %llu): %s", worlds[q], (unsigned long long)(seed0 + (uint64_t)q), why);
+                use[q] = fresh.back().get();
             }
-            batches[q] = outs[q]->batch;
         }
+        std::vector<imgenv_reset_batch> batches((size_t)n);
+        for (int q = 0; q < n; q++) batches[q] = use[q]->batch;
         h->spawn_ahead_n = std::min(256, std::max(8, 2 * n));  // twice what this step needed
         if (trace) tp[3] = std::chrono::steady_clock::now();
         rc = imgenv_reset_worlds(h, n, worlds.data(), batches.data(), stream);
+        if (rc == IMGENV_OK) {
+            *n_out = n;
+            for (int q = 0; q < n && worlds_out && q < cap; q++) worlds_out[q] = worlds[q];
+            for (int q = 0; q < n; q++) h->spawn_ahead.erase(seed0 + (uint64_t)q);  // consumed
+        }
     } else if (trace) {
         tp[3] = std::chrono::steady_clock::now();
     }
@@ -2095,7 +2132,12 @@ extern "C" int imgenv_records(imgenv_t* h, double** records, int64_t* bytes_per_
 
 extern "C" int imgenv_outputs(imgenv_t* h, imgenv_out* out) {
     if (!h || !out) FAIL(IMGENV_EINVAL, "null argument");
-    *out = h->out;
+    // a caller built against an older, shorter imgenv_out says so in struct_size and gets no more than that many bytes
+    // (fields are only ever appended); 0 = the caller's struct is this library's
+    const int32_t want = out->struct_size;
+    if (want < 0 || want > (int32_t)sizeof(imgenv_out)) FAIL(IMGENV_EINVAL, "imgenv_out.struct_size %d (this library's is %d)", want, (int)sizeof(imgenv_out));
+    if (want == 0) *out = h->out;
+    else memcpy(out, &h->out, (size_t)want);
     return IMGENV_OK;
 }
 

@@ -25,6 +25,7 @@
 
 #include "orca_device.h"
 #include "world.h"
+#include "exp_hooks.h"
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
@@ -1233,10 +1234,6 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     if (tid < 16) src[NC + tid] = 255;  // dummy free cells behind the view (padded path entries)
     if (tid < 3) skip_cnt[tid] = 0;
     __syncthreads();
-#ifdef IMGENV_EXP_SKIP_CROP
-    for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) *(uint32_t*)(src + c4) = 0xFFFFFFFFu;
-    if (false)
-#endif
     for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
         const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds the 4 bits
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
@@ -1281,11 +1278,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
             }
             uint32_t v[4];
 #pragma unroll
-#ifdef IMGENV_EXP_CROP_U8
-            for (int q = 0; q < 4; q++) v[q] = ((const uint8_t*)w.cell)[idx[q]];  // timing experiment: byte gathers
-#else
             for (int q = 0; q < 4; q++) v[q] = w.cell[idx[q]];
-#endif
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 // free (>= 250, agent.cpp:394-401) and no other robot on it: the plain class, or this robot as the only owner
@@ -1304,19 +1297,10 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     }
     __syncthreads();
     PHASE_MARK(1);
-#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 1
-    return;  // instruction accounting: collision + crop only
-#endif
+    EXP_STOP_AFTER(1);  // instruction accounting builds: collision + crop only
 
     // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
-#ifdef IMGENV_EXP_SKIP_HITS
-    for (int b = tid; b < w.B; b += NT) hit[b] = 0xFFFFFFFFu;
-    if (tid == 0) hit[w.B] = 0u;
-    __syncthreads();
-    if (false) {
-#else
     if (laser) {
-#endif
         const uint4* rows = (const uint4*)k.ray_rows;
         const int n_chunks = k.ray_kpad >> 3;
         for (int b0 = 0; b0 < w.B; b0 += NT) {
@@ -1370,9 +1354,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
         for (int i = tid; i < n2; i += NT) reach_tab[n0 + n1 + i] = max(reach_tab[n0 + 2 * i], reach_tab[n0 + min(2 * i + 2, n1 - 1)]);
     }
     PHASE_MARK(2);
-#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 2
-    return;  // instruction accounting: collision + crop + first hits
-#endif
+    EXP_STOP_AFTER(2);  // ... + first hits
 
     // (4) laser_map (agent.cpp:437) per cell from its top beam, the own footprint stamped 100 (agent.cpp:503),
     //     stored as uint8 and as float16(v / 255) (yaml_env.py:431-438).  Class index: 0 -> 0, 1 -> 100, 2 -> 200, 3 -> 255
@@ -1385,9 +1367,6 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     uint32_t* skip_list = (uint32_t*)src;  // the crop is dead once the beams have their hits
     const uint32_t no_beam = ((uint32_t)w.B << 16) | 0xFFFFu;  // top_ent of a cell no beam crosses
     int n_skip = 0;
-#ifdef IMGENV_EXP_SKIP_FINAL
-    if (false)
-#endif
     for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
         uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
         if (laser) {
@@ -1475,56 +1454,16 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     } else {
         n_skip = __builtin_amdgcn_readfirstlane(n_skip);  // lane 0 ran every round of the loop above
     }
-#ifdef IMGENV_EXP_SKIP_RESOLVE
-    n_skip = 0;
-#endif
     if (n_skip > 0) {
-#ifndef IMGENV_EXP_NO_DRAIN
         __builtin_amdgcn_s_waitcnt(0);  // the provisional stores of this wave have landed
         __syncthreads();
-#endif
         const int n_even = (n_skip + 1) & ~1;
         uint2* desc = (uint2*)(skip_list + n_even);
         uint32_t* slots = (uint32_t*)colt;
-#ifdef IMGENV_EXP_TINY_RESOLVE  // test build: hardly any room, most cells take the fallbacks
-        const int cap_d = 5, cap_r = 2;
-#else
-        const int cap_d = (NCp / 4 - n_even) / 2, cap_r = 4 * Wv;
-#endif
+        const int cap_d = EXP_RESOLVE_CAP((NCp / 4 - n_even) / 2, 5), cap_r = EXP_RESOLVE_CAP(4 * Wv, 2);  // (test builds: hardly any room)
         const uint2 NOP = make_uint2(0xFFFFFFFFu, 0u);
         const uint32_t h01 = h0 | (h1 << 16);
-#ifdef IMGENV_EXP_RESOLVE_STATS  // how many cells are left alone, and how long the lists behind them are
-        if (tid == 0) {
-            atomicAdd(&w.dbg[16], 1ull);
-            atomicAdd(&w.dbg[17], (unsigned long long)n_skip);
-        }
-        for (int t = tid; t < n_skip; t += NT) {
-            const uint32_t e = skip_list[t];
-            for (uint32_t bits = e & 15u; bits != 0u; bits &= bits - 1u) {
-                const uint32_t c = (e >> 4) + (uint32_t)__builtin_ctz(bits);
-                const uint32_t cnt = k.inv_pack[c] >> 20;
-                atomicAdd(&w.dbg[18], 1ull);
-                atomicAdd(&w.dbg[19], (unsigned long long)cnt);
-                atomicMax(&w.dbg[20], (unsigned long long)cnt);
-                atomicAdd(&w.dbg[21 + min(cnt >> 3, 8u)], 1ull);
-                {  // where the walk ends: entry index of the first deciding beam (bins 1, 2, 3-4, 5-8, 9-16, 17+), or never
-                    const uint32_t pk = k.inv_pack[c], e0 = pk & 0xFFFFFu;
-                    uint32_t at = 0, verdict = 2;
-                    for (uint32_t q = 1; q < cnt && at == 0; q++) {
-                        const uint32_t ent = k.inv_ent[e0 + q], kk = ent & 0xFFFFu, hp = hit[ent >> 16], hk = hp >> 16;
-                        if (kk < hk) { at = q; verdict = 3; }
-                        else if (kk == hk) { at = q; verdict = 0; }
-                        else if (kk > (hp & 0xFFFFu)) at = q;
-                    }
-                    const int bin = at == 0 ? 6 : (at <= 2 ? (int)at - 1 : (at <= 4 ? 2 : (at <= 8 ? 3 : (at <= 16 ? 4 : 5))));
-                    atomicAdd(&w.dbg[8 + bin], 1ull);
-                    if (verdict != 2) atomicAdd(&w.dbg[15], 1ull);
-                    if (at == 0) atomicAdd(&w.dbg[30], (unsigned long long)cnt);  // entries walked for nothing
-                    else atomicAdd(&w.dbg[31], (unsigned long long)at);
-                }
-            }
-        }
-#endif
+        EXP_RESOLVE_STATS_CELLS(w, k, hit, skip_list, n_skip, tid, NT);
         int base_d = 0, base_r = 0;  // NW == 1: the two cursors live in scalar registers
         const int n_items = 4 * n_skip;
         for (int tb = 0; tb < n_items; tb += 4 * NT) {  // A: one (list entry, cell of its four) per lane, four rounds' loads in flight
@@ -1586,16 +1525,9 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
             skip_cnt[2] = base_r;
         }
         __syncthreads();
-#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 3
-        return;  // instruction accounting: ... + step A of the resolve
-#endif
+        EXP_STOP_AFTER(3);  // ... + step A of the resolve
         const int nd = min(skip_cnt[1], cap_d), nr = min(skip_cnt[2], cap_r);
-#ifdef IMGENV_EXP_RESOLVE_STATS
-        if (tid == 0) {
-            atomicAdd(&w.dbg[6], (unsigned long long)nd);
-            atomicAdd(&w.dbg[7], (unsigned long long)nr);
-        }
-#endif
+        EXP_RESOLVE_STATS_ROOM(w, nd, nr, tid);
         for (int t = tid; t < nd; t += NT) {  // B: descriptor = cell | entries - 1 << 16 | slot << 19 | stamped << 29 | one chunk << 31,
             const uint2 d = desc[t];          //                 first entry | chunk << 20
             const uint32_t c = d.x & 0xFFFFu;
@@ -1617,9 +1549,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
                 else atomicMin(&slots[(d.x >> 19) & 0x3FFu], key | c | (((d.x >> 29) & 1u) << 30));
             }
         }
-#if defined(IMGENV_EXP_STOP_AFTER) && IMGENV_EXP_STOP_AFTER == 4
-        return;  // instruction accounting: ... + step B
-#endif
+        EXP_STOP_AFTER(4);  // ... + step B
         if (nr > 0) {
             __syncthreads();
             for (int t = tid; t < nr; t += NT) {  // C

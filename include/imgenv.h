@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define IMGENV_ABI_VERSION 1
+#define IMGENV_ABI_VERSION 2  /* 2: imgenv_out grew (image / grid sizes, step_* arrays), spawn structs, IMGENV_FLAG_NO_VIEW_MAPS */
 
 /* error codes */
 #define IMGENV_OK 0
@@ -288,6 +288,8 @@ int imgenv_comm_init(imgenv_t* h, const void* id128, int32_t rank, int32_t n_ran
 /* what RCCL itself reports for the handle's communicator (ncclCommCount / ncclCommUserRank); IMGENV_ESTATE without one */
 int imgenv_comm_info(imgenv_t* h, int32_t* n_ranks, int32_t* rank);
 
+/* out->struct_size on entry: 0 (the caller's imgenv_out is this header's) or the size of the caller's older, shorter struct --
+ * then only that many bytes are written (fields are only ever appended at the end). */
 int imgenv_outputs(imgenv_t* h, imgenv_out* out);
 
 /* Multi-world handles (imgenv_cfg.n_worlds > 1): reset ONE world while the others keep their state -- what one env

@@ -154,6 +154,25 @@ def test_second_reset_reuses_handle(worlds):
         cpu.close()
 
 
+def test_aborted_step_is_recovered_by_reset(worlds):
+    """a step that was begun and never ended (the caller's exchange failed between imgenv_step_begin and imgenv_step_end) leaves
+    the fused tails' hand-over words half filled; a reset recovers the handle and the next episode matches the oracle"""
+    World, OracleWorld = worlds
+    grid, params, layout = small_world(70, 9, seed=31)   # more than one group of 64 robots
+    _, _, layout2 = small_world(70, 9, seed=32)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        rng = np.random.default_rng(5)
+        assert not run_pair(gpu, cpu, layout, [random_actions(rng, 70) for _ in range(4)])
+        gpu.step_begin(random_actions(rng, 70))  # k_integrate + k_obs are in flight; imgenv_step_end never comes
+        with pytest.raises(RuntimeError):
+            gpu.step_begin(random_actions(rng, 70))
+        assert not run_pair(gpu, cpu, layout2, [random_actions(rng, 70) for _ in range(8)])
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "python_post_*.npz")))
 
 

@@ -2,7 +2,9 @@
 roofline.traffic).  Units and corrections as the MI355X guide's HBM section prescribes: both counters are in
 KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is doubled (an upper bound
 for this path's gathers); WRITE_SIZE is taken as reported.
-usage: python tools/pmc_to_json.py <fetch_dir> <write_dir> [out.json]"""
+Optional SQ passes (SQ_WAVES, SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_INSTS_LDS ...) add per-wavefront instruction counts, which
+bench.py turns into the instruction-issue ceiling (roofline.issue).
+usage: python tools/pmc_to_json.py <fetch_dir> <write_dir> [out.json] [sq_dir ...]"""
 import collections
 import csv
 import glob
@@ -24,12 +26,24 @@ def per_launch(d, counter):
 
 fetch = per_launch(sys.argv[1], "FETCH_SIZE")
 write = per_launch(sys.argv[2], "WRITE_SIZE")
-out = {}
+out, sq_waves = {}, {}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):
         continue
     f, w = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
     out[k] = dict(fetch_size_bytes_raw=f, write_size_bytes_raw=w, hbm_bytes_per_launch=2 * f + w)
+for d in sys.argv[4:]:
+    for k, v in per_launch(d, "SQ_WAVES").items():
+        if k in out:
+            sq_waves[k] = v
+            out[k]["waves_per_launch"] = v
+for d in sys.argv[4:]:
+    for name, key in (("SQ_INSTS_VALU", "valu_per_wave"), ("SQ_INSTS_SALU", "salu_per_wave"), ("SQ_INSTS_LDS", "lds_per_wave"),
+                      ("SQ_INSTS_VMEM_RD", "vmem_rd_per_wave"), ("SQ_INSTS_VMEM_WR", "vmem_wr_per_wave"), ("SQ_WAVE_CYCLES", "wave_cycles_per_wave"),
+                      ("SQ_WAIT_ANY", "wait_any_per_wave")):
+        for k, v in per_launch(d, name).items():
+            if k in out and k in sq_waves:
+                out[k][key] = v / sq_waves[k]
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (8192 robots, 200 peds); "
                 "KiB -> bytes; FETCH doubled per the gfx950 correction; per kernel launch")
 path = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_latest.json"

@@ -4,7 +4,7 @@
 cd /root/repo
 export IMGENV_SERIAL=1
 i=0
-for f in "" -DIMGENV_EXP_STOP_AFTER=1 -DIMGENV_EXP_STOP_AFTER=2 -DIMGENV_EXP_SKIP_RESOLVE -DIMGENV_EXP_STOP_AFTER=3 -DIMGENV_EXP_STOP_AFTER=4 -DIMGENV_EXP_NO_DRAIN; do
+for f in "" -DIMGENV_EXP_STOP_AFTER=1 -DIMGENV_EXP_STOP_AFTER=2 -DIMGENV_EXP_STOP_AFTER=3 -DIMGENV_EXP_STOP_AFTER=4; do
   i=$((i+1))
   python3 tools/experiment.py $f --build-only --out=/tmp/exp_$i.so >/dev/null 2>&1
 done
