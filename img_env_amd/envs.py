@@ -374,112 +374,159 @@ class NeverStopWrapper(Wrapper):
         return states, reward, done, info
 
 
-class TrajectoryPathHelper:
-    """envs/wrapper/evaluation_wrapper/utils.py:5-129: path statistics of one episode's (v, w) commands"""
+class EpisodeStats:
+    """Running path statistics of every robot of an env at once, as tensors on the device the speeds live on: what the
+    reference's evaluation helper (envs/wrapper/evaluation_wrapper/utils.py:60-129) computes from the stored (v, w) arrays of
+    ONE robot -- variance of w, sign changes of w, mean |acceleration| and |jerk| of v and w, mean v and |w| -- accumulated step
+    by step instead (sums, last two commands), so nothing grows with the episode and nothing loops over robots."""
 
-    def __init__(self, dt):
-        self.dt = dt
-        self.v_array, self.w_array = [], []
-        self.w_zero = self.v_jerk = self.w_jerk = self.w_variance = self.w_avg = self.v_avg = self.w_acc = self.v_acc = 0
+    def __init__(self, n, dt, device):
+        import torch
+        self.dt = float(dt)
+        z = lambda: torch.zeros(n, dtype=torch.float64, device=device)  # noqa: E731
+        self.n = z()                        # commands so far
+        self.sum_v, self.sum_w, self.sum_ww, self.sum_absw = z(), z(), z(), z()
+        self.sum_abs_acc, self.sum_abs_jerk = [z(), z()], [z(), z()]  # v, w
+        self.prev, self.prev2 = [z(), z()], [z(), z()]                # last and last-but-one command
+        self.w_zero = z()
 
-    def add_vw(self, v, w):
-        self.v_array.append(v)
-        self.w_array.append(w)
+    def add(self, v, w):
+        import torch
+        v, w = v.to(torch.float64), w.to(torch.float64)
+        has1, has2 = self.n >= 1, self.n >= 2
+        for k, x in enumerate((v, w)):
+            acc = (x - self.prev[k]) / self.dt
+            acc_prev = (self.prev[k] - self.prev2[k]) / self.dt
+            self.sum_abs_acc[k] += torch.where(has1, acc.abs(), torch.zeros_like(acc))
+            self.sum_abs_jerk[k] += torch.where(has2, ((acc - acc_prev) / self.dt).abs(), torch.zeros_like(acc))
+        last = self.prev[1]  # (0 before the first command, like the helper's `tmp`)
+        self.w_zero += (((w == 0) & (last != 0)) | ((w > 0) & (last < 0)) | ((w < 0) & (last > 0))).to(torch.float64)
+        self.prev2 = [self.prev[0], self.prev[1]]
+        self.prev = [v, w]
+        self.n += 1
+        self.sum_v += v
+        self.sum_w += w
+        self.sum_ww += w * w
+        self.sum_absw += w.abs()
 
-    def reset(self):
-        """cal_w_variance, cal_w_zero, cal_jerk, cal_v_avg, cal_w_avg (utils.py:60-101, 123-129)"""
-        self.w_variance = np.var(self.w_array)
-        tmp = w_zero = 0
-        for w in self.w_array:  # sign changes of w, a zero in between counts once
-            if w == 0:
-                if tmp != 0:
-                    w_zero += 1
-            elif (w > 0 and tmp < 0) or (w < 0 and tmp > 0):
-                w_zero += 1
-            tmp = w
-        self.w_zero = w_zero
-        v_acc = np.diff(self.v_array, axis=0) / self.dt
-        self.v_jerk = np.average(np.abs(np.diff(v_acc, axis=0) / self.dt))
-        self.v_acc = np.average(np.abs(v_acc))
-        w_acc = np.diff(self.w_array, axis=0) / self.dt
-        self.w_jerk = np.average(np.abs(np.diff(w_acc, axis=0) / self.dt))
-        self.w_acc = np.average(np.abs(w_acc))
-        self.v_avg = np.average(self.v_array)
-        self.w_avg = np.average(np.abs(self.w_array))
-
-    def clear_vw_array(self):
-        self.v_array.clear()
-        self.w_array.clear()
-        self.w_zero = self.w_variance = self.w_avg = self.v_avg = self.w_jerk = self.v_jerk = self.v_acc = self.w_acc = 0
+    def finish(self):
+        """the episode's figures per robot; the accumulators start over"""
+        import torch
+        n = self.n.clamp(min=1)
+        mean_w = self.sum_w / n
+        out = dict(w_variance=self.sum_ww / n - mean_w * mean_w, w_zero=self.w_zero.clone(),
+                   v_acc=self.sum_abs_acc[0] / (n - 1).clamp(min=1), w_acc=self.sum_abs_acc[1] / (n - 1).clamp(min=1),
+                   v_jerk=self.sum_abs_jerk[0] / (n - 2).clamp(min=1), w_jerk=self.sum_abs_jerk[1] / (n - 2).clamp(min=1),
+                   v_avg=self.sum_v / n, w_avg=self.sum_absw / n)
+        for t in (self.n, self.sum_v, self.sum_w, self.sum_ww, self.sum_absw, self.w_zero, *self.sum_abs_acc, *self.sum_abs_jerk,
+                  *self.prev, *self.prev2):
+            t.zero_()
+        self.prev = [torch.zeros_like(self.n), torch.zeros_like(self.n)]
+        self.prev2 = [torch.zeros_like(self.n), torch.zeros_like(self.n)]
+        return out
 
 
 class TestEpisodeWrapper(Wrapper):
-    """envs/wrapper/evaluation_wrapper/TestEpisodeWrapper.py:8-119: episode statistics of ONE robot (the first), printed after
-    ``init_pose_bag_episodes`` episodes -- upon which the reference exits the process, and so does this."""
+    """Evaluation statistics over ``init_pose_bag_episodes`` episodes (the wrapper of that name in the reference's shipped
+    test.yaml, envs/wrapper/evaluation_wrapper/TestEpisodeWrapper.py:8-119): how episodes end -- arrive / static, pedestrian,
+    robot collision / time-out, by ``dones_info`` -- steps to arrive, mean speeds and the path figures of ``EpisodeStats``.
+    Kept for EVERY robot of the env as device tensors (the reference tracks one robot, "suppose only one agent here"); the
+    scalar attributes the reference exposes (``arrive_num``, ``v_sum``, ``w_variance_array`` ...) read robot 0, and the printed
+    rates pool all robots, which for a one-robot env are the reference's numbers.  After ``max_episodes`` episodes the
+    statistics are printed and, as in the reference, the process exits."""
     __test__ = False  # (not a pytest class)
+    CODES = (5, 10, 1, 2, 3)  # arrive, time-out, static / pedestrian / other-robot collision
 
     def __init__(self, env, cfg):
         super().__init__(env)
-        self.cur_episode = 0
         self.max_episodes = cfg["init_pose_bag_episodes"]
         self.dt = cfg["control_hz"]
-        self.arrive_num = self.static_coll_num = self.ped_coll_num = self.other_coll_num = 0
-        self.steps = self.tmp_steps = self.stuck_num = 0
-        self.v_sum = self.w_sum = 0
-        self.speed_step = 0
-        self.w_variance_array, self.v_jerk_array, self.w_jerk_array, self.w_zero_array = [], [], [], []
-        self.traj_helper = TrajectoryPathHelper(dt=self.dt)
+        self.cur_episode = 0
+        self.tmp_steps = 0
+        self._stats = None      # EpisodeStats, made at the first step (robot count and device come with the speeds)
+        self._ends = None       # [robot][code] episodes by how they ended
+        self._arrive_steps = self._speed_steps = self._v_sum = self._w_sum = None
+        self._episodes = []     # per counted episode: dict of [robot] tensors (rounded to 4 places like the reference's lists)
+
+    def _init(self, speeds):
+        import torch
+        n, dev = speeds.shape[0], speeds.device
+        self._stats = EpisodeStats(n, self.dt, dev)
+        self._ends = torch.zeros(n, 11, dtype=torch.int64, device=dev)
+        self._arrive_steps = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._speed_steps = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._v_sum = torch.zeros(n, dtype=torch.float64, device=dev)
+        self._w_sum = torch.zeros(n, dtype=torch.float64, device=dev)
 
     def step(self, action):
         states, reward, done, info = self.env.step(action)
+        speeds = info["speeds"]
+        if self._stats is None:
+            self._init(speeds)
         self.tmp_steps += 1
-        speeds = [float(x) for x in info["speeds"][0][:2]]  # "suppose only one agent here"
-        self.v_sum += speeds[0]
-        self.w_sum += abs(speeds[1])
-        self.traj_helper.add_vw(*speeds)
+        self._v_sum += speeds[:, 0].double()
+        self._w_sum += speeds[:, 1].double().abs()
+        self._stats.add(speeds[:, 0], speeds[:, 1])
         return states, reward, done, info
 
     def reset(self, **kwargs):
+        codes = kwargs.get("dones_info")
         if self.tmp_steps > 3:  # two or three steps: too short to count
             self.cur_episode += 1
-            self.dones_statistics(kwargs.get("dones_info"))
+            if codes is not None and self._stats is not None:
+                self._count(codes)
         if self.cur_episode == self.max_episodes:
             self.screen_out()
         self.tmp_steps = 0
         return self.env.reset(**kwargs)
 
-    def dones_statistics(self, t):
-        if t is None:
-            return
-        t = int(t[0])
-        self.speed_step += self.tmp_steps
-        if t == 5:
-            self.arrive_num += 1
-            self.steps += self.tmp_steps
-        elif t == 10:
-            self.stuck_num += 1
-        elif t == 1:
-            self.static_coll_num += 1
-        elif t == 2:
-            self.ped_coll_num += 1
-        elif t == 3:
-            self.other_coll_num += 1
-        else:
-            raise ValueError("[TestEpisodeWrapper]: No dones info: %r" % t)
-        self.traj_helper.reset()  # path_statistics
-        self.v_jerk_array.append(round(self.traj_helper.v_jerk, 4))
-        self.w_jerk_array.append(round(self.traj_helper.w_jerk, 4))
-        self.w_zero_array.append(self.traj_helper.w_zero)
-        self.w_variance_array.append(round(self.traj_helper.w_variance, 4))
-        self.traj_helper.clear_vw_array()
+    def _count(self, codes):
+        import torch
+        codes = torch.as_tensor(codes, device=self._ends.device).long()
+        known = torch.zeros_like(codes, dtype=torch.bool)
+        for c in self.CODES:
+            known |= codes == c
+        if not bool(known.all()):
+            raise ValueError("[TestEpisodeWrapper]: No dones info: %r" % codes[~known][0].item())
+        self._ends.scatter_add_(1, codes.view(-1, 1), torch.ones_like(codes).view(-1, 1))
+        self._speed_steps += self.tmp_steps
+        self._arrive_steps += torch.where(codes == 5, self.tmp_steps, 0)
+        ep = self._stats.finish()
+        self._episodes.append({k: (torch.round(v * 1e4) / 1e4 if k != "w_zero" else v) for k, v in ep.items()})
+
+    # ---- the reference's scalar attributes, for robot 0 ----
+    def _end0(self, code):
+        return 0 if self._ends is None else int(self._ends[0, code])
+
+    arrive_num = property(lambda self: self._end0(5))
+    stuck_num = property(lambda self: self._end0(10))
+    static_coll_num = property(lambda self: self._end0(1))
+    ped_coll_num = property(lambda self: self._end0(2))
+    other_coll_num = property(lambda self: self._end0(3))
+    steps = property(lambda self: 0 if self._arrive_steps is None else int(self._arrive_steps[0]))
+    speed_step = property(lambda self: 0 if self._speed_steps is None else int(self._speed_steps[0]))
+    v_sum = property(lambda self: 0.0 if self._v_sum is None else float(self._v_sum[0]))
+    w_sum = property(lambda self: 0.0 if self._w_sum is None else float(self._w_sum[0]))
+    w_variance_array = property(lambda self: [float(e["w_variance"][0]) for e in self._episodes])
+    v_jerk_array = property(lambda self: [float(e["v_jerk"][0]) for e in self._episodes])
+    w_jerk_array = property(lambda self: [float(e["w_jerk"][0]) for e in self._episodes])
+    w_zero_array = property(lambda self: [float(e["w_zero"][0]) for e in self._episodes])
 
     def statistics(self):
-        n = self.max_episodes
-        return dict(arrive_rate=self.arrive_num / n, static_coll_rate=self.static_coll_num / n, ped_coll_rate=self.ped_coll_num / n,
-                    other_coll_rate=self.other_coll_num / n, avg_arrive_steps=self.steps / max(1, self.arrive_num),
-                    stuck_rate=self.stuck_num / n, avg_v=self.v_sum / self.speed_step, avg_w=self.w_sum / self.speed_step,
-                    avg_w_variance=sum(self.w_variance_array) / n, avg_v_jerk=sum(self.v_jerk_array) / n,
-                    avg_w_jerk=sum(self.w_jerk_array) / n, avg_w_zero=sum(self.w_zero_array) / n)
+        """rates and averages over all robots and counted episodes"""
+        import torch
+        if self._ends is None:
+            return {}
+        robots = self._ends.shape[0]
+        n = self.max_episodes * robots
+        ends = self._ends.sum(dim=0)
+        speed_steps = max(1, int(self._speed_steps.sum()))
+        per_ep = {k: float(torch.stack([e[k] for e in self._episodes]).sum()) / n for k in ("w_variance", "v_jerk", "w_jerk", "w_zero")} \
+            if self._episodes else dict(w_variance=0.0, v_jerk=0.0, w_jerk=0.0, w_zero=0.0)
+        return dict(arrive_rate=int(ends[5]) / n, static_coll_rate=int(ends[1]) / n, ped_coll_rate=int(ends[2]) / n,
+                    other_coll_rate=int(ends[3]) / n, avg_arrive_steps=int(self._arrive_steps.sum()) / max(1, int(ends[5])),
+                    stuck_rate=int(ends[10]) / n, avg_v=float(self._v_sum.sum()) / speed_steps, avg_w=float(self._w_sum.sum()) / speed_steps,
+                    avg_w_variance=per_ep["w_variance"], avg_v_jerk=per_ep["v_jerk"], avg_w_jerk=per_ep["w_jerk"], avg_w_zero=per_ep["w_zero"])
 
     def screen_out(self):
         import sys

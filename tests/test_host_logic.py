@@ -74,6 +74,7 @@ def test_reset_batch_keeps_its_buffers_alive_and_typed():
 
 
 def test_envpos_spawn_rules():
+    """the product's EnvPos (the library's own sampler behind img_env_amd.spawn) keeps the reference's placement rules"""
     grid = worldgen.make_grid(320, 0)
     cfg = worldgen.make_yaml_cfg(16, 6, grid, n_obstacles=2)
     ep = spawn.EnvPos(cfg, seed=11)
@@ -82,11 +83,47 @@ def test_envpos_spawn_rules():
     starts = np.vstack([lay.robot_pose[:, :2], lay.ped_pose[:, :2]])
     assert _pairwise_min(starts) > 1.0 - 1e-9                          # free_check_robo_ped d = 1.0 (reset_helper.py:35-43)
     assert (np.linalg.norm(lay.robot_goal - lay.robot_pose[:, :2], axis=1) > float(cfg["target_min_dist"]) - 1e-9).all()
-    for p in ep.obs_range:                                             # starts clear of the obstacles (reset_helper.py:46-55)
-        assert (np.linalg.norm(starts - np.array(p[:2]), axis=1) > p[-1]).all()
+    module = 2 * 0.17                                                  # starts clear of the obstacles (reset_helper.py:46-55, 167-186)
+    for o in range(len(lay.obs_shape)):
+        rad = lay.obs_size[o, 2] if lay.obs_shape[o] == 0 else np.hypot(lay.obs_size[o, 0], lay.obs_size[o, 2])
+        assert (np.linalg.norm(starts[:16] - lay.obs_pose[o, :2], axis=1) > rad + module - 1e-6).all()
     same = spawn.EnvPos(cfg, seed=11).reset(extent)
     assert np.array_equal(same.robot_pose, lay.robot_pose)
     assert not np.array_equal(spawn.EnvPos(cfg, seed=12).reset(extent).robot_pose, lay.robot_pose)
+    second = ep.reset(extent)                                          # a new episode per call
+    assert not np.array_equal(second.robot_pose, lay.robot_pose)
+
+
+def test_envpos_matches_the_reference_sampler_statistically():
+    """the product's sampler (its own random stream) against the test-side replica of the reference's EnvPos (Python's
+    Mersenne Twister, pinned bit for bit on reference episodes): the same distributions of starts, goals and obstacle sizes
+    over many episodes of a range / range_view cast and of a circle cast"""
+    import json
+    import os
+    from spawn_replica import ReferenceEnvPos
+    grid = worldgen.make_grid(320, 0)
+    cfgs = [worldgen.make_yaml_cfg(6, 3, grid, n_obstacles=2)]
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "spawn_ref.npz"))
+    cfgs.append(json.loads(str(z["test@1/cfg"])))  # the shipped test.yaml cast: range_circle starts and targets
+    for cfg in cfgs:
+        nr = int(cfg["robot"]["total"])
+        ours, ref = spawn.EnvPos(cfg, seed=3), ReferenceEnvPos(cfg, seed=3)
+        A = [ours.reset() for _ in range(400)]
+        B = [ref.reset() for _ in range(400)]
+
+        def stats(L):
+            start = np.array([np.vstack([l.robot_pose[:, :2], l.ped_pose[:, :2]]) for l in L])   # [episode][agent][2]
+            goal = np.array([np.vstack([l.robot_goal, l.ped_goal]) for l in L])
+            d = np.linalg.norm(goal - start, axis=2)
+            osz = np.array([l.obs_size[:, 2] for l in L]) if len(L[0].obs_shape) else np.zeros((len(L), 1))
+            return start.mean(axis=(0, 1)), start.std(axis=(0, 1)), d.mean(), d.std(), osz.mean()
+        sa, sb = stats(A), stats(B)
+        span = max(sb[1].max(), 0.5)
+        assert np.all(np.abs(sa[0] - sb[0]) < 0.12 * span), (sa[0], sb[0])      # where agents start: mean ...
+        assert np.all(np.abs(sa[1] - sb[1]) < 0.12 * span), (sa[1], sb[1])      # ... and spread
+        assert abs(sa[2] - sb[2]) < 0.1 * sb[2] and abs(sa[3] - sb[3]) < 0.15 * max(sb[3], 0.2), (sa[2:4], sb[2:4])  # start -> goal distances
+        assert abs(sa[4] - sb[4]) < 0.02 + 0.05 * sb[4]                          # obstacle radii
+        assert nr == A[0].robot_pose.shape[0]
 
 
 def test_init_ped_dataset_shapes():
@@ -109,7 +146,7 @@ def _spawn_cases():
 
 @pytest.mark.parametrize("case", _spawn_cases()[1])
 def test_envpos_reproduces_the_reference_episodes(case):
-    """`spawn.EnvPos(cfg, seed)` against episodes the REFERENCE's own EnvPos placed after `random.seed(seed)`
+    """the test-side replica `spawn_replica.ReferenceEnvPos(cfg, seed)` against episodes the REFERENCE's own EnvPos placed after `random.seed(seed)`
     (tests/golden/gen_spawn_golden.py): obstacles, starts, targets, trajectories -- bit for bit.  Covers the spawn sections of
     the shipped circle.yaml / test.yaml / 10obs_5ped_baseline.yaml (range_circle starts and targets), a synthetic cast with
     every other pose type, and a circle too small for its cast (the "50 failed circle starts" path)."""
@@ -117,7 +154,8 @@ def test_envpos_reproduces_the_reference_episodes(case):
     z, _ = _spawn_cases()
     g = lambda k: z["%s/%s" % (case, k)]  # noqa: E731
     cfg = json.loads(str(g("cfg")))
-    ep = spawn.EnvPos(cfg, seed=int(g("seed")))
+    from spawn_replica import ReferenceEnvPos
+    ep = ReferenceEnvPos(cfg, seed=int(g("seed")))
     lay = ep.reset()
     nr = cfg["robot"]["total"]
     assert ep.circle_range == float(g("circle_range"))
@@ -145,7 +183,7 @@ def test_unsupported_spawn_layouts_fail_loudly():
     cfg = worldgen.make_yaml_cfg(2, 0, grid)
     cfg["robot"]["begin_poses_type"] = ["fix", "range"]  # fixed start + random target: the reference loops forever
     cfg["robot"]["begin_poses"] = [[3.0, 3.0, 0.0], cfg["robot"]["begin_poses"][1]]
-    with pytest.raises(ValueError, match="never leaves"):
+    with pytest.raises(RuntimeError, match="never leaves"):
         spawn.EnvPos(cfg, seed=0).reset(25.0)
 
 
@@ -243,3 +281,33 @@ def test_native_spawn_places_the_reference_casts(case):
                 assert (np.linalg.norm(starts[drawn] - lay.obs_pose[q, :2], axis=1) > radius).all()
     a, b = spawn.native_spawn(cfg, 5, sc), spawn.native_spawn(cfg, 5, sc)
     assert np.array_equal(a.robot_pose, b.robot_pose) and np.array_equal(a.ped_goal, b.ped_goal)
+
+
+def test_episode_stats_accumulate_what_the_reference_computes_from_lists():
+    """img_env_amd.envs.EpisodeStats (running sums for all robots at once) against the list-based formulas of the reference's
+    evaluation helper (envs/wrapper/evaluation_wrapper/utils.py:60-129), restated here with numpy"""
+    import torch
+    from img_env_amd.envs import EpisodeStats
+    rng = np.random.default_rng(0)
+    R, T, dt = 5, 40, 0.4
+    V, W = rng.uniform(0, 0.6, (T, R)), np.round(rng.uniform(-0.9, 0.9, (T, R)), 1)  # rounded: exact zeros occur
+    st = EpisodeStats(R, dt, "cpu")
+    for t in range(T):
+        st.add(torch.tensor(V[t]), torch.tensor(W[t]))
+    out = st.finish()
+    for r in range(R):
+        v, w = V[:, r], W[:, r]
+        tmp = w_zero = 0
+        for x in w:  # cal_w_zero
+            if x == 0:
+                if tmp != 0:
+                    w_zero += 1
+            elif (x > 0 and tmp < 0) or (x < 0 and tmp > 0):
+                w_zero += 1
+            tmp = x
+        va, wa = np.diff(v) / dt, np.diff(w) / dt
+        want = dict(w_variance=np.var(w), w_zero=w_zero, v_jerk=np.average(np.abs(np.diff(va) / dt)), w_jerk=np.average(np.abs(np.diff(wa) / dt)),
+                    v_acc=np.average(np.abs(va)), w_acc=np.average(np.abs(wa)), v_avg=np.average(v), w_avg=np.average(np.abs(w)))
+        for k, x in want.items():
+            assert abs(float(out[k][r]) - x) < 1e-9, (k, r)
+    assert float(st.n.sum()) == 0  # finish() starts the accumulators over
