@@ -18,6 +18,8 @@ FLAG_PRIVATE_GRIDS = 1
 FLAG_COMPOSE_DENSE = 2
 FLAG_COMPOSE_SPARSE = 4
 FLAG_NO_VIEW_MAPS = 8  # imgenv_out.view_maps not wanted (include/imgenv.h)
+FLAG_AGENT_STATE_EXTRAS = 16  # AgentState.hits_x / hits_y / angular_map as well
+ANGULAR_BINS = 72
 
 SHAPES = {"circle": SHAPE_CIRCLE, "rectangle": SHAPE_RECTANGLE, "leg": SHAPE_LEG}
 # Env.msg ped_scene_type strings (scenefactory.h:8-24): anything else is the EmptyScene
@@ -102,6 +104,7 @@ class Out(C.Structure):
         ("robot_pose", C.c_void_p), ("ped_state", C.c_void_p), ("counters", C.c_void_p),
         ("step_rewards", C.c_void_p), ("step_dones", C.c_void_p), ("step_dones_info", C.c_void_p), ("step_is_clean", C.c_void_p),
         ("step_is_arrives", C.c_void_p), ("step_is_collisions", C.c_void_p), ("step_all_down", C.c_void_p),
+        ("hits_x", C.c_void_p), ("hits_y", C.c_void_p), ("angular_map", C.c_void_p),
     ]
 
 
@@ -137,6 +140,9 @@ def out_layout(o, n_peds, hp, wp):
         "step_is_arrives": (np.uint8, (R,)),
         "step_is_collisions": (np.int8, (R,)),
         "step_all_down": (np.uint8, (R,)),
+        "hits_x": (np.float32, (R, B)),          # AgentState's remaining fields: null pointers unless FLAG_AGENT_STATE_EXTRAS
+        "hits_y": (np.float32, (R, B)),
+        "angular_map": (np.float32, (R, ANGULAR_BINS)),
     }
 
 

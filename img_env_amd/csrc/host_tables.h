@@ -104,11 +104,14 @@ struct RobotClassHost {
     std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
     std::vector<uint8_t> ray_run;  // [ray_maxlen][ray_stride] steps behind step k of beam b that share a row or column with it
+    // AgentState.hits_x / hits_y / angular_map (agent.cpp:405-438), only with IMGENV_FLAG_AGENT_STATE_EXTRAS
+    std::vector<float> ray_hx, ray_hy;  // [ray_maxlen + 1][ray_stride] float32(hit * cos / sin(beam angle)) for a hit at step k; last row: no hit
+    std::vector<uint16_t> bin_start;    // [73] first beam of each of the 72 angular_map bins (a beam's bin never decreases)
     std::vector<uint32_t> inv_pack, inv_ent, top_ent;
     std::vector<uint32_t> inv_cell;  // [NC][2] k_view's step (5): filter word, inv_pack
 };
 
-static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_big = false) {
+static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_big = false, bool extras = false) {
     for (int j = 0; j < 4; j++) k.sizes[j] = (double)k.size[j];
     k.sx = (double)k.sensor[0];
     k.sy = (double)k.sensor[1];
@@ -147,6 +150,9 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     k.ray_len.assign(k.ray_stride, 0);
     std::vector<std::vector<uint32_t>> cells(B);
     std::vector<std::vector<float>> dists(B);
+    std::vector<std::vector<float>> hxs(B), hys(B);
+    std::vector<float> nohit_x(B, 0.f), nohit_y(B, 0.f);
+    std::vector<int> beam_bin(B, 0);
     if (B > 0) {
         double sxv, syv;
         tf_apply(g.base_view, k.sx, k.sy, sxv, syv);
@@ -160,6 +166,12 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
         for (int b = 0; b < B; b++) {
             const double cur = g.a_begin + angle_step * b;
             const double x = max_range * cos(cur), y = max_range * sin(cur);
+            {   // hit_points_x_ / _y_ = hit * cos / sin(cur_angle); angular_map_i = int(angle_step * i / angular_map_step) (agent.cpp:417-435)
+                const double angular_map_step = fabs(g.a_end - g.a_begin) / IMGENV_ANGULAR_BINS;
+                beam_bin[b] = std::min(IMGENV_ANGULAR_BINS - 1, std::max(0, (int)(angle_step * b / angular_map_step)));
+                nohit_x[b] = (float)(6.0 * cos(cur));
+                nohit_y[b] = (float)(6.0 * sin(cur));
+            }
             double vx, vy;
             tf_apply(g.base_view, x, y, vx, vy);
             const int x2 = w2m(vx, res), y2 = w2m(vy, res);
@@ -179,7 +191,12 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
                 if (!(xx >= 0 && xx < Hv && yy >= 0 && yy < Wv)) break;  // "else return hit"
                 cells[b].push_back((uint32_t)(xx * Wv + yy));
                 const double cx = xx * res, cy = yy * res;
-                dists[b].push_back((float)sqrt((x0w - cx) * (x0w - cx) + (y0w - cy) * (y0w - cy)));
+                const double hit = sqrt((x0w - cx) * (x0w - cx) + (y0w - cy) * (y0w - cy));
+                dists[b].push_back((float)hit);
+                if (extras) {
+                    hxs[b].push_back((float)(hit * cos(cur)));
+                    hys[b].push_back((float)(hit * sin(cur)));
+                }
                 if (f < 0) {
                     f += d1;
                 } else {
@@ -193,6 +210,24 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
         }
     }
     if (k.ray_maxlen == 0) k.ray_maxlen = 1;
+    if (extras && B > 0) {
+        k.ray_hx.assign((size_t)(k.ray_maxlen + 1) * k.ray_stride, 0.f);
+        k.ray_hy.assign((size_t)(k.ray_maxlen + 1) * k.ray_stride, 0.f);
+        for (int b = 0; b < B; b++) {
+            for (size_t q = 0; q < hxs[b].size(); q++) {
+                k.ray_hx[q * k.ray_stride + b] = hxs[b][q];
+                k.ray_hy[q * k.ray_stride + b] = hys[b][q];
+            }
+            k.ray_hx[(size_t)k.ray_maxlen * k.ray_stride + b] = nohit_x[b];
+            k.ray_hy[(size_t)k.ray_maxlen * k.ray_stride + b] = nohit_y[b];
+        }
+        k.bin_start.assign(IMGENV_ANGULAR_BINS + 1, (uint16_t)B);
+        for (int b = B - 1; b >= 0; b--) k.bin_start[beam_bin[b]] = (uint16_t)b;
+        for (int m = IMGENV_ANGULAR_BINS - 1; m >= 0; m--)
+            if (k.bin_start[m] == (uint16_t)B || k.bin_start[m] > k.bin_start[m + 1]) k.bin_start[m] = k.bin_start[m + 1];  // an empty bin
+        for (int b = 1; b < B; b++)
+            if (beam_bin[b] < beam_bin[b - 1]) k.ok = false;
+    }
     k.ray_kpad = ((k.ray_maxlen + 7) / 8) * 8;
     if (force_big || NC + 16 > 0xFFFF || k.ray_maxlen > 255 || Hv > 256 || Wv > 256) k.ray_kpad = ((k.ray_maxlen + 31) / 32) * 32;  // k_beams_big: 32 steps a round
     // k_view packs a view cell into 16 bits and (step, row, col) of a hit into 8 bits each; beyond that the class is "big"

@@ -271,7 +271,7 @@ static size_t taps_lds_bytes(int B) { return 16 * (size_t)((B + 4) / 4) + 16 * (
 
 struct ArenaPlan {
     size_t total = 0;
-    size_t off[32];
+    size_t off[40];
     int n = 0;
     size_t add(size_t bytes) {
         off[n] = total;
@@ -313,6 +313,10 @@ static void plan_arena(const imgenv_cfg& c, const ViewGeom& g, int RL, ArenaPlan
     p.add(R);                    // 26 step_is_arrives
     p.add(R);                    // 27 step_is_collisions
     p.add(R);                    // 28 step_all_down
+    const bool extras = (c.flags & IMGENV_FLAG_AGENT_STATE_EXTRAS) != 0;
+    p.add(extras ? R * B * 4 : 0);  // 29 hits_x
+    p.add(extras ? R * B * 4 : 0);  // 30 hits_y
+    p.add(extras ? R * IMGENV_ANGULAR_BINS * 4 : 0);  // 31 angular_map
 }
 
 static int shard_of(const imgenv_cfg& c, int& r0, int& r1) {
@@ -501,7 +505,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             k.shape = shape;
             memcpy(k.size, cfg->robot_size + 4 * i, 16);
             memcpy(k.sensor, cfg->robot_sensor_cfg + 2 * i, 8);
-            build_robot_class(k, g, view_resize);
+            build_robot_class(k, g, view_resize, (cfg->flags & IMGENV_FLAG_AGENT_STATE_EXTRAS) != 0);
             h->rcls.push_back(std::move(k));
             found = (int)h->rcls.size() - 1;
         }
@@ -636,6 +640,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.ray_len, k.ray_len));
             TRY(dev_upload(h, &o.ray_dist, k.ray_dist));
             TRY(dev_upload(h, &o.ray_run, k.ray_run));
+            if (!k.ray_hx.empty()) {
+                TRY(dev_upload(h, &o.ray_hx, k.ray_hx));
+                TRY(dev_upload(h, &o.ray_hy, k.ray_hy));
+                TRY(dev_upload(h, &o.bin_start, k.bin_start));
+            }
             TRY(dev_upload(h, &o.inv_pack, k.inv_pack));
             TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
             TRY(dev_upload(h, &o.top_ent, k.top_ent));
@@ -927,6 +936,15 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     o.step_is_collisions = (int8_t*)(A + plan.off[27]);
     o.step_all_down = (uint8_t*)(A + plan.off[28]);
     d.step_all_down = o.step_all_down;
+    if ((cfg->flags & IMGENV_FLAG_AGENT_STATE_EXTRAS) && g.B > 0) {
+        o.hits_x = (float*)(A + plan.off[29]);
+        o.hits_y = (float*)(A + plan.off[30]);
+        o.angular_map = (float*)(A + plan.off[31]);
+    } else {
+        o.hits_x = o.hits_y = o.angular_map = nullptr;
+    }
+    d.hits_x = o.hits_x; d.hits_y = o.hits_y; d.angular_map = o.angular_map;
+    d.view_max_dist32 = cfg->view_max_dist;
     d.step_rewards = o.step_rewards; d.step_dones = o.step_dones; d.step_dones_info = o.step_dones_info;
     d.step_is_clean = o.step_is_clean; d.step_is_arrives = o.step_is_arrives; d.step_is_collisions = o.step_is_collisions;
     d.vector_states = o.vector_states; d.view_maps = o.view_maps; d.sensor_maps = o.sensor_maps;

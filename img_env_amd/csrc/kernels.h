@@ -1160,6 +1160,20 @@ __device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
     return x;
 }
 
+// angular_map_ (agent.cpp:407-433): nearest hit of each 1/72 of the field of view, one bin per thread from the beams' hit words
+// (first-hit step << 16 | ..., 0xFFFFFFFF = no hit); a bin's beams are a contiguous range
+__device__ __forceinline__ void angular_bins(const DevWorld& w, const RobotClassDev& k, const uint32_t* hit, int l, int tid, int nt) {
+    for (int m = tid; m < IMGENV_ANGULAR_BINS; m += nt) {
+        float best = w.view_max_dist32;
+        for (int b = k.bin_start[m]; b < (int)k.bin_start[m + 1]; b++) {
+            const uint32_t hp = hit[b];
+            const float hd = hp == 0xFFFFFFFFu ? 6.0f : k.ray_dist[(size_t)(hp >> 16) * k.ray_stride + b];
+            best = fminf(best, hd);
+        }
+        w.angular_map[(size_t)l * IMGENV_ANGULAR_BINS + m] = best;
+    }
+}
+
 // NW: wavefronts per robot.  1 when a launch fills the machine (instruction issue bounds it); 4 for small launches (a reset of
 // a few worlds), where the single wavefront's latency is all there is: the cells and beams are then spread over 256 lanes.
 template <bool POW2, bool A4, bool STAMP, int NW>
@@ -1335,10 +1349,16 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
                 hit[b] = has ? ((hk << 16) | (hk + run)) : 0xFFFFFFFFu;
                 w.lasers_raw[(size_t)l * w.B + b] = hd;
                 w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
+                if (w.hits_x) {  // hit_points_x_ / _y_ (agent.cpp:434-435), static per (step, beam); row ray_maxlen: no hit
+                    const size_t at = (size_t)(has ? hk : (uint32_t)k.ray_maxlen) * k.ray_stride + b;
+                    w.hits_x[(size_t)l * w.B + b] = k.ray_hx[at];
+                    w.hits_y[(size_t)l * w.B + b] = k.ray_hy[at];
+                }
             }
         }
         if (tid == 0) hit[w.B] = 0u;  // the dummy beam of cells without any (see the final pass)
         __syncthreads();
+        if (w.angular_map) angular_bins(w, k, hit, l, tid, NT);
         // how far the beams get at most, for the filter of (5): blocks of 16 beams every 8, of 32 every 16, of 64 every 32 (a cell's
         // beams lie inside one of them unless they are more than 33), largest hit word = largest first-hit step
         const int nb8 = (w.B >> 3) + 1, n0 = nb8, n1 = (nb8 + 1) >> 1, n2 = (nb8 + 3) >> 2;

@@ -331,6 +331,11 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
         hit_g[b] = has ? ((hk << 16) | end) : 0xFFFFFFFFu;
         w.lasers_raw[(size_t)l * B + b] = hd;
         w.lasers[(size_t)l * B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
+        if (w.hits_x) {  // hit_points_x_ / _y_ (agent.cpp:434-435)
+            const size_t hx = (size_t)(has ? hk : (uint32_t)rc.ray_maxlen) * stride + b;
+            w.hits_x[(size_t)l * B + b] = rc.ray_hx[hx];
+            w.hits_y[(size_t)l * B + b] = rc.ray_hy[hx];
+        }
     }
 }
 
@@ -355,6 +360,7 @@ __global__ __launch_bounds__(VBT_T) void k_taps_big(DevWorld w, int chunks, int 
     const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l]);
     const RobotClassDev rc = w.rc[cls];
     const BigClassDev k = w.big[cls];
+    if (commit && chunk == 0 && w.angular_map && w.use_laser) angular_bins(w, rc, hit_g, l, tid, VBT_T);
     const int n_hit4 = (B + 4) / 4;  // B words + the dummy beam, in 16-byte units
     uint32_t* hit = (uint32_t*)smem;
     uint32_t* vals = hit + 4 * n_hit4;                  // [VBT_T][4]: the pixel's 16 tap values, one byte each
@@ -456,6 +462,7 @@ __global__ __launch_bounds__(VBF_T) void k_fullview_big(DevWorld w, int chunks, 
     const uint32_t* hit = w.big_hit + (size_t)l * w.big_hit_stride;
     if (hit[B + 1] == 0u) return;  // frozen
     if (commit && chunk == 0 && threadIdx.x == 0) w.is_coll[l] = (int)hit[B + 2];
+    if (commit && chunk == 0 && w.angular_map && w.use_laser) angular_bins(w, w.rc[__builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l])], hit, l, (int)threadIdx.x, VBF_T);
     const int NC = w.Hv * w.Wv, c4 = (chunk * VBF_T + (int)threadIdx.x) * 4;
     if (c4 >= NC) return;
     const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l]);

@@ -58,6 +58,9 @@ struct RobotClassDev {
     const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or B << 16 | 0xFFFF
     const uint2* inv_cell;       // [Hv*Wv] k_view's step (5): {block of the reach table | none << 13 | own footprint << 14 | smallest step << 24, inv_pack}
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
+    // AgentState.hits_x / hits_y / angular_map (IMGENV_FLAG_AGENT_STATE_EXTRAS; null otherwise)
+    const float *ray_hx, *ray_hy;   // [ray_maxlen + 1][ray_stride] float32(hit * cos / sin(beam angle)) for a hit at step k; last row: no hit
+    const uint16_t* bin_start;      // [73] first beam of each angular_map bin
     int big;                     // views beyond k_view's 16 / 8-bit packing, or shrunk by cv2.resize (the shipped configs: 400 x
                                  // 400 cells, 1000 beams): the kernels of view_big.h and the tables of BigClassDev
 };
@@ -213,6 +216,8 @@ struct DevWorld {
     float* ped_vector_states;
     float* ped_maps;
     int8_t* is_collisions;
+    float *hits_x, *hits_y, *angular_map;  // AgentState's remaining fields, null unless asked for
+    float view_max_dist32;                 // float32(view_max_dist_): what an angular_map bin holds where nothing was hit
     // the step's own scalars (imgenv_out.step_*): written by a step's tail beside the arrays a reset rewrites
     double* step_rewards; uint8_t* step_dones; int32_t* step_dones_info; uint8_t* step_is_clean; uint8_t* step_is_arrives; int8_t* step_is_collisions; uint8_t* step_all_down;
     int* finished;             // page-locked host memory: [0] number of worlds whose robots are all done, [1..] their indices (k_finished)

@@ -61,6 +61,8 @@ class World:
         base = self.arena.data_ptr()
         self.out = {}
         for name, (dt, shape) in _cabi.out_layout(o, self.n_peds, cfg.ped_image_size[0], cfg.ped_image_size[1]).items():
+            if not getattr(o, name):  # an optional output this handle does not produce
+                continue
             off = getattr(o, name) - base
             n = int(np.prod(shape)) * np.dtype(dt).itemsize
             self.out[name] = self.arena[off:off + n].view(_torch_dtype(dt)).view(*shape)

@@ -164,6 +164,8 @@ typedef struct imgenv_cfg {
  * the library then evaluates only the 4 x 4 view cells each sensor_map pixel reads and never writes the full-size view;
  * view_maps keeps whatever it held.  ImageState (envs/state/state.py:4-28) has no such field, so img_env_amd's envs set it. */
 #define IMGENV_FLAG_NO_VIEW_MAPS 8
+/* also produce AgentState.hits_x / hits_y / angular_map (imgenv_out, below) */
+#define IMGENV_FLAG_AGENT_STATE_EXTRAS 16
 
 /* ResetEnv.srv:1-6 (img_env.cpp:162-292).  Poses are (x, y, qz, qw): geometry_msgs/Pose with a
  * planar orientation; yaw is recovered with tf::Matrix3x3(q).getRPY as the node does. */
@@ -233,7 +235,13 @@ typedef struct imgenv_out {
     int8_t* step_is_collisions;   /* [R] */
     uint8_t* step_all_down;       /* [R] 1 where all robots of the robot's world were done after that step (written by
                                    * imgenv_step_autoreset only) */
+    /* The remaining fields of AgentState.msg (src/comn_pkg/msg/AgentState.msg:4-6; filled at agent.cpp:405-438, sent at
+     * img_env.cpp:558-560), which ImageEnv never reads: NULL unless the handle was created with IMGENV_FLAG_AGENT_STATE_EXTRAS. */
+    float* hits_x;                /* [R][B] hit * cos(beam angle): the hit points in the sensor frame */
+    float* hits_y;                /* [R][B] hit * sin(beam angle) */
+    float* angular_map;           /* [R][72] nearest hit per 1/72 of the field of view, view_max_dist where nothing was hit */
 } imgenv_out;
+#define IMGENV_ANGULAR_BINS 72    /* agent.cpp:407 */
 
 typedef struct imgenv imgenv_t;
 

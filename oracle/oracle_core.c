@@ -139,6 +139,7 @@ struct oracle_world {
     uint8_t *is_arr, *py_done, *clean_state;
     uint8_t* view;
     double* hits;
+    double *hit_x, *hit_y, *amap; /* hit_points_x_, hit_points_y_, angular_map_ (agent.h:65-67) */
     /* peds */
     double *ppx, *ppy, *pyaw, *plx, *ply, *pvx, *pvy, *prem, *llx, *lly, *rlx, *rly, *pr_round;
     int *pstate, *ptraj_idx, *ptraj_len;
@@ -536,6 +537,9 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     ALLOC(w->clean_state, uint8_t, RL);
     ALLOC(w->view, uint8_t, (size_t)RL * w->Hv * w->Wv);
     ALLOC(w->hits, double, (size_t)RL * (w->B > 0 ? w->B : 1));
+    ALLOC(w->hit_x, double, (size_t)RL * (w->B > 0 ? w->B : 1));
+    ALLOC(w->hit_y, double, (size_t)RL * (w->B > 0 ? w->B : 1));
+    ALLOC(w->amap, double, (size_t)RL * IMGENV_ANGULAR_BINS);
     int P = w->P;
     ALLOC(w->ppx, double, P); ALLOC(w->ppy, double, P); ALLOC(w->pyaw, double, P);
     ALLOC(w->plx, double, P); ALLOC(w->ply, double, P); ALLOC(w->pvx, double, P); ALLOC(w->pvy, double, P);
@@ -569,6 +573,9 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     ALLOC(o->view_maps, uint8_t, RL * VW);
     ALLOC(o->sensor_maps, uint16_t, (size_t)RL * w->img_h * w->img_w);
     ALLOC(o->lasers_raw, float, (size_t)RL * (w->B > 0 ? w->B : 1));
+    ALLOC(o->hits_x, float, (size_t)RL * (w->B > 0 ? w->B : 1));
+    ALLOC(o->hits_y, float, (size_t)RL * (w->B > 0 ? w->B : 1));
+    ALLOC(o->angular_map, float, (size_t)RL * IMGENV_ANGULAR_BINS);
     ALLOC(o->lasers, double, (size_t)RL * (w->B > 0 ? w->B : 1));
     ALLOC(o->ped_vector_states, float, (size_t)RL * w->PV);
     ALLOC(o->ped_maps, float, (size_t)RL * 3 * w->Hp * w->Wp);
@@ -603,7 +610,7 @@ void oracle_destroy(oracle_world* w) {
     free(w->rcls); free(w->pcls); free(w->robot_cls); free(w->ped_cls); free(w->robot_size_last);
     free(w->static_map); free(w->obs_map); free(w->peds_map); free(w->priv); free(w->own_lo); free(w->own_hi);
     free(w->rec); free(w->gx); free(w->gy); free(w->l0v); free(w->l0w); free(w->l1v); free(w->l1w);
-    free(w->world_target); free(w->is_coll); free(w->is_arr); free(w->py_done); free(w->clean_state); free(w->view); free(w->hits);
+    free(w->world_target); free(w->is_coll); free(w->is_arr); free(w->py_done); free(w->clean_state); free(w->view); free(w->hits); free(w->hit_x); free(w->hit_y); free(w->amap);
     free(w->ppx); free(w->ppy); free(w->pyaw); free(w->plx); free(w->ply); free(w->pvx); free(w->pvy);
     free(w->prem); free(w->llx); free(w->lly); free(w->rlx); free(w->rly); free(w->pr_round);
     free(w->pstate); free(w->ptraj_idx); free(w->ptraj_len); free(w->ptraj); free(w->ptraj_v); free(w->pmax_speed);
@@ -612,7 +619,7 @@ void oracle_destroy(oracle_world* w) {
     rvo_destroy(w->rvo);
     sfm_destroy(w->sfm);
     imgenv_out* o = &w->out;
-    free(o->vector_states); free(o->view_maps); free(o->sensor_maps); free(o->lasers_raw); free(o->lasers);
+    free(o->vector_states); free(o->view_maps); free(o->sensor_maps); free(o->lasers_raw); free(o->lasers); free(o->hits_x); free(o->hits_y); free(o->angular_map);
     free(o->ped_vector_states); free(o->ped_maps); free(o->is_collisions); free(o->is_arrives);
     free(o->step_ds); free(o->ped_min_dists); free(o->base_rewards); free(o->base_dones); free(o->rewards); free(o->paper_rewards);
     free(o->dones); free(o->dones_info); free(o->is_clean); free(o->robot_pose); free(o->ped_state);
@@ -847,14 +854,23 @@ static void agent_view(oracle_world* w, int l, const gridview* g) {
         double max_range = sqrt(map_width * map_width + map_height * map_height);
         double angle_step = fabs(w->a_end - w->a_begin) / w->cfg.range_total;
         double* hits = w->hits + (size_t)l * w->B;
+        /* angular_map_, hit_points_x_ / _y_ (agent.cpp:407-436) */
+        const int angular_map_size = IMGENV_ANGULAR_BINS;
+        double* amap = w->amap + (size_t)l * angular_map_size;
+        for (int m = 0; m < angular_map_size; m++) amap[m] = w->max_d;
+        double angular_map_step = fabs(w->a_end - w->a_begin) / angular_map_size;
         for (int b = 0; b < w->cfg.range_total; b++) {
             double cur = w->a_begin + angle_step * b;
+            int angular_map_i = (int)(angle_step * b / angular_map_step);
             double x = max_range * cos(cur);
             double y = max_range * sin(cur);
             double vx, vy;
             tf_apply(&w->base_view, x, y, &vx, &vy);
             int x2 = w2m(vx, res), y2 = w2m(vy, res);
             hits[b] = bresenham(x0, y0, x2, y2, view, laser, Hv, Wv, res);
+            if (angular_map_i >= 0 && angular_map_i < angular_map_size && hits[b] < amap[angular_map_i]) amap[angular_map_i] = hits[b];
+            w->hit_x[(size_t)l * w->B + b] = hits[b] * cos(cur);
+            w->hit_y[(size_t)l * w->B + b] = hits[b] * sin(cur);
         }
         memcpy(view, laser, (size_t)Hv * Wv); /* view_map_ = laser_map (agent.cpp:437) */
     }
@@ -942,7 +958,12 @@ static void get_states(oracle_world* w) {
             float h = (float)w->hits[(size_t)l * B + b]; /* float32[] laser */
             o->lasers_raw[(size_t)l * B + b] = h;
             o->lasers[(size_t)l * B + b] = w->cfg.laser_norm ? (double)h / w->cfg.laser_max : (double)h;
+            o->hits_x[(size_t)l * B + b] = (float)w->hit_x[(size_t)l * B + b]; /* float32[] hits_x, hits_y (img_env.cpp:558-559) */
+            o->hits_y[(size_t)l * B + b] = (float)w->hit_y[(size_t)l * B + b];
         }
+        if (B > 0)
+            for (int m = 0; m < IMGENV_ANGULAR_BINS; m++) /* float32[] angular_map (img_env.cpp:560) */
+                o->angular_map[(size_t)l * IMGENV_ANGULAR_BINS + m] = (float)w->amap[(size_t)l * IMGENV_ANGULAR_BINS + m];
         const uint8_t* view = w->view + (size_t)l * Hv * Wv;
         memcpy(o->view_maps + (size_t)l * Hv * Wv, view, (size_t)Hv * Wv);
         /* _trans_cv2_sensor_map (yaml_env.py:431-438): cv2.resize INTER_CUBIC (a copy for equal sizes), float16, / 255 */

@@ -154,6 +154,39 @@ def test_second_reset_reuses_handle(worlds):
         cpu.close()
 
 
+@pytest.mark.parametrize("case", ["small_view", "shipped_geometry", "view_50_not_a4"])
+def test_agent_state_extras_match_oracle(worlds, case):
+    """AgentState.hits_x / hits_y / angular_map (AgentState.msg:4-6, agent.cpp:405-438, img_env.cpp:558-560): produced on request
+    (IMGENV_FLAG_AGENT_STATE_EXTRAS) by k_view and by the big-view kernels, against the oracle's literal beam loop"""
+    World, OracleWorld = worlds
+    from img_env_amd import _cabi, worldgen
+    from parity import EXTRAS
+    if case == "shipped_geometry":
+        kw = dict(RESAMPLED["test_yaml_geometry"])
+        n, P, steps = kw.pop("n_robots"), kw.pop("n_peds"), kw.pop("steps")
+        grid = _room_map(kw.pop("map_px"), kw["seed"])
+        gres, res, view_m, image = kw.pop("global_res"), kw.pop("res"), kw.pop("view_m"), kw.pop("image")
+        seed, n_obs = kw.pop("seed"), kw.pop("n_obstacles")
+        params = worldgen.make_params(n, P, res=res, view_cells=1, **kw)
+        params.update(global_resolution=gres, view_width=view_m, view_height=view_m, image_size=(image, image))
+        layout = worldgen.make_layout(grid, gres, n, P, seed=seed, n_obstacles=n_obs)
+    else:
+        n, steps = 12, 25
+        grid, params, layout = small_world(n, 5, seed=41, n_obstacles=3, **({"view_cells": 50} if case == "view_50_not_a4" else {}))
+    params = dict(params, flags=int(params.get("flags", 0)) | _cabi.FLAG_AGENT_STATE_EXTRAS)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        assert all(k in gpu.out for k in EXTRAS) and gpu.out["angular_map"].shape == (n, 72)
+        rng = np.random.default_rng(3)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(steps)], fields=EXACT + CLOSE + EXTRAS)
+        assert not fails, fails[:3]
+        s = cpu.snapshot()
+        assert (s["angular_map"] < s["angular_map"].max()).any() and np.abs(s["hits_x"]).max() > 0.5  # something was hit
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def test_aborted_step_is_recovered_by_reset(worlds):
     """a step that was begun and never ended (the caller's exchange failed between imgenv_step_begin and imgenv_step_end) leaves
     the fused tails' hand-over words half filled; a reset recovers the handle and the next episode matches the oracle"""
