@@ -1238,12 +1238,25 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     PHASE_MARK(0);
 
     // (2) egocentric crop (agent.cpp:373-404): 4 view cells per lane per round -> one LDS dword.
-    //     world = (m00 * (a res) + m01 * (b res)) + ox: the column products come from an LDS table, the row
-    //     products are shared by the 4 cells of a lane
+    //     Grid cell of view cell (a, b) = round(((m00 (a res) + m01 (b res)) + ox) / res), i.e. m00 a + m01 b + ox / res in cells
+    //     up to a few ulps.  An fp64 operation, a convert or a multiply costs a SIMD 4.2 cycles per wavefront, an integer add 2.4
+    //     (tools/micro/valu_issue.hip), so the fast path runs in 32.32 fixed point: the column terms (+ the origin + 0.5) come
+    //     from an LDS table, the row term is shared by the 4 cells of a lane, a cell costs one 64-bit add per axis, its index
+    //     is the high word and the low word tells how close the value is to a rounding boundary.  Coefficient rounding (2^-33
+    //     each) moves the sum by < 2^-24 cells for views below 256 cells; values within 2^-17 of a boundary -- and exact ties,
+    //     where C round() goes away from zero -- take the reference's own fp64 chain.  (Measured: 737 -> ~450 vector
+    //     instructions for the crop, the step +0.8 %: the phase waits for its gathers, 4 in flight per lane; 8 in flight need
+    //     76 registers -- 6 wavefronts per SIMD instead of 8 -- or spill, and lose 6 %.)
     const Tf2 vw = tf_mul(bw, w.view_base);  // get_view_world (agent.cpp:128-131)
-    for (int b = tid; b < Wv; b += NT) {
-        const double y = b * res;
-        colt[b] = make_double2(vw.m01 * y, vw.m11 * y);
+    const double two32 = 4294967296.0;
+    const double oxs = vw.ox * inv, oys = vw.oy * inv;
+    const long long M00 = (long long)rint(vw.m00 * two32), M10 = (long long)rint(vw.m10 * two32);
+    const bool fixed_ok = fabs(oxs) < 1048576.0 && fabs(oys) < 1048576.0;  // (always, for a pose anywhere near its map)
+    longlong2* coli = (longlong2*)colt;
+    {
+        const long long M01 = (long long)rint(vw.m01 * two32), M11 = (long long)rint(vw.m11 * two32);
+        const long long OX = (long long)rint(oxs * two32) + (1ll << 31), OY = (long long)rint(oys * two32) + (1ll << 31);
+        for (int b = tid; b < Wv; b += NT) coli[b] = make_longlong2(OX + b * M01, OY + b * M11);
     }
     if (tid < 16) src[NC + tid] = 255;  // dummy free cells behind the view (padded path entries)
     if (tid < 3) skip_cnt[tid] = 0;
@@ -1253,34 +1266,36 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
         if (fov) {
             const int a0 = (int)__umulhi((uint32_t)c4, wv_magic), b0 = c4 - a0 * Wv;
-            const double x0 = a0 * res;
-            const double rx0 = vw.m00 * x0, ry0 = vw.m10 * x0;
-            double tx[4], ty[4];
+            const long long rx0 = a0 * M00, ry0 = a0 * M10;
             int m[4], n[4];
-            bool tie = false;
+            bool risky = !fixed_ok;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                double rx = rx0, ry = ry0;
+                long long rx = rx0, ry = ry0;
                 int b = b0 + q;
                 if (!A4) {  // the group may run over the end of its row (or of the view)
                     const int c = min(c4 + q, NC - 1);
                     const int a = (int)__umulhi((uint32_t)c, wv_magic);
                     b = c - a * Wv;
-                    const double x = a * res;
-                    rx = vw.m00 * x;
-                    ry = vw.m10 * x;
+                    rx = a * M00;
+                    ry = a * M10;
                 }
-                const double2 cc = colt[b];
-                tx[q] = w2m_scale<POW2>((rx + cc.x) + vw.ox, res, inv);
-                ty[q] = w2m_scale<POW2>((ry + cc.y) + vw.oy, res, inv);
-                m[q] = round_even_i(tx[q], tie);
-                n[q] = round_even_i(ty[q], tie);
+                const longlong2 cc = coli[b];
+                const unsigned long long fx = (unsigned long long)(rx + cc.x), fy = (unsigned long long)(ry + cc.y);
+                m[q] = (int)(uint32_t)(fx >> 32);
+                n[q] = (int)(uint32_t)(fy >> 32);
+                const uint32_t G = 1u << 15;
+                risky |= ((uint32_t)fx + G < 2u * G) | ((uint32_t)fy + G < 2u * G);
             }
-            if (__builtin_expect(__any(tie), 0)) {  // an exact .5 somewhere in the wave: C round() goes away from zero
+            if (__builtin_expect(__any(risky), 0)) {  // close to a rounding boundary somewhere in the wave: the literal chain
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    m[q] = round_tie_fix(tx[q]);
-                    n[q] = round_tie_fix(ty[q]);
+                    const int c = min(c4 + q, NC - 1);
+                    const int a = (int)__umulhi((uint32_t)c, wv_magic), b = c - a * Wv;
+                    double wx, wy;
+                    tf_apply(vw, a * res, b * res, wx, wy);
+                    m[q] = w2m_t<POW2>(wx, res, inv);
+                    n[q] = w2m_t<POW2>(wy, res, inv);
                 }
             }
             uint32_t idx[4], okm[4];
