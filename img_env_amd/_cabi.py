@@ -18,6 +18,8 @@ FLAG_PRIVATE_GRIDS = 1
 FLAG_COMPOSE_DENSE = 2
 FLAG_COMPOSE_SPARSE = 4
 FLAG_NO_VIEW_MAPS = 8  # imgenv_out.view_maps not wanted (include/imgenv.h)
+FLAG_VIEW_TILED = 32  # views through the tiled kernels (csrc/view_big.h) / through k_view, where both can run
+FLAG_VIEW_WAVE = 64
 FLAG_AGENT_STATE_EXTRAS = 16  # AgentState.hits_x / hits_y / angular_map as well
 ANGULAR_BINS = 72
 

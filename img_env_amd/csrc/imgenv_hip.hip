@@ -505,7 +505,12 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             k.shape = shape;
             memcpy(k.size, cfg->robot_size + 4 * i, 16);
             memcpy(k.sensor, cfg->robot_sensor_cfg + 2 * i, 8);
-            build_robot_class(k, g, view_resize, (cfg->flags & IMGENV_FLAG_AGENT_STATE_EXTRAS) != 0);
+            // tiled kernels (view_big.h): where k_view cannot run (its packing -- decided in build_robot_class -- or a shrunk
+            // sensor_map) and on request.  (Measured on BASELINE cfg-5's 96 x 96 views, 8192 robots beside k_obs<16>: k_view
+            // 471 us per step, the tiled kernels 531 -- the same instruction count in three launches; k_view stays the default
+            // wherever it can run.)
+            const bool tiled = view_resize || ((cfg->flags & IMGENV_FLAG_VIEW_TILED) && !(cfg->flags & IMGENV_FLAG_VIEW_WAVE));
+            build_robot_class(k, g, tiled, (cfg->flags & IMGENV_FLAG_AGENT_STATE_EXTRAS) != 0);
             h->rcls.push_back(std::move(k));
             found = (int)h->rcls.size() - 1;
         }
@@ -1230,7 +1235,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
 #undef BEAMS_CASE
         // the last kernel of the chain commits the robots' new is_collision_
         if (d.resize) TIMED(h, IMGENV_K_TAPS, st, (k_taps_big<<<gt, dim3(VBT_T), taps_lds_bytes(d.B), st>>>(d, tap_chunks, full ? 0 : 1)));
-        if (full) TIMED(h, IMGENV_K_FULLVIEW, st, (k_fullview_big<<<gf, dim3(VBF_T), 0, st>>>(d, h->big_full_chunks, 1)));
+        if (full) TIMED(h, IMGENV_K_FULLVIEW, st, (k_fullview_big<<<gf, dim3(VBF_T), 16 * (size_t)((d.B + 4) / 4), st>>>(d, h->big_full_chunks, 1)));
         h->launches += (d.resize ? 1 : 0) + (full ? 1 : 0);
     } else {
         // one wavefront per robot when the launch fills the machine, four when it is small (a reset of a few worlds): then

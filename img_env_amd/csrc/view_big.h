@@ -25,7 +25,7 @@
 // occupied: such cells skip the beams altogether, which also keeps the walks away from the long ray lists around the sensor.
 #pragma once
 
-#define VBC_T 256    // k_crop_big: 4 wavefronts
+#define VBC_T 256    // k_crop_big: up to 4 wavefronts
 #define VBC_U 4      // tiles a wavefront keeps in flight
 #define VBB_T 256    // k_beams_big: one beam per thread
 #define VBT_T 256    // k_taps_big: one sensor_map pixel per thread
@@ -96,11 +96,12 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
     unsigned long long* plane1 = (unsigned long long*)(w.big_bits + ((size_t)l * 2 + 1) * w.big_words);
     const bool want_unknown = w.use_laser == 0;  // with the laser on only "occupied or not" survives into the outputs
     const int n_crop = k.n_crop, tb_n = k.tb;
-    const int first = chunk * ((VBC_T / WAVE) * tpw);  // tpw tiles per wavefront: more in big launches (workgroup dispatch has a price)
+    const int nw = (int)blockDim.x >> 6;  // wavefronts of this workgroup: 4, or 1 where the robots alone fill the chip
+    const int first = chunk * (nw * tpw);  // tpw tiles per wavefront: more in big launches (workgroup dispatch has a price)
     // lane q holds the descriptor of this wavefront's q-th tile (tpw <= 64): one load here, a readlane per tile below
     uint32_t my_tile = 0, my_fov_lo = 0, my_fov_hi = 0;
     {
-        const int ti = first + lane * (VBC_T / WAVE) + wave;
+        const int ti = first + lane * nw + wave;
         if (lane < tpw && ti < n_crop) {
             my_tile = k.crop_tiles[ti];
             const unsigned long long f = k.crop_masks[ti];
@@ -109,12 +110,12 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
         }
     }
     for (int it = 0; it < tpw; it += VBC_U) {
-        if (first + it * (VBC_T / WAVE) + wave >= n_crop) break;  // uniform
+        if (first + it * nw + wave >= n_crop) break;  // uniform
         uint32_t idx[VBC_U], tile_w[VBC_U];
         unsigned long long look[VBC_U], risky = 0ull;  // lane masks (scalar registers)
 #pragma unroll
         for (int u = 0; u < VBC_U; u++) {
-            const int ti = first + (it + u) * (VBC_T / WAVE) + wave;  // consecutive wavefronts take consecutive tiles
+            const int ti = first + (it + u) * nw + wave;  // consecutive wavefronts take consecutive tiles
             const bool valid = ti < n_crop;
             const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, it + u);
             const unsigned long long fov = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_fov_hi, it + u) << 32) |
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
         if (__builtin_expect(risky != 0ull || !fixed_ok, 0)) {  // somebody within 2^-17 of a rounding boundary: the reference's own chain
 #pragma unroll
             for (int u = 0; u < VBC_U; u++) {
-                const int ti = first + (it + u) * (VBC_T / WAVE) + wave;
+                const int ti = first + (it + u) * nw + wave;
                 const bool valid = ti < n_crop;
                 const uint32_t tile = k.crop_tiles[valid ? ti : 0];
                 const unsigned long long fov = valid ? k.crop_masks[ti] : 0ull;
@@ -453,60 +454,92 @@ __global__ __launch_bounds__(VBT_T) void k_taps_big(DevWorld w, int chunks, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// (4) the full view: laser_map per cell + own footprint (agent.cpp:419-437, 503), 4 cells per thread; view_maps when it is
-// an output, sensor_maps (float16) when nothing is shrunk
+// (4) the full view: laser_map per cell + own footprint (agent.cpp:419-437, 503), 4 cells per thread, 1024 per workgroup;
+// view_maps when it is an output, sensor_maps (float16) when nothing is shrunk.  LDS: the robot's hit words.
 __global__ __launch_bounds__(VBF_T) void k_fullview_big(DevWorld w, int chunks, int commit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
     const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
     const int l = act_member(w, w.Rw, t);
     const int B = w.B;
-    const uint32_t* hit = w.big_hit + (size_t)l * w.big_hit_stride;
-    if (hit[B + 1] == 0u) return;  // frozen
-    if (commit && chunk == 0 && threadIdx.x == 0) w.is_coll[l] = (int)hit[B + 2];
-    if (commit && chunk == 0 && w.angular_map && w.use_laser) angular_bins(w, w.rc[__builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l])], hit, l, (int)threadIdx.x, VBF_T);
-    const int NC = w.Hv * w.Wv, c4 = (chunk * VBF_T + (int)threadIdx.x) * 4;
-    if (c4 >= NC) return;
+    const uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
+    if (hit_g[B + 1] == 0u) return;  // frozen
+    if (commit && chunk == 0 && tid == 0) w.is_coll[l] = (int)hit_g[B + 2];
     const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l]);
     const RobotClassDev rc = w.rc[cls];
     const BigClassDev k = w.big[cls];
+    if (commit && chunk == 0 && w.angular_map && w.use_laser) angular_bins(w, rc, hit_g, l, tid, VBF_T);
+    const bool laser = w.use_laser != 0;
+    uint32_t* hit = (uint32_t*)smem;
+    if (laser) {
+        for (int q = tid; q < (B + 4) / 4; q += VBF_T) ((uint4*)hit)[q] = ((const uint4*)hit_g)[q];  // B words + the dummy beam
+        __syncthreads();
+    }
+    const int NC = w.Hv * w.Wv, c4 = (chunk * VBF_T + tid) * 4;
+    if (c4 >= NC) return;
     const uint32_t* plane0 = w.big_bits + (size_t)l * 2 * w.big_words;
     const uint32_t* plane1 = plane0 + w.big_words;
-    const bool laser = w.use_laser != 0;
     const uint32_t Wv = (uint32_t)w.Wv, tb_n = (uint32_t)k.tb;
     const uint32_t stamp = (rc.stamp_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;
-    uint32_t top[4] = {0u, 0u, 0u, 0u};
+    // class index per cell: 0 -> 0, 1 -> 100, 2 -> 200, 3 -> 255 (as in k_view)
+    uint32_t I = 0x02020202u;
     if (laser) {
+        uint32_t top[4] = {0u, 0u, 0u, 0u};
         if (c4 + 4 <= NC) {
             const uint4 t4 = *(const uint4*)(rc.top_ent + c4);
             top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
         } else {
             for (int q = 0; q < 4 && c4 + q < NC; q++) top[q] = rc.top_ent[c4 + q];
         }
-    }
-    uint32_t val[4];
+        uint32_t alone = 0;
+        I = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t c = (uint32_t)min(c4 + q, NC - 1);
-        const bool st = ((stamp >> q) & 1u) != 0u;
-        uint32_t addr = 0;
-        if (!laser || st) {  // the crop bit itself is only needed without the laser or under the own footprint
-            const uint32_t a = c / Wv, b = c - a * Wv;
-            addr = ((a >> 3) * tb_n + (b >> 3)) * 64u + (a & 7u) * 8u + (b & 7u);
+        for (int q = 0; q < 4; q++) {  // the top beam's verdict
+            const uint32_t kk = top[q] & 0xFFFFu, hp = hit[top[q] >> 16], hk = hp >> 16;
+            I |= (kk < hk ? 3u : (kk == hk ? 0u : 2u)) << (8 * q);
+            alone |= ((kk > hk) & (kk <= (hp & 0xFFFFu))) ? (1u << q) : 0u;
         }
-        val[q] = (laser && !st) ? big_laser_value(rc, k, hit, c, top[q]) : big_cell_value(rc, k, hit, plane0, plane1, laser, c, top[q], addr, st);
+        for (uint32_t m = alone; m != 0u; m &= m - 1u) {  // cells that beam leaves alone: the list behind it
+            const int q = __builtin_ctz(m);
+            const uint32_t v = big_walk(rc, hit, k.inv[min(c4 + q, NC - 1)]);
+            I = (I & ~(0xFFu << (8 * q))) | ((v == 255u ? 3u : (v == 0u ? 0u : 2u)) << (8 * q));
+        }
+    }
+    if (!laser || stamp != 0u) {  // the crop bit itself is only needed without the laser or under the own footprint
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (laser && !((stamp >> q) & 1u)) continue;
+            const uint32_t c = (uint32_t)min(c4 + q, NC - 1), a = c / Wv, b = c - a * Wv;
+            const uint32_t addr = ((a >> 3) * tb_n + (b >> 3)) * 64u + (a & 7u) * 8u + (b & 7u);
+            const bool occ = ((plane0[addr >> 5] >> (addr & 31u)) & 1u) != 0u;
+            uint32_t ci = (I >> (8 * q)) & 0xFFu;
+            if (!laser) {
+                const bool unk = ((plane1[addr >> 5] >> (addr & 31u)) & 1u) != 0u;
+                ci = occ ? 0u : (unk ? 2u : 3u);
+            } else if (!occ) {
+                ci = 1u;  // under the own footprint a beam can only write 0 where the crop is occupied: 100 (agent.cpp:307-312)
+            }
+            if (((stamp >> q) & 1u) && ci != 0u) ci = 1u;
+            I = (I & ~(0xFFu << (8 * q))) | (ci << (8 * q));
+        }
     }
     uint8_t* out_u8 = w.view_maps + (size_t)l * NC;
     uint16_t* out_f16 = w.sensor_maps + (size_t)l * NC;  // only when nothing is shrunk
     const bool vec = (NC & 3) == 0;  // then every robot's rows start on a 4-cell boundary
+    const uint32_t lut_u8 = 0u | (100u << 8) | (200u << 16) | (255u << 24);
     if (w.keep_view_maps) {
-        if (vec) *(uint32_t*)(out_u8 + c4) = val[0] | (val[1] << 8) | (val[2] << 16) | (val[3] << 24);
-        else for (int q = 0; q < 4 && c4 + q < NC; q++) out_u8[c4 + q] = (uint8_t)val[q];
+        const uint32_t packed = __builtin_amdgcn_perm(lut_u8, lut_u8, I);
+        if (vec) *(uint32_t*)(out_u8 + c4) = packed;
+        else for (int q = 0; q < 4 && c4 + q < NC; q++) out_u8[c4 + q] = (uint8_t)(packed >> (8 * q));
     }
     if (!w.resize) {
-        const uint32_t f0 = w.f16_lut[val[0]], f1 = w.f16_lut[val[1]], f2 = w.f16_lut[val[2]], f3 = w.f16_lut[val[3]];
-        if (vec) *(uint2*)(out_f16 + c4) = make_uint2(f0 | (f1 << 16), f2 | (f3 << 16));
-        else {
-            const uint32_t f[4] = {f0, f1, f2, f3};
-            for (int q = 0; q < 4 && c4 + q < NC; q++) out_f16[c4 + q] = (uint16_t)f[q];
-        }
+        const uint32_t h0 = w.f16_lut[0], h1 = w.f16_lut[100], h2 = w.f16_lut[200], h3 = w.f16_lut[255];
+        const uint32_t lut_lo = (h0 & 0xFFu) | ((h1 & 0xFFu) << 8) | ((h2 & 0xFFu) << 16) | ((h3 & 0xFFu) << 24);
+        const uint32_t lut_hi = (h0 >> 8) | ((h1 >> 8) << 8) | ((h2 >> 8) << 16) | ((h3 >> 8) << 24);
+        // two float16 values per v_perm: selector bytes (c, c + 4) pick the low byte out of lut_lo and the high one out of lut_hi
+        const uint32_t s01 = __builtin_amdgcn_perm(I, I, 0x01010000u) | 0x04000400u, s23 = __builtin_amdgcn_perm(I, I, 0x03030202u) | 0x04000400u;
+        const uint32_t f01 = __builtin_amdgcn_perm(lut_hi, lut_lo, s01), f23 = __builtin_amdgcn_perm(lut_hi, lut_lo, s23);
+        if (vec) *(uint2*)(out_f16 + c4) = make_uint2(f01, f23);
+        else for (int q = 0; q < 4 && c4 + q < NC; q++) out_f16[c4 + q] = (uint16_t)((q < 2 ? f01 : f23) >> (16 * (q & 1)));
     }
 }

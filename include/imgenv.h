@@ -166,6 +166,12 @@ typedef struct imgenv_cfg {
 #define IMGENV_FLAG_NO_VIEW_MAPS 8
 /* also produce AgentState.hits_x / hits_y / angular_map (imgenv_out, below) */
 #define IMGENV_FLAG_AGENT_STATE_EXTRAS 16
+/* Which kernels compute the views.  Default: one wavefront per robot (k_view) wherever it can run; the tiled kernels that
+ * spread one robot's view over the chip (csrc/view_big.h) for views k_view cannot pack (beyond 255 x 255 cells or 255 ray
+ * steps) and for shrunk sensor_maps.  IMGENV_FLAG_VIEW_TILED asks for the tiled kernels where both can run; the result is the
+ * same. */
+#define IMGENV_FLAG_VIEW_TILED 32
+#define IMGENV_FLAG_VIEW_WAVE 64  /* (reserved: k_view is the default) */
 
 /* ResetEnv.srv:1-6 (img_env.cpp:162-292).  Poses are (x, y, qz, qw): geometry_msgs/Pose with a
  * planar orientation; yaw is recovered with tf::Matrix3x3(q).getRPY as the node does. */

@@ -39,6 +39,11 @@ CASES = {
                                view_width=3.75, view_height=3.75),  # int(3.75 / 0.1) = 37 cells
     # BASELINE cfg-5 geometry: 96 x 96 view, 720 beams
     "view96_720beams": dict(n_robots=10, n_peds=6, seed=27, view_cells=96, beams=720, grid_size=240),
+    # the tiled kernels (csrc/view_big.h) on views k_view could also take: full-size view and float16 sensor_map from
+    # k_fullview_big, nothing shrunk (IMGENV_FLAG_VIEW_TILED)
+    "view96_720beams_tiled": dict(n_robots=10, n_peds=6, seed=27, view_cells=96, beams=720, grid_size=240),
+    "view_50_not_a4_tiled": dict(n_robots=16, n_peds=6, seed=25, view_cells=50),
+    "no_laser_tiled": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "no_laser": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "time_limit": dict(n_robots=4, n_peds=2, seed=9, time_max=6),
 }
@@ -60,6 +65,9 @@ def test_hip_matches_oracle(worlds, case):
     kw = dict(CASES[case])
     n = kw["n_robots"]
     grid, params, layout = small_world(**kw)
+    if case.endswith("_tiled"):
+        from img_env_amd import _cabi
+        params = dict(params, flags=int(params.get("flags", 0)) | _cabi.FLAG_VIEW_TILED)
     gpu, cpu = World(params, grid), OracleWorld(params, grid)
     try:
         rng = np.random.default_rng(kw["seed"] + 50)

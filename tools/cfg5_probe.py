@@ -13,10 +13,11 @@ from img_env_amd import worldgen  # noqa: E402
 from img_env_amd.world import World  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 32: views through the tiled kernels, 64: through k_view
 P = 1000
 grid = worldgen.make_grid(800, 0)
 layout = worldgen.make_layout(grid, 0.125, R, P, seed=100, clearance=0.7)
-w = World(worldgen.make_params(R, P, res=0.125, view_cells=96, beams=720, scene="ervoscene"), grid)
+w = World(dict(worldgen.make_params(R, P, res=0.125, view_cells=96, beams=720, scene="ervoscene"), flags=FLAGS), grid)
 w.reset(layout)
 a = torch.zeros(R, 3, device="cuda")
 a[:, 1] = torch.rand(R, device="cuda") * 1.8 - 0.9
