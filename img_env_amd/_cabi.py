@@ -255,7 +255,8 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_destroy", "imgenv_reset", "imgenv_step", "imgenv_step_begin", "imgenv_step_end",
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
-           "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_cv_resize_u8")
+           "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_step_autoreset_device", "imgenv_autoreset_last",
+           "imgenv_world_placement", "imgenv_cv_resize_u8")
 K_COUNT = 11
 
 
@@ -280,6 +281,9 @@ def bind(lib):
     lib.imgenv_reset_world.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ResetBatch), C.c_void_p]
     lib.imgenv_reset_worlds.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(ResetBatch), C.c_void_p]
     lib.imgenv_spawn.argtypes = [C.POINTER(SpawnCfg), C.c_uint64] + [C.c_void_p] * 9
+    lib.imgenv_step_autoreset_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SpawnCfg), C.c_uint64, C.c_void_p]
+    lib.imgenv_autoreset_last.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.imgenv_world_placement.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)] + [C.c_void_p] * 9
     lib.imgenv_reset_worlds_spawn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(SpawnCfg),
                                               C.POINTER(C.c_uint64), C.c_void_p]
     lib.imgenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -119,6 +119,14 @@ struct imgenv {
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
     double trace_acc[4] = {0, 0, 0, 0};  // IMGENV_TRACE_RESET: host time inside imgenv_step_autoreset
     long trace_calls = 0, trace_resets = 0;
+    // device-side auto-reset (csrc/spawn_device.h): pool of placements drawn ahead on a side stream
+    bool sd_ready = false, dev_reset_used = false;
+    int act_hint = 0;  // device-side auto-reset: robots the reset chain is expected to cover (picks the small-launch kernel variants)
+    uint64_t sd_fp = 0;
+    hipStream_t side3 = nullptr;
+    hipEvent_t ev_fill = nullptr, ev_consumed = nullptr;
+    void* sd_storage = nullptr;  // SpawnDev (defined behind the kernels)
+    void (*sd_delete)(void*) = nullptr;
     bool chain_open = false;  // a chain of launches that hands over through tail_sig / tail_cnt has started and not been completed
     std::vector<RvoObstacles> rvos;  // one obstacle set per world
     int sfm_cap_obs = 0;
@@ -393,6 +401,13 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         for (auto& c : h->stage_gen[g]) (void)hipHostFree(c.p);
         if (h->ev_gen[g]) (void)hipEventDestroy(h->ev_gen[g]);
     }
+    if (h->side3) {
+        (void)hipStreamSynchronize(h->side3);
+        (void)hipStreamDestroy(h->side3);
+    }
+    if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
+    if (h->ev_consumed) (void)hipEventDestroy(h->ev_consumed);
+    if (h->sd_storage && h->sd_delete) h->sd_delete(h->sd_storage);
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1190,7 +1205,9 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     {
         const int n_blocks = n_p > n_g ? n_p : n_g;
-        const bool small = n_blocks <= 1024;  // four wavefronts per robot / pedestrian when the launch cannot fill the machine
+        // four wavefronts per robot / pedestrian when the launch cannot fill the machine (device-side auto-reset: by the expected
+        // number of robots, the grid itself is sized for every world)
+        const bool small = (d.act_n_dev ? std::min(n_blocks, h->act_hint) : n_blocks) <= 1024;
         const dim3 gr(n_blocks), br(small ? 4 * WAVE : WAVE);
         const size_t lds = 4 * (size_t)d.box_cells + 16;
         const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
@@ -1240,7 +1257,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     } else {
         // one wavefront per robot when the launch fills the machine, four when it is small (a reset of a few worlds): then
         // the single wavefront's latency is all there is
-        const bool small = n_l <= 1024;
+        const bool small = (d.act_n_dev ? std::min(n_l, h->act_hint) : n_l) <= 1024;
         const dim3 gv(n_l), bv(small ? 4 * WAVE : WAVE);
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
@@ -1449,7 +1466,8 @@ struct ObstInst {
     int shape, world;
 };
 template <bool POW2>
-__global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst, int stamp) {
+__global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst, int stamp, const int* n_dev, int per_world) {
+    if (n_dev && (int)blockIdx.x >= *n_dev * per_world) return;  // device-side auto-reset: per_world instances for each finished world
     const ObstInst o = inst[blockIdx.x];
     const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
     uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)o.world * w.Gs;
@@ -1477,6 +1495,8 @@ __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstI
         }
     }
 }
+
+#include "spawn_device.h"  // device-side auto-reset: k_spawn_fill, k_finished_dev, k_respawn, k_restore_maps_dev
 
 // the obstacle list of one world's reset batch: instances for k_reset_obstacles, the RVO polygons with their BSP
 // (RVOScene::addObs + processObs, rvoscene.h:19-26, img_env.cpp:283) and the social-force segments (pedscene.h:22-26)
@@ -1526,6 +1546,9 @@ static int put_world_rvo(imgenv* h, int k) {
     static_assert(sizeof(RvoObstHost) == sizeof(RvoObstDev) && sizeof(RvoNodeHost) == sizeof(RvoNodeDev), "layout");
     const RvoObstacles& r = h->rvos[k];
     bool all = false;
+    if (h->dev_reset_used && ((int)r.ob.size() > h->cap_obst || (int)r.nodes.size() > h->cap_nodes))
+        FAIL(IMGENV_ESTATE, "world %d: more RVO obstacle vertices than the handle has room for, after imgenv_step_autoreset_device has taken over "
+                            "the per-world obstacle tables (reset every world with imgenv_reset first)", k);
     if ((int)r.ob.size() > h->cap_obst) {
         h->cap_obst = (int)r.ob.size() * 2;
         if (int rc = dev_alloc(h, &h->d_obst, (size_t)h->cap_obst * h->W)) return rc;
@@ -1734,8 +1757,16 @@ static int reset_blocks(imgenv* h, int n, const int* list) {
 
 static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int whole) {
     DevWorld& d = h->d;
-    RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size()));
-    RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W));
+    if (!list) {
+        RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size()));
+        RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W));
+    } else {  // only the listed worlds' entries: the device-side auto-reset keeps the others' up to date itself
+        for (int q = 0; q < n; q++) {
+            const int k = list[q];
+            for (int t = 0; t < 4; t++) RTRY(stage_put(h, h->d_wobst + (size_t)t * h->W + k, &h->wobst[(size_t)t * h->W + k], sizeof(int)));
+            RTRY(stage_put(h, h->d_world_epoch + k, &h->world_epoch[k], sizeof(int)));
+        }
+    }
     if (list) RTRY(stage_put(h, h->d_act_list, list, sizeof(int) * n));  // for the launches after k_reset_apply
     const size_t n_inst = h->oinst.size();
     if (n_inst > h->cap_oinst) {
@@ -1772,8 +1803,8 @@ static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int w
         h->seg_max = 0;
     }
     if (n_inst) {
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0);
-        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0);
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0);
+        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0);
     }
     if (d.sharded) k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, h->pin_rob3);
     HIPCHK(hipGetLastError());
@@ -1811,6 +1842,7 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         RTRY(stage_put(h, h->d.bbox, init, sizeof(init)));
     }
     h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
+    h->dev_reset_used = false;  // every world's host copy is current again
     RTRY(reset_launch(h, nullptr, 0, st, 1));  // no host wait: the copies read the handle's pinned chunks
     h->has_reset = true;
     return IMGENV_OK;
@@ -2103,6 +2135,233 @@ extern "C" int imgenv_step_autoreset(imgenv_t* h, const float* actions, const im
         }
     }
     return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------- device-side auto-reset
+template <typename T>
+static int sd_alloc(imgenv* h, T** out, size_t n) {
+    return dev_alloc(h, out, n);
+}
+static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t seed0, hipStream_t st) {
+    const int na = cfg->n_robots + cfg->n_peds, nob = cfg->n_obstacles;
+    if (na > SPAWN_MAX_AGENTS || nob > SPAWN_MAX_OBST)
+        FAIL(IMGENV_EINVAL, "device-side auto-reset places at most %d agents and %d obstacles per world", SPAWN_MAX_AGENTS, SPAWN_MAX_OBST);
+    if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET)
+        FAIL(IMGENV_EINVAL, "device-side auto-reset: pedsim and dataset scenes are reset by the host (imgenv_step_autoreset)");
+    if (h->Pw > 0 && (h->traj_cap < 2 || !h->d_traj)) FAIL(IMGENV_ESTATE, "device-side auto-reset: reset every world once first (trajectories of two points)");
+    if (!h->sd_storage) {
+        h->sd_storage = new SpawnDev();
+        h->sd_delete = [](void* p) { delete (SpawnDev*)p; };
+    }
+    SpawnDev& c = *(SpawnDev*)h->sd_storage;
+    memset(&c, 0, sizeof(c));
+    c.n_robots = cfg->n_robots; c.n_peds = cfg->n_peds; c.n_obstacles = nob; c.go_back = cfg->go_back; c.ignore_obstacle = cfg->ignore_obstacle;
+    c.rvo = h->NA > 0 ? 1 : 0;
+    c.clearance = cfg->clearance; c.target_min_dist = cfg->target_min_dist; c.circle0 = cfg->circle_ranges[0]; c.circle1 = cfg->circle_ranges[1];
+    std::vector<DevSpawnAgent> ag((size_t)(na ? na : 1));
+    std::vector<double> multi;
+    for (int a = 0; a < na; a++) {
+        const imgenv_spawn_agent& g = cfg->agents[a];
+        DevSpawnAgent& o = ag[a];
+        memset(&o, 0, sizeof(o));
+        o.begin_type = g.begin_type; o.target_type = g.target_type; o.module_size = g.module_size;
+        memcpy(o.begin, g.begin, sizeof(o.begin));
+        memcpy(o.target, g.target, sizeof(o.target));
+        if (g.begin_type == IMGENV_POSE_RANGE_MULTI) {
+            if (g.n_begin_multi < 1 || !g.begin_multi) FAIL(IMGENV_EINVAL, "range_multi start without ranges");
+            o.begin_multi = (int)(multi.size() / 6); o.n_begin_multi = g.n_begin_multi;
+            multi.insert(multi.end(), g.begin_multi, g.begin_multi + 6 * (size_t)g.n_begin_multi);
+        }
+        if (g.target_type == IMGENV_POSE_RANGE_MULTI) {
+            if (g.n_target_multi < 1 || !g.target_multi) FAIL(IMGENV_EINVAL, "range_multi target without ranges");
+            o.target_multi = (int)(multi.size() / 6); o.n_target_multi = g.n_target_multi;
+            multi.insert(multi.end(), g.target_multi, g.target_multi + 6 * (size_t)g.n_target_multi);
+        }
+    }
+    if (multi.empty()) multi.push_back(0.0);
+    std::vector<DevSpawnObstacle> ob((size_t)(nob ? nob : 1));
+    for (int q = 0; q < nob; q++) {
+        ob[q].shape = cfg->obstacles[q].shape; ob[q].pose_type = cfg->obstacles[q].pose_type;
+        memcpy(ob[q].size_range, cfg->obstacles[q].size_range, sizeof(ob[q].size_range));
+        memcpy(ob[q].pose, cfg->obstacles[q].pose, sizeof(ob[q].pose));
+    }
+    RTRY(dev_upload(h, &c.agents, ag));
+    RTRY(dev_upload(h, &c.obstacles, ob));
+    RTRY(dev_upload(h, &c.multi, multi));
+    const int W = h->W, S = std::max(64, W);  // one placement per world can be needed in a single step
+    c.S = S;
+    c.seed0 = seed0;
+    c.cap_o = std::max(16, std::min(SPAWN_BSP_CAP, 16 * std::max(nob, 1)));
+    c.cap_n = c.cap_o;
+    RTRY(dev_alloc(h, &c.slot_serial, (size_t)S, 0xFF));
+    RTRY(dev_alloc(h, &c.consumed, 2));
+    RTRY(dev_alloc(h, &c.slot_status, (size_t)S));
+    RTRY(dev_alloc(h, &c.s_agents, (size_t)S * (na ? na : 1)));
+    RTRY(dev_alloc(h, &c.s_obst, (size_t)S * (nob ? nob : 1)));
+    RTRY(dev_alloc(h, &c.s_inst, (size_t)S * (nob ? nob : 1)));
+    RTRY(dev_alloc(h, &c.s_rvo, (size_t)S * c.cap_o));
+    RTRY(dev_alloc(h, &c.s_nodes, (size_t)S * c.cap_n));
+    RTRY(dev_alloc(h, &c.s_rvo_n, (size_t)S * 4));
+    RTRY(dev_alloc(h, &c.fin_list, (size_t)W));
+    RTRY(dev_alloc(h, &c.fin_n, 1));
+    RTRY(dev_alloc(h, &c.inst_out, (size_t)W * (nob ? nob : 1)));
+    RTRY(dev_alloc(h, &c.place_agents, (size_t)W * (na ? na : 1)));
+    RTRY(dev_alloc(h, &c.place_obst, (size_t)W * (nob ? nob : 1)));
+    RTRY(dev_alloc(h, &c.place_serial, (size_t)W, 0xFF));
+    // the per-world RVO tables take over from the host's copies: room for any placement's polygons in every world
+    if (h->NA > 0 && (h->cap_obst < c.cap_o || h->cap_nodes < c.cap_n)) {
+        HIPCHK(hipStreamSynchronize(st));
+        const int co = std::max(h->cap_obst, c.cap_o), cn = std::max(h->cap_nodes, c.cap_n);
+        RvoObstDev* no = nullptr;
+        RvoNodeDev* nn = nullptr;
+        RTRY(dev_alloc(h, &no, (size_t)co * W));
+        RTRY(dev_alloc(h, &nn, (size_t)cn * W));
+        for (int q = 0; q < W; q++) {
+            const RvoObstacles& rq = h->rvos[q];
+            if ((int)rq.ob.size() > co || (int)rq.nodes.size() > cn) FAIL(IMGENV_ESTATE, "world %d holds more RVO obstacle vertices than a placement can have", q);
+            if (!rq.ob.empty()) HIPCHK(hipMemcpy(no + (size_t)q * co, rq.ob.data(), sizeof(RvoObstDev) * rq.ob.size(), hipMemcpyHostToDevice));
+            if (!rq.nodes.empty()) HIPCHK(hipMemcpy(nn + (size_t)q * cn, rq.nodes.data(), sizeof(RvoNodeDev) * rq.nodes.size(), hipMemcpyHostToDevice));
+            h->wobst[q] = q * co;
+            h->wobst[h->W + q] = q * cn;
+            h->wobst[2 * h->W + q] = (int)rq.ob.size();
+            h->wobst[3 * h->W + q] = rq.root;
+        }
+        HIPCHK(hipMemcpy(h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size(), hipMemcpyHostToDevice));
+        h->d_obst = no; h->d_nodes = nn; h->cap_obst = co; h->cap_nodes = cn;
+        h->d.obst = no; h->d.onodes = nn;
+    }
+    c.cap_o = h->NA > 0 ? h->cap_obst : c.cap_o;  // the worlds' slices and the slots' share one stride
+    c.cap_n = h->NA > 0 ? h->cap_nodes : c.cap_n;
+    if (h->NA > 0) {  // (slot arrays were sized with the smaller capacity: again with the handle's)
+        RTRY(dev_alloc(h, &c.s_rvo, (size_t)S * c.cap_o));
+        RTRY(dev_alloc(h, &c.s_nodes, (size_t)S * c.cap_n));
+    }
+    c.world_epoch = h->d_world_epoch;
+    c.n_obst_w = h->d_wobst + 2 * (size_t)W;
+    c.oroot_w = h->d_wobst + 3 * (size_t)W;
+    c.w_obst = h->d_obst;
+    c.w_nodes = h->d_nodes;
+    c.traj = h->d_traj;
+    c.traj_len = h->d_traj_len;
+    c.traj_cap = h->traj_cap;
+    if (!h->side3) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming | hipEventDisableSystemFence));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_consumed, hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+    HIPCHK(hipStreamSynchronize(st));  // (set-up only: the uploads above were synchronous copies)
+    k_spawn_fill<<<dim3(S), dim3(WAVE), 0, h->side3>>>(c);
+    HIPCHK(hipEventRecord(h->ev_fill, h->side3));
+    h->sd_ready = true;
+    return 0;
+}
+
+extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, void* stream) {
+    if (!h || !actions) FAIL(IMGENV_EINVAL, "null argument");
+    if (int rc = spawn_cfg_check(cfg)) return rc;
+    if (cfg->n_robots != h->Rw || cfg->n_peds != h->Pw)
+        FAIL(IMGENV_EINVAL, "spawn cfg is for %d robots / %d pedestrians, a world of this handle has %d / %d", cfg->n_robots,
+             cfg->n_peds, h->Rw, h->Pw);
+    if (h->RL != h->R) FAIL(IMGENV_EINVAL, "imgenv_step_autoreset_device needs all robots of every world on this handle");
+    if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t fp = spawn_cfg_fingerprint(*cfg);
+    if (!h->sd_ready || fp != h->sd_fp) {  // the first call fixes seed0: the k-th world reset from now on takes placement seed0 + k
+        if (int rc = spawn_device_setup(h, cfg, seed0, st)) return rc;
+        h->sd_fp = fp;
+    }
+    SpawnDev& c = *(SpawnDev*)h->sd_storage;
+    if (int rc = imgenv_step(h, actions, stream)) return rc;
+    DevWorld& d = h->d;
+    const int W = h->W, nob = c.n_obstacles;
+    k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
+    HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));  // the pool has been refilled for what the last step consumed
+    if (!h->d_act_list) RTRY(dev_alloc(h, &h->d_act_list, (size_t)W));
+    k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
+    k_restore_maps_dev<<<dim3((unsigned)W * MAP_BLOCKS), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, MAP_BLOCKS);
+    if (nob > 0) {
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
+        else k_reset_obstacles<false><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
+    }
+    HIPCHK(hipGetLastError());
+    // the launches behind: sized for every world, the list and its length read from device memory
+    set_active(h, c.fin_list, W);
+    d.act_n_dev = c.fin_n;
+    {   // how many worlds the last steps reset (page-locked, written by k_finished_dev; stale by a step or two: a hint only)
+        const int last = h->finished_host[0];
+        h->act_hint = std::max(8, 4 * std::max(last, 0)) * std::max(h->Rw, h->Pw);
+    }
+    d.ptraj = h->d_traj;
+    d.traj_cap = h->traj_cap;
+    h->launches = 4;
+    const int rc = launch_views(h, st, 1);
+    set_active(h, nullptr, 0);
+    d.act_n_dev = nullptr;
+    if (rc) return rc;
+    // refill, underneath the next step: the slots whose placements were just handed out
+    HIPCHK(hipEventRecord(h->ev_consumed, st));
+    HIPCHK(hipStreamWaitEvent(h->side3, h->ev_consumed, 0));
+    k_spawn_fill<<<dim3(c.S), dim3(WAVE), 0, h->side3>>>(c);
+    HIPCHK(hipEventRecord(h->ev_fill, h->side3));
+    h->dev_reset_used = true;
+    return IMGENV_OK;
+}
+
+// What the last imgenv_step_autoreset_device did (for checkers and hosts that want to know; synchronises `stream`): the worlds it
+// reset, ascending (up to cap of them), their number, and the placement number the first of them took.
+extern "C" int imgenv_autoreset_last(imgenv_t* h, int32_t* worlds_out, int32_t cap, int32_t* n_out, uint64_t* first_placement, void* stream) {
+    if (!h || !n_out) FAIL(IMGENV_EINVAL, "null argument");
+    if (!h->sd_ready) FAIL(IMGENV_ESTATE, "no imgenv_step_autoreset_device yet");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (int rc = check_device_flags(h)) return rc;
+    SpawnDev& c = *(SpawnDev*)h->sd_storage;
+    const int n = h->finished_host[0];
+    *n_out = n;
+    for (int q = 0; q < n && worlds_out && q < cap; q++) worlds_out[q] = h->finished_host[1 + q];
+    if (first_placement) {
+        unsigned long long two[2];
+        HIPCHK(hipMemcpy(two, c.consumed, sizeof(two), hipMemcpyDeviceToHost));
+        *first_placement = two[1];
+    }
+    return IMGENV_OK;
+}
+
+// The placement world `world` currently runs, as its device-side reset received it (the arrays of imgenv_spawn(); any may be
+// NULL), and its number.  Synchronises the device.
+extern "C" int imgenv_world_placement(imgenv_t* h, int32_t world, uint64_t* placement, double* robot_pose, double* robot_goal, double* ped_pose,
+                                      double* ped_goal, double* ped_traj, int32_t* ped_traj_len, int32_t* obs_shape, float* obs_size, double* obs_pose) {
+    if (!h) FAIL(IMGENV_EINVAL, "null argument");
+    if (!h->sd_ready) FAIL(IMGENV_ESTATE, "no imgenv_step_autoreset_device yet");
+    if (world < 0 || world >= h->W) FAIL(IMGENV_EINVAL, "world out of range");
+    HIPCHK(hipDeviceSynchronize());
+    SpawnDev& c = *(SpawnDev*)h->sd_storage;
+    const int nr = c.n_robots, np = c.n_peds, na = nr + np, nob = c.n_obstacles;
+    unsigned long long serial = 0;
+    HIPCHK(hipMemcpy(&serial, c.place_serial + world, sizeof(serial), hipMemcpyDeviceToHost));
+    if (placement) *placement = serial;
+    if (serial == ~0ull) FAIL(IMGENV_ESTATE, "world %d has not been reset by the device yet", world);
+    std::vector<SlotAgent> ag((size_t)(na ? na : 1));
+    std::vector<SlotObstacle> ob((size_t)(nob ? nob : 1));
+    if (na) HIPCHK(hipMemcpy(ag.data(), c.place_agents + (size_t)world * na, sizeof(SlotAgent) * na, hipMemcpyDeviceToHost));
+    if (nob) HIPCHK(hipMemcpy(ob.data(), c.place_obst + (size_t)world * nob, sizeof(SlotObstacle) * nob, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nr; i++) {
+        if (robot_pose) { robot_pose[4 * i] = ag[i].x; robot_pose[4 * i + 1] = ag[i].y; robot_pose[4 * i + 2] = ag[i].qz; robot_pose[4 * i + 3] = ag[i].qw; }
+        if (robot_goal) { robot_goal[2 * i] = ag[i].gx; robot_goal[2 * i + 1] = ag[i].gy; }
+    }
+    for (int j = 0; j < np; j++) {
+        const SlotAgent& a = ag[nr + j];
+        if (ped_pose) { ped_pose[4 * j] = a.x; ped_pose[4 * j + 1] = a.y; ped_pose[4 * j + 2] = a.qz; ped_pose[4 * j + 3] = a.qw; }
+        if (ped_goal) { ped_goal[2 * j] = a.gx; ped_goal[2 * j + 1] = a.gy; }
+        if (ped_traj) memcpy(ped_traj + 6 * (size_t)j, a.traj, sizeof(a.traj));
+        if (ped_traj_len) ped_traj_len[j] = a.traj_len;
+    }
+    for (int q = 0; q < nob; q++) {
+        if (obs_shape) obs_shape[q] = ob[q].shape;
+        if (obs_size) memcpy(obs_size + 4 * (size_t)q, ob[q].size, sizeof(ob[q].size));
+        if (obs_pose) { obs_pose[4 * q] = ob[q].x; obs_pose[4 * q + 1] = ob[q].y; obs_pose[4 * q + 2] = ob[q].qz; obs_pose[4 * q + 3] = ob[q].qw; }
+    }
+    return IMGENV_OK;
 }
 
 extern "C" int imgenv_comm_unique_id(void* id128) {

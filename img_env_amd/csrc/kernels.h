@@ -135,6 +135,10 @@ __device__ __forceinline__ uint32_t cell_seen_class(uint32_t v, uint32_t self, u
     if (base >= CLS_LOW && (kind == STAMP_MANY || (kind == STAMP_ONE && (v >> STAMP_OWNER_SHIFT) != self))) return CLS_TWO;
     return base;
 }
+// robots / pedestrians of a launch: the host's count, or (device-side auto-reset) what k_finished_dev counted
+__device__ __forceinline__ int act_count_l(const DevWorld& w) { return w.act_n_dev ? *w.act_n_dev * w.Rw : w.act_nl; }
+__device__ __forceinline__ int act_count_g(const DevWorld& w) { return w.act_n_dev ? *w.act_n_dev * w.Rw : w.act_ng; }
+__device__ __forceinline__ int act_count_p(const DevWorld& w) { return w.act_n_dev ? *w.act_n_dev * w.Pw : w.act_np; }
 // the t-th robot (per_world = Rw) or pedestrian (Pw) of a launch: everything, or the members of the listed worlds
 __device__ __forceinline__ int act_member(const DevWorld& w, int per_world, int t) {
     if (!w.act_list) return t;
@@ -158,7 +162,7 @@ __device__ __forceinline__ void tail_group(const DevWorld& w, int g);
 __device__ __forceinline__ void tail_count(const DevWorld& w, int t, bool later) {
     int run = 0;
     if (lane_id() == 0 && later) {
-        const int g = t >> 6, members = min(WAVE, w.act_nl - (g << 6));
+        const int g = t >> 6, members = min(WAVE, act_count_l(w) - (g << 6));
         run = atomicAdd(&w.tail_cnt[g * TAIL_CNT_STRIDE], 1) + 1 == members;
     }
     if (__builtin_amdgcn_readfirstlane(run)) tail_group(w, t >> 6);
@@ -218,6 +222,7 @@ __device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l,
 // then Agent::computeNeighbors + computeNewVelocity for pedestrian j = blockIdx.x.
 __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
     __shared__ OrcaScratch s;
+    if ((int)blockIdx.x >= act_count_p(w)) return;
     const int j = act_member(w, w.Pw, blockIdx.x);
     const int lane = lane_id();
     const int wld = world_of_ped(w, j);
@@ -972,11 +977,11 @@ __global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel) 
     WAVE_T0();
     if (STAMP && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // tail_group tallies this step's dones (k_compose does this otherwise)
     const Region g = grid_region(w);
-    if (b < w.act_ng) {
+    if (b < act_count_g(w)) {
         const int i = act_member(w, w.Rw, b);
         raster_robot<POW2, STAMP, NW>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
     }
-    if (b < w.act_np) {
+    if (b < act_count_p(w)) {
         const int j = act_member(w, w.Pw, b);
         raster_ped<POW2, STAMP, NW>(w, j, w.pc[w.ped_cls[j]], g);
     }
@@ -1039,6 +1044,7 @@ __global__ void k_compose(DevWorld w) {
     size_t G = w.act_cells, c0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (w.act_list) {
         const unsigned per_world = (w.Gs / 4 + blockDim.x - 1) / blockDim.x, q = blockIdx.x / per_world;
+        if (w.act_n_dev && (int)q >= *w.act_n_dev) return;
         const size_t base = (size_t)w.act_list[q] * w.Gs;
         c0 = base + ((size_t)(blockIdx.x - q * per_world) * blockDim.x + threadIdx.x) * 4;
         G = base + w.Gs;
@@ -1182,6 +1188,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     const int tid = threadIdx.x;
     // A4: Wv % 4 == 0 (a lane's 4 consecutive cells share their row and nothing runs over the end of the view)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, blockIdx.x);
     const int lane = lane_id();
     if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value (counted in tail_group)
@@ -1772,6 +1779,7 @@ __device__ __forceinline__ void sort_pairs_in_registers(double (&key)[E], uint32
 template <int E>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8 : 4, 8))) void k_obs(DevWorld w, int PP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, blockIdx.x), lane = lane_id();
     const int i = w.r0 + l;
     // the pedestrians of this robot's world: indices below are relative to p_lo
@@ -1986,7 +1994,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
 // and needs many registers, so it stays out of the kernels that run the tails.
 __global__ void k_state(DevWorld w) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < w.act_nl) state_robot(w, act_member(w, w.Rw, t));
+    if (t < act_count_l(w)) state_robot(w, act_member(w, w.Rw, t));
 }
 
 // Per-robot work that needs the new poses only, on the side stream beside the rasters and the view:
@@ -1998,7 +2006,7 @@ __global__ void k_state(DevWorld w) {
 __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
     __shared__ float2 ped_xy[SIDE_PED_TILE];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = t < w.act_ng;
+    const bool valid = t < act_count_g(w);
     const int i = act_member(w, w.Rw, valid ? t : 0);
     if (rvo_agents) {
         const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
@@ -2071,7 +2079,7 @@ __global__ __launch_bounds__(1024) void k_finished(DevWorld w) {
 // are in its exchange word, read at device scope (the wavefronts that wrote them ran on other compute units).
 __device__ __forceinline__ void tail_group(const DevWorld& w, int g) {
     const int t = (g << 6) + lane_id();
-    const bool valid = t < w.act_nl;
+    const bool valid = t < act_count_l(w);
     const int l = act_member(w, w.Rw, valid ? t : 0);
     const int is_reset = w.tail_is_reset;
     int done = 0;

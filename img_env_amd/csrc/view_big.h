@@ -54,7 +54,7 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
     // block g: XCD g % 8 takes robots g % 8, g % 8 + 8, ... with all their chunks
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
     const int t = (slot / chunks) * 8 + xcd, chunk = slot % chunks;
-    if (t >= n_robots) return;
+    if (t >= n_robots || t >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, t);
     const bool frozen = w.is_coll[l] || w.is_arr[l];  // the view keeps its last value (agent.cpp:358-360)
     // the kernels behind this one go by this word: is_collision_ itself changes underneath them (committed by the last one)
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
     __shared__ uint32_t best_sh;
     const int tid = threadIdx.x;
     const int t = (int)blockIdx.x / quarters, quarter = (int)blockIdx.x - t * quarters;
+    if (t >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, t);
     const int B = w.B;
     uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(VBT_T) void k_taps_big(DevWorld w, int chunks, int 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = lane_id();
     const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
+    if (t >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, t);
     const int B = w.B;
     const uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(VBF_T) void k_fullview_big(DevWorld w, int chunks, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
+    if (t >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, t);
     const int B = w.B;
     const uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;

@@ -35,7 +35,7 @@ class VecImageEnv:
     their rows of the returned state are already the new episode's first observation, as with NeverStopWrapper).
     """
 
-    def __init__(self, cfg, env_num=None, seed=None, auto_reset=True, native_spawn=False):
+    def __init__(self, cfg, env_num=None, seed=None, auto_reset=True, native_spawn=False, device_reset=False):
         import torch
         from .world import World
         self.cfg = cfg
@@ -49,7 +49,12 @@ class VecImageEnv:
         self.env_poses = [spawn.EnvPos(cfg, seed=None if seed is None else seed + k) for k in range(self.env_num)]
         # native_spawn: the placements of an episode are drawn inside the library (csrc/spawn_host.h: EnvPos' rules, its own
         # random stream) -- the Python EnvPos costs 40-170 us per small env, twenty times the device's whole step
-        self.native_spawn = bool(native_spawn)
+        # device_reset: NeverStopWrapper without the host in the loop (imgenv_step_autoreset_device): finished envs are found,
+        # placed and reset by kernels alone, ``step`` returns without synchronising and ``info["reset_envs"]`` is None --
+        # ``info["all_down"]`` (a device tensor, per robot) says which envs started over
+        self.device_reset = bool(device_reset)
+        self.native_spawn = bool(native_spawn) or self.device_reset
+        native_spawn = self.native_spawn
         self._spawn_cfg = spawn.make_spawn_cfg(cfg) if native_spawn else None
         self._spawn_seed = (0x9E3779B97F4A7C15 * (1 + (seed or 0))) & 0xFFFFFFFFFFFFFFFF
         self._episodes = 0
@@ -105,8 +110,16 @@ class VecImageEnv:
                 "collision": o["step_is_collisions"], "all_down": self._all_down, "reset_envs": finished}
         return self._state(), o["step_rewards"], o["step_dones"], info
 
+    def _step_device(self, actions):
+        o = self.world.step_autoreset_device(self._actions(actions), self._spawn_cfg, self._spawn_seed + self._episodes)
+        info = {"dones_info": o["step_dones_info"], "is_clean": o["step_is_clean"], "arrive": o["step_is_arrives"],
+                "collision": o["step_is_collisions"], "all_down": self._all_down, "reset_envs": None}
+        return self._state(), o["step_rewards"], o["step_dones"], info
+
     def step(self, actions):
         import torch
+        if self.device_reset and self.auto_reset:
+            return self._step_device(actions)
         if self.native_spawn and self.auto_reset:
             return self._step_native(actions)
         o = self.world.step(self._actions(actions))

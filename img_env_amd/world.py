@@ -167,6 +167,37 @@ class World:
                                                    self.n_worlds, C.byref(n), self._stream()), "imgenv_step_autoreset")
         return self.out, list(self._finished_buf[:n.value])
 
+    def step_autoreset_device(self, actions, spawn_cfg, seed0):
+        """``imgenv_step_autoreset_device``: the same without the host in the loop -- finished worlds are found, placed and
+        reset by kernels alone, the call returns once everything is queued (no synchronisation, nothing read back).  The first
+        call fixes ``seed0``: the k-th world reset from then on takes placement ``seed0 + k``."""
+        a = self._actions(actions)
+        self._check(self.lib.imgenv_step_autoreset_device(self.h, C.c_void_p(a.data_ptr()), C.byref(spawn_cfg[0]),
+                                                          C.c_uint64(int(seed0) & 0xFFFFFFFFFFFFFFFF), self._stream()),
+                    "imgenv_step_autoreset_device")
+        return self.out
+
+    def autoreset_last(self):
+        """(worlds the last ``step_autoreset_device`` reset, placement number of the first of them); synchronises the stream"""
+        if self._finished_buf is None:
+            self._finished_buf = (C.c_int32 * self.n_worlds)()
+        n, first = C.c_int32(0), C.c_uint64(0)
+        self._check(self.lib.imgenv_autoreset_last(self.h, self._finished_buf, self.n_worlds, C.byref(n), C.byref(first), self._stream()),
+                    "imgenv_autoreset_last")
+        return list(self._finished_buf[:n.value]), int(first.value)
+
+    def world_placement(self, world, n_obstacles):
+        """the placement ``world`` currently runs, as its device-side reset received it: ``(ResetLayout, placement number)``"""
+        from .worldgen import ResetLayout
+        R, P, O = self.n_robots // self.n_worlds, self.n_peds // self.n_worlds, int(n_obstacles)
+        out = dict(robot_pose=np.zeros((R, 4)), robot_goal=np.zeros((R, 2)), ped_pose=np.zeros((P, 4)), ped_goal=np.zeros((P, 2)),
+                   ped_traj=np.zeros((P, 2, 3)), ped_traj_len=np.zeros(P, np.int32), obs_shape=np.zeros(O, np.int32),
+                   obs_size=np.zeros((O, 4), np.float32), obs_pose=np.zeros((O, 4)))
+        serial = C.c_uint64(0)
+        self._check(self.lib.imgenv_world_placement(self.h, int(world), C.byref(serial), *[a.ctypes.data for a in out.values()]),
+                    "imgenv_world_placement")
+        return ResetLayout(**out), int(serial.value)
+
     def step_begin(self, actions):
         a = self._actions(actions)
         self._check(self.lib.imgenv_step_begin(self.h, C.c_void_p(a.data_ptr()), self._stream()), "imgenv_step_begin")

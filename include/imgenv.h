@@ -378,6 +378,22 @@ int imgenv_reset_worlds_spawn(imgenv_t* h, int32_t n, const int32_t* worlds, con
 int imgenv_step_autoreset(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, int32_t* worlds_out,
                           int32_t cap, int32_t* n_out, void* stream);
 
+/* imgenv_step_autoreset() without the host in the loop (csrc/spawn_device.h): the finished worlds are found, placed and reset by
+ * kernels alone -- placements are drawn ahead into a pool on a side stream with the same rules and random stream as
+ * imgenv_spawn() but the device's libm (a placement may differ from the host's in the last bit) -- and the call returns as
+ * soon as everything is queued on `stream`: no synchronisation, nothing read back.  The FIRST call with a given spawn cfg
+ * fixes seed0: the k-th world reset from then on (in step order, ascending world index within a step) takes placement
+ * seed0 + k, as a loop of imgenv_step_autoreset() calls fed seed0 + (worlds reset so far) would hand them out.  RVO, ERVO and
+ * empty scenes; at most 64 agents and 24 obstacles per world. */
+int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, void* stream);
+/* What the last such call did, for checkers and hosts that do want to know (synchronises `stream`): the worlds it reset
+ * (ascending, up to cap), their number, and the placement number of the first of them. */
+int imgenv_autoreset_last(imgenv_t* h, int32_t* worlds_out, int32_t cap, int32_t* n_out, uint64_t* first_placement, void* stream);
+/* The placement world `world` currently runs as its device-side reset received it -- the arrays of imgenv_spawn(), any may be
+ * NULL -- and its number.  Synchronises the device. */
+int imgenv_world_placement(imgenv_t* h, int32_t world, uint64_t* placement, double* robot_pose, double* robot_goal, double* ped_pose,
+                           double* ped_goal, double* ped_traj, int32_t* ped_traj_len, int32_t* obs_shape, float* obs_size, double* obs_pose);
+
 /* The two OpenCV resizes of the path for one-channel 8-bit images, as the library performs them (OpenCV 4.2.0's generic
  * fixed-point CPU path restated, csrc/cv_resize.h): host buffers, no device needed.  kind 0: INTER_LINEAR, 1: INTER_CUBIC. */
 int imgenv_cv_resize_u8(int kind, const uint8_t* src, int32_t sh, int32_t sw, uint8_t* dst, int32_t dh, int32_t dw);

@@ -341,3 +341,106 @@ def test_vec_env_with_native_spawn_matches_oracles_fed_the_same_placements(E, R,
         vec.close()
         for c in cpus:
             c.close()
+
+
+@pytest.mark.parametrize("E,R,P,view", [(5, 3, 4, 48), (6, 1, 0, 48), (3, 2, 1, 48), (70, 2, 3, 48)])
+def test_vec_env_with_device_side_reset_matches_oracles_fed_the_same_placements(E, R, P, view):
+    """VecImageEnv(device_reset=True): imgenv_step_autoreset_device finds the finished envs, draws their placements (pool filled
+    ahead on a side stream, csrc/spawn_device.h), builds their RVO obstacle trees and resets them without the host in the loop.
+    One oracle per env, fed the placement each world really received (imgenv_world_placement), checks every step; the
+    placements keep the reference's spawn rules; their numbers follow the documented order (seed0 + k, ascending world)."""
+    import copy
+    import torch
+    from img_env_amd import spawn, worldgen
+    from img_env_amd.vec_env import VecImageEnv
+    from oracle_binding import OracleWorld, build_oracle
+    from parity import compare
+    build_oracle()
+    grid = worldgen.make_grid(200, 3)
+    n_obs = 3
+    cfg = worldgen.make_yaml_cfg(R, P, grid, time_max=5, n_obstacles=n_obs, seed=9)
+    vec = VecImageEnv(copy.deepcopy(cfg), env_num=E, seed=9, device_reset=True)
+    cpus = [OracleWorld(vec.params, vec.grid) for _ in range(E)]
+    fields = tuple(f for f in ("is_collisions", "is_arrives", "view_maps", "sensor_maps", "vector_states", "lasers", "ped_maps",
+                               "ped_vector_states", "rewards", "dones", "dones_info", "robot_pose"))
+
+    def check(where):
+        snap = vec.world.snapshot()
+        for k, c in enumerate(cpus):
+            mine = {f: snap[f][k * R:(k + 1) * R] for f in fields}
+            bad = compare(mine, c.snapshot(), fields)
+            assert not bad, (where, k, bad)
+
+    try:
+        seed0 = vec._spawn_seed
+        vec.reset()  # the first episodes: placed by the host-side library spawn (imgenv_reset_worlds_spawn)
+        for k in range(E):
+            cpus[k].reset(spawn.native_spawn(cfg, seed0 + k))
+        check("reset")
+        rng = np.random.default_rng(2)
+        resets, expect_serial = 0, 0
+        for s in range(16):
+            a = np.zeros((E * R, 3), np.float32)
+            a[:, 0], a[:, 1] = rng.uniform(0, 0.6, E * R), rng.uniform(-0.9, 0.9, E * R)
+            _, rew, done, info = vec.step(torch.as_tensor(a, device="cuda"))
+            assert info["reset_envs"] is None
+            worlds, first = vec.world.autoreset_last()
+            rew, done, dinfo = rew.cpu().numpy(), done.cpu().numpy(), info["dones_info"].cpu().numpy()
+            down = info["all_down"].cpu().numpy()
+            assert [k for k in range(E) if down[k * R:(k + 1) * R].all()] == worlds, s
+            assert first == expect_serial, s
+            for k, c in enumerate(cpus):
+                c.step(a[k * R:(k + 1) * R])
+                ref = c.snapshot()  # what the step itself returned, also for the envs the library has already reset
+                assert np.array_equal(rew[k * R:(k + 1) * R], ref["rewards"]), (s, k)
+                assert np.array_equal(done[k * R:(k + 1) * R], ref["dones"]), (s, k)
+                assert np.array_equal(dinfo[k * R:(k + 1) * R], ref["dones_info"]), (s, k)
+            for q, k in enumerate(worlds):  # the envs that ended: their oracles get the placements the device drew
+                lay, serial = vec.world.world_placement(k, n_obs)
+                assert serial == first + q, (s, k)
+                lay.ignore_obstacle = bool(cfg["ped_sim"].get("ignore_obstacle", False))
+                cpus[k].reset(lay)
+                # the reference's placement rules (reset_helper.py:35-55, 289): starts apart and clear of the obstacles, goals away
+                starts = np.vstack([lay.robot_pose[:, :2], lay.ped_pose[:, :2]])
+                if len(starts) > 1:
+                    d = np.linalg.norm(starts[:, None] - starts[None], axis=2) + 10 * np.eye(len(starts))
+                    assert d.min() > 1.0 - 1e-9
+                assert (np.linalg.norm(lay.robot_goal - lay.robot_pose[:, :2], axis=1) > float(cfg["target_min_dist"]) - 1e-9).all()
+            expect_serial += len(worlds)
+            resets += len(worlds)
+            check(s)
+        assert resets >= 2 * E
+    finally:
+        vec.close()
+        for c in cpus:
+            c.close()
+
+
+def test_device_side_placements_follow_the_host_sampler():
+    """the device's sampler (same rules, same xoshiro stream, the device's libm) against the library's host sampler, placement
+    by placement: equal up to the last bits wherever no rejection test was that close -- nearly always"""
+    import copy
+    import torch
+    from img_env_amd import spawn, worldgen
+    from img_env_amd.vec_env import VecImageEnv
+    grid = worldgen.make_grid(200, 3)
+    E, R, P, n_obs = 24, 2, 3, 3
+    cfg = worldgen.make_yaml_cfg(R, P, grid, time_max=3, n_obstacles=n_obs, seed=4)
+    vec = VecImageEnv(copy.deepcopy(cfg), env_num=E, seed=4, device_reset=True)
+    try:
+        vec.reset()
+        a = torch.zeros(E * R, 3, device="cuda")
+        seen = same = 0
+        for s in range(12):
+            vec.step(a)
+            worlds, first = vec.world.autoreset_last()
+            for q, k in enumerate(worlds):
+                lay, serial = vec.world.world_placement(k, n_obs)
+                ref = spawn.native_spawn(cfg, vec._spawn_seed + E + serial)  # the device was told seed0 = spawn seed + E first episodes
+                seen += 1
+                same += int(np.allclose(lay.robot_pose, ref.robot_pose, atol=1e-9) and np.allclose(lay.ped_pose, ref.ped_pose, atol=1e-9) and
+                            np.allclose(lay.robot_goal, ref.robot_goal, atol=1e-9) and np.allclose(lay.obs_pose, ref.obs_pose, atol=1e-9) and
+                            np.array_equal(lay.ped_traj_len, ref.ped_traj_len) and np.allclose(lay.obs_size, ref.obs_size))
+        assert seen >= 3 * E and same >= 0.98 * seen, (seen, same)
+    finally:
+        vec.close()

@@ -24,7 +24,7 @@ VIEW, IMAGE, BEAMS = 400, 48, 1000
 ALGORITHMIC_BYTES = {"k_crop_big": VIEW * VIEW, "k_view": 4 * BEAMS, "k_taps_big": 2 * IMAGE * IMAGE, "k_fullview_big": VIEW * VIEW}
 
 
-def measure(envs=256, steps=100, view_maps=False, device=0):
+def measure(envs=256, steps=100, view_maps=False, device=0, device_reset=True):
     import torch
     from PIL import Image
     from img_env_amd import worldgen
@@ -39,7 +39,7 @@ def measure(envs=256, steps=100, view_maps=False, device=0):
     cfg = worldgen.shipped_test_yaml_cfg("room.png", sections)
     cfg.update(map_dir=tmp, seed=1, keep_view_maps=bool(view_maps), device=device)
     E = envs
-    vec = VecImageEnv(cfg, env_num=E, seed=1, native_spawn=True)
+    vec = VecImageEnv(cfg, env_num=E, seed=1, native_spawn=True, device_reset=device_reset)
     try:
         vec.reset()
         g = torch.Generator(device="cuda").manual_seed(1)
@@ -61,18 +61,24 @@ def measure(envs=256, steps=100, view_maps=False, device=0):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_reset = 0
+        down = torch.zeros((), dtype=torch.int64, device="cuda")
         for s in range(steps):
             _, _, _, info = vec.step(acts[s % 16])
-            n_reset += len(info["reset_envs"])
+            if info["reset_envs"] is None:  # device-side reset: nothing comes back to the host; count on the device
+                down += info["all_down"].sum()
+            else:
+                n_reset += len(info["reset_envs"])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        n_reset += int(down.item())
     finally:
         vec.close()
     kernel_us = {k: round(1e3 * ms / n, 1) for k, (ms, n) in tm.items() if n}
     dominant = max((k for k in kernel_us if k in ALGORITHMIC_BYTES), key=kernel_us.get)
     achieved = ALGORITHMIC_BYTES[dominant] * E / (kernel_us[dominant] * 1e-6) / 1e9
     return dict(config="shipped test.yaml geometry: 733x733 grid @0.015 m, 400x400 view -> 48x48 (INTER_CUBIC), 1000 beams, "
-                       "1 robot + 4 leg peds + 4 obstacles per env%s" % ("" if view_maps else "; full-size view not materialised"),
+                       "1 robot + 4 leg peds + 4 obstacles per env%s; auto-reset %s" % ("" if view_maps else "; full-size view not materialised",
+                                                                                         "on the device" if device_reset else "through the host"),
                 envs=E, steps=steps, env_resets=n_reset, value=E * steps / dt, unit="robot-steps/s", us_per_step=1e6 * dt / steps,
                 reference_cpp_core_one_cpu_core=194, kernel_us=kernel_us,
                 roofline=dict(bound="hbm", kernel=dominant, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
@@ -85,5 +91,6 @@ if __name__ == "__main__":
     ap.add_argument("--envs", type=int, default=64)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--view-maps", action="store_true", help="materialise the 400 x 400 view_maps output as well")
+    ap.add_argument("--host-reset", action="store_true", help="imgenv_step_autoreset (host in the loop) instead of the device-side reset")
     args = ap.parse_args()
-    print(json.dumps(measure(args.envs, args.steps, args.view_maps)))
+    print(json.dumps(measure(args.envs, args.steps, args.view_maps, device_reset=not args.host_reset)))

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(envs=1024, robots=4, peds=3, obstacles=2, steps=300, time_max=100, natives=(False, True)):
+def measure(envs=1024, robots=4, peds=3, obstacles=2, steps=300, time_max=100, natives=(False, True, "device")):
     """robot-steps/s of VecImageEnv over `steps` steps, after the envs have drifted out of phase"""
     import torch
     from img_env_amd import worldgen
@@ -22,7 +22,7 @@ def measure(envs=1024, robots=4, peds=3, obstacles=2, steps=300, time_max=100, n
     out = {}
     for native in natives:
         cfg = worldgen.make_yaml_cfg(robots, peds, grid, time_max=time_max, n_obstacles=obstacles, seed=5)
-        env = VecImageEnv(cfg, env_num=envs, seed=5, native_spawn=native)
+        env = VecImageEnv(cfg, env_num=envs, seed=5, native_spawn=bool(native), device_reset=native == "device")
         n = len(env)
         g = torch.Generator(device="cuda").manual_seed(1)
         acts = torch.zeros(16, n, 3, device="cuda")
@@ -36,14 +36,19 @@ def measure(envs=1024, robots=4, peds=3, obstacles=2, steps=300, time_max=100, n
             env.step(acts[s % 16])
         torch.cuda.synchronize()
         resets, t0 = 0, time.perf_counter()
+        down = torch.zeros((), dtype=torch.int64, device="cuda")
         for s in range(steps):
             _, _, _, info = env.step(acts[s % 16])
-            resets += len(info["reset_envs"])
+            if info["reset_envs"] is None:  # device-side reset: nothing comes back to the host; count on the device
+                down += info["all_down"].sum()
+            else:
+                resets += len(info["reset_envs"])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        resets += int(down.item()) // robots
         res = dict(robot_steps_per_s=n * steps / dt, us_per_step=1e6 * dt / steps, env_resets_per_step=resets / steps,
                    first_reset_ms=1e3 * t_reset)
-        if native:  # the same steps without the reset half: what NeverStopWrapper costs on top of the step
+        if native is True:  # the same steps without the reset half: what NeverStopWrapper costs on top of the step
             env.auto_reset = False
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -51,7 +56,7 @@ def measure(envs=1024, robots=4, peds=3, obstacles=2, steps=300, time_max=100, n
                 env.step(acts[s % 16])
             torch.cuda.synchronize()
             res["us_per_step_without_resets"] = 1e6 * (time.perf_counter() - t0) / steps
-        out["native_spawn" if native else "python_spawn"] = res
+        out["device_reset" if native == "device" else ("native_spawn" if native else "python_spawn")] = res
         env.close()
     return dict(envs=envs, robots_per_env=robots, peds_per_env=peds, **out)
 
