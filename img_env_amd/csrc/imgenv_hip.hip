@@ -121,6 +121,17 @@ struct imgenv {
     long trace_calls = 0, trace_resets = 0;
     // device-side auto-reset (csrc/spawn_device.h): pool of placements drawn ahead on a side stream
     bool sd_ready = false, dev_reset_used = false;
+    bool wobst_all = false;  // the per-world RVO table has to be uploaded as a whole (its slices moved)
+    // ... and, on request (IMGENV_GRAPH=1), the whole step + reset chain as one hipGraph: per-step values then live in device
+    // memory (DevWorld::step_vars), the actions are copied into a buffer of the handle, and a step costs the host one copy and
+    // one graph launch.  Off by default -- measured (1024 envs x 4 robots, tools/host_issue_probe.py): this runtime issues a
+    // replayed graph node by node, 222 us of host time per step against 195 us for the same ~25 plain launches
+    int* d_step_vars = nullptr;
+    float* act_buf = nullptr;
+    hipStream_t gstream = nullptr;  // capture stream
+    hipGraphExec_t gexec = nullptr;
+    int dev_calls = 0;              // un-graphed calls since the set-up (the first ones warm the path up)
+    bool no_graph = true;           // unless IMGENV_GRAPH=1
     int act_hint = 0;  // device-side auto-reset: robots the reset chain is expected to cover (picks the small-launch kernel variants)
     uint64_t sd_fp = 0;
     hipStream_t side3 = nullptr;
@@ -401,6 +412,8 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         for (auto& c : h->stage_gen[g]) (void)hipHostFree(c.p);
         if (h->ev_gen[g]) (void)hipEventDestroy(h->ev_gen[g]);
     }
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
     if (h->side3) {
         (void)hipStreamSynchronize(h->side3);
         (void)hipStreamDestroy(h->side3);
@@ -1103,6 +1116,10 @@ static int check_device_flags(imgenv* h) {
     if (!e) return 0;
     if (e[0]) FAIL(IMGENV_EDEVICE, "ORCA: a pedestrian sees more obstacle segments than the neighbour scratch holds");
     if (e[1]) FAIL(IMGENV_EDEVICE, "ORCA: obstacle BSP walk overflowed its stack");
+    if (e[2])
+        FAIL(IMGENV_EDEVICE, "device-side auto-reset: a finished world could not be given its placement (code %d: 100 the pool did not hold it; "
+                             "1 a fixed start with a random target; 2-4 no admissible placement within 200000 draws; 10-16 the RVO obstacle tree "
+                             "outgrew its scratch)", e[2]);
     if (e[4])
         FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth) -- more than "
                              "8 agents piled up outside the tree's 10 m x 10 m root square, where the reference recurses forever "
@@ -1559,6 +1576,7 @@ static int put_world_rvo(imgenv* h, int k) {
         if (int rc = dev_alloc(h, &h->d_nodes, (size_t)h->cap_nodes * h->W)) return rc;
         all = true;
     }
+    if (all) h->wobst_all = true;  // every world's slice moved: the whole per-world table goes up with this reset
     for (int q = all ? 0 : k; q < (all ? h->W : k + 1); q++) {  // a grown array is refilled from the host copies
         const RvoObstacles& rq = h->rvos[q];
         if (!rq.ob.empty()) RTRY(stage_put(h, h->d_obst + (size_t)q * h->cap_obst, rq.ob.data(), sizeof(RvoObstDev) * rq.ob.size()));
@@ -1757,8 +1775,19 @@ static int reset_blocks(imgenv* h, int n, const int* list) {
 
 static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int whole) {
     DevWorld& d = h->d;
+    if (h->sd_ready) {  // a host-side reset draws obstacles the device-side restore does not know: whole-map restore next time
+        static const std::vector<int> zeros(1 << 16, 0);
+        SpawnDev& c = *(SpawnDev*)h->sd_storage;
+        if (!list) {
+            for (int k0 = 0; k0 < h->W; k0 += (int)zeros.size())
+                RTRY(stage_put(h, c.w_inst_valid + k0, zeros.data(), sizeof(int) * (size_t)std::min<int>((int)zeros.size(), h->W - k0)));
+        } else {
+            for (int q = 0; q < n; q++) RTRY(stage_put(h, c.w_inst_valid + list[q], zeros.data(), sizeof(int)));
+        }
+    }
+    if (!list || h->wobst_all) RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size()));
+    h->wobst_all = false;
     if (!list) {
-        RTRY(stage_put(h, h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size()));
         RTRY(stage_put(h, h->d_world_epoch, h->world_epoch.data(), sizeof(int) * h->W));
     } else {  // only the listed worlds' entries: the device-side auto-reset keeps the others' up to date itself
         for (int q = 0; q < n; q++) {
@@ -1842,6 +1871,10 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         RTRY(stage_put(h, h->d.bbox, init, sizeof(init)));
     }
     h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
+    if (h->d_step_vars) {
+        static const int zero = 0;
+        RTRY(stage_put(h, h->d_step_vars, &zero, sizeof(int)));
+    }
     h->dev_reset_used = false;  // every world's host copy is current again
     RTRY(reset_launch(h, nullptr, 0, st, 1));  // no host wait: the copies read the handle's pinned chunks
     h->has_reset = true;
@@ -1961,6 +1994,10 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     hipStream_t st = (hipStream_t)stream;
     DevWorld& d = h->d;
     h->launches = 0;
+    if (d.step_vars) {  // the device-side twins of h->elapsed / h->stamp_seq (advanced here; the host's in imgenv_step_end)
+        k_tick<<<dim3(1), dim3(1), 0, st>>>(h->d_step_vars, h->stamp ? 1 : 0);
+        h->launches += 1;
+    }
     // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
     // step's views and was joined at the end of that step; its velocities are applied by k_integrate's pedestrian blocks
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
@@ -2209,6 +2246,8 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     RTRY(dev_alloc(h, &c.place_agents, (size_t)W * (na ? na : 1)));
     RTRY(dev_alloc(h, &c.place_obst, (size_t)W * (nob ? nob : 1)));
     RTRY(dev_alloc(h, &c.place_serial, (size_t)W, 0xFF));
+    RTRY(dev_alloc(h, &c.w_inst, (size_t)W * (nob ? nob : 1)));
+    RTRY(dev_alloc(h, &c.w_inst_valid, (size_t)W));
     // the per-world RVO tables take over from the host's copies: room for any placement's polygons in every world
     if (h->NA > 0 && (h->cap_obst < c.cap_o || h->cap_nodes < c.cap_n)) {
         HIPCHK(hipStreamSynchronize(st));
@@ -2245,6 +2284,23 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     c.traj = h->d_traj;
     c.traj_len = h->d_traj_len;
     c.traj_cap = h->traj_cap;
+    if (!h->d_step_vars && getenv("IMGENV_GRAPH") && getenv("IMGENV_GRAPH")[0] == '1') {
+        RTRY(dev_alloc(h, &h->d_step_vars, 2));
+        RTRY(dev_alloc(h, &h->act_buf, (size_t)h->RL * 3));
+        HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+        h->no_graph = false;
+    }
+    if (h->d_step_vars) {
+        HIPCHK(hipStreamSynchronize(st));
+        const int vars[2] = {h->elapsed, (int)h->stamp_seq};
+        HIPCHK(hipMemcpy(h->d_step_vars, vars, sizeof(vars), hipMemcpyHostToDevice));
+        h->d.step_vars = h->d_step_vars;
+    }
+    if (h->gexec) {  // a chain captured for another spawn cfg
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+    }
+    h->dev_calls = 0;
     if (!h->side3) {
         HIPCHK(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -2257,6 +2313,52 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     return 0;
 }
 
+// one step + the reset of whatever it finished, everything queued on `st` and the handle's side streams (all joined again)
+static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t st) {
+    SpawnDev& c = *(SpawnDev*)h->sd_storage;
+    DevWorld& d = h->d;
+    const int W = h->W, nob = c.n_obstacles;
+    // the pool, underneath the step: the slots whose placements the previous step handed out
+    HIPCHK(hipEventRecord(h->ev_consumed, st));
+    HIPCHK(hipStreamWaitEvent(h->side3, h->ev_consumed, 0));
+    k_spawn_fill<<<dim3(c.S), dim3(WAVE), 0, h->side3>>>(c);
+    HIPCHK(hipEventRecord(h->ev_fill, h->side3));
+    if (int rc = imgenv_step(h, actions, st)) return rc;
+    k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
+    HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
+    k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
+    if (h->pow2) k_restore_maps_dev<true><<<dim3((unsigned)W * MAP_BLOCKS), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, MAP_BLOCKS);
+    else k_restore_maps_dev<false><<<dim3((unsigned)W * MAP_BLOCKS), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, MAP_BLOCKS);
+    if (nob > 0) {
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
+        else k_reset_obstacles<false><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
+        k_keep_instances<<<dim3((unsigned)(W * nob + 255) / 256), dim3(256), 0, st>>>(c);
+    }
+    HIPCHK(hipGetLastError());
+    if (h->stamp) {
+        // The step's rasters have stamped the finished worlds' agents where they stood BEFORE the reset, with this step's tag,
+        // and the map restore above only puts the obstacles' cells back: the reset's own rasters and views get a tag of their
+        // own, under which those stamps have expired like any older ones (two tags per step; the sweep comes round accordingly)
+        h->stamp_seq += 1;
+        d.stamp_tag = h->stamp_seq % STAMP_TAGS + 1;
+        if (d.step_vars) k_tick_seq<<<dim3(1), dim3(1), 0, st>>>(h->d_step_vars);
+        if (h->stamp_seq % STAMP_TAGS == 0) {
+            const unsigned blocks = (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
+            k_cell_base<<<dim3(blocks), dim3(256), 0, st>>>(d);
+        }
+    }
+    // the launches behind: sized for every world, the list and its length read from device memory
+    set_active(h, c.fin_list, W);
+    d.act_n_dev = c.fin_n;
+    d.ptraj = h->d_traj;
+    d.traj_cap = h->traj_cap;
+    h->launches += 5;
+    const int rc = launch_views(h, st, 1);
+    set_active(h, nullptr, 0);
+    d.act_n_dev = nullptr;
+    return rc;
+}
+
 extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, void* stream) {
     if (!h || !actions) FAIL(IMGENV_EINVAL, "null argument");
     if (int rc = spawn_cfg_check(cfg)) return rc;
@@ -2265,47 +2367,65 @@ extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, c
              cfg->n_peds, h->Rw, h->Pw);
     if (h->RL != h->R) FAIL(IMGENV_EINVAL, "imgenv_step_autoreset_device needs all robots of every world on this handle");
     if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
+    if (h->obs_forked) FAIL(IMGENV_ESTATE, "imgenv_step_autoreset_device between imgenv_step_begin and imgenv_step_end");
     hipStream_t st = (hipStream_t)stream;
     const uint64_t fp = spawn_cfg_fingerprint(*cfg);
     if (!h->sd_ready || fp != h->sd_fp) {  // the first call fixes seed0: the k-th world reset from now on takes placement seed0 + k
         if (int rc = spawn_device_setup(h, cfg, seed0, st)) return rc;
         h->sd_fp = fp;
     }
-    SpawnDev& c = *(SpawnDev*)h->sd_storage;
-    if (int rc = imgenv_step(h, actions, stream)) return rc;
-    DevWorld& d = h->d;
-    const int W = h->W, nob = c.n_obstacles;
-    k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
-    HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));  // the pool has been refilled for what the last step consumed
-    if (!h->d_act_list) RTRY(dev_alloc(h, &h->d_act_list, (size_t)W));
-    k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
-    k_restore_maps_dev<<<dim3((unsigned)W * MAP_BLOCKS), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, MAP_BLOCKS);
-    if (nob > 0) {
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
-        else k_reset_obstacles<false><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
-    }
-    HIPCHK(hipGetLastError());
-    // the launches behind: sized for every world, the list and its length read from device memory
-    set_active(h, c.fin_list, W);
-    d.act_n_dev = c.fin_n;
+    if (!h->d_act_list) RTRY(dev_alloc(h, &h->d_act_list, (size_t)h->W));
     {   // how many worlds the last steps reset (page-locked, written by k_finished_dev; stale by a step or two: a hint only)
         const int last = h->finished_host[0];
-        h->act_hint = std::max(8, 4 * std::max(last, 0)) * std::max(h->Rw, h->Pw);
+        h->act_hint = std::max(8, 4 * std::max(last, 0)) * std::max(std::max(h->Rw, h->Pw), 1);
     }
-    d.ptraj = h->d_traj;
-    d.traj_cap = h->traj_cap;
-    h->launches = 4;
-    const int rc = launch_views(h, st, 1);
-    set_active(h, nullptr, 0);
-    d.act_n_dev = nullptr;
-    if (rc) return rc;
-    // refill, underneath the next step: the slots whose placements were just handed out
-    HIPCHK(hipEventRecord(h->ev_consumed, st));
-    HIPCHK(hipStreamWaitEvent(h->side3, h->ev_consumed, 0));
-    k_spawn_fill<<<dim3(c.S), dim3(WAVE), 0, h->side3>>>(c);
-    HIPCHK(hipEventRecord(h->ev_fill, h->side3));
-    h->dev_reset_used = true;
-    return IMGENV_OK;
+    // The chain as a graph: captured on the third call (the first ones have loaded every kernel), replayed from then on --
+    // except while per-kernel timing is on and on the steps that sweep the stamped class layer (every STAMP_TAGS-th)
+    const bool sweep = h->stamp && ((h->stamp_seq + 1) % STAMP_TAGS == 0 || (h->stamp_seq + 2) % STAMP_TAGS == 0);
+    const bool graphable = !h->no_graph && h->t_mode == 0 && !sweep && !h->comm && !h->serial;
+    if (graphable && !h->gexec && h->dev_calls >= 2) {
+        if (int rc = check_device_flags(h)) return rc;
+        // (the capture runs nothing: the host's counters, which the chain advances as it is issued, are put back)
+        const int elapsed0 = h->elapsed, launches0 = h->launches;
+        const uint32_t seq0 = h->stamp_seq, tag0 = h->d.stamp_tag;
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed));
+        const int rc = autoreset_device_chain(h, h->act_buf, h->gstream);
+        const hipError_t e = hipStreamEndCapture(h->gstream, &graph);
+        h->elapsed = elapsed0;
+        h->launches = launches0;
+        h->stamp_seq = seq0;
+        h->d.stamp_tag = tag0;
+        if (rc || e != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            h->no_graph = true;  // this runtime cannot capture the chain: plain launches from now on
+        } else {
+            const hipError_t e2 = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e2 != hipSuccess) {
+                h->gexec = nullptr;
+                (void)hipGetLastError();
+                h->no_graph = true;
+            }
+        }
+    }
+    int rc = IMGENV_OK;
+    if (graphable && h->gexec) {
+        if (int rc2 = check_device_flags(h)) return rc2;
+        HIPCHK(hipMemcpyAsync(h->act_buf, actions, sizeof(float) * 3 * (size_t)h->RL, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipGraphLaunch(h->gexec, st));
+        h->elapsed += 1;  // the host's twins of the device-side counters (imgenv_step_end, and the reset chain's own tag)
+        if (h->stamp) {
+            h->stamp_seq += 2;
+            h->d.stamp_tag = h->stamp_seq % STAMP_TAGS + 1;
+        }
+    } else {
+        rc = autoreset_device_chain(h, actions, st);
+        h->dev_calls += 1;
+    }
+    if (rc == IMGENV_OK) h->dev_reset_used = true;
+    return rc;
 }
 
 // What the last imgenv_step_autoreset_device did (for checkers and hosts that want to know; synchronises `stream`): the worlds it

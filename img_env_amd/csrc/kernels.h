@@ -135,6 +135,14 @@ __device__ __forceinline__ uint32_t cell_seen_class(uint32_t v, uint32_t self, u
     if (base >= CLS_LOW && (kind == STAMP_MANY || (kind == STAMP_ONE && (v >> STAMP_OWNER_SHIFT) != self))) return CLS_TWO;
     return base;
 }
+// per-step values: kernel arguments, or (replayed chains) the device-side counters k_tick advances
+__device__ __forceinline__ int tail_elapsed_of(const DevWorld& w) { return w.step_vars ? w.step_vars[0] : w.tail_elapsed; }
+__device__ __forceinline__ uint32_t stamp_tag_of(const DevWorld& w) { return w.step_vars ? (uint32_t)w.step_vars[1] % STAMP_TAGS + 1u : w.stamp_tag; }
+__global__ void k_tick(int* vars, int stamp) {
+    vars[0] += 1;  // TimeLimitWrapper._elapsed_steps (base.py:224)
+    if (stamp) vars[1] += 1;  // this step's stamps get a new tag
+}
+__global__ void k_tick_seq(int* vars) { vars[1] += 1; }  // the reset chain of a device-side auto-reset stamps under its own tag
 // robots / pedestrians of a launch: the host's count, or (device-side auto-reset) what k_finished_dev counted
 __device__ __forceinline__ int act_count_l(const DevWorld& w) { return w.act_n_dev ? *w.act_n_dev * w.Rw : w.act_nl; }
 __device__ __forceinline__ int act_count_g(const DevWorld& w) { return w.act_n_dev ? *w.act_n_dev * w.Rw : w.act_ng; }
@@ -784,7 +792,7 @@ __device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t 
     const uint32_t next = (uint32_t)__shfl_down((int)ci, 1);
     if (in && (lane == WAVE - 1 || next != ci)) {
         const uint32_t v = w.cell[c], base = v & 7u;
-        if (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW)) stamp_ped(w, c, v, w.stamp_tag);
+        if (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW)) stamp_ped(w, c, v, stamp_tag_of(w));
     }
 }
 
@@ -875,7 +883,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             for (int e = tid; e < n_cached; e += NT) {
                 const uint32_t c = list[e].x;
                 if (STAMP) {
-                    stamp_robot(w, c, (uint32_t)i, w.stamp_tag);
+                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w));
                 } else {
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
@@ -916,7 +924,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 } else {
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
                     if (STAMP) {
-                        stamp_robot(w, c, (uint32_t)i, w.stamp_tag);
+                        stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w));
                     } else {
                         atomicMin(&w.own_lo[c], id);
                         atomicMax(&w.own_hi[c], id);
@@ -946,7 +954,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c = cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
                 if (STAMP) {
-                    stamp_robot(w, c, (uint32_t)i, w.stamp_tag);
+                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w));
                 } else {
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
@@ -1117,7 +1125,7 @@ __device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, co
         int m, n;
         w2m_pair<POW2>(wx, wy, res, inv, m, n);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            const uint32_t cc = cell_seen_class<STAMP>(w.cell[(size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n], self, w.stamp_tag);
+            const uint32_t cc = cell_seen_class<STAMP>(w.cell[(size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n], self, stamp_tag_of(w));
             if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
         }
     }
@@ -1208,7 +1216,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
     // the `cell` values this robot sees as free (>= 250, agent.cpp:394-401).  Composed layer: the plain class, or this robot as
     // the only owner.  STAMP layer: base class HIGH under this robot's own stamp of this step, or under no stamp of this step
     // (tested on the word with base and tag XORed against HIGH and our tag: a non-zero multiple of 32)
-    const uint32_t tag = STAMP ? w.stamp_tag : 0u;
+    const uint32_t tag = STAMP ? stamp_tag_of(w) : 0u;
     const uint32_t free_plain = CLS_HIGH;
     const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
                                     : (CLS_HIGH | CLS_ROBOT | (self << 8));
@@ -1229,7 +1237,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
         const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
         for (int e = lane; e < n_cov; e += WAVE) {
             const uint2 ce = list[e];
-            const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, w.stamp_tag);
+            const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, stamp_tag_of(w));
             best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
         }
     } else {
@@ -2090,7 +2098,7 @@ __device__ __forceinline__ void tail_group(const DevWorld& w, int g) {
         const unsigned long long sig = __hip_atomic_load(&w.tail_sig[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double min_dist = w.tail_fused ? (double)__uint_as_float((uint32_t)(sig >> 32)) : w.ped_min_dists[l];
         // TimeLimitWrapper counts per world: steps since that world's last reset
-        done = tail_robot(w, l, is_reset, w.tail_elapsed - w.world_epoch[world_of_robot(w, w.r0 + l)], (int)((sig >> 8) & 0xFFull), min_dist);
+        done = tail_robot(w, l, is_reset, tail_elapsed_of(w) - w.world_epoch[world_of_robot(w, w.r0 + l)], (int)((sig >> 8) & 0xFFull), min_dist);
         w.tail_sig[l] = 0ull;  // for the next chain of launches
     }
     if (lane_id() == 0) w.tail_cnt[g * TAIL_CNT_STRIDE] = 0;

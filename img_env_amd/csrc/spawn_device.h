@@ -69,6 +69,8 @@ struct SpawnDev {
     SlotAgent* place_agents;           // [W][n_robots + n_peds] the placement each world currently runs (imgenv_world_placement)
     SlotObstacle* place_obst;          // [W][n_obstacles]
     unsigned long long* place_serial;  // [W] its number
+    ObstInst* w_inst;                  // [W][n_obstacles] the obstacles drawn on each world's map ...
+    int* w_inst_valid;                 // [W] ... where the device knows them (k_restore_maps_dev puts only their cells back)
     int* world_epoch;                  // [W] (writable alias of DevWorld::world_epoch)
     int* n_obst_w;                     // [W] writable aliases of the per-world RVO table
     int* oroot_w;
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(WAVE) void k_respawn(DevWorld w, SpawnDev c, int el
     const unsigned long long n = c.consumed[1] + (unsigned long long)q;
     const int s = (int)(n % (unsigned long long)c.S);
     if (c.slot_serial[s] != n || c.slot_status[s] != 0) {  // the pool did not hold this placement, or it could not be placed
-        if (tid == 0) w.err[1] = c.slot_serial[s] != n ? 100 : c.slot_status[s];
+        if (tid == 0) w.err[2] = c.slot_serial[s] != n ? 100 : c.slot_status[s];
         return;
     }
     const int nr = c.n_robots, np = c.n_peds, na = nr + np;
@@ -665,20 +667,56 @@ __global__ __launch_bounds__(WAVE) void k_respawn(DevWorld w, SpawnDev c, int el
     if (tid == 0) {
         c.n_obst_w[world] = n_ob;
         c.oroot_w[world] = c.s_rvo_n[4 * s + 2];
-        c.world_epoch[world] = elapsed;  // its TimeLimitWrapper starts over
+        c.world_epoch[world] = w.step_vars ? w.step_vars[0] : elapsed;  // its TimeLimitWrapper starts over
     }
 }
 
 // obs_map_ of every finished world starts from the static map again (img_env.cpp:166-168); STAMP mode: the class layer's base
-// classes with it.  MAP_BLOCKS blocks per world, sized for every world of the handle.
+// classes with it.  The only cells that ever differ from the static map are the ones the world's obstacles were drawn on
+// (Agent::draw(obs_map, 0) at reset), so a world whose current obstacles are known (w_inst: every world the device has reset
+// before) gets those cells back -- a few thousand -- instead of the whole map (0.5 MB + 2 MB of class words at 733 x 733 cells);
+// stamps of the old episode stay on the class layer and expire with their step tags as always.  map_blocks blocks per world,
+// sized for every world of the handle.
+template <bool POW2>
 __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c, const uint8_t* __restrict__ static_map, int stamp, int map_blocks) {
-    const int q = blockIdx.x / map_blocks;
+    const int q = blockIdx.x / map_blocks, part = blockIdx.x - q * map_blocks;
     if (q >= *c.fin_n) return;
     const int world = c.fin_list[q];
+    uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs;
+    uint32_t* cell = w.cell + (size_t)world * w.Gs;
+    if (c.w_inst_valid[world]) {
+        const double resolution = 0.01;
+        for (int e = 0; e < c.n_obstacles; e++) {
+            const ObstInst o = c.w_inst[(size_t)world * c.n_obstacles + e];
+            const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
+            const int nn = o.n1 - o.n0 + 1, total = (o.m1 - o.m0 + 1) * nn;
+            const bool circle = o.shape == IMGENV_SHAPE_CIRCLE;
+            for (int s = part * 256 + (int)threadIdx.x; s < total; s += map_blocks * 256) {  // the footprint samples of k_reset_obstacles
+                const int m = o.m0 + s / nn, n = o.n0 + s % nn;
+                double px = m * resolution, py = n * resolution;
+                if (circle) {
+                    if (!(sqrt(m * resolution * m * resolution + n * resolution * n * resolution) <= o.r)) continue;
+                    px = px + o.cx;
+                    py = py + o.cy;
+                }
+                double wx, wy;
+                tf_apply(bw, px, py, wx, wy);
+                int gm, gn;
+                w2m_pair<POW2>(wx, wy, w.res, w.inv_res, gm, gn);
+                if (gm >= 0 && gm < w.Hg && gn >= 0 && gn < w.Wg) {
+                    const size_t at = (size_t)gm * w.Wg + gn;
+                    const uint32_t v = static_map[at];
+                    map[at] = (uint8_t)v;
+                    if (stamp) cell[at] = v <= 2 ? v : (v < 250 ? CLS_LOW : CLS_HIGH);
+                }
+            }
+        }
+        return;
+    }
     const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;
-    uint4* dst = (uint4*)(const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs);
-    uint4* cls = (uint4*)(w.cell + (size_t)world * w.Gs);
-    for (size_t e = (size_t)(blockIdx.x - q * map_blocks) * blockDim.x + threadIdx.x; e < n16; e += (size_t)map_blocks * blockDim.x) {
+    uint4* dst = (uint4*)map;
+    uint4* cls = (uint4*)cell;
+    for (size_t e = (size_t)part * blockDim.x + threadIdx.x; e < n16; e += (size_t)map_blocks * blockDim.x) {
         const uint4 v = ((const uint4*)static_map)[e];
         dst[e] = v;
         if (stamp) {
@@ -695,4 +733,13 @@ __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c
             }
         }
     }
+}
+
+// the obstacles the finished worlds now carry (for the next restore), once they have been drawn
+__global__ void k_keep_instances(SpawnDev c) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nob = c.n_obstacles;
+    if (t >= *c.fin_n * nob) return;
+    const int q = t / nob, e = t - q * nob, world = c.fin_list[q];
+    c.w_inst[(size_t)world * nob + e] = c.inst_out[(size_t)q * nob + e];
+    if (e == 0) c.w_inst_valid[world] = 1;
 }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
     const long long OX = uniform_i64((long long)rint(oxs * two32) + (1ll << 31)), OY = uniform_i64((long long)rint(oys * two32) + (1ll << 31));
     const bool fixed_ok = fabs(oxs) < 1048576.0 && fabs(oys) < 1048576.0;  // (always, for a pose anywhere near its map)
     const int Hg = w.Hg, Wg = w.Wg;
-    const uint32_t self = (uint32_t)i, tag = STAMP ? w.stamp_tag : 0u;
+    const uint32_t self = (uint32_t)i, tag = STAMP ? stamp_tag_of(w) : 0u;
     const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
                                     : (CLS_HIGH | CLS_ROBOT | (self << 8));
     const uint32_t base_tag_mask = 7u | (0xFFu << STAMP_TAG_SHIFT), base_tag_ours = CLS_HIGH | (tag << STAMP_TAG_SHIFT);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
             const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
             for (int e = tid; e < n_cov; e += VBB_T) {
                 const uint2 ce = list[e];
-                const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, w.stamp_tag);
+                const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, stamp_tag_of(w));
                 best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
             }
         } else {
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
                 int m, n;
                 w2m_pair<POW2>(wx, wy, w.res, w.inv_res, m, n);
                 if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-                    const uint32_t cc = cell_seen_class<STAMP>(w.cell[cell0 + (size_t)m * w.Wg + n], self, w.stamp_tag);
+                    const uint32_t cc = cell_seen_class<STAMP>(w.cell[cell0 + (size_t)m * w.Wg + n], self, stamp_tag_of(w));
                     if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
                 }
             }

@@ -113,6 +113,10 @@ struct DevWorld {
     // device-side auto-reset (spawn_device.h): the list's length lives in device memory, the launches are sized for every world
     // of the handle and blocks beyond the count leave at once (act_nw ... act_np then hold the launch's capacity)
     const int* act_n_dev;
+    // Replayed launch chains (imgenv_step_autoreset_device as a hipGraph) cannot take per-step values as kernel arguments: when
+    // set, the step counter (TimeLimitWrapper._elapsed_steps) and the stamp sequence live here, advanced by k_tick at the
+    // start of every step: [0] steps so far, [1] stamp sequence
+    const int* step_vars;
     // the step's per-robot scalars (tail_group in kernels.h) are run by k_view / k_obs wavefronts themselves
     unsigned long long* tail_sig;  // [RL] exchange word: k_obs' min_dist (float bits) << 32 | k_view's collision code << 8 | who has been here (2 view, 1 obs)
     int* tail_cnt;                 // [ceil(RL / 64)][32] (one per 128-byte line) robots of the group whose two wavefronts have both been here

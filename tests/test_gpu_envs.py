@@ -409,6 +409,11 @@ def test_vec_env_with_device_side_reset_matches_oracles_fed_the_same_placements(
             expect_serial += len(worlds)
             resets += len(worlds)
             check(s)
+            if s == 2 and E > 1:  # a reset by the HOST in between (its obstacles are news to the device-side map restore)
+                ep = vec._episodes
+                vec.reset_envs([1])
+                cpus[1].reset(spawn.native_spawn(cfg, seed0 + ep))
+                check("manual reset")
         assert resets >= 2 * E
     finally:
         vec.close()

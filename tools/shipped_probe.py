@@ -61,16 +61,18 @@ def measure(envs=256, steps=100, view_maps=False, device=0, device_reset=True):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_reset = 0
-        down = torch.zeros((), dtype=torch.int64, device="cuda")
+        if device_reset:
+            worlds, first = w.autoreset_last()
+            placed0 = first + len(worlds)
         for s in range(steps):
             _, _, _, info = vec.step(acts[s % 16])
-            if info["reset_envs"] is None:  # device-side reset: nothing comes back to the host; count on the device
-                down += info["all_down"].sum()
-            else:
+            if info["reset_envs"] is not None:  # (device-side reset: nothing comes back to the host)
                 n_reset += len(info["reset_envs"])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        n_reset += int(down.item())
+        if device_reset:  # placements handed out meanwhile
+            worlds, first = w.autoreset_last()
+            n_reset = first + len(worlds) - placed0
     finally:
         vec.close()
     kernel_us = {k: round(1e3 * ms / n, 1) for k, (ms, n) in tm.items() if n}

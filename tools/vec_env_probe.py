@@ -35,17 +35,17 @@ def measure(envs=1024, robots=4, peds=3, obstacles=2, steps=300, time_max=100, n
         for s in range(time_max + 20):  # past the first wave of time limits: the envs drift out of phase as robots collide
             env.step(acts[s % 16])
         torch.cuda.synchronize()
+        placed0 = sum(env.world.autoreset_last()[::-1][0:1]) + len(env.world.autoreset_last()[0]) if native == "device" else 0
         resets, t0 = 0, time.perf_counter()
-        down = torch.zeros((), dtype=torch.int64, device="cuda")
         for s in range(steps):
             _, _, _, info = env.step(acts[s % 16])
-            if info["reset_envs"] is None:  # device-side reset: nothing comes back to the host; count on the device
-                down += info["all_down"].sum()
-            else:
+            if info["reset_envs"] is not None:  # (device-side reset: nothing comes back to the host)
                 resets += len(info["reset_envs"])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        resets += int(down.item()) // robots
+        if native == "device":  # placements handed out meanwhile
+            worlds, first = env.world.autoreset_last()
+            resets = first + len(worlds) - placed0
         res = dict(robot_steps_per_s=n * steps / dt, us_per_step=1e6 * dt / steps, env_resets_per_step=resets / steps,
                    first_reset_ms=1e3 * t_reset)
         if native is True:  # the same steps without the reset half: what NeverStopWrapper costs on top of the step
