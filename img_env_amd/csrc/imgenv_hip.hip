@@ -141,6 +141,7 @@ struct imgenv {
     bool chain_open = false;  // a chain of launches that hands over through tail_sig / tail_cnt has started and not been completed
     std::vector<RvoObstacles> rvos;  // one obstacle set per world
     int sfm_cap_obs = 0;
+    std::vector<int> sfm_nobs_w;  // pedscene, several worlds: obstacle segments of each world's crowd
     // live timing (imgenv_timing)
     int t_mode = 0, t_which = -1;
     unsigned t_tick = 0;
@@ -443,8 +444,6 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (cfg->n_peds / W > cfg->max_ped)
         FAIL(IMGENV_EINVAL, "n_peds %d > max_ped %d (IndexError in yaml_env.py:401)", cfg->n_peds / W, cfg->max_ped);
     if (cfg->n_peds / W > 65000) FAIL(IMGENV_EINVAL, "more than 65000 pedestrians in one world unsupported");
-    if (W > 1 && cfg->ped_scene_type == IMGENV_SCENE_PEDSIM)
-        FAIL(IMGENV_EINVAL, "n_worlds > 1 is not available for the pedsim scene (one social-force crowd per handle)");
     if (W > 1 && (((size_t)Hg * Wg + 15) & ~(size_t)15) * (size_t)W >= ((size_t)1 << 32))
         FAIL(IMGENV_EINVAL, "n_worlds x map cells must stay below 2^32");
     if (cfg->n_robots >= (int)OWNER_MULTI) FAIL(IMGENV_EINVAL, "more than 2^24 - 3 robots unsupported");
@@ -452,8 +451,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (cfg->state_dim < 3 || cfg->state_dim > 5) FAIL(IMGENV_EINVAL, "state_dim must be 3, 4 or 5");
     if (cfg->ped_vec_dim != 7) FAIL(IMGENV_EINVAL, "ped_vec_dim must be 7");
     if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM) {
-        const int n_sfm = cfg->n_peds + (cfg->relation_ped_robo == 1 ? cfg->n_robots : 0);
-        if (cfg->relation_ped_robo == 1 && cfg->n_robots > 8)
+        const int n_sfm = (cfg->n_peds + (cfg->relation_ped_robo == 1 ? cfg->n_robots : 0)) / W;  // one crowd (one PedScene) per world
+        if (cfg->relation_ped_robo == 1 && cfg->n_robots / W > 8)
             FAIL(IMGENV_EINVAL, "pedscene with relation_ped_robo=1 and more than 8 robots: the reference node recurses forever in "
                                 "Ttree::addAgent (all robot Tagents start at (0,0,0), ped_tree.cpp:65-96)");
         if (n_sfm > SFM_MAX_AGENTS) FAIL(IMGENV_EINVAL, "pedscene crowds larger than %d agents are not supported", SFM_MAX_AGENTS);
@@ -869,19 +868,24 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         d.sfm.err = dev + 4;
     }
     if (cfg->ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene(): Tscene(0,10,10,10), addPed, addRobot (pedscene.h:17-80)
+        // one crowd per world (the reference: one node process = one PedScene per env), every array W slices back to back;
+        // every world starts as a fresh process does: the same default-seeded draws
         SfmDev& f = d.sfm;
-        const int n = P + (cfg->relation_ped_robo == 1 ? R : 0);
-        f.n = n; f.n_peds = P; f.n_obs = 0; f.cap_nodes = 16384;
+        const int Pw = h->Pw, Rw = h->Rw;
+        const int n = Pw + (cfg->relation_ped_robo == 1 ? Rw : 0), n1 = n ? n : 1;
+        f.n = n; f.n_peds = Pw; f.n_obs = 0; f.W = W;
+        f.cap_nodes = W > 1 ? 2048 : 16384;  // (libpedsim's tree only ever grows: a crowd that outgrows its pool raises the overflow flag)
+        f.cap_obs = 0;
         PedsimRng rng;
-        std::vector<double> p0((size_t)(n ? n : 1) * 3, 0.0), vmax(n ? n : 1, 0.0);
+        std::vector<double> p0((size_t)n1 * 3, 0.0), vmax(n1, 0.0);
         std::vector<SfmNode> nodes(f.cap_nodes);
-        std::vector<int> treehash(n ? n : 1, 0);
+        std::vector<int> treehash(n1, 0);
         int n_nodes = 0, err = 0;
         sfm_q_new(nodes.data(), &n_nodes, f.cap_nodes, 0, 10, 10, 10);
         // every Tagent() draws its vmax (peds then robots, also robots that stay outside the scene)
         for (int a = 0; a < n; a++) {
             vmax[a] = rng.normal_fresh(1.2, 0.2);
-            if (a < P) {
+            if (a < Pw) {
                 p0[3 * a] = rng.glibc_rand() / 2147483647.0 * 10.0;
                 p0[3 * a + 1] = rng.glibc_rand() / 2147483647.0 * 10.0;
                 vmax[a] = (double)h->pmax[a];
@@ -892,20 +896,32 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             imgenv_destroy(h);
             FAIL(IMGENV_EINVAL, "pedscene quadtree construction overflowed (%d)", err);
         }
-        TRY(dev_alloc(h, &f.p, (size_t)(n ? n : 1) * 3));
-        TRY(dev_alloc(h, &f.v, (size_t)(n ? n : 1) * 3));
-        TRY(dev_alloc(h, &f.vmax, n)); TRY(dev_alloc(h, &f.wpx, (size_t)(n ? n : 1) * SFM_MAX_WP));
-        TRY(dev_alloc(h, &f.wpy, (size_t)(n ? n : 1) * SFM_MAX_WP)); TRY(dev_alloc(h, &f.wpr, (size_t)(n ? n : 1) * SFM_MAX_WP));
-        TRY(dev_alloc(h, &f.dq, (size_t)(n ? n : 1) * SFM_MAX_WP)); TRY(dev_alloc(h, &f.dq_n, n));
-        TRY(dev_alloc(h, &f.dest, n, 0xFF)); TRY(dev_alloc(h, &f.last, n, 0xFF));  // -1
-        TRY(dev_alloc(h, &f.nodes, f.cap_nodes)); TRY(dev_alloc(h, &f.n_nodes, 1)); TRY(dev_alloc(h, &f.treehash, n));
-        TRY(dev_alloc(h, &f.pair_f, (size_t)(n ? n : 1) * (n ? n : 1) * 3)); TRY(dev_alloc(h, &f.pair_code, (size_t)(n ? n : 1) * (n ? n : 1)));
-        TRY(dev_alloc(h, &f.g_nb, (size_t)SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32))); TRY(dev_alloc(h, &f.g_sh, (size_t)4 * SFM_MAX_AGENTS));
-        HIPCHK_H(hipMemcpy(f.p, p0.data(), sizeof(double) * 3 * (n ? n : 1), hipMemcpyHostToDevice));
-        HIPCHK_H(hipMemcpy(f.vmax, vmax.data(), sizeof(double) * (n ? n : 1), hipMemcpyHostToDevice));
-        HIPCHK_H(hipMemcpy(f.nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
-        HIPCHK_H(hipMemcpy(f.n_nodes, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK_H(hipMemcpy(f.treehash, treehash.data(), sizeof(int) * (n ? n : 1), hipMemcpyHostToDevice));
+        const size_t Wn = (size_t)W * n1;
+        TRY(dev_alloc(h, &f.p, Wn * 3));
+        TRY(dev_alloc(h, &f.v, Wn * 3));
+        TRY(dev_alloc(h, &f.vmax, Wn)); TRY(dev_alloc(h, &f.wpx, Wn * SFM_MAX_WP));
+        TRY(dev_alloc(h, &f.wpy, Wn * SFM_MAX_WP)); TRY(dev_alloc(h, &f.wpr, Wn * SFM_MAX_WP));
+        TRY(dev_alloc(h, &f.dq, Wn * SFM_MAX_WP)); TRY(dev_alloc(h, &f.dq_n, Wn));
+        TRY(dev_alloc(h, &f.dest, Wn, 0xFF)); TRY(dev_alloc(h, &f.last, Wn, 0xFF));  // -1
+        TRY(dev_alloc(h, &f.nodes, (size_t)W * f.cap_nodes)); TRY(dev_alloc(h, &f.n_nodes, W)); TRY(dev_alloc(h, &f.treehash, Wn));
+        TRY(dev_alloc(h, &f.pair_f, (size_t)W * n1 * n1 * 3)); TRY(dev_alloc(h, &f.pair_code, (size_t)W * n1 * n1));
+        TRY(dev_alloc(h, &f.g_nb, (size_t)W * SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32))); TRY(dev_alloc(h, &f.g_sh, (size_t)W * 4 * SFM_MAX_AGENTS));
+        if (W > 1) {  // room for every world's obstacle segments up front (a slice cannot grow without moving the others)
+            f.cap_obs = 64;
+            int* nobs = nullptr;
+            TRY(dev_alloc(h, &f.obs, (size_t)W * f.cap_obs * 4));
+            TRY(dev_alloc(h, &nobs, W));
+            f.n_obs_w = nobs;
+            h->sfm_cap_obs = f.cap_obs;
+            h->sfm_nobs_w.assign(W, 0);
+        }
+        for (int k = 0; k < W; k++) {
+            HIPCHK_H(hipMemcpy(f.p + (size_t)k * n1 * 3, p0.data(), sizeof(double) * 3 * n1, hipMemcpyHostToDevice));
+            HIPCHK_H(hipMemcpy(f.vmax + (size_t)k * n1, vmax.data(), sizeof(double) * n1, hipMemcpyHostToDevice));
+            HIPCHK_H(hipMemcpy(f.nodes + (size_t)k * f.cap_nodes, nodes.data(), sizeof(SfmNode) * n_nodes, hipMemcpyHostToDevice));
+            HIPCHK_H(hipMemcpy(f.n_nodes + k, &n_nodes, sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK_H(hipMemcpy(f.treehash + (size_t)k * n1, treehash.data(), sizeof(int) * n1, hipMemcpyHostToDevice));
+        }
     }
     TRY(dev_alloc(h, &d.prof, 16 + 12 * (size_t)RL));
     d.state_in_integrate = P == 0 ? 1 : 0;
@@ -1100,9 +1116,11 @@ __device__ __forceinline__ void reset_ped(const DevWorld& w, const int* list, in
         w.apy[j] = (float)y;
     }
     if (w.scene == IMGENV_SCENE_PEDSIM) {  // setPosition(x, y, 0) (pedscene.h:34-36); velocity persists
-        w.sfm.p[3 * j] = x;
-        w.sfm.p[3 * j + 1] = y;
-        w.sfm.p[3 * j + 2] = 0.0;
+        const int k = w.W > 1 ? j / w.Pw : 0;
+        double* p = w.sfm.p + 3 * ((size_t)k * w.sfm.n + (size_t)(j - k * w.sfm.n_peds));  // its world's crowd
+        p[0] = x;
+        p[1] = y;
+        p[2] = 0.0;
     }
     w.ped_state[4 * j] = x;
     w.ped_state[4 * j + 1] = y;
@@ -1605,12 +1623,20 @@ static int stage_world(imgenv* h, int k, int q_list, const imgenv_reset_batch* b
     RTRY(put_world_rvo(h, k));
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {
         const int nob = (int)sfm_obs.size() / 4;
-        if (nob > h->sfm_cap_obs) {
-            h->sfm_cap_obs = nob * 2;
-            if (int rc = dev_alloc(h, &d.sfm.obs, (size_t)h->sfm_cap_obs * 4)) return rc;
+        if (W > 1) {  // world k's slice and count
+            if (nob > h->sfm_cap_obs) FAIL(IMGENV_EINVAL, "world %d: more than %d obstacles in a pedscene world of a multi-world handle", k, h->sfm_cap_obs);
+            if (nob) RTRY(stage_put(h, d.sfm.obs + (size_t)k * d.sfm.cap_obs * 4, sfm_obs.data(), sizeof(double) * sfm_obs.size()));
+            h->sfm_nobs_w[k] = nob;
+            RTRY(stage_put(h, const_cast<int*>(d.sfm.n_obs_w) + k, &h->sfm_nobs_w[k], sizeof(int)));
+        } else {
+            if (nob > h->sfm_cap_obs) {
+                h->sfm_cap_obs = nob * 2;
+                if (int rc = dev_alloc(h, &d.sfm.obs, (size_t)h->sfm_cap_obs * 4)) return rc;
+                d.sfm.cap_obs = h->sfm_cap_obs;
+            }
+            if (nob) RTRY(stage_put(h, d.sfm.obs, sfm_obs.data(), sizeof(double) * sfm_obs.size()));
+            d.sfm.n_obs = nob;
         }
-        if (nob) RTRY(stage_put(h, d.sfm.obs, sfm_obs.data(), sizeof(double) * sfm_obs.size()));
-        d.sfm.n_obs = nob;
     }
     // pedestrians (img_env.cpp:220-250)
     if (Pw > 0) {
@@ -1662,9 +1688,10 @@ static int stage_world(imgenv* h, int k, int q_list, const imgenv_reset_batch* b
             d.ptraj_v = h->d_traj_v;
         }
         if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM) {  // PedScene::setWayPoint (pedscene.h:38-46): [goal r=1, trajectory r=z]
-            std::vector<double> wx((size_t)P * SFM_MAX_WP, 0.0), wy(wx), wr(wx);
-            std::vector<int> dq((size_t)P * SFM_MAX_WP, 0), dqn(P, 0), dest(P, 0), last(P, -1);
-            for (int j = 0; j < P; j++) {
+            // (this world's pedestrians: the first Pw agents of its crowd)
+            std::vector<double> wx((size_t)Pw * SFM_MAX_WP, 0.0), wy(wx), wr(wx);
+            std::vector<int> dq((size_t)Pw * SFM_MAX_WP, 0), dqn(Pw, 0), dest(Pw, 0), last(Pw, -1);
+            for (int j = 0; j < Pw; j++) {
                 int nw = 0;
                 wx[(size_t)j * SFM_MAX_WP] = b->ped_goal[2 * j];
                 wy[(size_t)j * SFM_MAX_WP] = b->ped_goal[2 * j + 1];
@@ -1681,13 +1708,14 @@ static int stage_world(imgenv* h, int k, int q_list, const imgenv_reset_batch* b
                 dest[j] = 0;  // addWaypoint leaves destination = waypoints.front() without popping it (ped_agent.cpp:97-100)
             }
             const SfmDev& f = d.sfm;
-            RTRY(stage_put(h, f.wpx, wx.data(), wx.size() * 8));
-            RTRY(stage_put(h, f.wpy, wy.data(), wy.size() * 8));
-            RTRY(stage_put(h, f.wpr, wr.data(), wr.size() * 8));
-            RTRY(stage_put(h, f.dq, dq.data(), dq.size() * 4));
-            RTRY(stage_put(h, f.dq_n, dqn.data(), dqn.size() * 4));
-            RTRY(stage_put(h, f.dest, dest.data(), dest.size() * 4));
-            RTRY(stage_put(h, f.last, last.data(), last.size() * 4));
+            const size_t a0 = (size_t)k * f.n;  // first agent of world k's crowd
+            RTRY(stage_put(h, f.wpx + a0 * SFM_MAX_WP, wx.data(), wx.size() * 8));
+            RTRY(stage_put(h, f.wpy + a0 * SFM_MAX_WP, wy.data(), wy.size() * 8));
+            RTRY(stage_put(h, f.wpr + a0 * SFM_MAX_WP, wr.data(), wr.size() * 8));
+            RTRY(stage_put(h, f.dq + a0 * SFM_MAX_WP, dq.data(), dq.size() * 4));
+            RTRY(stage_put(h, f.dq_n + a0, dqn.data(), dqn.size() * 4));
+            RTRY(stage_put(h, f.dest + a0, dest.data(), dest.size() * 4));
+            RTRY(stage_put(h, f.last + a0, last.data(), last.size() * 4));
         }
         d.ptraj = h->d_traj;
         d.traj_cap = h->traj_cap;
@@ -2001,16 +2029,17 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
     // step's views and was joined at the end of that step; its velocities are applied by k_integrate's pedestrian blocks
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
-        const int n_sfm = h->d.sfm.n, n_pairs = n_sfm * n_sfm;
+        const int n_sfm = h->d.sfm.n, n_pairs = n_sfm * n_sfm;  // (of one world's crowd; a workgroup per world)
+        const unsigned nw = (unsigned)h->W, pb = (unsigned)((n_pairs + SFM_MAX_AGENTS - 1) / SFM_MAX_AGENTS);
         if (n_pairs <= 4096) {  // small crowd: one launch
-            TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 0)));
+            TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 0)));
             h->launches += 1;
         } else {  // the n^2 pair terms (three correctly rounded atan2 each) spread over the chip between two one-workgroup launches
             const bool on = timing_on(h, IMGENV_K_ORCA);
             if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, st, 0)) return rc_; }
-            k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 1);
-            k_sfm<<<dim3((n_pairs + SFM_MAX_AGENTS - 1) / SFM_MAX_AGENTS), dim3(SFM_MAX_AGENTS), 0, st>>>(d, 2);
-            k_sfm<<<dim3(1), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 3);
+            k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 1);
+            k_sfm<<<dim3(nw * pb), dim3(SFM_MAX_AGENTS), 0, st>>>(d, 2);
+            k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 3);
             if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, st, 1)) return rc_; }
             h->launches += 3;
         }

@@ -456,17 +456,22 @@ __global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w, int phase) {
     SfmNode* sfm_nodes = (SfmNode*)sfm_dyn;
     __shared__ int sfm_hash[SFM_MAX_AGENTS];
     __shared__ int sfm_nn;
+    // one crowd per world: phases 0, 1, 3 run one workgroup per world, phase 2 (the pair terms) pblocks of them
+    const int pblocks = phase == 2 ? (int)gridDim.x / w.sfm.W : 1;
+    const int world = (int)blockIdx.x / pblocks, pblock = (int)blockIdx.x - world * pblocks;
+    const SfmDev f = sfm_of_world(w.sfm, world);
 #ifdef IMGENV_PHASE_PROFILE
-    sfm_step(w.sfm, w.step_hz, phase, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn, w.dbg);
+    sfm_step(f, w.step_hz, phase, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn, pblock, pblocks, w.dbg);
 #else
-    sfm_step(w.sfm, w.step_hz, phase, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn);
+    sfm_step(f, w.step_hz, phase, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn, pblock, pblocks);
 #endif
     if (phase == 1 || phase == 2) return;
-    const int j = threadIdx.x;
-    if (j >= w.P) return;
+    const int jw = threadIdx.x;
+    if (jw >= f.n_peds) return;
+    const int j = world * f.n_peds + jw;  // the pedestrian's index in the handle
     const double ox = w.ppx[j], oy = w.ppy[j];
-    const double x = w.sfm.p[3 * j], y = w.sfm.p[3 * j + 1];
-    const double vx = w.sfm.v[3 * j], vy = w.sfm.v[3 * j + 1];
+    const double x = f.p[3 * jw], y = f.p[3 * jw + 1];
+    const double vx = f.v[3 * jw], vy = f.v[3 * jw + 1];
     w.plx[j] = ox;
     w.ply[j] = oy;
     w.ppx[j] = x;
@@ -864,7 +869,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
     // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
     if (tid == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
-        double* p = w.sfm.p + 3 * (size_t)(w.P + i);
+        double* p = w.sfm.p + 3 * ((size_t)world * w.sfm.n + w.sfm.n_peds + (size_t)(i - world * w.Rw));  // the world's crowd: pedestrians, then robots
         p[0] = r[0];
         p[1] = r[1];
         p[2] = 1.0;

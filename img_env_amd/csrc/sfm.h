@@ -42,8 +42,10 @@ struct SfmNode {  // Ped::Ttree
     int agents[SFM_LEAF_CAP];  // std::set<const Tagent*>, kept sorted by agent index
 };
 
-struct SfmDev {
-    int n, n_peds, n_obs, cap_nodes;
+struct SfmDev {  // one crowd, or W of them back to back (one per world of a multi-world handle: sfm_of_world)
+    int n, n_peds, n_obs, cap_nodes;  // agents / pedestrians of ONE crowd
+    int W, cap_obs;                   // crowds; obstacle segments a crowd has room for
+    const int* n_obs_w;               // [W] obstacle segments per crowd (W > 1; n_obs otherwise)
     double* p;     // [n][3]
     double* v;     // [n][3]
     double* vmax;  // [n]
@@ -59,6 +61,27 @@ struct SfmDev {
     uint32_t* g_nb;            // [SFM_MAX_AGENTS][SFM_MAX_AGENTS / 32] neighbour sets, phase 1 -> 2 of a split step
     double* g_sh;              // [4][SFM_MAX_AGENTS] desired direction x / y and two angles per agent, phase 1 -> 2, 3
 };
+
+#if defined(__HIPCC__)
+// crowd k of a multi-world handle: the same record with every array moved on to its slice
+__device__ __forceinline__ SfmDev sfm_of_world(const SfmDev& f, int k) {
+    SfmDev g = f;
+    const size_t n = (size_t)f.n, a = (size_t)k * n;
+    g.p += a * 3; g.v += a * 3; g.vmax += a;
+    g.wpx += a * SFM_MAX_WP; g.wpy += a * SFM_MAX_WP; g.wpr += a * SFM_MAX_WP;
+    g.dq += a * SFM_MAX_WP; g.dq_n += a; g.dest += a; g.last += a;
+    g.obs += (size_t)k * f.cap_obs * 4;
+    g.nodes += (size_t)k * f.cap_nodes;
+    g.n_nodes += k;
+    g.treehash += a;
+    g.pair_f += (size_t)k * n * n * 3;
+    g.pair_code += (size_t)k * n * n;
+    g.g_nb += (size_t)k * SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32);
+    g.g_sh += (size_t)k * 4 * SFM_MAX_AGENTS;
+    if (f.n_obs_w) g.n_obs = f.n_obs_w[k];
+    return g;
+}
+#endif
 
 // ---- Ttree (ped_tree.cpp:18-137) on flat arrays, shared by the host (initial tree) and the device ----
 SFM_HD inline int sfm_q_new(SfmNode* nodes, int* n_nodes, int cap, double x, double y, double w, double h) {
@@ -213,6 +236,7 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
                          double* sh_lds /* LDS [4][SFM_MAX_AGENTS]: desired direction x / y and two angles per agent */,
                          unsigned short* stk /* LDS [SFM_WALK_CAP][blockDim.x]: walk stacks; later one "left its leaf" flag per agent */,
                          SfmNode* lnodes /* LDS [SFM_LDS_NODES] */, int* lhash /* LDS [SFM_MAX_AGENTS] */, int* ln_nodes /* LDS [1] */,
+                         int pblock /* phase 2: this workgroup of the crowd's pblocks */, int pblocks,
                          unsigned long long* stamp = nullptr /* debug: wall-clock marks of thread 0 */) {
 #define SFM_STAMP(q) do { if (stamp && threadIdx.x == 0) stamp[q] = wall_clock64(); } while (0)
     SFM_STAMP(0);
@@ -307,8 +331,8 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
     // thread and round: the three correctly rounded atan2 of a pair are ~1500 serial instructions, and an agent has up to
     // n - 1 neighbours.  Each term is evaluated exactly as the reference does and parked in HBM; the agents then add
     // their terms in neighbour order, so the sums round as the sequential loops do.
-    for (int pq = (phase == 2 ? blockIdx.x * blockDim.x : 0) + threadIdx.x; phase != 3 && pq < n * n;
-         pq += (phase == 2 ? gridDim.x : 1) * blockDim.x) {
+    for (int pq = (phase == 2 ? pblock * blockDim.x : 0) + threadIdx.x; phase != 3 && pq < n * n;
+         pq += (phase == 2 ? pblocks : 1) * blockDim.x) {
         const int pi = pq / n, o = pq - pi * n;
         unsigned char code = 0;  // bits 0-1: lookahead vote + 1, bit 2: has a social term
         d3 term = D3(0, 0, 0);

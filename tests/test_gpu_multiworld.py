@@ -278,9 +278,6 @@ def test_bad_multi_world_configurations_are_rejected(worlds):
         p[k] = np.asarray(p[k])[:7]
     with pytest.raises(ValueError, match="multiples of n_worlds"):
         World(p, grid)
-    grid, params, _ = small_world(4, 4, seed=1, scene="pedscene", grid_size=80)
-    with pytest.raises(ValueError, match="pedsim"):
-        World(_stack_params(params, 2), grid)
     grid, params, _ = small_world(4, 4, seed=1)
     p = _stack_params(params, 2)
     p["robot_begin"], p["robot_end"] = 0, 4
@@ -306,4 +303,23 @@ def test_stamped_layer_survives_its_tag_coming_round(worlds):
     World, OracleWorld = worlds
     fails, _, _ = _run(World, OracleWorld, 2, 3, 2, 300, {120: [1], 254: [0], 255: [1]}, seed=38, n_obstacles=2, grid_size=100,
                        clearance=0.6, time_max=1000, flags=4)
+    assert not fails, fails[:3]
+
+
+def test_pedscene_worlds_match_one_oracle_each(worlds):
+    """a social-force crowd per world (the reference: one PedScene per env process, pedscene.h:17-91): 3 worlds x (2 robots that
+    are crowd members, 7 pedestrians, own obstacle segments), per-world resets in mid-flight -- positions persist in the
+    library's quadtree per world, velocities persist across resets per world"""
+    World, OracleWorld = worlds
+    fails, snap, _ = _run(World, OracleWorld, W=3, Rw=2, Pw=7, steps=14, resets={4: [1], 9: [0, 2]}, seed=71, scene="pedscene",
+                          grid_size=88, n_obstacles=3)
+    assert not fails, fails[:3]
+    assert np.abs(snap["ped_state"][:, 2:]).max() > 0.05  # the crowds really moved
+
+
+def test_pedscene_worlds_above_64_agents_use_the_spread_pair_terms(worlds):
+    """two worlds of 70 social-force agents each: the n^2 pair terms run in their own launch, a share of workgroups per world"""
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, W=2, Rw=1, Pw=69, steps=5, resets={2: [1]}, seed=73, scene="pedscene", grid_size=88,
+                       n_obstacles=2, relation_ped_robo=1, clearance=0.45)
     assert not fails, fails[:3]

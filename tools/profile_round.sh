@@ -34,10 +34,15 @@ for cfg in cfg2 cfg4 cfg5 mw; do
   db=$(ls $out/${tag}_$cfg/*/*.db $out/${tag}_$cfg/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python3 tools/rocpd_stats.py $db > $out/${tag}_${cfg}_kernel_stats.txt
 done
-python3 tools/pmc_to_json.py $out/${tag}_fetch $out/${tag}_write $out/${tag}_pmc.json > /dev/null
+python3 tools/pmc_to_json.py $out/${tag}_fetch $out/${tag}_write $out/${tag}_pmc.json $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 > /dev/null
 python3 tools/pmc_summary.py $out/${tag}_fetch $out/${tag}_write > $out/${tag}_pmc_hbm.txt
 python3 tools/pmc_summary.py $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 > $out/${tag}_pmc_sq.txt
 python3 bench.py 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
+# the reference's shipped geometry (test.yaml: 400 x 400 views shrunk to 48 x 48, 1000 beams): timeline + kernel stats at 256 envs,
+# kernel stats + counters at 2048
+bash tools/profile_shipped.sh ${tag}_shipped256 256
+bash tools/profile_shipped.sh ${tag}_shipped2048 2048
+PMC_CMD="python3 /root/repo/tools/shipped_probe.py --envs 2048 --steps 6" bash tools/profile_pmc.sh ${tag}_shipped2048
 # keep the returned directory small: the raw traces stay on the box
 rm -rf $out/${tag}_trace $out/${tag}_mw $out/${tag}_cfg2 $out/${tag}_cfg4 $out/${tag}_cfg5 $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 $out/${tag}_fetch $out/${tag}_write
 du -sh $out
