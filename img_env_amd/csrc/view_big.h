@@ -26,7 +26,7 @@
 #pragma once
 
 #define VBC_T 256    // k_crop_big: up to 4 wavefronts
-#define VBC_U 4      // tiles a wavefront keeps in flight
+#define VBC_U 4      // tiles a wavefront keeps in flight (8: measured slower, 321 against 304 us for 2048 shipped views)
 #define VBB_T 256    // k_beams_big: one beam per thread
 #define VBT_T 256    // k_taps_big: one sensor_map pixel per thread
 #define VBF_T 256    // k_fullview_big
@@ -34,14 +34,6 @@
 __device__ __forceinline__ long long uniform_i64(long long v) {  // a value known to be the same in every lane, into scalar registers
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(unsigned long long)v);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)v >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-
-// a (>= 0) times a 64-bit m, both wave-uniform, in 32-bit pieces the scalar unit has instructions for (a 64-bit multiply-add
-// of uniform values would be selected as v_mad_u64_u32, i.e. onto the vector unit)
-__device__ __forceinline__ long long umul_i64(int a, long long m) {
-    const uint32_t mlo = (uint32_t)(unsigned long long)m, mhi = (uint32_t)((unsigned long long)m >> 32);
-    const uint32_t lo = (uint32_t)a * mlo, hi = __umulhi((uint32_t)a, mlo) + (uint32_t)a * mhi;
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
@@ -98,16 +90,34 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
     const int n_crop = k.n_crop, tb_n = k.tb;
     const int nw = (int)blockDim.x >> 6;  // wavefronts of this workgroup: 4, or 1 where the robots alone fill the chip
     const int first = chunk * (nw * tpw);  // tpw tiles per wavefront: more in big launches (workgroup dispatch has a price)
-    // lane q holds the descriptor of this wavefront's q-th tile (tpw <= 64): one load here, a readlane per tile below
-    uint32_t my_tile = 0, my_fov_lo = 0, my_fov_hi = 0;
+    // lane q prepares this wavefront's q-th tile (tpw <= 64): its field-of-view mask and its word in the bitmap stay in the
+    // lane (a readlane per tile below), the corner term of the transform goes through a wavefront-private LDS record that
+    // every lane reads back with one broadcast ds_read_b128 per tile.  (The products on the scalar unit instead cost ~28 scalar
+    // instructions per tile, and a compute unit issues one scalar instruction per cycle, tools/micro/gather_rate.hip: 323 -> 304 us
+    // for 2048 shipped views.)  Where the time goes (same launch, parts switched off one at a time): 155 us of instruction issue
+    // (~40 vector + scalar instructions per tile), + 72 us for the map-byte gather, + 44 us for the segment tags, + 20 us for the
+    // stores -- the parts add up instead of overlapping, and the gathers' price follows the number of cache lines a tile
+    // touches (231 us with every robot heading along the map's rows, 336 us at 45 degrees).  Measured and dropped: 8 tiles in
+    // flight (321 us), a per-region LDS window of the map loaded as aligned dwords (400-540 us: more lines per tile than the
+    // gathers it replaces, since a rotated region's bounding box is twice its area).
+    __shared__ longlong2 corner[VBC_T / WAVE][WAVE];
+    uint32_t my_word = 0xFFFFFFFFu, my_fov_lo = 0, my_fov_hi = 0;
     {
         const int ti = first + lane * nw + wave;
+        long long tx = OX, ty = OY;
         if (lane < tpw && ti < n_crop) {
-            my_tile = k.crop_tiles[ti];
+            const uint32_t tile = k.crop_tiles[ti];
             const unsigned long long f = k.crop_masks[ti];
             my_fov_lo = (uint32_t)f;
             my_fov_hi = (uint32_t)(f >> 32);
+            my_word = (tile >> 16) * (uint32_t)tb_n + (tile & 0xFFFFu);
+            const long long ta8 = (long long)((tile >> 16) * 8u), tb8 = (long long)((tile & 0xFFFFu) * 8u);
+            tx += ta8 * M00 + tb8 * M01;
+            ty += ta8 * M10 + tb8 * M11;
         }
+        corner[wave][lane] = make_longlong2(tx, ty);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     for (int it = 0; it < tpw; it += VBC_U) {
         if (first + it * nw + wave >= n_crop) break;  // uniform
@@ -115,19 +125,16 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
         unsigned long long look[VBC_U], risky = 0ull;  // lane masks (scalar registers)
 #pragma unroll
         for (int u = 0; u < VBC_U; u++) {
-            const int ti = first + (it + u) * nw + wave;  // consecutive wavefronts take consecutive tiles
-            const bool valid = ti < n_crop;
-            const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, it + u);
+            // (consecutive wavefronts take consecutive tiles: tile (it + u) of this wavefront is first + (it + u) * nw + wave)
             const unsigned long long fov = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_fov_hi, it + u) << 32) |
                                            (uint32_t)__builtin_amdgcn_readlane((int)my_fov_lo, it + u);  // 0 past the end of the list
-            const int ta8 = (int)(tile >> 16) * 8, tb8 = (int)(tile & 0xFFFFu) * 8;
-            tile_w[u] = valid ? (tile >> 16) * (uint32_t)tb_n + (tile & 0xFFFFu) : 0xFFFFFFFFu;
-            const long long Tx = OX + umul_i64(ta8, M00) + umul_i64(tb8, M01), Ty = OY + umul_i64(ta8, M10) + umul_i64(tb8, M11);  // wave-uniform
-            const unsigned long long Fx = (unsigned long long)(Tx + Lx), Fy = (unsigned long long)(Ty + Ly);
+            tile_w[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_word, it + u);  // 0xFFFFFFFF past the end
+            const longlong2 T = corner[wave][it + u];
+            const unsigned long long Fx = (unsigned long long)(T.x + Lx), Fy = (unsigned long long)(T.y + Ly);
             const int m = (int)(uint32_t)(Fx >> 32), n = (int)(uint32_t)(Fy >> 32);
             const uint32_t G = 1u << 15;
             risky |= fov & __ballot(((uint32_t)Fx + G < 2u * G) | ((uint32_t)Fy + G < 2u * G));
-            look[u] = fov & __ballot(((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg));
+            look[u] = fov & __ballot((uint32_t)m < (uint32_t)Hg) & __ballot((uint32_t)n < (uint32_t)Wg);  // (two compares straight into lane masks)
             idx[u] = min((uint32_t)(m * Wg + n), last_cell);  // any valid address for the lanes that do not look
         }
         if (__builtin_expect(risky != 0ull || !fixed_ok, 0)) {  // somebody within 2^-17 of a rounding boundary: the reference's own chain
