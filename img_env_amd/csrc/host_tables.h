@@ -99,7 +99,8 @@ struct RobotClassHost {
     std::vector<uint16_t> ray_end;    // [ray_maxlen][ray_stride] last step behind step k of beam b that shares its row or column (k itself if none)
     std::vector<uint32_t> big_inv;    // [NC][2] rays through a view cell: first entry of inv_ent, count
     std::vector<uint32_t> crop_tiles; // tiles with at least one cell inside the field of view: ta << 16 | tb ...
-    std::vector<uint64_t> crop_masks; // ... and their cells inside it (bit = (a % 8) * 8 + b % 8)
+    std::vector<uint64_t> crop_masks; // ... and their cells inside it (bit = (a % 8) * 8 + b % 8), + 8 zero entries
+    int n_crop = 0;
     std::vector<uint32_t> tap_top, tap_inv, tap_addr;  // [16][image_h * image_w] the 4 x 4 source cells of every pixel of the shrunk sensor_map (build_big_taps)
     std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
@@ -277,6 +278,8 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
             k.crop_tiles.push_back(0);
             k.crop_masks.push_back(0);
         }
+        k.n_crop = (int)k.crop_tiles.size();
+        k.crop_masks.insert(k.crop_masks.end(), 8, 0);  // k_crop_big loads the masks of a whole round (<= 8 tiles) at once
     } else {
         // chunk-major: the 8 steps 8c..8c+7 of beam b sit at ((c * ray_stride) + b) * 8; padding = a free dummy cell behind the view
         k.ray_rows.assign((size_t)(k.ray_kpad / 8) * k.ray_stride * 8, (uint16_t)NC);

@@ -645,6 +645,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     }
     TRY(dev_alloc(h, &d.cell, Gp));
     TRY(dev_alloc(h, &d.seg_tag, Gp / 64 + 2));
+    d.crop_map = nullptr;
 
     // class tables
     size_t max_stride = WAVE;
@@ -741,6 +742,30 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     }
     d.keep_view_maps = (cfg->flags & IMGENV_FLAG_NO_VIEW_MAPS) ? 0 : 1;
     if (h->big_view) {  // view_big.h: tiled crop bitmap + hit words per local robot, static tables per class
+        if (h->stamp && G < ((size_t)1 << 24)) {  // view_big.h: the map as k_crop_big wants it (world.h)
+            const uint32_t wt = (uint32_t)(Wg + 7) / 8, ht = (uint32_t)(Hg + 7) / 8;
+            d.crop_wt = wt;
+            d.crop_ws = wt * ht * 64;
+            d.crop_magic = (((unsigned long long)1 << 40) + (unsigned long long)Wg - 1) / (unsigned long long)Wg;
+            for (int m = 0; m < Hg; m++)  // (the multiply-shift division is exact on this map: row starts and row ends)
+                for (int e = 0; e < 2; e++) {
+                    const unsigned long long cl = (unsigned long long)m * Wg + (e ? Wg - 1 : 0);
+                    if ((int)((cl * d.crop_magic) >> 40) != m) {
+                        imgenv_destroy(h);
+                        FAIL(IMGENV_EINVAL, "internal: row of cell %llu by multiply-shift", cl);
+                    }
+                }
+            std::vector<uint8_t> tiled((size_t)d.crop_ws, 0);
+            for (int m = 0; m < Hg; m++)
+                for (int n = 0; n < Wg; n++)
+                    tiled[(((size_t)(m >> 3) * wt + (n >> 3)) << 6) | ((m & 7) << 3) | (n & 7)] = static_map[(size_t)m * Wg + n] >= 250 ? 128 : 0;
+            uint8_t* sc = nullptr;
+            TRY(dev_alloc(h, &sc, (size_t)d.crop_ws));
+            HIPCHK_H(hipMemcpy(sc, tiled.data(), tiled.size(), hipMemcpyHostToDevice));
+            d.static_crop = sc;
+            TRY(dev_alloc(h, &d.crop_map, (size_t)d.crop_ws * W));
+            for (int k = 0; k < W; k++) HIPCHK_H(hipMemcpy(d.crop_map + (size_t)k * d.crop_ws, sc, (size_t)d.crop_ws, hipMemcpyDeviceToDevice));
+        }
         std::vector<BigClassDev> bc(h->rcls.size());
         int max_crop = 1;
         for (size_t c = 0; c < h->rcls.size(); c++) {
@@ -753,7 +778,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             }
             o.ta = k.big_ta;
             o.tb = k.big_tb;
-            o.n_crop = (int)k.crop_tiles.size();
+            o.n_crop = k.n_crop;
             max_crop = std::max(max_crop, o.n_crop);
             TRY(dev_upload(h, &o.crop_tiles, k.crop_tiles));
             TRY(dev_upload(h, &o.crop_masks, k.crop_masks));
@@ -1269,8 +1294,9 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         const int tpw = n_l >= 512 ? 32 : 8, crop_chunks = (h->big_max_crop + (VBC_T / WAVE) * tpw - 1) / ((VBC_T / WAVE) * tpw);
         const dim3 gc((unsigned)((n_l + 7) / 8 * 8) * (unsigned)crop_chunks), gb((unsigned)n_l * (unsigned)quarters);
         const dim3 gt((unsigned)n_l * (unsigned)tap_chunks), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
-        if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
-        else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
+        if (h->stamp && d.crop_map) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true, true><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
+        else if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true, false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
+        else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false, false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
         const int variant = (h->pow2 ? 4 : 0) | (h->stamp ? 2 : 0) | (h->big_bits_in_lds ? 1 : 0);
 #define BEAMS_CASE(N, P2, ST, LB) \
     case N: TIMED(h, IMGENV_K_VIEW, st, (k_beams_big<P2, ST, LB><<<gb, dim3(VBB_T), h->lds_view_big, st>>>(d, quarters))); break;
@@ -1477,6 +1503,11 @@ __global__ __launch_bounds__(256) void k_reset_apply(DevWorld w, ResetArgs a) {
                 }
             }
         }
+        if (w.crop_map) {  // view_big.h's one-byte-per-cell summary of the map starts over with it
+            const uint4* src = (const uint4*)w.static_crop;
+            uint4* cm = (uint4*)(w.crop_map + (size_t)world * w.crop_ws);
+            for (size_t e = (size_t)(b - q * MAP_BLOCKS) * blockDim.x + threadIdx.x; e < w.crop_ws / 16; e += (size_t)MAP_BLOCKS * blockDim.x) cm[e] = src[e];
+        }
         return;
     }
     b -= a.n_worlds * MAP_BLOCKS;
@@ -1526,6 +1557,7 @@ __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstI
             if (map[at] > 2) {
                 map[at] = 0;
                 if (stamp) w.cell[(size_t)o.world * w.Gs + at] = CLS_STATIC;  // the class layer's base class follows
+                if (w.crop_map) w.crop_map[(size_t)o.world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = 0;  // ... and view_big.h's byte: not free, no stamp
             }
         }
     }

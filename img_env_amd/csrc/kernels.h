@@ -94,7 +94,18 @@ __device__ __forceinline__ bool stamp_is_current(uint32_t v, uint32_t tag) { ret
 // seg_tag: the tag again, once per 64 consecutive cells of the layer: where it is not this step's, no cell of the segment
 // carries a stamp of this step, and the obstacle map alone says what a view sees there (k_crop_big reads a byte per cell
 // instead of this layer's word)
-__device__ __forceinline__ void stamp_robot(const DevWorld& w, size_t c, uint32_t i, uint32_t tag) {
+// crop_map (world.h): the byte of world-local cell index cl, and the mark a stamp leaves there (every stamp of a step writes
+// the same byte: plain stores)
+__device__ __forceinline__ uint32_t crop_tiled(const DevWorld& w, uint32_t m, uint32_t n) {
+    return (((m >> 3) * w.crop_wt + (n >> 3)) << 6) | ((m & 7u) << 3) | (n & 7u);
+}
+__device__ __forceinline__ uint32_t crop_tag_of(uint32_t tag) { return tag % 127u + 1u; }
+__device__ __forceinline__ void crop_mark(const DevWorld& w, size_t c, int world, uint32_t base, uint32_t tag) {
+    if (!w.crop_map) return;
+    const uint32_t cl = (uint32_t)(c - (size_t)world * w.Gs), m = (uint32_t)(((unsigned long long)cl * w.crop_magic) >> 40), n = cl - m * (uint32_t)w.Wg;
+    w.crop_map[(size_t)world * w.crop_ws + crop_tiled(w, m, n)] = (uint8_t)((base == CLS_HIGH ? 128u : 0u) | crop_tag_of(tag));
+}
+__device__ __forceinline__ void stamp_robot(const DevWorld& w, size_t c, uint32_t i, uint32_t tag, int world) {
     uint32_t* cell = w.cell + c;
     w.seg_tag[c >> 6] = (uint8_t)tag;
     uint32_t old = *cell;
@@ -103,20 +114,26 @@ __device__ __forceinline__ void stamp_robot(const DevWorld& w, size_t c, uint32_
         uint32_t nw;
         if (kind == 0u) nw = (old & 7u) | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (i << STAMP_OWNER_SHIFT);
         else if (kind == STAMP_ONE && (old >> STAMP_OWNER_SHIFT) != i) nw = (old & 7u) | (STAMP_MANY << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT);
-        else return;  // this robot already, several already, or a pedestrian
+        else return;  // this robot already, several already, or a pedestrian (whoever stamped first this step marked crop_map)
         const uint32_t seen = atomicCAS(cell, old, nw);
-        if (seen == old) return;
+        if (seen == old) {
+            if (kind == 0u) crop_mark(w, c, world, old & 7u, tag);
+            return;
+        }
         old = seen;
     }
 }
 // view_ped (img_env.cpp:594-618): a pedestrian sample lands on the cell
-__device__ __forceinline__ void stamp_ped(const DevWorld& w, size_t c, uint32_t old /* the word as just read */, uint32_t tag) {
+__device__ __forceinline__ void stamp_ped(const DevWorld& w, size_t c, uint32_t old /* the word as just read */, uint32_t tag, int world) {
     uint32_t* cell = w.cell + c;
     w.seg_tag[c >> 6] = (uint8_t)tag;
     for (;;) {
         if (stamp_is_current(old, tag) && ((old >> STAMP_KIND_SHIFT) & 3u) == STAMP_PED) return;
         const uint32_t seen = atomicCAS(cell, old, (old & 7u) | (STAMP_PED << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT));
-        if (seen == old) return;
+        if (seen == old) {
+            if (!stamp_is_current(old, tag)) crop_mark(w, c, world, old & 7u, tag);
+            return;
+        }
         old = seen;
     }
 }
@@ -785,7 +802,7 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
 // the last lane of each run of equal cells stamp (consecutive samples are lattice neighbours and mostly share their cell:
 // ~10 compare-and-swaps per pedestrian instead of 900 dependent loads).  Call from wave-uniform control flow.
 template <bool STAMP>
-__device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t c, int rule, int lane) {
+__device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t c, int rule, int lane, int world) {
     if (!STAMP) {
         if (in) {
             const uint32_t o = w.obs_map[c];
@@ -797,14 +814,15 @@ __device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t 
     const uint32_t next = (uint32_t)__shfl_down((int)ci, 1);
     if (in && (lane == WAVE - 1 || next != ci)) {
         const uint32_t v = w.cell[c], base = v & 7u;
-        if (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW)) stamp_ped(w, c, v, stamp_tag_of(w));
+        if (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW)) stamp_ped(w, c, v, stamp_tag_of(w), world);
     }
 }
 
 template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
-    const uint32_t cell0 = (uint32_t)world_of_ped(w, j) * w.Gs;  // this world's copy of the layers
+    const int world = world_of_ped(w, j);
+    const uint32_t cell0 = (uint32_t)world * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id(), tid = threadIdx.x;
     const double res = w.res, inv = w.inv_res;
@@ -816,7 +834,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
             int m, n;
             w2m_pair<POW2>(wx, wy, res, inv, m, n);
             const bool in = q0 + tid < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
-            ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), 0, lane);
+            ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), 0, lane, world);
         }
     } else if (k.shape == IMGENV_SHAPE_LEG) {
         for (int leg = 0; leg < 2; leg++) {
@@ -835,7 +853,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
                 int m, n;
                 w2m_pair<POW2>(wx, wy, res, inv, m, n);
                 const bool in = q0 + tid < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
-                ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), leg + 1, lane);
+                ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), leg + 1, lane, world);
             }
         }
     }
@@ -888,7 +906,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             for (int e = tid; e < n_cached; e += NT) {
                 const uint32_t c = list[e].x;
                 if (STAMP) {
-                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w));
+                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w), world);
                 } else {
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);
@@ -929,7 +947,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 } else {
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
                     if (STAMP) {
-                        stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w));
+                        stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w), world);
                     } else {
                         atomicMin(&w.own_lo[c], id);
                         atomicMax(&w.own_hi[c], id);
@@ -959,7 +977,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c = cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
                 if (STAMP) {
-                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w));
+                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w), world);
                 } else {
                     atomicMin(&w.own_lo[c], id);
                     atomicMax(&w.own_hi[c], id);

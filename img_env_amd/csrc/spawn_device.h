@@ -708,10 +708,16 @@ __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c
                     const uint32_t v = static_map[at];
                     map[at] = (uint8_t)v;
                     if (stamp) cell[at] = v <= 2 ? v : (v < 250 ? CLS_LOW : CLS_HIGH);
+                    if (w.crop_map) w.crop_map[(size_t)world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = v >= 250 ? 128 : 0;  // (a stamp left on it has expired)
                 }
             }
         }
         return;
+    }
+    if (w.crop_map) {
+        const uint4* src = (const uint4*)w.static_crop;
+        uint4* cm = (uint4*)(w.crop_map + (size_t)world * w.crop_ws);
+        for (size_t e = (size_t)part * blockDim.x + threadIdx.x; e < w.crop_ws / 16; e += (size_t)map_blocks * blockDim.x) cm[e] = src[e];
     }
     const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;
     uint4* dst = (uint4*)map;

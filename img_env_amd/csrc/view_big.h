@@ -37,11 +37,24 @@ __device__ __forceinline__ long long uniform_i64(long long v) {  // a value know
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// lane q (wave-uniform) of v becomes the wave-uniform value x
+__device__ __forceinline__ void write_lane(uint32_t& v, uint32_t x, int q) {
+    const uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(xs), "s"(q) : "m0");
+}
+__device__ __forceinline__ uint32_t crop_tiled_at(uint32_t wt, uint32_t m, uint32_t n) {  // crop_tiled (kernels.h) with the pitch in a register
+    // = ((m >> 3) * wt + (n >> 3)) * 64 + (m & 7) * 8 + (n & 7), in six instructions: m << 3 already is (m >> 3) * 64 + (m & 7) * 8
+    const uint32_t n6 = ((n & ~7u) << 3) | (n & 7u);  // (n >> 3) * 64 + (n & 7): v_and, v_lshlrev, v_and_or
+    return (m << 3) + (__umul24(m >> 3, (wt - 1u) << 6) + n6);  // v_lshrrev + v_mad_u32_u24 + v_lshl_add
+}
+
 // ------------------------------------------------------------------------------------------------
 // (2) egocentric crop (agent.cpp:373-404), tiled.  All workgroups of one robot run on the same XCD (blockIdx modulo 8), so the
 // robot's window of the map is fetched from HBM once and shared through that XCD's L2.  STAMP mode reads the obstacle map
 // itself (one byte per cell) and the class layer's word only inside 64-cell segments some raster stamped this step (seg_tag).
-template <bool STAMP>
+// TILED (STAMP mode with w.crop_map): ONE byte gather per cell from the map's 8 x 8-block copy (free bit + crop tag of the last
+// stamp, world.h) -- 4-6 half cache lines per tile whatever the heading instead of a dozen map rows + the segment tags.
+template <bool STAMP, bool TILED>
 __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int n_robots, int tpw) {
     // block g: XCD g % 8 takes robots g % 8, g % 8 + 8, ... with all their chunks
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
@@ -77,8 +90,10 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
     const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
                                     : (CLS_HIGH | CLS_ROBOT | (self << 8));
     const uint32_t base_tag_mask = 7u | (0xFFu << STAMP_TAG_SHIFT), base_tag_ours = CLS_HIGH | (tag << STAMP_TAG_SHIFT);
-    const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs, last_cell = (uint32_t)(Hg * Wg - 1);
-    const uint8_t* obs = w.obs_map + cell0;
+    const int world = world_of_robot(w, i);
+    const uint32_t cell0 = (uint32_t)world * w.Gs, last_cell = (uint32_t)(Hg * Wg - 1);
+    const uint8_t* obs = TILED ? w.crop_map + (size_t)world * w.crop_ws : w.obs_map + cell0;
+    const uint32_t ctag = crop_tag_of(tag), Wt = w.crop_wt, last_byte = w.crop_ws - 1u;
     const uint32_t* cls = w.cell + cell0;
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int da = lane >> 3, db = lane & 7;
@@ -90,26 +105,31 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
     const int n_crop = k.n_crop, tb_n = k.tb;
     const int nw = (int)blockDim.x >> 6;  // wavefronts of this workgroup: 4, or 1 where the robots alone fill the chip
     const int first = chunk * (nw * tpw);  // tpw tiles per wavefront: more in big launches (workgroup dispatch has a price)
-    // lane q prepares this wavefront's q-th tile (tpw <= 64): its field-of-view mask and its word in the bitmap stay in the
-    // lane (a readlane per tile below), the corner term of the transform goes through a wavefront-private LDS record that
-    // every lane reads back with one broadcast ds_read_b128 per tile.  (The products on the scalar unit instead cost ~28 scalar
-    // instructions per tile, and a compute unit issues one scalar instruction per cycle, tools/micro/gather_rate.hip: 323 -> 304 us
-    // for 2048 shipped views.)  Where the time goes (same launch, parts switched off one at a time): 155 us of instruction issue
-    // (~40 vector + scalar instructions per tile), + 72 us for the map-byte gather, + 44 us for the segment tags, + 20 us for the
-    // stores -- the parts add up instead of overlapping, and the gathers' price follows the number of cache lines a tile
-    // touches (231 us with every robot heading along the map's rows, 336 us at 45 degrees).  Measured and dropped: 8 tiles in
-    // flight (321 us), a per-region LDS window of the map loaded as aligned dwords (400-540 us: more lines per tile than the
-    // gathers it replaces, since a rotated region's bounding box is twice its area).
+    // lane q prepares this wavefront's q-th tile (tpw <= 64): its word in the bitmap stays in the lane (the tile's result comes
+    // back to it by v_writelane, one store per wavefront at the end), the corner term of the transform goes through a
+    // wavefront-private LDS record that every lane reads back with one broadcast ds_read_b128 per tile; the field-of-view masks
+    // of a round's tiles come in one scalar load.
+    // How it got here (2048 shipped views, us per launch): 323 with the corner products on the scalar unit (~28 scalar
+    // instructions per tile; a compute unit issues one per cycle, tools/micro/gather_rate.hip) -> 304 with the LDS records.
+    // Parts switched off one at a time then said: 155 of instruction issue (~40 vector + scalar instructions per tile) + 72 for
+    // the gather of map bytes + 44 for the segment tags + 20 for the stores, adding up instead of overlapping, the gathers'
+    // price following the cache lines a tile touches (231 with every robot heading along the map's rows, 336 at 45 degrees).
+    // -> 196 with crop_map (one byte gather per cell, 8 x 8 blocks: world.h) -> 151 with lane masks kept in scalar registers
+    // (a vector load in the rare literal path had turned every mask of the loop into a vector register pair), the guard band
+    // folded into the corner, the tiled index in six instructions, masks by scalar load: 17 vector instructions per tile.
+    // Measured and dropped: 8 tiles in flight (321 against 304), a per-region LDS window of the map loaded as aligned dwords
+    // (400-540: a rotated region's bounding box is twice its area -- more lines per tile than the gathers it replaces).
     __shared__ longlong2 corner[VBC_T / WAVE][WAVE];
-    uint32_t my_word = 0xFFFFFFFFu, my_fov_lo = 0, my_fov_hi = 0;
+    // The corner carries the guard band too: with 2^15 added, "within 2^-17 of a rounding boundary" reads low word < 2^16, and
+    // the high word is the cell wherever that test says the fast path holds.
+    uint32_t my_word = 0xFFFFFFFFu, my_tile = 0;
+    const int wave_first = first + wave * tpw;  // a wavefront takes tpw consecutive tiles of the list
     {
-        const int ti = first + lane * nw + wave;
-        long long tx = OX, ty = OY;
+        const int ti = wave_first + lane;
+        long long tx = OX + (1ll << 15), ty = OY + (1ll << 15);
         if (lane < tpw && ti < n_crop) {
             const uint32_t tile = k.crop_tiles[ti];
-            const unsigned long long f = k.crop_masks[ti];
-            my_fov_lo = (uint32_t)f;
-            my_fov_hi = (uint32_t)(f >> 32);
+            my_tile = tile;
             my_word = (tile >> 16) * (uint32_t)tb_n + (tile & 0xFFFFu);
             const long long ta8 = (long long)((tile >> 16) * 8u), tb8 = (long long)((tile & 0xFFFFu) * 8u);
             tx += ta8 * M00 + tb8 * M01;
@@ -119,37 +139,50 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    uint32_t res_lo = 0, res_hi = 0, unk_lo = 0, unk_hi = 0;  // lane q: the bitmap words of tile q
+    // the masks of a round's tiles come through the scalar cache (constant address space), in ONE load: the table is padded with zeros
+    typedef const unsigned long long __attribute__((address_space(4))) * const_u64_ptr;
     for (int it = 0; it < tpw; it += VBC_U) {
-        if (first + it * nw + wave >= n_crop) break;  // uniform
-        uint32_t idx[VBC_U], tile_w[VBC_U];
-        unsigned long long look[VBC_U], risky = 0ull;  // lane masks (scalar registers)
+        if (wave_first + it >= n_crop) break;  // uniform
+        const const_u64_ptr round = (const_u64_ptr)(uintptr_t)(k.crop_masks + (wave_first + it));
+        uint32_t idx[VBC_U];
+        int mm[VBC_U], nn[VBC_U];  // (TILED: the cell itself, for the class words of stamped cells)
+        unsigned long long look[VBC_U], fovs[VBC_U], risky = 0ull;  // lane masks (scalar registers)
 #pragma unroll
         for (int u = 0; u < VBC_U; u++) {
-            // (consecutive wavefronts take consecutive tiles: tile (it + u) of this wavefront is first + (it + u) * nw + wave)
-            const unsigned long long fov = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_fov_hi, it + u) << 32) |
-                                           (uint32_t)__builtin_amdgcn_readlane((int)my_fov_lo, it + u);  // 0 past the end of the list
-            tile_w[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_word, it + u);  // 0xFFFFFFFF past the end
+            const unsigned long long fov = round[u];  // 0 past the end of the list
+            fovs[u] = fov;
             const longlong2 T = corner[wave][it + u];
             const unsigned long long Fx = (unsigned long long)(T.x + Lx), Fy = (unsigned long long)(T.y + Ly);
             const int m = (int)(uint32_t)(Fx >> 32), n = (int)(uint32_t)(Fy >> 32);
-            const uint32_t G = 1u << 15;
-            risky |= fov & __ballot(((uint32_t)Fx + G < 2u * G) | ((uint32_t)Fy + G < 2u * G));
+            risky |= fov & __ballot(min((uint32_t)Fx, (uint32_t)Fy) < (1u << 16));
             look[u] = fov & __ballot((uint32_t)m < (uint32_t)Hg) & __ballot((uint32_t)n < (uint32_t)Wg);  // (two compares straight into lane masks)
-            idx[u] = min((uint32_t)(m * Wg + n), last_cell);  // any valid address for the lanes that do not look
+            if (TILED) {
+                mm[u] = m;
+                nn[u] = n;
+                idx[u] = min(crop_tiled_at(Wt, (uint32_t)m, (uint32_t)n), last_byte);
+            } else {
+                idx[u] = min((uint32_t)(m * Wg + n), last_cell);  // any valid address for the lanes that do not look
+            }
         }
         if (__builtin_expect(risky != 0ull || !fixed_ok, 0)) {  // somebody within 2^-17 of a rounding boundary: the reference's own chain
 #pragma unroll
             for (int u = 0; u < VBC_U; u++) {
-                const int ti = first + (it + u) * nw + wave;
-                const bool valid = ti < n_crop;
-                const uint32_t tile = k.crop_tiles[valid ? ti : 0];
-                const unsigned long long fov = valid ? k.crop_masks[ti] : 0ull;
+                // (tile and mask by readlane again, not from memory: a vector load here would turn every lane mask of the loop
+                // into a vector register pair and the mask algebra below into vector instructions)
+                const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, it + u);
                 const int a = (int)(tile >> 16) * 8 + da, b = (int)(tile & 0xFFFFu) * 8 + db;
                 double wx, wy;
                 tf_apply(vw, a * res, b * res, wx, wy);
                 const int m = w2m(wx, res), n = w2m(wy, res);
-                look[u] = fov & __ballot(((uint32_t)m < (uint32_t)Hg) & ((uint32_t)n < (uint32_t)Wg));
-                idx[u] = min((uint32_t)(m * Wg + n), last_cell);
+                look[u] = fovs[u] & __ballot((uint32_t)m < (uint32_t)Hg) & __ballot((uint32_t)n < (uint32_t)Wg);
+                if (TILED) {
+                    mm[u] = m;
+                    nn[u] = n;
+                    idx[u] = min(crop_tiled_at(Wt, (uint32_t)m, (uint32_t)n), last_byte);
+                } else {
+                    idx[u] = min((uint32_t)(m * Wg + n), last_cell);
+                }
             }
         }
         // free = >= 250 in this robot's private grid (agent.cpp:394-401)
@@ -160,19 +193,24 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
 #pragma unroll
             for (int u = 0; u < VBC_U; u++) {
                 o[u] = obs[idx[u]];
-                sg[u] = w.seg_tag[(cell0 + idx[u]) >> 6];
+                if (!TILED) sg[u] = w.seg_tag[(cell0 + idx[u]) >> 6];
             }
 #pragma unroll
             for (int u = 0; u < VBC_U; u++) {
-                free_cell[u] = __ballot(o[u] >= 250u);
-                stamped[u] = look[u] & __ballot(sg[u] == tag);
+                if (TILED) {
+                    free_cell[u] = __ballot(o[u] >= 128u);
+                    stamped[u] = look[u] & __ballot((o[u] & 127u) == ctag);
+                } else {
+                    free_cell[u] = __ballot(o[u] >= 250u);
+                    stamped[u] = look[u] & __ballot(sg[u] == tag);
+                }
                 any_stamped |= stamped[u];
             }
             if (any_stamped != 0ull) {  // near a robot or a pedestrian: class HIGH with nobody else's stamp of this step on it
 #pragma unroll
                 for (int u = 0; u < VBC_U; u++) {
                     if (stamped[u] == 0ull) continue;
-                    const uint32_t v = cls[idx[u]];
+                    const uint32_t v = cls[TILED ? min((uint32_t)(mm[u] * Wg + nn[u]), last_cell) : idx[u]];
                     const uint32_t x = (v & base_tag_mask) ^ base_tag_ours;
                     const unsigned long long f2 = __ballot((v == free_own) | (((x & 7u) == 0u) & (x != 0u)));
                     free_cell[u] = (free_cell[u] & ~stamped[u]) | (f2 & stamped[u]);
@@ -186,12 +224,19 @@ __global__ __launch_bounds__(VBC_T) void k_crop_big(DevWorld w, int chunks, int 
             for (int u = 0; u < VBC_U; u++) free_cell[u] = __ballot((v[u] == (uint32_t)CLS_HIGH) | (v[u] == free_own));
         }
 #pragma unroll
-        for (int u = 0; u < VBC_U; u++) {
-            if (lane == 0 && tile_w[u] != 0xFFFFFFFFu) {
-                plane0[tile_w[u]] = look[u] & ~free_cell[u];
-                if (want_unknown) plane1[tile_w[u]] = ~look[u];
+        for (int u = 0; u < VBC_U; u++) {  // the tile's words go to the lane that prepared it
+            const unsigned long long occ = look[u] & ~free_cell[u];
+            write_lane(res_lo, (uint32_t)occ, it + u);
+            write_lane(res_hi, (uint32_t)(occ >> 32), it + u);
+            if (want_unknown) {
+                write_lane(unk_lo, (uint32_t)~look[u], it + u);
+                write_lane(unk_hi, (uint32_t)(~look[u] >> 32), it + u);
             }
         }
+    }
+    if (my_word != 0xFFFFFFFFu) {  // one store instruction for the wavefront's tiles (consecutive words, mostly)
+        plane0[my_word] = ((unsigned long long)res_hi << 32) | res_lo;
+        if (want_unknown) plane1[my_word] = ((unsigned long long)unk_hi << 32) | unk_lo;
     }
 }
 

@@ -146,6 +146,14 @@ struct DevWorld {
     uint32_t* cell;          // composed layer: class byte | (owning robot or OWNER_MULTI) << 8, one gather per lookup
                              // (STAMP mode: base class | this step's stamp, and the three layers above do not exist)
     uint8_t* seg_tag;        // STAMP mode: [cells / 64] tag of the last step that stamped a cell of the segment
+    // STAMP mode with big views (view_big.h): everything k_crop_big needs of a cell in ONE byte, in 8 x 8-cell blocks so that a
+    // rotated 8 x 8 tile of the view touches 4-6 half cache lines instead of a dozen map rows: bit 7 = the obstacle map leaves
+    // the cell free (>= 250), bits 0-6 = crop tag (stamp tag % 127 + 1) of the last stamp on it, 0 = none.  Byte of cell (m, n) of world k:
+    // k * crop_ws + ((m / 8) * crop_wt + n / 8) * 64 + (m % 8) * 8 + n % 8.  Written wherever obs_map or a stamp is.
+    uint8_t* crop_map;               // null: k_crop_big goes by obs_map + seg_tag
+    unsigned long long crop_magic;   // ceil(2^40 / Wg): row of a cell index below 2^24 = (index * crop_magic) >> 40
+    uint32_t crop_wt, crop_ws;       // blocks per row of blocks; bytes per world
+    const uint8_t* static_crop;      // [crop_ws] crop_map of the static map (every reset starts from it)
     // class records travel by value in the kernel arguments: scalar loads, and their table pointers are known
     // to be global (no flat loads, no reloads after stores)
     RobotClassDev rc[RC_INLINE];
