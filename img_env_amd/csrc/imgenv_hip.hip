@@ -1532,15 +1532,22 @@ struct ObstInst {
     int shape, world;
 };
 template <bool POW2>
-__global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst, int stamp, const int* n_dev, int per_world) {
-    if (n_dev && (int)blockIdx.x >= *n_dev * per_world) return;  // device-side auto-reset: per_world instances for each finished world
-    const ObstInst o = inst[blockIdx.x];
+__global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst, int stamp, const int* n_dev, int per_world, int parts,
+                                                        ObstInst* keep, int* keep_valid) {
+    // parts workgroups share an obstacle's samples (a reset of a few worlds is a handful of obstacles: their latency is the launch's)
+    const int t = (int)blockIdx.x / parts, part = (int)blockIdx.x - t * parts;
+    if (n_dev && t >= *n_dev * per_world) return;  // device-side auto-reset: per_world instances for each finished world
+    const ObstInst o = inst[t];
+    if (keep && part == 0 && threadIdx.x == 0) {  // ... which remembers what each world now carries, for the next restore (k_restore_maps_dev)
+        keep[(size_t)o.world * per_world + (t % per_world)] = o;
+        keep_valid[o.world] = 1;
+    }
     const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
     uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)o.world * w.Gs;
     const double resolution = 0.01;
     const int nn = o.n1 - o.n0 + 1, total = (o.m1 - o.m0 + 1) * nn;
     const bool circle = o.shape == IMGENV_SHAPE_CIRCLE;
-    for (int q = threadIdx.x; q < total; q += blockDim.x) {
+    for (int q = part * (int)blockDim.x + (int)threadIdx.x; q < total; q += parts * (int)blockDim.x) {
         const int m = o.m0 + q / nn, n = o.n0 + q % nn;
         double px = m * resolution, py = n * resolution;
         if (circle) {
@@ -1892,8 +1899,8 @@ static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int w
         h->seg_max = 0;
     }
     if (n_inst) {
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0);
-        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0);
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0, 1, nullptr, nullptr);
+        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0, 1, nullptr, nullptr);
     }
     if (d.sharded) k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, h->pin_rob3);
     HIPCHK(hipGetLastError());
@@ -2388,12 +2395,13 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
     k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
     HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
     k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
-    if (h->pow2) k_restore_maps_dev<true><<<dim3((unsigned)W * MAP_BLOCKS), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, MAP_BLOCKS);
-    else k_restore_maps_dev<false><<<dim3((unsigned)W * MAP_BLOCKS), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, MAP_BLOCKS);
+    const int restore_blocks = W <= 4096 ? 4 * MAP_BLOCKS : MAP_BLOCKS;  // per world (most of the launch returns at once: few worlds finish in a step)
+    if (h->pow2) k_restore_maps_dev<true><<<dim3((unsigned)(W * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
+    else k_restore_maps_dev<false><<<dim3((unsigned)(W * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
     if (nob > 0) {
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
-        else k_reset_obstacles<false><<<dim3((unsigned)W * nob), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob);
-        k_keep_instances<<<dim3((unsigned)(W * nob + 255) / 256), dim3(256), 0, st>>>(c);
+        const int parts = W * nob <= 16384 ? 4 : 1;
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)(W * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
+        else k_reset_obstacles<false><<<dim3((unsigned)(W * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
     }
     HIPCHK(hipGetLastError());
     if (h->stamp) {
@@ -2413,7 +2421,7 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
     d.act_n_dev = c.fin_n;
     d.ptraj = h->d_traj;
     d.traj_cap = h->traj_cap;
-    h->launches += 5;
+    h->launches += 4;
     const int rc = launch_views(h, st, 1);
     set_active(h, nullptr, 0);
     d.act_n_dev = nullptr;

@@ -741,11 +741,3 @@ __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c
     }
 }
 
-// the obstacles the finished worlds now carry (for the next restore), once they have been drawn
-__global__ void k_keep_instances(SpawnDev c) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, nob = c.n_obstacles;
-    if (t >= *c.fin_n * nob) return;
-    const int q = t / nob, e = t - q * nob, world = c.fin_list[q];
-    c.w_inst[(size_t)world * nob + e] = c.inst_out[(size_t)q * nob + e];
-    if (e == 0) c.w_inst_valid[world] = 1;
-}
