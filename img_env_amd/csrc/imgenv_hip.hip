@@ -616,7 +616,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
 
     // grids (one copy per world)
     TRY(dev_alloc(h, &h->d_obs_map, Gp));
-    for (int k = 0; k < W; k++) HIPCHK_H(hipMemcpy(h->d_obs_map + (size_t)k * h->Gs, static_map, G, hipMemcpyHostToDevice));
+    HIPCHK_H(hipMemcpy(h->d_obs_map, static_map, G, hipMemcpyHostToDevice));
+    for (size_t filled = 1; filled < (size_t)W; filled *= 2)  // the other worlds' copies: log2(W) device copies instead of W uploads
+        HIPCHK_H(hipMemcpy(h->d_obs_map + filled * h->Gs, h->d_obs_map, std::min(filled, (size_t)W - filled) * h->Gs, hipMemcpyDeviceToDevice));
     TRY(dev_alloc(h, &h->d_static_map, (G + 15) & ~(size_t)15));
     HIPCHK_H(hipMemcpy(h->d_static_map, static_map, G, hipMemcpyHostToDevice));
     TRY(dev_alloc(h, &h->d_world_epoch, W));
@@ -764,7 +766,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             HIPCHK_H(hipMemcpy(sc, tiled.data(), tiled.size(), hipMemcpyHostToDevice));
             d.static_crop = sc;
             TRY(dev_alloc(h, &d.crop_map, (size_t)d.crop_ws * W));
-            for (int k = 0; k < W; k++) HIPCHK_H(hipMemcpy(d.crop_map + (size_t)k * d.crop_ws, sc, (size_t)d.crop_ws, hipMemcpyDeviceToDevice));
+            HIPCHK_H(hipMemcpy(d.crop_map, sc, (size_t)d.crop_ws, hipMemcpyDeviceToDevice));
+            for (size_t filled = 1; filled < (size_t)W; filled *= 2)
+                HIPCHK_H(hipMemcpy(d.crop_map + filled * d.crop_ws, d.crop_map, std::min(filled, (size_t)W - filled) * d.crop_ws, hipMemcpyDeviceToDevice));
         }
         std::vector<BigClassDev> bc(h->rcls.size());
         int max_crop = 1;
