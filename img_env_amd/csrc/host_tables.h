@@ -82,6 +82,10 @@ static ViewGeom make_view_geom(const imgenv_cfg& c) {
     return g;
 }
 
+// a bit of the crop bitmap as k_beams_big wants it: the byte address of its 32-bit word in bits 5.., the bit in bits 0-4 -- one
+// shift gives the LDS address, v_bfe_u32 takes the bit number from the entry's low bits as it is
+static inline uint32_t big_bit_entry(uint32_t bit_address) { return ((bit_address >> 5) << 7) | (bit_address & 31u); }
+
 struct RobotClassHost {
     int shape;
     float size[4], sensor[2];
@@ -95,7 +99,7 @@ struct RobotClassHost {
     // big views (csrc/view_big.h).  The cropped view lives as a bitmap in 8 x 8 tiles: bit address of view cell (a, b) =
     // ((a / 8) * big_tb + b / 8) * 64 + (a % 8) * 8 + b % 8, so that one wavefront crops one tile and stores one 64-bit ballot
     int big_ta = 0, big_tb = 0;       // tiles per column / per row
-    std::vector<uint32_t> big_cells;  // [ray_kpad / 4][ray_stride][4] bit address of step k of beam b; past the ray's end: the always-free bit behind the bitmap
+    std::vector<uint32_t> big_cells;  // [ray_kpad / 4][ray_stride][4] bitmap bit of step k of beam b as (byte address of its 32-bit word) << 5 | bit (big_bit_entry); past the ray's end: the always-free bit behind the bitmap
     std::vector<uint16_t> ray_end;    // [ray_maxlen][ray_stride] last step behind step k of beam b that shares its row or column (k itself if none)
     std::vector<uint32_t> big_inv;    // [NC][2] rays through a view cell: first entry of inv_ent, count
     std::vector<uint32_t> crop_tiles; // tiles with at least one cell inside the field of view: ta << 16 | tb ...
@@ -240,7 +244,7 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     k.big_tb = (Wv + 7) / 8;
     if (k.big) {
         const uint32_t free_bit = (uint32_t)k.big_ta * (uint32_t)k.big_tb * 64u;  // the word behind the bitmap stays zero
-        k.big_cells.assign((size_t)k.ray_kpad * k.ray_stride, free_bit);  // k_beams_big walks 32 steps at a time
+        k.big_cells.assign((size_t)k.ray_kpad * k.ray_stride, big_bit_entry(free_bit));  // k_beams_big walks 32 steps at a time
         k.ray_rows.assign(8, 0);
         k.ray_dist.assign((size_t)k.ray_maxlen * k.ray_stride, 6.0f);
         k.ray_end.assign((size_t)k.ray_maxlen * k.ray_stride, 0);
@@ -309,7 +313,7 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
         for (size_t q = 0; q < cells[b].size(); q++) {
             if (k.big) {
                 const uint32_t a = cells[b][q] / (uint32_t)Wv, bb = cells[b][q] % (uint32_t)Wv;
-                k.big_cells[((q / 4) * (size_t)k.ray_stride + b) * 4 + q % 4] = ((a >> 3) * (uint32_t)k.big_tb + (bb >> 3)) * 64u + (a & 7u) * 8u + (bb & 7u);
+                k.big_cells[((q / 4) * (size_t)k.ray_stride + b) * 4 + q % 4] = big_bit_entry(((a >> 3) * (uint32_t)k.big_tb + (bb >> 3)) * 64u + (a & 7u) * 8u + (bb & 7u));
                 k.ray_dist[q * k.ray_stride + b] = dists[b][q];
             } else {
                 k.ray_rows[((q / 8) * (size_t)k.ray_stride + b) * 8 + (q % 8)] = (uint16_t)cells[b][q];

@@ -291,10 +291,10 @@ __device__ __forceinline__ uint32_t big_cell_value(const RobotClassDev& rc, cons
 // contiguous), one LDS bit lookup per step; a wavefront leaves as soon as all its beams have hit or ended.
 template <bool POW2, bool STAMP, bool LDSBM>
 __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t best_sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the bitmap at LDS address 0 (a path entry >> 5 IS its word's address), one word behind it
     const int tid = threadIdx.x;
     const int t = (int)blockIdx.x / quarters, quarter = (int)blockIdx.x - t * quarters;
+    uint32_t& best_sh = *(uint32_t*)(smem + (LDSBM ? 4 * (size_t)w.big_words : 0));
     if (t >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, t);
     const int B = w.B;
@@ -362,19 +362,22 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
     const int b = quarter * VBB_T + tid, bb = min(b, B - 1);
     const int len = b < B ? (int)rc.ray_len[bb] : 0;
     uint32_t hk = 0xFFFFFFFFu;
-    const uint4* col = (const uint4*)k.cells + bb;  // [kpad / 4][stride] four steps per entry
+    const uint4* col = (const uint4*)k.cells + bb;  // [kpad / 4][stride] four steps per entry (host_tables.h big_bit_entry)
     for (int k0 = 0; k0 < kpad; k0 += 32) {
         uint4 a4[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) a4[j] = col[(size_t)((k0 >> 2) + j) * stride];  // padded steps point at the free bit
-        uint32_t m = 0;
+        uint32_t m = 0;  // step k0 + s ends up in bit 31 - s: three vector instructions a step (address, v_bfe_u32, v_lshl_or_b32)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t ad[4] = {a4[j].x, a4[j].y, a4[j].z, a4[j].w};
 #pragma unroll
-            for (int q = 0; q < 4; q++) m |= ((plane0[ad[q] >> 5] >> (ad[q] & 31u)) & 1u) << (4 * j + q);
+            for (int q = 0; q < 4; q++) {
+                const uint32_t word = *(const uint32_t*)((const unsigned char*)plane0 + (ad[q] >> 5));
+                m = (m << 1) | __builtin_amdgcn_ubfe(word, ad[q], 1u);
+            }
         }
-        if (m != 0u && hk == 0xFFFFFFFFu) hk = (uint32_t)k0 + (uint32_t)__builtin_ctz(m);
+        if (m != 0u && hk == 0xFFFFFFFFu) hk = (uint32_t)k0 + (uint32_t)__builtin_clz(m);
         if (__all((hk != 0xFFFFFFFFu) | (k0 + 32 >= len))) break;
     }
     if (b < B) {

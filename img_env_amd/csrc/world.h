@@ -72,7 +72,7 @@ struct BigClassDev {
     int n_crop;                  // tiles that touch the field of view
     const uint32_t* crop_tiles;  // [n_crop] ta << 16 | tb
     const uint64_t* crop_masks;  // [n_crop] the tile's cells inside the field of view
-    const uint32_t* cells;       // [ray_kpad / 4][ray_stride][4] bit address of steps 4c..4c+3 of beam b (past the end: the free bit behind the bitmap)
+    const uint32_t* cells;       // [ray_kpad / 4][ray_stride][4] bitmap bit of steps 4c..4c+3 of beam b as word byte address << 5 | bit (past the end: the free bit behind the bitmap)
     const uint16_t* ray_end;     // [ray_maxlen][ray_stride] last step behind (k, b) in the row or column of its cell
     const uint2* inv;            // [Hv*Wv] rays through a view cell: {first entry of inv_ent, count}
     // the 4 x 4 source cells of every pixel of a shrunk sensor_map (host_tables.h build_big_taps), [16][img_h * img_w] each
