@@ -33,3 +33,26 @@ def test_tables_reproduce_the_sequential_laser_map(checker, view_w, view_h, res,
     out = subprocess.run([checker, str(view_w), str(view_h), str(res), str(beams), str(a0), str(a1), "7"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+@pytest.fixture(scope="module")
+def big_checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bvt") / "big_view_tables_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "big_view_tables_check.cpp"), "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("view_w,view_h,res,beams,a0,a1,map_h,map_w", [
+    (6, 6, 0.015, 1000, -1.5708, 1.5708, 733, 733),  # the reference's shipped test.yaml: 400 x 400 cells, 1000 beams, 733 x 733 map
+    (12, 12, 0.25, 360, -1.5708, 1.5708, 400, 400),  # the headline view through the tiled kernels (IMGENV_FLAG_VIEW_TILED)
+    (11.25, 12.5, 0.25, 200, -3.14159, 3.14159, 61, 203),  # 50 x 45 cells (not multiples of 8), full circle; an odd map
+    (5, 7, 0.25, 33, -0.7, 2.1, 9, 4100),            # a small odd view; a map wider than 4096 cells
+])
+def test_big_view_tables_and_crop_map_indices(big_checker, view_w, view_h, res, beams, a0, a1, map_h, map_w):
+    """tests/host/big_view_tables_check.cpp: path table (word address << 5 | bit entries) against the per-cell ray lists, crop tile
+    list against the field of view, and crop_map's index arithmetic (blocked index in its six-instruction form, row of a cell
+    index by multiply-shift) against their definitions"""
+    out = subprocess.run([big_checker, str(view_w), str(view_h), str(res), str(beams), str(a0), str(a1), str(map_h), str(map_w)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
