@@ -137,6 +137,52 @@ __device__ __forceinline__ void stamp_ped(const DevWorld& w, size_t c, uint32_t 
         old = seen;
     }
 }
+// The same two merges for SEVERAL cells of one lane at once: the words are read together, the first compare-and-swaps go out
+// together, and only a lane that lost a race (another raster stamped the same cell in between) falls back to the loops above.
+// A raster that stamps its cells one after the other pays two memory round trips per cell -- in a reset of a few worlds, or
+// with a few hundred robots in a launch, that chain of round trips IS the kernel's duration.
+template <int U>
+__device__ __forceinline__ void stamp_robot_batch(const DevWorld& w, const uint32_t (&c)[U], const bool (&go)[U], uint32_t i, uint32_t tag, int world) {
+    uint32_t old[U], nw[U], seen[U];
+    bool cas[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) old[u] = go[u] ? w.cell[c[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t kind = stamp_is_current(old[u], tag) ? (old[u] >> STAMP_KIND_SHIFT) & 3u : 0u;
+        cas[u] = go[u];
+        nw[u] = 0;
+        if (kind == 0u) nw[u] = (old[u] & 7u) | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (i << STAMP_OWNER_SHIFT);
+        else if (kind == STAMP_ONE && (old[u] >> STAMP_OWNER_SHIFT) != i) nw[u] = (old[u] & 7u) | (STAMP_MANY << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT);
+        else cas[u] = false;  // this robot already, several already, or a pedestrian
+        if (go[u]) w.seg_tag[c[u] >> 6] = (uint8_t)tag;
+        seen[u] = cas[u] ? atomicCAS(w.cell + c[u], old[u], nw[u]) : old[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (!cas[u]) continue;
+        if (seen[u] != old[u]) stamp_robot(w, c[u], i, tag, world);  // lost a race: from the top
+        else if (!stamp_is_current(old[u], tag)) crop_mark(w, c[u], world, old[u] & 7u, tag);
+    }
+}
+// (v: the words as just read -- the caller has looked at their base classes already)
+template <int U>
+__device__ __forceinline__ void stamp_ped_batch(const DevWorld& w, const uint32_t (&c)[U], const bool (&go)[U], const uint32_t (&v)[U], uint32_t tag, int world) {
+    uint32_t seen[U];
+    bool cas[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        cas[u] = go[u] && !(stamp_is_current(v[u], tag) && ((v[u] >> STAMP_KIND_SHIFT) & 3u) == STAMP_PED);
+        if (go[u]) w.seg_tag[c[u] >> 6] = (uint8_t)tag;
+        seen[u] = cas[u] ? atomicCAS(w.cell + c[u], v[u], (v[u] & 7u) | (STAMP_PED << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT)) : v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (!cas[u]) continue;
+        if (seen[u] != v[u]) stamp_ped(w, c[u], seen[u], tag, world);
+        else if (!stamp_is_current(v[u], tag)) crop_mark(w, c[u], world, v[u] & 7u, tag);
+    }
+}
 // value of a cell in robots_[self].global_map_ as a class code 0..4 (img_env.cpp:594-629), from the layer word v: a
 // pedestrian reads as 1; another robot (or several) as 2 unless the map already holds 0 / 1 / 2 there (agent.cpp:315-322)
 template <bool STAMP>
@@ -818,6 +864,32 @@ __device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t 
     }
 }
 
+// PED_BATCH rounds of samples at once (see stamp_ped_batch): the words of all rounds are read together
+#define PED_BATCH 4
+template <bool STAMP>
+__device__ __forceinline__ void ped_samples(const DevWorld& w, const bool (&in)[PED_BATCH], const uint32_t (&c)[PED_BATCH], int rule, int lane, int world) {
+    if (!STAMP) {
+#pragma unroll
+        for (int u = 0; u < PED_BATCH; u++) ped_sample<false>(w, in[u], c[u], rule, lane, world);
+        return;
+    }
+    bool last[PED_BATCH], go[PED_BATCH];
+    uint32_t v[PED_BATCH];
+#pragma unroll
+    for (int u = 0; u < PED_BATCH; u++) {  // the last lane of each run of equal cells stamps (ped_sample)
+        const uint32_t ci = in[u] ? c[u] : 0xFFFFFFFFu;
+        const uint32_t next = (uint32_t)__shfl_down((int)ci, 1);
+        last[u] = in[u] && (lane == WAVE - 1 || next != ci);
+        v[u] = last[u] ? w.cell[c[u]] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < PED_BATCH; u++) {
+        const uint32_t base = v[u] & 7u;
+        go[u] = last[u] && (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW));
+    }
+    stamp_ped_batch<PED_BATCH>(w, c, go, v, stamp_tag_of(w), world);
+}
+
 template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
@@ -827,14 +899,20 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
     const int lane = lane_id(), tid = threadIdx.x;
     const double res = w.res, inv = w.inv_res;
     if (k.shape == IMGENV_SHAPE_CIRCLE) {
-        for (int q0 = 0; q0 < k.n_bbox; q0 += NT) {  // wave-uniform trip count (lane shuffles inside)
-            const int q = min(q0 + tid, k.n_bbox - 1);
-            double wx, wy;
-            tf_apply(bw, k.bx[q], k.by[q], wx, wy);
-            int m, n;
-            w2m_pair<POW2>(wx, wy, res, inv, m, n);
-            const bool in = q0 + tid < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
-            ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), 0, lane, world);
+        for (int q0 = 0; q0 < k.n_bbox; q0 += NT * PED_BATCH) {  // wave-uniform trip count (lane shuffles inside)
+            uint32_t cc[PED_BATCH];
+            bool in[PED_BATCH];
+#pragma unroll
+            for (int u = 0; u < PED_BATCH; u++) {
+                const int q = min(q0 + u * NT + tid, k.n_bbox - 1);
+                double wx, wy;
+                tf_apply(bw, k.bx[q], k.by[q], wx, wy);
+                int m, n;
+                w2m_pair<POW2>(wx, wy, res, inv, m, n);
+                in[u] = q0 + u * NT + tid < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+                cc[u] = cell0 + (uint32_t)(m * w.Wg + n);
+            }
+            ped_samples<STAMP>(w, in, cc, 0, lane, world);
         }
     } else if (k.shape == IMGENV_SHAPE_LEG) {
         for (int leg = 0; leg < 2; leg++) {
@@ -845,15 +923,21 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
             const int n_s = leg == 0 ? k.n_left : k.n_right;
             const double* sx = leg == 0 ? k.lx : k.rx;
             const double* sy = leg == 0 ? k.ly : k.ry;
-            for (int q0 = 0; q0 < n_s; q0 += NT) {
-                const int q = min(q0 + tid, n_s - 1);
-                double bx, by, wx, wy;
-                tf_apply(lb, sx[q], sy[q], bx, by);
-                tf_apply(bw, bx, by, wx, wy);
-                int m, n;
-                w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                const bool in = q0 + tid < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
-                ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), leg + 1, lane, world);
+            for (int q0 = 0; q0 < n_s; q0 += NT * PED_BATCH) {
+                uint32_t cc[PED_BATCH];
+                bool in[PED_BATCH];
+#pragma unroll
+                for (int u = 0; u < PED_BATCH; u++) {
+                    const int q = min(q0 + u * NT + tid, n_s - 1);
+                    double bx, by, wx, wy;
+                    tf_apply(lb, sx[q], sy[q], bx, by);
+                    tf_apply(bw, bx, by, wx, wy);
+                    int m, n;
+                    w2m_pair<POW2>(wx, wy, res, inv, m, n);
+                    in[u] = q0 + u * NT + tid < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+                    cc[u] = cell0 + (uint32_t)(m * w.Wg + n);
+                }
+                ped_samples<STAMP>(w, in, cc, leg + 1, lane, world);
             }
         }
     }
@@ -903,13 +987,24 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         const int n_cached = w.fp_n[l];
         if (n_cached >= 0 && cached[0] == r[0] && cached[1] == r[1] && cached[2] == r[2]) {
             const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
-            for (int e = tid; e < n_cached; e += NT) {
-                const uint32_t c = list[e].x;
+            for (int e0 = 0; e0 < n_cached; e0 += NT * 4) {
+                uint32_t c[4];
+                bool go[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * NT + tid;
+                    go[u] = e < n_cached;
+                    c[u] = go[u] ? list[e].x : 0u;
+                }
                 if (STAMP) {
-                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w), world);
+                    stamp_robot_batch<4>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
                 } else {
-                    atomicMin(&w.own_lo[c], id);
-                    atomicMax(&w.own_hi[c], id);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (go[u]) {
+                            atomicMin(&w.own_lo[c[u]], id);
+                            atomicMax(&w.own_hi[c[u]], id);
+                        }
                 }
             }
             return;
@@ -963,35 +1058,58 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         }
     }
     if (use_box) {
+        uint32_t* n_sh = stray_flag + 1;  // NW > 1: entries of the cell list so far
         if (NW > 1 && stray) *stray_flag = 1;
+        if (NW > 1 && tid == 0) *n_sh = 0;
         __syncthreads();
-        if (NW > 1 && tid >= WAVE) return;  // the first wavefront turns the box into stamps and the cell list
+        // every wavefront turns its share of the box into stamps and list entries, four box cells per lane at a time (the words
+        // of all four are read together and their compare-and-swaps go out together: stamp_robot_batch)
         uint2* list = w.fp_cells + (size_t)(local ? l : 0) * w.fp_cap;
         int n_out = 0;
-        for (int b0 = 0; b0 < ncell; b0 += WAVE) {  // wave-uniform trip count (ballot inside)
-            const int b = b0 + lane;
-            const uint32_t last = b < ncell ? box[b] : 0u;
-            uint32_t c = 0;
-            if (last) {
+        for (int b0 = 0; b0 < ncell; b0 += NT * 4) {  // wave-uniform trip count (ballots inside)
+            uint32_t c[4], last[4];
+            bool go[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int b = b0 + u * NT + tid;
+                last[u] = b < ncell ? box[b] : 0u;
+                go[u] = last[u] != 0u;
                 const int bm = b / side;
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
-                c = cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n;
-                if (STAMP) {
-                    stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w), world);
-                } else {
-                    atomicMin(&w.own_lo[c], id);
-                    atomicMax(&w.own_hi[c], id);
-                }
+                c[u] = go[u] ? cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n : 0u;
+            }
+            if (STAMP) {
+                stamp_robot_batch<4>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (go[u]) {
+                        atomicMin(&w.own_lo[c[u]], id);
+                        atomicMax(&w.own_hi[c[u]], id);
+                    }
             }
             if (local) {
-                const unsigned long long mask = __ballot(last != 0);
-                const int pos = n_out + __popcll(mask & ((1ull << lane) - 1ull));
-                if (last && pos < w.fp_cap) list[pos] = make_uint2(c, last);
-                n_out += __popcll(mask);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned long long mask = __ballot(go[u]);
+                    const int cnt = __popcll(mask);
+                    int base = n_out;
+                    if (NW > 1) {  // (the list's order does not matter: k_view takes a maximum over it)
+                        if (lane == 0 && cnt) base = (int)atomicAdd(n_sh, (uint32_t)cnt);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                    }
+                    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (go[u] && pos < w.fp_cap) list[pos] = make_uint2(c[u], last[u]);
+                    n_out += cnt;
+                }
             }
         }
+        if (NW > 1) {
+            __syncthreads();
+            n_out = (int)*n_sh;
+        }
         const bool any_stray = NW > 1 ? *stray_flag != 0 : __any(stray);
-        if (local && lane == 0) w.fp_n[l] = (n_out <= w.fp_cap && !any_stray) ? n_out : -1;
+        if (local && tid == 0) w.fp_n[l] = (n_out <= w.fp_cap && !any_stray) ? n_out : -1;
     } else if (local && tid == 0) {
         w.fp_n[l] = -1;
     }
@@ -1000,7 +1118,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
 // NW: wavefronts per workgroup.  1 when a launch fills the machine; 4 in small launches (a reset of a few worlds), where the
 // 15 rounds of footprint samples of one wavefront are pure latency.
 template <bool POW2, bool STAMP, int NW>
-__global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel) {
+__global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel, int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
@@ -1008,12 +1126,15 @@ __global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel) 
     WAVE_T0();
     if (STAMP && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // tail_group tallies this step's dones (k_compose does this otherwise)
     const Region g = grid_region(w);
-    if (b < act_count_g(w)) {
+    // split > 0 (small launches): the first `split` blocks draw robots, the ones behind them pedestrians -- a robot and a
+    // pedestrian one after the other in the same block is twice one block's chain of memory round trips
+    if (b < act_count_g(w) && (split == 0 || b < split)) {
         const int i = act_member(w, w.Rw, b);
         raster_robot<POW2, STAMP, NW>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
     }
-    if (b < act_count_p(w)) {
-        const int j = act_member(w, w.Pw, b);
+    const int bp = split > 0 ? b - split : b;
+    if (bp >= 0 && bp < act_count_p(w)) {
+        const int j = act_member(w, w.Pw, bp);
         raster_ped<POW2, STAMP, NW>(w, j, w.pc[w.ped_cls[j]], g);
     }
     if (b < w.RL) WAVE_DONE(2);
