@@ -149,6 +149,10 @@ __device__ __forceinline__ void stamp_robot_batch(const DevWorld& w, const uint3
     for (int u = 0; u < U; u++) old[u] = go[u] ? w.cell[c[u]] : 0u;
 #pragma unroll
     for (int u = 0; u < U; u++) {
+        cas[u] = false;
+        seen[u] = 0u;
+        nw[u] = 0u;
+        if (!__any(go[u])) continue;  // (a round nobody takes part in)
         const uint32_t kind = stamp_is_current(old[u], tag) ? (old[u] >> STAMP_KIND_SHIFT) & 3u : 0u;
         cas[u] = go[u];
         nw[u] = 0;
@@ -864,46 +868,50 @@ __device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t 
     }
 }
 
-// PED_BATCH rounds of samples at once (see stamp_ped_batch): the words of all rounds are read together
-#define PED_BATCH 4
-template <bool STAMP>
-__device__ __forceinline__ void ped_samples(const DevWorld& w, const bool (&in)[PED_BATCH], const uint32_t (&c)[PED_BATCH], int rule, int lane, int world) {
+// PB rounds of samples at once (see stamp_ped_batch): the words of all rounds are read together.  Four in small launches, where a
+// block's chain of round trips is the launch's duration; one where the launch fills the chip (measured: batches cost 10 % there)
+template <bool STAMP, int PB>
+__device__ __forceinline__ void ped_samples(const DevWorld& w, const bool (&in)[PB], const uint32_t (&c)[PB], int rule, int lane, int world) {
     if (!STAMP) {
 #pragma unroll
-        for (int u = 0; u < PED_BATCH; u++) ped_sample<false>(w, in[u], c[u], rule, lane, world);
+        for (int u = 0; u < PB; u++) ped_sample<false>(w, in[u], c[u], rule, lane, world);
         return;
     }
-    bool last[PED_BATCH], go[PED_BATCH];
-    uint32_t v[PED_BATCH];
+    bool last[PB], go[PB];
+    uint32_t v[PB];
 #pragma unroll
-    for (int u = 0; u < PED_BATCH; u++) {  // the last lane of each run of equal cells stamps (ped_sample)
+    for (int u = 0; u < PB; u++) {  // the last lane of each run of equal cells stamps (ped_sample)
         const uint32_t ci = in[u] ? c[u] : 0xFFFFFFFFu;
         const uint32_t next = (uint32_t)__shfl_down((int)ci, 1);
         last[u] = in[u] && (lane == WAVE - 1 || next != ci);
         v[u] = last[u] ? w.cell[c[u]] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < PED_BATCH; u++) {
+    for (int u = 0; u < PB; u++) {
         const uint32_t base = v[u] & 7u;
         go[u] = last[u] && (rule == 2 || (rule == 1 ? base != CLS_STATIC : base >= CLS_LOW));
     }
-    stamp_ped_batch<PED_BATCH>(w, c, go, v, stamp_tag_of(w), world);
+    stamp_ped_batch<PB>(w, c, go, v, stamp_tag_of(w), world);
 }
 
 template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
+    constexpr int PB = NW > 1 ? 4 : 1;
     const int world = world_of_ped(w, j);
     const uint32_t cell0 = (uint32_t)world * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id(), tid = threadIdx.x;
     const double res = w.res, inv = w.inv_res;
     if (k.shape == IMGENV_SHAPE_CIRCLE) {
-        for (int q0 = 0; q0 < k.n_bbox; q0 += NT * PED_BATCH) {  // wave-uniform trip count (lane shuffles inside)
-            uint32_t cc[PED_BATCH];
-            bool in[PED_BATCH];
+        for (int q0 = 0; q0 < k.n_bbox; q0 += NT * PB) {  // wave-uniform trip count (lane shuffles inside)
+            uint32_t cc[PB];
+            bool in[PB];
 #pragma unroll
-            for (int u = 0; u < PED_BATCH; u++) {
+            for (int u = 0; u < PB; u++) {
+                in[u] = false;
+                cc[u] = 0u;
+                if (q0 + u * NT >= k.n_bbox) continue;  // uniform
                 const int q = min(q0 + u * NT + tid, k.n_bbox - 1);
                 double wx, wy;
                 tf_apply(bw, k.bx[q], k.by[q], wx, wy);
@@ -912,7 +920,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
                 in[u] = q0 + u * NT + tid < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
                 cc[u] = cell0 + (uint32_t)(m * w.Wg + n);
             }
-            ped_samples<STAMP>(w, in, cc, 0, lane, world);
+            ped_samples<STAMP, PB>(w, in, cc, 0, lane, world);
         }
     } else if (k.shape == IMGENV_SHAPE_LEG) {
         for (int leg = 0; leg < 2; leg++) {
@@ -923,11 +931,14 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
             const int n_s = leg == 0 ? k.n_left : k.n_right;
             const double* sx = leg == 0 ? k.lx : k.rx;
             const double* sy = leg == 0 ? k.ly : k.ry;
-            for (int q0 = 0; q0 < n_s; q0 += NT * PED_BATCH) {
-                uint32_t cc[PED_BATCH];
-                bool in[PED_BATCH];
+            for (int q0 = 0; q0 < n_s; q0 += NT * PB) {
+                uint32_t cc[PB];
+                bool in[PB];
 #pragma unroll
-                for (int u = 0; u < PED_BATCH; u++) {
+                for (int u = 0; u < PB; u++) {
+                    in[u] = false;
+                    cc[u] = 0u;
+                    if (q0 + u * NT >= n_s) continue;  // uniform
                     const int q = min(q0 + u * NT + tid, n_s - 1);
                     double bx, by, wx, wy;
                     tf_apply(lb, sx[q], sy[q], bx, by);
@@ -937,7 +948,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
                     in[u] = q0 + u * NT + tid < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
                     cc[u] = cell0 + (uint32_t)(m * w.Wg + n);
                 }
-                ped_samples<STAMP>(w, in, cc, leg + 1, lane, world);
+                ped_samples<STAMP, PB>(w, in, cc, leg + 1, lane, world);
             }
         }
     }
@@ -957,6 +968,7 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
 template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const RobotClassDev& k, uint32_t* box, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
+    constexpr int UB = NW > 1 ? 4 : 1;   // cells a lane stamps at once (stamp_robot_batch)
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id(), tid = threadIdx.x;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
@@ -987,20 +999,21 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         const int n_cached = w.fp_n[l];
         if (n_cached >= 0 && cached[0] == r[0] && cached[1] == r[1] && cached[2] == r[2]) {
             const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
-            for (int e0 = 0; e0 < n_cached; e0 += NT * 4) {
-                uint32_t c[4];
-                bool go[4];
+            for (int e0 = 0; e0 < n_cached; e0 += NT * UB) {
+                uint32_t c[UB];
+                bool go[UB];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < UB; u++) {
                     const int e = e0 + u * NT + tid;
                     go[u] = e < n_cached;
                     c[u] = go[u] ? list[e].x : 0u;
                 }
+                // (rounds past the end of a short list cost a few predicated-off instructions each)
                 if (STAMP) {
-                    stamp_robot_batch<4>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
+                    stamp_robot_batch<UB>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < UB; u++)
                         if (go[u]) {
                             atomicMin(&w.own_lo[c[u]], id);
                             atomicMax(&w.own_hi[c[u]], id);
@@ -1066,12 +1079,16 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         // of all four are read together and their compare-and-swaps go out together: stamp_robot_batch)
         uint2* list = w.fp_cells + (size_t)(local ? l : 0) * w.fp_cap;
         int n_out = 0;
-        for (int b0 = 0; b0 < ncell; b0 += NT * 4) {  // wave-uniform trip count (ballots inside)
-            uint32_t c[4], last[4];
-            bool go[4];
+        for (int b0 = 0; b0 < ncell; b0 += NT * UB) {  // wave-uniform trip count (ballots inside)
+            uint32_t c[UB], last[UB];
+            bool go[UB];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < UB; u++) {
                 const int b = b0 + u * NT + tid;
+                last[u] = 0u;
+                go[u] = false;
+                c[u] = 0u;
+                if (b0 + u * NT >= ncell) continue;  // uniform: a small box is one round
                 last[u] = b < ncell ? box[b] : 0u;
                 go[u] = last[u] != 0u;
                 const int bm = b / side;
@@ -1079,10 +1096,10 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 c[u] = go[u] ? cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n : 0u;
             }
             if (STAMP) {
-                stamp_robot_batch<4>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
+                stamp_robot_batch<UB>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < UB; u++)
                     if (go[u]) {
                         atomicMin(&w.own_lo[c[u]], id);
                         atomicMax(&w.own_hi[c[u]], id);
@@ -1090,7 +1107,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             }
             if (local) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < UB; u++) {
                     const unsigned long long mask = __ballot(go[u]);
                     const int cnt = __popcll(mask);
                     int base = n_out;
