@@ -2451,7 +2451,7 @@ extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, c
     if (!h->d_act_list) RTRY(dev_alloc(h, &h->d_act_list, (size_t)h->W));
     {   // how many worlds the last steps reset (page-locked, written by k_finished_dev; stale by a step or two: a hint only)
         const int last = h->finished_host[0];
-        h->act_hint = std::max(8, 4 * std::max(last, 0)) * std::max(std::max(h->Rw, h->Pw), 1);
+        h->act_hint = std::max(8, 2 * std::max(last, 0)) * std::max(std::max(h->Rw, h->Pw), 1);  // (twice the last count: with four times, 64 worlds of 4 pedestrians sat ON the 1024 threshold and flipped between the kernel variants)
     }
     // The chain as a graph: captured on the third call (the first ones have loaded every kernel), replayed from then on --
     // except while per-kernel timing is on and on the steps that sweep the stamped class layer (every STAMP_TAGS-th)
