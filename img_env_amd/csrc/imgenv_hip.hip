@@ -1294,9 +1294,14 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
                         // beams) -> the shrunk sensor_map (a thread per pixel) -> the full view, only where it is an output
         const int quarters = std::max(1, (d.B + VBB_T - 1) / VBB_T), tap_chunks = (d.img_w * d.img_h + VBT_T - 1) / VBT_T;
         const bool full = d.keep_view_maps || !d.resize;
-        // tiles per wavefront: 8 while the launch is small (a reset of a few worlds: every robot on ~40 workgroups), 32 once
-        // there are enough robots to fill the chip anyway (the dispatcher starts about one workgroup per nanosecond)
-        const int tpw = n_l >= 512 ? 32 : 8, crop_chunks = (h->big_max_crop + (VBC_T / WAVE) * tpw - 1) / ((VBC_T / WAVE) * tpw);
+        // tiles per wavefront: 8 while the launch is a handful of robots (a reset of a few worlds: every robot on ~40 workgroups), 32-64
+        // once there are enough robots to fill the chip anyway
+        // (measured again after the kernel's gathers stopped binding it: a wavefront's prologue -- pose, fixed-point terms, its tiles'
+        // corner records -- is worth ~8 tiles, so even 256 robots want 32 tiles per wavefront: 36 -> 29 us; 2048 robots 64: 152 -> 133.
+        // Handing the fixed-point terms over from the robot's raster instead of recomputing them per wavefront was measured too:
+        // 155 us at 2048 robots, i.e. worse -- the prologue's cost is its loads, not its arithmetic.)
+        const int n_eff = d.act_n_dev ? std::min(n_l, h->act_hint) : n_l;
+        const int tpw = n_eff >= 1024 ? 64 : n_eff >= 48 ? 32 : 8, crop_chunks = (h->big_max_crop + (VBC_T / WAVE) * tpw - 1) / ((VBC_T / WAVE) * tpw);
         const dim3 gc((unsigned)((n_l + 7) / 8 * 8) * (unsigned)crop_chunks), gb((unsigned)n_l * (unsigned)quarters);
         const dim3 gt((unsigned)n_l * (unsigned)tap_chunks), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
         if (h->stamp && d.crop_map) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true, true><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
