@@ -1545,8 +1545,9 @@ template <bool POW2>
 __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstInst* __restrict__ inst, int stamp, const int* n_dev, int per_world, int parts,
                                                         ObstInst* keep, int* keep_valid) {
     // parts workgroups share an obstacle's samples (a reset of a few worlds is a handful of obstacles: their latency is the launch's)
-    const int t = (int)blockIdx.x / parts, part = (int)blockIdx.x - t * parts;
-    if (n_dev && t >= *n_dev * per_world) return;  // device-side auto-reset: per_world instances for each finished world
+    const int t0 = (int)blockIdx.x / parts, part = (int)blockIdx.x - t0 * parts;
+    // device-side auto-reset: per_world instances for each finished world, the grid sized for a guess of their number
+    for (int t = t0; t < (n_dev ? *n_dev * per_world : t0 + 1); t += (int)gridDim.x / parts) {
     const ObstInst o = inst[t];
     if (keep && part == 0 && threadIdx.x == 0) {  // ... which remembers what each world now carries, for the next restore (k_restore_maps_dev)
         keep[(size_t)o.world * per_world + (t % per_world)] = o;
@@ -1577,6 +1578,7 @@ __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstI
                 if (w.crop_map) w.crop_map[(size_t)o.world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = 0;  // ... and view_big.h's byte: not free, no stamp
             }
         }
+    }
     }
 }
 
@@ -2405,13 +2407,16 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
     k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
     HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
     k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
-    const int restore_blocks = W <= 4096 ? 4 * MAP_BLOCKS : MAP_BLOCKS;  // per world (most of the launch returns at once: few worlds finish in a step)
-    if (h->pow2) k_restore_maps_dev<true><<<dim3((unsigned)(W * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
-    else k_restore_maps_dev<false><<<dim3((unsigned)(W * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
+    // grids for a guess of the finished worlds (four times the last count; the kernels stride over the rest if there are more)
+    const int last_n = h->finished_host[0];  // (page-locked, written by k_finished_dev: stale by a step or two)
+    const int guess = std::min(W, std::max(16, 4 * std::max(last_n, 0)));
+    const int restore_blocks = 4 * MAP_BLOCKS;  // per world
+    if (h->pow2) k_restore_maps_dev<true><<<dim3((unsigned)(guess * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
+    else k_restore_maps_dev<false><<<dim3((unsigned)(guess * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
     if (nob > 0) {
-        const int parts = W * nob <= 16384 ? 4 : 1;
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)(W * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
-        else k_reset_obstacles<false><<<dim3((unsigned)(W * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
+        const int parts = 4;
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)(guess * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
+        else k_reset_obstacles<false><<<dim3((unsigned)(guess * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
     }
     HIPCHK(hipGetLastError());
     if (h->stamp) {

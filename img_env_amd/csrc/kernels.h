@@ -868,8 +868,8 @@ __device__ __forceinline__ void ped_sample(const DevWorld& w, bool in, uint32_t 
     }
 }
 
-// PB rounds of samples at once (see stamp_ped_batch): the words of all rounds are read together.  Four in small launches, where a
-// block's chain of round trips is the launch's duration; one where the launch fills the chip (measured: batches cost 10 % there)
+// PB rounds of samples at once (see stamp_ped_batch): the words of all rounds are read together (the robots' batches, by contrast,
+// only pay in small launches: raster_robot)
 template <bool STAMP, int PB>
 __device__ __forceinline__ void ped_samples(const DevWorld& w, const bool (&in)[PB], const uint32_t (&c)[PB], int rule, int lane, int world) {
     if (!STAMP) {
@@ -897,7 +897,7 @@ __device__ __forceinline__ void ped_samples(const DevWorld& w, const bool (&in)[
 template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
-    constexpr int PB = NW > 1 ? 4 : 1;
+    constexpr int PB = 4;  // rounds of samples per batch (ped_samples)
     const int world = world_of_ped(w, j);
     const uint32_t cell0 = (uint32_t)world * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
