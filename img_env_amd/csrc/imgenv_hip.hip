@@ -1548,37 +1548,37 @@ __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstI
     const int t0 = (int)blockIdx.x / parts, part = (int)blockIdx.x - t0 * parts;
     // device-side auto-reset: per_world instances for each finished world, the grid sized for a guess of their number
     for (int t = t0; t < (n_dev ? *n_dev * per_world : t0 + 1); t += (int)gridDim.x / parts) {
-    const ObstInst o = inst[t];
-    if (keep && part == 0 && threadIdx.x == 0) {  // ... which remembers what each world now carries, for the next restore (k_restore_maps_dev)
-        keep[(size_t)o.world * per_world + (t % per_world)] = o;
-        keep_valid[o.world] = 1;
-    }
-    const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
-    uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)o.world * w.Gs;
-    const double resolution = 0.01;
-    const int nn = o.n1 - o.n0 + 1, total = (o.m1 - o.m0 + 1) * nn;
-    const bool circle = o.shape == IMGENV_SHAPE_CIRCLE;
-    for (int q = part * (int)blockDim.x + (int)threadIdx.x; q < total; q += parts * (int)blockDim.x) {
-        const int m = o.m0 + q / nn, n = o.n0 + q % nn;
-        double px = m * resolution, py = n * resolution;
-        if (circle) {
-            if (!(sqrt(m * resolution * m * resolution + n * resolution * n * resolution) <= o.r)) continue;
-            px = px + o.cx;
-            py = py + o.cy;
+        const ObstInst o = inst[t];
+        if (keep && part == 0 && threadIdx.x == 0) {  // ... which remembers what each world now carries, for the next restore (k_restore_maps_dev)
+            keep[(size_t)o.world * per_world + (t % per_world)] = o;
+            keep_valid[o.world] = 1;
         }
-        double wx, wy;
-        tf_apply(bw, px, py, wx, wy);
-        int gm, gn;
-        w2m_pair<POW2>(wx, wy, w.res, w.inv_res, gm, gn);
-        if (gm >= 0 && gm < w.Hg && gn >= 0 && gn < w.Wg) {
-            const size_t at = (size_t)gm * w.Wg + gn;
-            if (map[at] > 2) {
-                map[at] = 0;
-                if (stamp) w.cell[(size_t)o.world * w.Gs + at] = CLS_STATIC;  // the class layer's base class follows
-                if (w.crop_map) w.crop_map[(size_t)o.world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = 0;  // ... and view_big.h's byte: not free, no stamp
+        const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
+        uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)o.world * w.Gs;
+        const double resolution = 0.01;
+        const int nn = o.n1 - o.n0 + 1, total = (o.m1 - o.m0 + 1) * nn;
+        const bool circle = o.shape == IMGENV_SHAPE_CIRCLE;
+        for (int q = part * (int)blockDim.x + (int)threadIdx.x; q < total; q += parts * (int)blockDim.x) {
+            const int m = o.m0 + q / nn, n = o.n0 + q % nn;
+            double px = m * resolution, py = n * resolution;
+            if (circle) {
+                if (!(sqrt(m * resolution * m * resolution + n * resolution * n * resolution) <= o.r)) continue;
+                px = px + o.cx;
+                py = py + o.cy;
+            }
+            double wx, wy;
+            tf_apply(bw, px, py, wx, wy);
+            int gm, gn;
+            w2m_pair<POW2>(wx, wy, w.res, w.inv_res, gm, gn);
+            if (gm >= 0 && gm < w.Hg && gn >= 0 && gn < w.Wg) {
+                const size_t at = (size_t)gm * w.Wg + gn;
+                if (map[at] > 2) {
+                    map[at] = 0;
+                    if (stamp) w.cell[(size_t)o.world * w.Gs + at] = CLS_STATIC;  // the class layer's base class follows
+                    if (w.crop_map) w.crop_map[(size_t)o.world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = 0;  // ... and view_big.h's byte: not free, no stamp
+                }
             }
         }
-    }
     }
 }
 

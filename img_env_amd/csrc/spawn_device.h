@@ -683,64 +683,64 @@ __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c
     // exist still costs the dispatcher its nanosecond -- 65 536 of them were most of this kernel's 30 us at 2048 envs)
     const int q0 = blockIdx.x / map_blocks, part = blockIdx.x - q0 * map_blocks, q_stride = (int)gridDim.x / map_blocks;
     for (int q = q0; q < *c.fin_n; q += q_stride) {
-    const int world = c.fin_list[q];
-    uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs;
-    uint32_t* cell = w.cell + (size_t)world * w.Gs;
-    if (c.w_inst_valid[world]) {
-        const double resolution = 0.01;
-        for (int e = 0; e < c.n_obstacles; e++) {
-            const ObstInst o = c.w_inst[(size_t)world * c.n_obstacles + e];
-            const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
-            const int nn = o.n1 - o.n0 + 1, total = (o.m1 - o.m0 + 1) * nn;
-            const bool circle = o.shape == IMGENV_SHAPE_CIRCLE;
-            for (int s = part * 256 + (int)threadIdx.x; s < total; s += map_blocks * 256) {  // the footprint samples of k_reset_obstacles
-                const int m = o.m0 + s / nn, n = o.n0 + s % nn;
-                double px = m * resolution, py = n * resolution;
-                if (circle) {
-                    if (!(sqrt(m * resolution * m * resolution + n * resolution * n * resolution) <= o.r)) continue;
-                    px = px + o.cx;
-                    py = py + o.cy;
+        const int world = c.fin_list[q];
+        uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs;
+        uint32_t* cell = w.cell + (size_t)world * w.Gs;
+        if (c.w_inst_valid[world]) {
+            const double resolution = 0.01;
+            for (int e = 0; e < c.n_obstacles; e++) {
+                const ObstInst o = c.w_inst[(size_t)world * c.n_obstacles + e];
+                const Tf2 bw = tf_from_pose_sc(o.x, o.y, o.sh, o.ch);
+                const int nn = o.n1 - o.n0 + 1, total = (o.m1 - o.m0 + 1) * nn;
+                const bool circle = o.shape == IMGENV_SHAPE_CIRCLE;
+                for (int s = part * 256 + (int)threadIdx.x; s < total; s += map_blocks * 256) {  // the footprint samples of k_reset_obstacles
+                    const int m = o.m0 + s / nn, n = o.n0 + s % nn;
+                    double px = m * resolution, py = n * resolution;
+                    if (circle) {
+                        if (!(sqrt(m * resolution * m * resolution + n * resolution * n * resolution) <= o.r)) continue;
+                        px = px + o.cx;
+                        py = py + o.cy;
+                    }
+                    double wx, wy;
+                    tf_apply(bw, px, py, wx, wy);
+                    int gm, gn;
+                    w2m_pair<POW2>(wx, wy, w.res, w.inv_res, gm, gn);
+                    if (gm >= 0 && gm < w.Hg && gn >= 0 && gn < w.Wg) {
+                        const size_t at = (size_t)gm * w.Wg + gn;
+                        const uint32_t v = static_map[at];
+                        map[at] = (uint8_t)v;
+                        if (stamp) cell[at] = v <= 2 ? v : (v < 250 ? CLS_LOW : CLS_HIGH);
+                        if (w.crop_map) w.crop_map[(size_t)world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = v >= 250 ? 128 : 0;  // (a stamp left on it has expired)
+                    }
                 }
-                double wx, wy;
-                tf_apply(bw, px, py, wx, wy);
-                int gm, gn;
-                w2m_pair<POW2>(wx, wy, w.res, w.inv_res, gm, gn);
-                if (gm >= 0 && gm < w.Hg && gn >= 0 && gn < w.Wg) {
-                    const size_t at = (size_t)gm * w.Wg + gn;
-                    const uint32_t v = static_map[at];
-                    map[at] = (uint8_t)v;
-                    if (stamp) cell[at] = v <= 2 ? v : (v < 250 ? CLS_LOW : CLS_HIGH);
-                    if (w.crop_map) w.crop_map[(size_t)world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = v >= 250 ? 128 : 0;  // (a stamp left on it has expired)
+            }
+            continue;
+        }
+        if (w.crop_map) {
+            const uint4* src = (const uint4*)w.static_crop;
+            uint4* cm = (uint4*)(w.crop_map + (size_t)world * w.crop_ws);
+            for (size_t e = (size_t)part * blockDim.x + threadIdx.x; e < w.crop_ws / 16; e += (size_t)map_blocks * blockDim.x) cm[e] = src[e];
+        }
+        const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;
+        uint4* dst = (uint4*)map;
+        uint4* cls = (uint4*)cell;
+        for (size_t e = (size_t)part * blockDim.x + threadIdx.x; e < n16; e += (size_t)map_blocks * blockDim.x) {
+            const uint4 v = ((const uint4*)static_map)[e];
+            dst[e] = v;
+            if (stamp) {
+                const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t c4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t o = (wd[k] >> (8 * j)) & 0xFFu;
+                        c4[j] = o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH);
+                    }
+                    cls[4 * e + k] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
                 }
             }
         }
-        continue;
-    }
-    if (w.crop_map) {
-        const uint4* src = (const uint4*)w.static_crop;
-        uint4* cm = (uint4*)(w.crop_map + (size_t)world * w.crop_ws);
-        for (size_t e = (size_t)part * blockDim.x + threadIdx.x; e < w.crop_ws / 16; e += (size_t)map_blocks * blockDim.x) cm[e] = src[e];
-    }
-    const size_t n16 = ((size_t)w.Hg * w.Wg + 15) / 16;
-    uint4* dst = (uint4*)map;
-    uint4* cls = (uint4*)cell;
-    for (size_t e = (size_t)part * blockDim.x + threadIdx.x; e < n16; e += (size_t)map_blocks * blockDim.x) {
-        const uint4 v = ((const uint4*)static_map)[e];
-        dst[e] = v;
-        if (stamp) {
-            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t c4[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t o = (wd[k] >> (8 * j)) & 0xFFu;
-                    c4[j] = o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH);
-                }
-                cls[4 * e + k] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
-            }
-        }
-    }
     }
 }
 
