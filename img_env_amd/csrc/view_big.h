@@ -37,11 +37,15 @@ __device__ __forceinline__ long long uniform_i64(long long v) {  // a value know
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-// lane q (wave-uniform) of v becomes the wave-uniform value x
+// lane q (wave-uniform) of v becomes the wave-uniform value x  (m0 is named as clobbered on purpose -- the compiler may keep a
+// value of its own there -- which clang reports as "reserved register on the clobber list")
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void write_lane(uint32_t& v, uint32_t x, int q) {
     const uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(xs), "s"(q) : "m0");
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ uint32_t crop_tiled_at(uint32_t wt, uint32_t m, uint32_t n) {  // crop_tiled (kernels.h) with the pitch in a register
     // = ((m >> 3) * wt + (n >> 3)) * 64 + (m & 7) * 8 + (n & 7), in six instructions: m << 3 already is (m >> 3) * 64 + (m & 7) * 8
     const uint32_t n6 = ((n & ~7u) << 3) | (n & 7u);  // (n >> 3) * 64 + (n & 7): v_and, v_lshlrev, v_and_or
