@@ -118,13 +118,15 @@ SFM_HD inline void sfm_set_erase(SfmNode& q, int a) {
 // (node, agent); an item whose node is a leaf inserts and may split the leaf, pushing the former members.
 // `work`: 2 * SFM_MAX_DEPTH * 8 ints for the explicit stack (the device passes LDS: a dynamically indexed private array
 // would sit in scratch memory, ~1 us per push / pop); nullptr = a local array (host)
+// `start`: the node the descent begins at -- the root, or a node the agent's descent is known to pass through (internal nodes
+// never change once they exist, so a descent that was walked on an earlier state of the tree is still a prefix of today's)
 SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err,
-                                 int* work = nullptr) {
+                                 int* work = nullptr, int start = 0) {
     int local_stack[2 * SFM_MAX_DEPTH * 8];
     int* st_node = work ? work : local_stack;
     int* st_agent = st_node + SFM_MAX_DEPTH * 8;
     int sp = 0;
-    st_node[sp] = 0;
+    st_node[sp] = start;
     st_agent[sp++] = agent;
     while (sp > 0) {
         --sp;
@@ -179,12 +181,12 @@ SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* tre
 
 // Tscene::moveAgent -> Ttree::moveAgent (ped_tree.cpp:131-137)
 SFM_HD inline void sfm_move_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int a, int* err,
-                                  int* work = nullptr) {
+                                  int* work = nullptr, int start = 0) {
     const int leaf = treehash[a];
     const SfmNode& q = nodes[leaf];
     const double px = p[3 * a], py = p[3 * a + 1];
     if ((px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h))) {
-        sfm_add_agent(nodes, n_nodes, cap, treehash, p, a, err, work);  // scene->placeAgent(a): from the root
+        sfm_add_agent(nodes, n_nodes, cap, treehash, p, a, err, work, start);  // scene->placeAgent(a): from the root
         sfm_set_erase(nodes[leaf], a);                            // erased from the OLD leaf, even if it is the new one
     }
 }
@@ -486,10 +488,33 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
     // scene->moveAgent(this) in agent order (ped_tree.cpp:131-137).  Whether an agent left its leaf is tested by all agents
     // at once; the tree surgery itself stays serial.  The parallel verdicts hold as long as no leaf has been split in this
     // round (a split re-homes the leaf's members); after a split the remaining agents are re-tested one by one.
+    // An agent that did leave also walks its descent from the root NOW, all of them at once (a dependent LDS access per level,
+    // ~20 levels once the tree has grown: most of the serial section's time when it was walked there): stk[blockDim.x + a] is
+    // the leaf it reaches -- unless its position sits exactly on a centre line (the reference then descends into several
+    // children): 0, the serial code starts from the root.
     if (i < n) {
         const SfmNode& q = nodes[treehash[i]];
         const double px = lp[3 * i], py = lp[3 * i + 1];
-        stk[i] = ((px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h))) ? 1 : 0;
+        const bool left = (px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h));
+        int node = 0;
+        if (left) {
+            for (int depth = 0; depth < SFM_MAX_DEPTH && !nodes[node].isleaf; depth++) {
+                const SfmNode& t = nodes[node];
+                const double cx = t.x + t.w / 2, cy = t.y + t.h / 2;
+                int cnt = 0, nxt = 0;
+                if ((px >= cx) && (py >= cy)) { cnt++; nxt = t.child[2]; }
+                if ((px <= cx) && (py <= cy)) { cnt++; nxt = t.child[0]; }
+                if ((px >= cx) && (py <= cy)) { cnt++; nxt = t.child[1]; }
+                if ((px <= cx) && (py >= cy)) { cnt++; nxt = t.child[3]; }
+                if (cnt != 1) {
+                    node = 0;
+                    break;
+                }
+                node = nxt;
+            }
+        }
+        stk[i] = left ? 1 : 0;
+        stk[blockDim.x + i] = (unsigned short)(node < 65536 ? node : 0);
     }
     __syncthreads();
     if (i == 0) {
@@ -498,7 +523,9 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         bool split = false;
         for (int a = 0; a < n && lerr == 0; a++) {
             if (!split && !stk[a]) continue;
-            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds);  // the LDS angle table (8 KB) is free by now
+            // (an agent a split re-homed has no descent of its own: from the root)
+            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds /* the LDS angle table (8 KB) is free by now */,
+                           stk[a] ? (int)stk[blockDim.x + a] : 0);
             split = *n_nodes != nodes_before;
         }
         if (lerr) *s.err = lerr;
