@@ -517,14 +517,69 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         stk[blockDim.x + i] = (unsigned short)(node < 65536 ? node : 0);
     }
     __syncthreads();
+    // Most of the moves commute.  A leaf is SAFE if its members plus everybody who wants in are at most 8, counted before
+    // anything moves: whatever the order, it cannot split, and without a split a leaf's set simply ends as old members +
+    // arrivals - departures (an agent's own insert-then-erase keeps its order: that is what removes it altogether when its old
+    // and new leaf are the same, ped_tree.cpp:131-137).  Agents whose old AND new leaf are safe do their insert and erase all at
+    // once, a lock per leaf; the others -- a leaf they touch may split, which re-homes its members and changes what "old leaf"
+    // means for them -- are replayed serially afterwards, in agent order, as the reference does.  (A descent that was not
+    // unique, or a tree that lives in HBM: everything serially.)
+    int* arrivals = (int*)sh_lds;              // [SFM_LDS_NODES] (the LDS angle table, 8 KB, is free by now)
+    int* leaf_lock = arrivals + SFM_LDS_NODES;  // [SFM_LDS_NODES]
+    unsigned short* need_serial = stk + 2 * blockDim.x;
+    if (in_lds) {
+        for (int q = threadIdx.x; q < 2 * SFM_LDS_NODES; q += blockDim.x) arrivals[q] = 0;
+        if (i == 0) *need_serial = 0;
+        __syncthreads();
+        const bool mover = i < n && stk[i];
+        const int T = mover ? (int)stk[blockDim.x + i] : 0, old = mover ? treehash[i] : 0;
+        if (mover) {
+            if (T == 0 || !nodes[T].isleaf) *need_serial = 1;
+            else atomicAdd(&arrivals[T], 1);
+        }
+        __syncthreads();
+        const bool par = mover && *need_serial == 0 && nodes[T].n_agents + arrivals[T] <= 8 && nodes[old].n_agents + arrivals[old] <= 8;
+        __syncthreads();  // every verdict stands before anything moves
+        int lerr = 0;
+        // (the loops run until the whole wavefront is through: with a per-lane exit the compiler may sink the critical section
+        // behind the loop, where a lane that holds the lock waits for the lanes that spin on it)
+        bool done = !par;
+        for (int spin = 0; !__all(done) && spin < (1 << 20); spin++) {
+            if (!done) {
+                int expected = 0;
+                if (__hip_atomic_compare_exchange_strong(&leaf_lock[T], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    sfm_set_insert(nodes[T], i, &lerr);
+                    __hip_atomic_store(&leaf_lock[T], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    done = true;
+                }
+            }
+        }
+        if (par && !done) lerr = 5;
+        if (par) treehash[i] = T;
+        done = !par;
+        for (int spin = 0; !__all(done) && spin < (1 << 20); spin++) {
+            if (!done) {
+                int expected = 0;
+                if (__hip_atomic_compare_exchange_strong(&leaf_lock[old], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    sfm_set_erase(nodes[old], i);
+                    __hip_atomic_store(&leaf_lock[old], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    done = true;
+                }
+            }
+        }
+        if (par && !done) lerr = 5;
+        if (par) stk[i] = 2;  // done: the serial replay below passes it by (also after a split, when it re-tests everybody else)
+        if (lerr) *s.err = lerr;
+        __syncthreads();
+    }
     if (i == 0) {
         int lerr = 0;  // s.err is page-locked host memory: touched only to report
         const int nodes_before = *n_nodes;
         bool split = false;
         for (int a = 0; a < n && lerr == 0; a++) {
-            if (!split && !stk[a]) continue;
+            if (stk[a] == 2 || (!split && !stk[a])) continue;
             // (an agent a split re-homed has no descent of its own: from the root)
-            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds /* the LDS angle table (8 KB) is free by now */,
+            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds /* (the counters above are dead) */,
                            stk[a] ? (int)stk[blockDim.x + a] : 0);
             split = *n_nodes != nodes_before;
         }
