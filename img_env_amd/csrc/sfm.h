@@ -120,8 +120,10 @@ SFM_HD inline void sfm_set_erase(SfmNode& q, int a) {
 // would sit in scratch memory, ~1 us per push / pop); nullptr = a local array (host)
 // `start`: the node the descent begins at -- the root, or a node the agent's descent is known to pass through (internal nodes
 // never change once they exist, so a descent that was walked on an earlier state of the tree is still a prefix of today's)
+// `rehomed`: one flag per agent; a split sets it to 1 for every member it re-homes (unless it is 2), so that a caller that
+// decides ahead of time who has left its leaf can re-test exactly the agents whose leaf changed
 SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err,
-                                 int* work = nullptr, int start = 0) {
+                                 int* work = nullptr, int start = 0, unsigned short* rehomed = nullptr) {
     int local_stack[2 * SFM_MAX_DEPTH * 8];
     int* st_node = work ? work : local_stack;
     int* st_agent = st_node + SFM_MAX_DEPTH * 8;
@@ -155,6 +157,7 @@ SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* tre
                     }
                     st_node[sp] = node;
                     st_agent[sp++] = q.agents[k];
+                    if (rehomed && rehomed[q.agents[k]] != 2) rehomed[q.agents[k]] = 1;
                 }
                 q.n_agents = 0;
             }
@@ -181,12 +184,12 @@ SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* tre
 
 // Tscene::moveAgent -> Ttree::moveAgent (ped_tree.cpp:131-137)
 SFM_HD inline void sfm_move_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int a, int* err,
-                                  int* work = nullptr, int start = 0) {
+                                  int* work = nullptr, int start = 0, unsigned short* rehomed = nullptr) {
     const int leaf = treehash[a];
     const SfmNode& q = nodes[leaf];
     const double px = p[3 * a], py = p[3 * a + 1];
     if ((px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h))) {
-        sfm_add_agent(nodes, n_nodes, cap, treehash, p, a, err, work, start);  // scene->placeAgent(a): from the root
+        sfm_add_agent(nodes, n_nodes, cap, treehash, p, a, err, work, start, rehomed);  // scene->placeAgent(a): from the root
         sfm_set_erase(nodes[leaf], a);                            // erased from the OLD leaf, even if it is the new one
     }
 }
@@ -486,8 +489,8 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
     __syncthreads();
     SFM_STAMP(5);
     // scene->moveAgent(this) in agent order (ped_tree.cpp:131-137).  Whether an agent left its leaf is tested by all agents
-    // at once; the tree surgery itself stays serial.  The parallel verdicts hold as long as no leaf has been split in this
-    // round (a split re-homes the leaf's members); after a split the remaining agents are re-tested one by one.
+    // at once: the verdict stands as long as the agent's leaf is the same; a split re-homes the leaf's members, and those are
+    // flagged (sfm_add_agent) and tested again when their turn comes.
     // An agent that did leave also walks its descent from the root NOW, all of them at once (a dependent LDS access per level,
     // ~20 levels once the tree has grown: most of the serial section's time when it was walked there): stk[blockDim.x + a] is
     // the leaf it reaches -- unless its position sits exactly on a centre line (the reference then descends into several
@@ -517,6 +520,7 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         stk[blockDim.x + i] = (unsigned short)(node < 65536 ? node : 0);
     }
     __syncthreads();
+    SFM_STAMP(7);
     // Most of the moves commute.  A leaf is SAFE if its members plus everybody who wants in are at most 8, counted before
     // anything moves: whatever the order, it cannot split, and without a split a leaf's set simply ends as old members +
     // arrivals - departures (an agent's own insert-then-erase keeps its order: that is what removes it altogether when its old
@@ -572,20 +576,21 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         if (lerr) *s.err = lerr;
         __syncthreads();
     }
+    SFM_STAMP(8);
     if (i == 0) {
         int lerr = 0;  // s.err is page-locked host memory: touched only to report
-        const int nodes_before = *n_nodes;
-        bool split = false;
+        // Who left its leaf was decided for all agents at once; that verdict stands for an agent as long as its leaf is the
+        // same.  A split re-homes the leaf's members: those (and only those) are flagged and tested again at their turn.
         for (int a = 0; a < n && lerr == 0; a++) {
-            if (stk[a] == 2 || (!split && !stk[a])) continue;
+            if (stk[a] != 1) continue;
             // (an agent a split re-homed has no descent of its own: from the root)
             sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds /* (the counters above are dead) */,
-                           stk[a] ? (int)stk[blockDim.x + a] : 0);
-            split = *n_nodes != nodes_before;
+                           (int)stk[blockDim.x + a], stk);
         }
         if (lerr) *s.err = lerr;
     }
     __syncthreads();
+    SFM_STAMP(9);
     if (in_lds) {  // back to HBM for the next step (and for imgenv_reset, which rebuilds the tree there)
         const int words = *ln_nodes * (int)(sizeof(SfmNode) / 4);
         for (int q = threadIdx.x; q < words; q += blockDim.x) ((uint32_t*)s.nodes)[q] = ((const uint32_t*)lnodes)[q];

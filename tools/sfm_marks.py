@@ -26,5 +26,6 @@ buf = (C.c_ulonglong * 32)()
 for rep in range(3):
     w.step(a)
     w.lib.imgenv_debug_marks(w.h, buf)
-    v = list(buf)[:7]
-    print([round((v[q + 1] - v[q]) / 100.0, 1) for q in range(6)], "us: walk, desired+angles, pairs, sums+obstacle, move, tree surgery")
+    v = list(buf)[:10]
+    print([round((v[q + 1] - v[q]) / 100.0, 1) for q in range(5)], "us: walk, desired+angles, pairs, sums+obstacle, move;  tree surgery:",
+          [round((v[b] - v[a]) / 100.0, 1) for a, b in ((5, 7), (7, 8), (8, 9), (9, 6))], "us: who left + descents, commuting moves, serial replay, tree back to HBM")
