@@ -595,7 +595,7 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
     }
     __syncthreads();
     SFM_STAMP(9);
-    if (in_lds) {  // back to HBM for the next step (and for imgenv_reset, which rebuilds the tree there)
+    if (in_lds) {  // back to HBM for the next step (a reset only moves positions, as Tagent::setPosition does: the tree catches up in the next step)
         const int words = *ln_nodes * (int)(sizeof(SfmNode) / 4);
         for (int q = threadIdx.x; q < words; q += blockDim.x) ((uint32_t*)s.nodes)[q] = ((const uint32_t*)lnodes)[q];
         if (i < n) s.treehash[i] = lhash[i];
