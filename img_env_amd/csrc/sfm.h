@@ -120,7 +120,7 @@ SFM_HD inline void sfm_set_erase(SfmNode& q, int a) {
 // would sit in scratch memory, ~1 us per push / pop); nullptr = a local array (host)
 // `start`: the node the descent begins at -- the root, or a node the agent's descent is known to pass through (internal nodes
 // never change once they exist, so a descent that was walked on an earlier state of the tree is still a prefix of today's)
-// `rehomed`: one flag per agent; a split sets it to 1 for every member it re-homes (unless it is 2), so that a caller that
+// `rehomed`: one flag per agent; a split sets it to 3 for every member it re-homes (unless it is 2), so that a caller that
 // decides ahead of time who has left its leaf can re-test exactly the agents whose leaf changed
 SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err,
                                  int* work = nullptr, int start = 0, unsigned short* rehomed = nullptr) {
@@ -157,7 +157,7 @@ SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* tre
                     }
                     st_node[sp] = node;
                     st_agent[sp++] = q.agents[k];
-                    if (rehomed && rehomed[q.agents[k]] != 2) rehomed[q.agents[k]] = 1;
+                    if (rehomed && rehomed[q.agents[k]] != 2) rehomed[q.agents[k]] = 3;  // (3: its leaf changed -- test it again)
                 }
                 q.n_agents = 0;
             }
@@ -531,7 +531,9 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
     // and new leaf are the same, ped_tree.cpp:131-137).  Agents whose old AND new leaf are safe do their insert and erase all at
     // once, a lock per leaf; the others -- a leaf they touch may split, which re-homes its members and changes what "old leaf"
     // means for them -- are replayed serially afterwards, in agent order, as the reference does.  (A descent that was not
-    // unique, or a tree that lives in HBM: everything serially.)
+    // unique, or a tree that lives in HBM: everything serially.)  A finer test -- the leaf's count along the replay order,
+    // departures included -- was tried and is wrong as it stands: moves done out of order can push a leaf past 8 for a while,
+    // and a serial arrival that meets it then splits it.
     int* arrivals = (int*)sh_lds;              // [SFM_LDS_NODES] (the LDS angle table, 8 KB, is free by now)
     int* leaf_lock = arrivals + SFM_LDS_NODES;  // [SFM_LDS_NODES]
     unsigned short* need_serial = stk + 2 * blockDim.x;
@@ -586,10 +588,22 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         // Who left its leaf was decided for all agents at once; that verdict stands for an agent as long as its leaf is the
         // same.  A split re-homes the leaf's members: those (and only those) are flagged and tested again at their turn.
         for (int a = 0; a < n && lerr == 0; a++) {
-            if (stk[a] != 1) continue;
-            // (an agent a split re-homed has no descent of its own: from the root)
-            sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds /* (the counters above are dead) */,
-                           (int)stk[blockDim.x + a], stk);
+            const int flag = stk[a];
+            if (flag != 1 && flag != 3) continue;
+            const int start = stk[blockDim.x + a];
+            if (flag == 1) {  // left its leaf, and the leaf is still the one that verdict was about: no second test
+                const int old = treehash[a];
+                SfmNode& t = nodes[start];
+                if (start != 0 && t.isleaf && t.n_agents < 8) {  // room in the leaf its descent ended at: no stack, no split
+                    sfm_set_insert(t, a, &lerr);
+                    treehash[a] = start;
+                } else {
+                    sfm_add_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds /* (the counters above are dead) */, start, stk);
+                }
+                sfm_set_erase(nodes[old], a);  // erased from the OLD leaf, even if it is the new one (ped_tree.cpp:131-137)
+            } else {  // a split re-homed it: Ttree::moveAgent as it stands, its descent (if it has one) still a valid prefix
+                sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds, start, stk);
+            }
         }
         if (lerr) *s.err = lerr;
     }
