@@ -518,7 +518,7 @@ __device__ __forceinline__ void ped_update_one(const DevWorld& w, int j) {
 __global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w, int phase) {
     __shared__ uint32_t nb_bits[SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32)];
     __shared__ double sfm_sh[4 * SFM_MAX_AGENTS];
-    __shared__ unsigned short sfm_stk[SFM_WALK_CAP * SFM_MAX_AGENTS];
+    __shared__ __attribute__((aligned(16))) unsigned short sfm_stk[SFM_WALK_CAP * SFM_MAX_AGENTS];  // (its last row doubles as eight 32-bit words: sfm_step)
     extern __shared__ __attribute__((aligned(16))) unsigned char sfm_dyn[];  // [SFM_LDS_NODES] nodes (phases 0, 1, 3; none in phase 2)
     SfmNode* sfm_nodes = (SfmNode*)sfm_dyn;
     __shared__ int sfm_hash[SFM_MAX_AGENTS];

@@ -266,6 +266,22 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         if (i == 0) *ln_nodes = n_nodes0;
         __syncthreads();
     }
+    // Tscene::getNeighbors asks for the agents of every leaf a 40 m square touches, in a scene of 10 m x 10 m: for an agent
+    // anywhere near the scene that is EVERY leaf, and the walk (a visit of every node, per agent: most of this phase's time once
+    // the tree has grown) returns the same set for all of them -- the agents that are in the tree at all.  That set is gathered
+    // once, every thread a few nodes; only an agent whose square does not contain the root's rectangle walks.
+    uint32_t* in_tree = (uint32_t*)(stk + (size_t)(SFM_WALK_CAP - 1) * blockDim.x);  // [8]: the last row of the walk stacks' LDS
+    if (phase <= 1) {
+        if (i < SFM_MAX_AGENTS / 32) in_tree[i] = 0;
+        __syncthreads();
+        const int nn_now = *n_nodes;
+        for (int q = threadIdx.x; q < nn_now; q += blockDim.x) {
+            const SfmNode& t = nodes[q];
+            if (t.isleaf)
+                for (int k = 0; k < t.n_agents; k++) atomicOr(&in_tree[t.agents[k] >> 5], 1u << (t.agents[k] & 31));
+        }
+        __syncthreads();
+    }
     d3 desiredforce = D3(0, 0, 0), socialforce = D3(0, 0, 0), obstacleforce = D3(0, 0, 0), lookaheadforce = D3(0, 0, 0);
     d3 me_p = D3(0, 0, 0), me_v = D3(0, 0, 0);
     uint32_t* mine = nb_bits + (size_t)i * (SFM_MAX_AGENTS / 32);
@@ -278,11 +294,14 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         me_p = ld3(s.p, i);
         me_v = ld3(s.v, i);
         // Tscene::getNeighbors(p.x, p.y, 20) (ped_scene.cpp:217-252): agents of the leaves the square touches
-        for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) mine[k] = 0;
+        const SfmNode& root = nodes[0];
+        const bool whole_tree = ((me_p.x + 20.0) > (root.x + root.w)) && ((me_p.x - 20.0) < root.x) && ((me_p.y + 20.0) > (root.y + root.h)) &&
+                                ((me_p.y - 20.0) < root.y);  // the square contains the root's rectangle: every child test below passes
+        for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) mine[k] = whole_tree ? in_tree[k] : 0u;
         // depth-first walk with the stack in LDS (a dynamically indexed private array would live in scratch memory):
-        // entry k of thread i sits at stk[k * blockDim.x + i]
+        // entry k of thread i sits at stk[k * blockDim.x + i]  (SFM_WALK_CAP - 1 entries: the last row holds in_tree)
         int sp = 0;
-        stk[(sp++) * blockDim.x + i] = 0;
+        if (!whole_tree) stk[(sp++) * blockDim.x + i] = 0;
         while (sp > 0) {
             const SfmNode& t = nodes[stk[(--sp) * blockDim.x + i]];
             if (t.isleaf) {
@@ -292,7 +311,7 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
                     const SfmNode& ch = nodes[t.child[c]];
                     if (((me_p.x + 20.0) > ch.x) && ((me_p.x - 20.0) < (ch.x + ch.w)) && ((me_p.y + 20.0) > ch.y) &&
                         ((me_p.y - 20.0) < (ch.y + ch.h))) {
-                        if (sp < SFM_WALK_CAP) stk[(sp++) * blockDim.x + i] = (unsigned short)t.child[c];
+                        if (sp < SFM_WALK_CAP - 1) stk[(sp++) * blockDim.x + i] = (unsigned short)t.child[c];
                         else *s.err = 4;
                     }
                 }
