@@ -26,7 +26,7 @@ def stack_params(params, W):
 
 
 def measure(E, Rw, Pw, grid_cells, res=0.125, steps=300, warmup=100, time_max=100, policy="active", kernels=True, resets=True,
-            clearance=None, device=0, flags=0):
+            clearance=None, device=0, flags=0, scene="rvoscene"):
     import torch
     from img_env_amd import worldgen
     from img_env_amd.world import World
@@ -34,7 +34,7 @@ def measure(E, Rw, Pw, grid_cells, res=0.125, steps=300, warmup=100, time_max=10
     grid = worldgen.make_grid(grid_cells, 0)
     if clearance is None:
         clearance = 1.0 if Rw * 1.0 <= 0.25 * (grid_cells * res) ** 2 else 0.7
-    params = worldgen.make_params(Rw, Pw, res=res, view_cells=48, beams=360, scene="rvoscene", time_max=time_max, flags=flags)
+    params = worldgen.make_params(Rw, Pw, res=res, view_cells=48, beams=360, scene=scene, time_max=time_max, flags=flags)
     layouts = [worldgen.make_layout(grid, res, Rw, Pw, seed=500 + s, clearance=clearance) for s in range(8)]
     world = World(stack_params(params, E), grid, device=device)
     R = E * Rw
@@ -106,9 +106,10 @@ def main():
     ap.add_argument("--policy", default="active")
     ap.add_argument("--no-resets", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="IMGENV_FLAG_*: 2 composed class layer, 4 stamped")
+    ap.add_argument("--scene", default="rvoscene", help="rvoscene / ervoscene / pedscene")
     args = ap.parse_args()
     print(json.dumps(measure(args.worlds, args.robots, args.peds, args.grid, args.res, args.steps, args.warmup, policy=args.policy,
-                             resets=not args.no_resets, flags=args.flags)))
+                             resets=not args.no_resets, flags=args.flags, scene=args.scene)))
 
 
 if __name__ == "__main__":
