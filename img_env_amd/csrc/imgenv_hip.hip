@@ -1549,6 +1549,7 @@ __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstI
     // device-side auto-reset: per_world instances for each finished world, the grid sized for a guess of their number
     for (int t = t0; t < (n_dev ? *n_dev * per_world : t0 + 1); t += (int)gridDim.x / parts) {
         const ObstInst o = inst[t];
+        if (o.world < 0) continue;  // (a finished world whose placement failed: k_respawn)
         if (keep && part == 0 && threadIdx.x == 0) {  // ... which remembers what each world now carries, for the next restore (k_restore_maps_dev)
             keep[(size_t)o.world * per_world + (t % per_world)] = o;
             keep_valid[o.world] = 1;
@@ -2393,6 +2394,41 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     return 0;
 }
 
+// A host-side reset between two device-side steps may have re-laid the tables k_respawn writes into: stage_world grows the
+// trajectory table when a batch brings longer waypoint lists, put_world_rvo the per-world RVO slices (after imgenv_reset has
+// handed them back to the host).  SpawnDev travels by value with every launch, so its copies of those pointers and strides are
+// simply taken from the handle again; a changed RVO stride also moves the pool's slot arrays (slots and worlds share one
+// stride), whose placements are then drawn again.
+static int spawn_dev_refresh(imgenv* h, hipStream_t st) {
+    SpawnDev& c = *(SpawnDev*)h->sd_storage;
+    const bool stride = h->NA > 0 && (c.cap_o != h->cap_obst || c.cap_n != h->cap_nodes);
+    const bool moved = c.traj != h->d_traj || c.traj_len != h->d_traj_len || c.traj_cap != h->traj_cap ||
+                       (h->NA > 0 && (c.w_obst != h->d_obst || c.w_nodes != h->d_nodes));
+    if (!stride && !moved) return 0;
+    if (stride) {
+        HIPCHK(hipStreamSynchronize(h->side3));  // (a fill in flight writes the old slot arrays)
+        HIPCHK(hipStreamSynchronize(st));
+        c.cap_o = h->cap_obst;
+        c.cap_n = h->cap_nodes;
+        RTRY(dev_alloc(h, &c.s_rvo, (size_t)c.S * c.cap_o));
+        RTRY(dev_alloc(h, &c.s_nodes, (size_t)c.S * c.cap_n));
+        HIPCHK(hipMemset(c.slot_serial, 0xFF, sizeof(unsigned long long) * (size_t)c.S));  // every slot is drawn again (the chain's own fill)
+    }
+    c.w_obst = h->d_obst;
+    c.w_nodes = h->d_nodes;
+    c.n_obst_w = h->d_wobst + 2 * (size_t)h->W;
+    c.oroot_w = h->d_wobst + 3 * (size_t)h->W;
+    c.traj = h->d_traj;
+    c.traj_len = h->d_traj_len;
+    c.traj_cap = h->traj_cap;
+    if (h->gexec) {  // the captured chain carries the old copies
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+        h->dev_calls = 0;
+    }
+    return 0;
+}
+
 // one step + the reset of whatever it finished, everything queued on `st` and the handle's side streams (all joined again)
 static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t st) {
     SpawnDev& c = *(SpawnDev*)h->sd_storage;
@@ -2458,6 +2494,7 @@ extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, c
         if (int rc = spawn_device_setup(h, cfg, seed0, st)) return rc;
         h->sd_fp = fp;
     }
+    if (int rc = spawn_dev_refresh(h, st)) return rc;
     if (!h->d_act_list) RTRY(dev_alloc(h, &h->d_act_list, (size_t)h->W));
     {   // how many worlds the last steps reset (page-locked, written by k_finished_dev; stale by a step or two: a hint only)
         const int last = h->finished_host[0];
@@ -2622,8 +2659,12 @@ extern "C" int imgenv_outputs(imgenv_t* h, imgenv_out* out) {
     // (fields are only ever appended); 0 = the caller's struct is this library's
     const int32_t want = out->struct_size;
     if (want < 0 || want > (int32_t)sizeof(imgenv_out)) FAIL(IMGENV_EINVAL, "imgenv_out.struct_size %d (this library's is %d)", want, (int)sizeof(imgenv_out));
-    if (want == 0) *out = h->out;
-    else memcpy(out, &h->out, (size_t)want);
+    if (want == 0) {
+        *out = h->out;
+    } else {
+        memcpy(out, &h->out, (size_t)want);
+        out->struct_size = want;  // what the caller really holds, not this library's larger size
+    }
     return IMGENV_OK;
 }
 

@@ -606,6 +606,9 @@ __global__ __launch_bounds__(WAVE) void k_respawn(DevWorld w, SpawnDev c, int el
     const int s = (int)(n % (unsigned long long)c.S);
     if (c.slot_serial[s] != n || c.slot_status[s] != 0) {  // the pool did not hold this placement, or it could not be placed
         if (tid == 0) w.err[2] = c.slot_serial[s] != n ? 100 : c.slot_status[s];
+        // the world keeps its episode (the error surfaces at the next synchronising call): nothing of the chain behind may
+        // take this list entry for a reset -- no obstacle instances to draw, no map to restore
+        for (int e = tid; e < c.n_obstacles; e += WAVE) c.inst_out[(size_t)q * c.n_obstacles + e].world = -1;
         return;
     }
     const int nr = c.n_robots, np = c.n_peds, na = nr + np;
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c
     const int q0 = blockIdx.x / map_blocks, part = blockIdx.x - q0 * map_blocks, q_stride = (int)gridDim.x / map_blocks;
     for (int q = q0; q < *c.fin_n; q += q_stride) {
         const int world = c.fin_list[q];
+        if (c.place_serial[world] != c.consumed[1] + (unsigned long long)q) continue;  // k_respawn could not place it: the old episode's map stays
         uint8_t* map = const_cast<uint8_t*>(w.obs_map) + (size_t)world * w.Gs;
         uint32_t* cell = w.cell + (size_t)world * w.Gs;
         if (c.w_inst_valid[world]) {

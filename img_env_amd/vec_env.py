@@ -58,6 +58,9 @@ class VecImageEnv:
         self._spawn_cfg = spawn.make_spawn_cfg(cfg) if native_spawn else None
         self._spawn_seed = (0x9E3779B97F4A7C15 * (1 + (seed or 0))) & 0xFFFFFFFFFFFFFFFF
         self._episodes = 0
+        # device-side resets number their placements seed0 + k on their own: a stream 2^63 away from the host-side resets'
+        # (_spawn_seed + episodes so far), so that an env reset by the host never replays an episode the device handed out
+        self._device_seed0 = (self._spawn_seed + (1 << 63)) & 0xFFFFFFFFFFFFFFFF
         self._extent = max(self.grid.shape) * float(cfg["global_map"]["resolution"])
         if not cfg.get("keep_view_maps", False):
             # ImageState has no full-size view: where the view is shrunk into the sensor_map (the shipped 400 x 400 -> 48 x 48)
@@ -111,7 +114,7 @@ class VecImageEnv:
         return self._state(), o["step_rewards"], o["step_dones"], info
 
     def _step_device(self, actions):
-        o = self.world.step_autoreset_device(self._actions(actions), self._spawn_cfg, self._spawn_seed + self._episodes)
+        o = self.world.step_autoreset_device(self._actions(actions), self._spawn_cfg, self._device_seed0)
         info = {"dones_info": o["step_dones_info"], "is_clean": o["step_is_clean"], "arrive": o["step_is_arrives"],
                 "collision": o["step_is_collisions"], "all_down": self._all_down, "reset_envs": None}
         return self._state(), o["step_rewards"], o["step_dones"], info

@@ -441,7 +441,7 @@ def test_device_side_placements_follow_the_host_sampler():
             worlds, first = vec.world.autoreset_last()
             for q, k in enumerate(worlds):
                 lay, serial = vec.world.world_placement(k, n_obs)
-                ref = spawn.native_spawn(cfg, vec._spawn_seed + E + serial)  # the device was told seed0 = spawn seed + E first episodes
+                ref = spawn.native_spawn(cfg, (vec._device_seed0 + serial) & 0xFFFFFFFFFFFFFFFF)  # the device's own stream (2^63 away from the host-side resets')
                 seen += 1
                 same += int(np.allclose(lay.robot_pose, ref.robot_pose, atol=1e-9) and np.allclose(lay.ped_pose, ref.ped_pose, atol=1e-9) and
                             np.allclose(lay.robot_goal, ref.robot_goal, atol=1e-9) and np.allclose(lay.obs_pose, ref.obs_pose, atol=1e-9) and

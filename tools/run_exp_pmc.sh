@@ -3,6 +3,7 @@
 # knock-out; then the kernel's duration in each build (kernel trace, serial streams)
 cd /root/repo
 export IMGENV_SERIAL=1
+rm -f /tmp/exp_*.so
 i=0
 for f in "" -DIMGENV_EXP_STOP_AFTER=1 -DIMGENV_EXP_STOP_AFTER=2 -DIMGENV_EXP_STOP_AFTER=3 -DIMGENV_EXP_STOP_AFTER=4; do
   i=$((i+1))
@@ -10,7 +11,7 @@ for f in "" -DIMGENV_EXP_STOP_AFTER=1 -DIMGENV_EXP_STOP_AFTER=2 -DIMGENV_EXP_STO
 done
 cd /tmp && export TMPDIR=/tmp
 rm -f /root/repo/gpurun_out/pmc_exp.txt
-for i in ${EXP_BUILDS:-1 2 3 4 5 6 7}; do
+for i in ${EXP_BUILDS:-1 2 3 4 5}; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES -d /root/repo/gpurun_out/pmc_exp_$i -o p --output-format csv -- python3 /root/repo/tools/exp_run.py /tmp/exp_$i.so 8 > /root/repo/gpurun_out/pmc_exp_$i.log 2>&1
   echo "== build $i" >> /root/repo/gpurun_out/pmc_exp.txt
   python3 /root/repo/tools/pmc_summary.py /root/repo/gpurun_out/pmc_exp_$i | grep -A9 "k_view<true, true, false, 1>" >> /root/repo/gpurun_out/pmc_exp.txt
