@@ -7,16 +7,20 @@ N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-
 environment), or plainly as above -- the parent process then starts one child per GPU itself (it never touches a GPU) and
 relays rank 0's JSON line.
 
-Workload (BASELINE.json metric, configs[2] = SURVEY "cfg-3"): ONE world with 8192 robots per GPU and
-200 ORCA pedestrians (rvoscene) on a 400x400 occupancy grid, 48x48 sensor_map + 3-channel ped_map,
-360-beam laser.  A step is one env.step() of every robot: pedestrian advance, pose integrate, rasters,
-collision + crop + laser + stamp, observation + reward/done.  Inputs (actions) are resident in HBM.
-Episodes end by the time limit (time_max = 100) and are followed by a full reset inside the timed
-region, like NeverStopWrapper does.
+Workload (BASELINE.json metric, configs[2] = SURVEY "cfg-3"): ONE world with 8192 robots and 200 ORCA pedestrians
+(rvoscene) on a 400x400 occupancy grid, 48x48 sensor_map + 3-channel ped_map, 360-beam laser.  A step is one env.step()
+of every robot: pedestrian advance, pose integrate, rasters, collision + crop + laser + stamp, observation + reward/done.
+Inputs (actions) are resident in HBM.  Episodes end by the time limit (time_max = 100) and are followed by a full reset
+inside the timed region, like NeverStopWrapper does.
 
-Multi-GPU: the world's robots are sharded contiguously over the ranks (weak scaling: 8192 robots per
-GPU); the one exchange per step is an RCCL all-gather of the robot records between pose integration and
-the robot raster.  Pedestrians are advanced redundantly on every rank.
+Multi-GPU (`--gpus N`): the world's robots are sharded contiguously over the ranks; the one exchange per step is an RCCL
+all-gather of the robot records between pose integration and the robot raster.  Pedestrians are
+advanced redundantly on every rank.  Two BASELINE configurations:
+  * `--config cfg3` (default; the `metric`'s wording, "whole node at 8192 robots"): the SAME 8192-robot world on the same
+    400x400 grid at every N, 8192 / N robots per rank -- STRONG scaling;
+  * `--config cfg4` (BASELINE configs[3]): 8192 robots PER GPU beside 200 social-force pedestrians (pedscene) on the 400x400
+    grid at 0.5 m, i.e. 65 536 robots at N = 8 -- WEAK scaling (the layout of tests/test_gpu_parity.py::
+    test_cfg4_full_size_and_shard_match_oracle: the crowd stays inside libpedsim's 10 m root square, robots are no crowd members).
 
 Two action policies are timed, both on the same world:
   * "active"  (the reported `value`): v = 0, w ~ U(-0.9, 0.9).  Robots turn in place, so no robot
@@ -36,22 +40,53 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-ROBOTS_PER_GPU = 8192
+ROBOTS = 8192     # cfg-3: robots of the world (all GPUs together); cfg-4: robots per GPU
+ROBOTS_PER_GPU = ROBOTS
 N_PEDS = 200
 GRID = 400
 TIME_MAX = 100
 
+#: the two BASELINE configurations bench.py can time (worldgen.PRESETS holds the same numbers)
+#: cfg3 res / clearance: SURVEY 8(d) density rule for 8192 robots on 400x400: R*0.25 m^2 <= 0.5*(Hg*res)^2 -> 0.25 m; starts 0.7 m
+#: apart, so that two r=0.17 m footprints never share a 0.25 m cell at reset
+WORKLOADS = {
+    "cfg3": dict(scene="rvoscene", res=0.25, clearance=0.7, relation_ped_robo=1, scaling="strong", ped_box=None,
+                 name="cfg-3: one world, %(R)d robots (%(RL)d per GPU x %(N)d GPUs%(strong)s), %(P)d ORCA peds (rvoscene)"),
+    "cfg4": dict(scene="pedscene", res=0.5, clearance=0.5, relation_ped_robo=0, scaling="weak", ped_box=(0.5, 9.5),
+                 name="cfg-4: one world, %(R)d robots (%(RL)d per GPU x %(N)d GPUs, weak scaling: 65536 at 8 GPUs), %(P)d social-force "
+                      "peds (pedscene, inside libpedsim's 10 m root square)"),
+}
+RES, CLEARANCE = WORKLOADS["cfg3"]["res"], WORKLOADS["cfg3"]["clearance"]
 
-RES = 0.25        # SURVEY 8(d) density rule for 8192 robots on 400x400: R*0.25 m^2 <= 0.5*(Hg*res)^2 -> 0.25 m
-CLEARANCE = 0.7   # start-to-start distance: two r=0.17 m footprints never share a 0.25 m cell at reset
+
+def grid_cells(n_gpus=1):
+    """BASELINE's 400x400 at every GPU count (the tools' name for it)"""
+    return GRID
 
 
-def grid_cells(n_gpus):
-    """400x400 for one GPU (BASELINE).  A collision-free placement needs ~1.1 m^2 per robot at this
-    resolution, so the multi-GPU weak-scaling world grows its area with the robot count (BASELINE's
-    65536 robots on 400x400 cannot be placed without overlapping footprints at any resolution)."""
-    side = int(np.ceil(GRID * np.sqrt(n_gpus) / 8.0)) * 8
-    return side
+def make_workload(cfg_name, R, P, n_layouts, robot_begin=0, robot_end=None, sort_x=False, seed0=100):
+    """grid, params and reset layouts of a BASELINE configuration with R robots in the world"""
+    from img_env_amd import worldgen
+    wl = WORKLOADS[cfg_name]
+    grid = worldgen.make_grid(GRID, 0)
+    layouts = [worldgen.make_layout(grid, wl["res"], R, P, seed=seed0 + s, clearance=wl["clearance"]) for s in range(n_layouts)]
+    for lay in layouts:
+        if wl["ped_box"] is not None:  # libpedsim's quadtree covers x in [0, 10], y in [10, 20] only (pedscene.h:18): the crowd stays in its square
+            rng = np.random.default_rng(13)
+            lo, hi = wl["ped_box"]
+            lay.ped_pose[:, :2] = rng.uniform(lo, hi, (P, 2))
+            lay.ped_traj[:, :, :2] = rng.uniform(lo, hi, lay.ped_traj[:, :, :2].shape)
+            lay.ped_goal[:] = rng.uniform(lo, hi, (P, 2))
+        if sort_x:
+            # robots are numbered along x, so that a rank's contiguous shard is a vertical strip of the map: each rank then
+            # rasterises only the robots its own strip can see (the library clips to the shard's bounding box + view reach)
+            order = np.argsort(lay.robot_pose[:, 0], kind="stable")
+            lay.robot_pose = lay.robot_pose[order].copy()
+            lay.robot_goal = lay.robot_goal[order].copy()
+    params = worldgen.make_params(R, P, res=wl["res"], view_cells=48, beams=360, scene=wl["scene"], time_max=TIME_MAX,
+                                  relation_ped_robo=wl["relation_ped_robo"], robot_begin=robot_begin,
+                                  robot_end=R if robot_end is None else robot_end)
+    return grid, params, layouts
 
 
 def algorithmic_bytes(P, hv=48, wv=48, beams=360, max_ped=N_PEDS):
@@ -73,16 +108,13 @@ def _cpu_model():
     return "unknown"
 
 
-def _oracle_world(n_robots, n_peds, grid_cells, res, clearance, seed):
+def _oracle_world(cfg_name, n_robots, n_peds, seed):
     """an oracle world of the benchmark's geometry (TEST / BASELINE infrastructure: bench.py's cpu_baseline leg only)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from img_env_amd import worldgen
     from oracle_binding import OracleWorld
-    grid = worldgen.make_grid(grid_cells, 0)
-    params = worldgen.make_params(n_robots, n_peds, res=res, view_cells=48, beams=360, scene="rvoscene", time_max=TIME_MAX)
-    layout = worldgen.make_layout(grid, res, n_robots, n_peds, seed=seed, clearance=clearance)
+    grid, params, layouts = make_workload(cfg_name, n_robots, n_peds, 1, seed0=seed)
     w = OracleWorld(params, grid)
-    w.reset(layout)
+    w.reset(layouts[0])
     return w
 
 
@@ -106,13 +138,13 @@ def cpu_worker(args):
     R / k robots beside the benchmark's 200 pedestrians on the benchmark's map -- the reference's env_num idiom (one
     single-threaded node per env, create_launch.py:57-66).  Never imports torch, never touches a GPU."""
     n = args.cpu_worker_robots
-    w = _oracle_world(n, args.peds, GRID, RES, CLEARANCE, seed=1000 + args.cpu_worker)
+    w = _oracle_world(args.config, n, args.peds, seed=1000 + args.cpu_worker)
     steps, dt = _oracle_run(w, n, args.cpu_worker_seconds, 10 ** 9, start_at=args.cpu_worker_start)
     w.close()
     print(json.dumps(dict(worker=args.cpu_worker, robots=n, steps=steps, seconds=dt)))
 
 
-def cpu_baseline(params, grid, layout, peds, seconds=6.0, all_core_seconds=6.0):
+def cpu_baseline(cfg_name, params, grid, layout, peds, seconds=6.0, all_core_seconds=6.0):
     """The CPU oracle (literal single-thread C restatement of the reference, `kind: "port"`) on this box's host cores:
     (a) ONE thread on the very world the GPU timed (8192 robots in one shared world), and
     (b) ALL cores the way the reference itself scales on a CPU -- one single-threaded process per core, each its own world of
@@ -136,7 +168,7 @@ def cpu_baseline(params, grid, layout, peds, seconds=6.0, all_core_seconds=6.0):
     def all_cores(per):
         start = time.time() + 6.0 + 0.02 * cores  # imports + world set-up of every worker fit in here
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(k), "--cpu-worker-robots", str(per),
-                                   "--cpu-worker-seconds", str(all_core_seconds), "--cpu-worker-start", repr(start), "--peds", str(peds)],
+                                   "--cpu-worker-seconds", str(all_core_seconds), "--cpu-worker-start", repr(start), "--peds", str(peds), "--config", cfg_name],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(cores)]
         total, slowest, ok = 0.0, 0.0, 0
         for pr in procs:
@@ -159,10 +191,10 @@ def cpu_baseline(params, grid, layout, peds, seconds=6.0, all_core_seconds=6.0):
     return dict(value=best if (ok1 or ok2) else None, unit="robot-steps/s", cores=max(ok1, ok2), kind="port", cpu_model=_cpu_model(),
                 nproc=cores, single_thread_value=single, all_cores_split_world_value=split, all_cores_1024_robot_worlds_value=big,
                 sample="all cores: %d single-threaded oracle processes side by side (one per hardware thread, the reference's env_num "
-                       "idiom), each its own world + %d ORCA peds on the 400x400 map @%.2f m, v=0 policy: %d robots per world (the "
+                       "idiom), each its own world + %d %s peds on the 400x400 map @%.2f m, v=0 policy: %d robots per world (the "
                        "benchmark's %d split over the cores, %.1f s) and 1024 robots per world (%.1f s); value = the better of the two; "
                        "single_thread_value: 1 thread, %d steps of the same %d-robot shared world the GPU ran, %.1f s"
-                       % (max(ok1, ok2), peds, RES, per, R, t1, t2, steps, R, dt))
+                       % (max(ok1, ok2), peds, WORKLOADS[cfg_name]["scene"], WORKLOADS[cfg_name]["res"], per, R, t1, t2, steps, R, dt))
 
 
 def launch_ranks(args):
@@ -195,7 +227,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--robots-per-gpu", type=int, default=ROBOTS_PER_GPU)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg3", help="BASELINE configuration: cfg3 = the metric's 8192-robot "
+                    "world, strong-scaled over the GPUs (default); cfg4 = 8192 robots per GPU beside 200 social-force pedestrians, weak scaling")
+    ap.add_argument("--robots-per-gpu", type=int, default=None, help="diagnostic: robots per GPU instead of the configuration's")
     ap.add_argument("--peds", type=int, default=N_PEDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-episode", action="store_true")
@@ -226,30 +260,29 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world_size))
-    RL = args.robots_per_gpu
+    wl = WORKLOADS[args.config]
+    if args.robots_per_gpu:  # diagnostic override: that many robots on every rank, whatever the configuration says
+        RL = args.robots_per_gpu
+    elif wl["scaling"] == "strong":
+        if ROBOTS % world_size:
+            raise SystemExit("bench.py: %d robots do not split over %d GPUs" % (ROBOTS, world_size))
+        RL = ROBOTS // world_size
+    else:
+        RL = ROBOTS_PER_GPU
     R = RL * world_size
     P = args.peds
-    res, clearance = RES, CLEARANCE
-    side = grid_cells(world_size)
-    grid = worldgen.make_grid(side, 0)
+    res, clearance = wl["res"], wl["clearance"]
+    side = GRID
     n_layouts = 2 + (args.steps + args.warmup) // (TIME_MAX + 1)
-    layouts = [worldgen.make_layout(grid, res, R, P, seed=100 + s, clearance=clearance) for s in range(min(n_layouts, 4))]
-    if world_size > 1:
-        # robots are numbered along x, so that a rank's contiguous shard is a vertical strip of the map: each rank then
-        # rasterises only the robots its own strip can see (the library clips to the shard's bounding box + view reach)
-        for lay in layouts:
-            order = np.argsort(lay.robot_pose[:, 0], kind="stable")
-            lay.robot_pose = lay.robot_pose[order].copy()
-            lay.robot_goal = lay.robot_goal[order].copy()
-    params = worldgen.make_params(R, P, res=res, view_cells=48, beams=360, scene="rvoscene", time_max=TIME_MAX,
-                                  robot_begin=rank * RL, robot_end=(rank + 1) * RL)
+    grid, params, layouts = make_workload(args.config, R, P, min(n_layouts, 4 if R <= 16384 else 2), robot_begin=rank * RL, robot_end=(rank + 1) * RL,
+                                          sort_x=world_size > 1)
 
     # The CPU baseline runs FIRST, before this process makes its first GPU call: its all-core leg starts worker processes,
     # and nothing may be started from a process that holds a GPU context on this pool.
     cpu_base = None
     if world_size == 1 and not args.no_cpu_baseline and not args.force_dist:
         try:
-            cpu_base = cpu_baseline(dict(params), grid, layouts[0], P)
+            cpu_base = cpu_baseline(args.config, dict(params), grid, layouts[0], P)
         except Exception as e:
             cpu_base = {"value": None, "unit": "robot-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
@@ -444,7 +477,7 @@ def main():
 
     launches_per_step = world.launches()
     multi_world = None
-    if world_size == 1 and not args.no_multi_world and not args.force_dist:
+    if world_size == 1 and args.config == "cfg3" and not args.no_multi_world and not args.force_dist:
         # secondary: the reference's own env_num idiom -- E independent worlds of R/E robots at
         # 0.125 m in ONE handle, every world with its own obstacle map, crowd and time limit, reset on its own when its
         # time limit runs out (imgenv_reset_worlds); no collective, so N GPUs simply hold N times the worlds
@@ -458,7 +491,7 @@ def main():
             multi_world = {"error": repr(e)}
 
     vec_env = None
-    if world_size == 1 and not args.no_multi_world and not args.force_dist:
+    if world_size == 1 and args.config == "cfg3" and not args.no_multi_world and not args.force_dist:
         # secondary: the trainer's end-to-end loop -- 1024 reference envs of 4 robots behind VecImageEnv (the wrapper stack's
         # outputs, NeverStopWrapper-style resets inside the library: imgenv_step_autoreset), Python call to Python return
         try:
@@ -470,7 +503,7 @@ def main():
             vec_env = {"error": repr(e)}
 
     shipped = None
-    if world_size == 1 and not args.no_multi_world and not args.force_dist:
+    if world_size == 1 and args.config == "cfg3" and not args.no_multi_world and not args.force_dist:
         # secondary: the geometry of the reference's shipped envs/cfg/test.yaml (BASELINE cfg-1): 400 x 400 cell views shrunk to
         # 48 x 48, 1000 beams, one robot + 4 leg pedestrians + 4 obstacles per env, VecImageEnv end to end with auto-resets
         try:
@@ -486,7 +519,7 @@ def main():
         achieved = kernel_bytes / dur_s / 1e9
         traffic, path_traffic, traffic_source = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
+        if os.path.exists(pmc) and args.config == "cfg3" and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
             try:
                 counters = json.load(open(pmc))
                 traffic = counters.get(dominant, {}).get("hbm_bytes_per_launch")
@@ -504,7 +537,7 @@ def main():
         issue = None
         try:
             cnt = json.load(open(pmc)).get(dominant, {}) if os.path.exists(pmc) else {}
-            if cnt.get("valu_per_wave") and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
+            if cnt.get("valu_per_wave") and args.config == "cfg3" and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
                 waves, vpw = cnt["waves_per_launch"], cnt["valu_per_wave"]
                 lo, hi = (waves * vpw * c / (1024 * 2.4e9) * 1e6 for c in (2.4, 4.2))
                 issue = {"valu_per_wave": vpw, "waves_per_launch": waves, "cycles_model": "4.2 cycles per wave64 VALU instruction per SIMD "
@@ -516,14 +549,12 @@ def main():
             "metric": "robot-steps/sec (whole node) at 8192 robots, 48x48 maps, 360 lasers",
             "value": value, "unit": "robot-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg-3: one world, %d robots/GPU x %d GPUs, %d ORCA peds (rvoscene), %dx%d grid "
-                                   "@%.3f m%s, 48x48 sensor_map + 3ch ped_map, 360-beam laser, time_max %d, full reset whenever the time limit "
-                                   "runs out (%d inside the %d timed steps)"
-                                   % (RL, world_size, P, side, side, res,
-                                      "" if world_size == 1 else " (weak scaling: BASELINE's 400x400 grown to %dx%d cells so that %d robots "
-                                      "can be placed without overlapping)" % (side, side, R),
-                                      TIME_MAX, resets_timed, args.steps),
+            "scaling": wl["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (wl["name"] % dict(R=R, RL=RL, N=world_size, P=P, strong="" if world_size == 1 else
+                                                      ": strong scaling, the same world at every GPU count")) +
+                                   ", %dx%d grid @%.3f m, 48x48 sensor_map + 3ch ped_map, 360-beam laser, time_max %d, full reset whenever the "
+                                   "time limit runs out (%d inside the %d timed steps)" % (side, side, res, TIME_MAX, resets_timed, args.steps),
+                       "baseline_config": args.config,
                        "robots": R, "peds": P, "grid": side, "resolution": res, "view": 48, "beams": 360,
                        "policy": "active: v=0, w~U(-0.9,0.9): every robot-step runs the full view path",
                        "parallelism": ("robot-sharded x%d, RCCL all-gather of robot records (%s)" % (

@@ -1,5 +1,7 @@
 import os
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -8,9 +10,45 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+SHARD_JOB = {}  # the two-process HIP shard run (tests/shard_ranks.py): started here, judged by tests/test_gpu_shard_processes.py
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_tests_selected(config):
+    expr = (config.getoption("markexpr", "") or "").strip()
+    if "not gpu" in expr:
+        return False
+    try:
+        import torch
+        return torch.cuda.device_count() > 0  # (counting devices does not initialise the GPU)
+    except Exception:
+        return False
+
+
+def pytest_collection_finish(session):
+    """The ranks of the two-process shard test are child processes, and nothing may be started from a process that already holds
+    a GPU context on this pool: so their launcher (which never touches the GPU itself) is started now -- the tests are collected,
+    none has run, no module touches the GPU at import -- and runs underneath the other tests."""
+    if os.environ.get("IMGENV_NO_SHARD_JOB") or not _gpu_tests_selected(session.config):
+        return
+    if session.config.getoption("collectonly", False) or not any("test_gpu_shard_processes" in it.nodeid for it in session.items):
+        return
+    out = tempfile.mkdtemp(prefix="imgenv_shard_")
+    SHARD_JOB["dir"] = out
+    SHARD_JOB["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_ranks.py"), "launch", out],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    pr = SHARD_JOB.get("proc")
+    if pr is not None and pr.poll() is None:
+        try:
+            pr.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            pr.kill()
 
 
 @pytest.fixture(scope="session")
