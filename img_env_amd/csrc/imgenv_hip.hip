@@ -1250,7 +1250,17 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         k_side_robots<<<dim3((n_g + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
         h->launches += 1;
         if (h->NA > 0) {
-            TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(n_p), dim3(WAVE), 0, s_orca>>>(d)));
+            // groups of up to 8 pedestrians of one world per wavefront; an agent's LDS scratch sized by the largest obstacle table
+            // any world of the handle can hold, the table itself staged into LDS when it fits 256 segments
+            OrcaLaunch L;
+            const int per_world = h->W > 1 ? h->Pw : h->P, cap = std::max(std::max(h->cap_obst, d.n_obst), 1);
+            L.G = per_world >= 8 ? 8 : per_world > 2 ? 4 : per_world;
+            L.groups = (per_world + L.G - 1) / L.G;
+            L.cap_on = std::min(ORCA_MAX_ON, cap);
+            L.cap_stack = std::min(ORCA_STACK, cap + 1);
+            L.stage_obst = cap <= 256 ? cap : 0;
+            const unsigned blocks = (unsigned)((n_p / per_world) * L.groups);
+            TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(blocks), dim3(WAVE), orca_lds_bytes(L), s_orca>>>(d, L)));
             h->launches += 1;
         }
         if (overlap) {
@@ -1328,7 +1338,13 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     } else {
         // one wavefront per robot when the launch fills the machine, four when it is small (a reset of a few worlds): then
         // the single wavefront's latency is all there is
-        const bool small = (d.act_n_dev ? std::min(n_l, h->act_hint) : n_l) <= 1024;
+        // ... and whenever a view's LDS (crop + hit words + column table: 15 KB at 96 x 96 cells and 720 beams) would leave a
+        // compute unit with 16 or fewer one-wavefront workgroups -- four or fewer wavefronts per SIMD where the registers allow
+        // eight: four wavefronts then share one view's LDS (cfg-5, 8192 robots: k_view 252 -> 179 us alone, the step 472 -> 377 us;
+        // at 48 x 48 cells, 5 KB and 32 workgroups per unit, it loses: 63 -> 87 us)
+        static const int force_nw = getenv("IMGENV_VIEW_NW") ? atoi(getenv("IMGENV_VIEW_NW")) : 0;  // (measurement switch)
+        const bool lds_bound = (160 * 1024) / ((h->lds_view + 1279) / 1280 * 1280) <= 16;
+        const bool small = force_nw ? force_nw == 4 : (lds_bound || (d.act_n_dev ? std::min(n_l, h->act_hint) : n_l) <= 1024);
         const dim3 gv(n_l), bv(small ? 4 * WAVE : WAVE);
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \

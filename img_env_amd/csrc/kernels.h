@@ -294,83 +294,146 @@ __device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l,
 // Pedestrian advance (ORCA)
 
 // PedAgent::arrive + _get_cur_goal + RVOScene::step pref velocity (img_env.cpp:306-319, rvoscene.h:36-46),
-// then Agent::computeNeighbors + computeNewVelocity for pedestrian j = blockIdx.x.
-__global__ __launch_bounds__(WAVE) void k_orca(DevWorld w) {
-    __shared__ OrcaScratch s;
-    if ((int)blockIdx.x >= act_count_p(w)) return;
-    const int j = act_member(w, w.Pw, blockIdx.x);
+// then Agent::computeNeighbors + computeNewVelocity -- for a GROUP of up to ORCA_GROUP_MAX pedestrians of one world per
+// wavefront (workgroup = (listed world, group); lane g < G owns agent g of the group, all 64 lanes share the scans):
+//   * the world's obstacle segments + BSP nodes are copied into LDS once (a pedestrian's tree walk and half-plane construction
+//     are chains of dependent loads: ~100 HBM round trips per agent before, LDS accesses now);
+//   * every candidate neighbour is loaded once and tested against each agent of the group;
+//   * tree walk, half-planes and the linear programs run on one lane per agent.
+// (Before: one pedestrian per wavefront, everything serial on lane 0 out of HBM -- 129 us at 2048 shipped envs x 4 pedestrians,
+// where its 8192 wavefronts also took k_crop_big's issue slots.)
+struct OrcaLaunch {
+    int G;          // agents per wavefront
+    int groups;     // wavefronts per world
+    int cap_on;     // obstacle neighbours an agent's scratch holds (the handle's largest obstacle table, at most ORCA_MAX_ON)
+    int cap_stack;  // tree levels its walk may stack up
+    int stage_obst; // obstacle segments / nodes the LDS staging area holds (0: read them from HBM)
+};
+#define ORCA_GROUP_MAX 8
+__host__ __device__ inline size_t orca_lds_bytes(const OrcaLaunch& L) {
+    return ((size_t)L.G * orca_scratch_bytes(L.cap_on, L.cap_stack) + (size_t)L.stage_obst * (sizeof(RvoObstDev) + sizeof(RvoNodeDev)) +
+            ORCA_NEAR_CAP * sizeof(int) + 15) & ~(size_t)15;
+}
+__global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
-    const int wld = world_of_ped(w, j);
-    const int p_lo = w.W > 1 ? wld * w.Pw : 0, n_p = w.W > 1 ? w.Pw : w.P;  // the pedestrians of this one's world
-    if (w.W > 1) {  // ... and its obstacles
-        w.obst += w.obst_base[wld];
-        w.onodes += w.node_base[wld];
-        w.n_obst = w.n_obst_w[wld];
-        w.oroot = w.oroot_w[wld];
+    const int n_p = w.W > 1 ? w.Pw : w.P;  // the pedestrians of one world
+    const int q = (int)blockIdx.x / L.groups, gi = (int)blockIdx.x - q * L.groups;
+    if (q * n_p >= act_count_p(w)) return;
+    const int wld = w.W > 1 ? (w.act_list ? w.act_list[q] : q) : 0;
+    const int p_lo = wld * n_p, a0 = gi * L.G;
+    const int G = min(L.G, n_p - a0);  // agents of this group
+    const bool mine = lane < G;
+    const int j = p_lo + a0 + (mine ? lane : 0);
+    // LDS: G scratches | staged obstacles | staged nodes | near_sorted
+    const size_t sb = orca_scratch_bytes(L.cap_on, L.cap_stack);
+    OrcaScratch s;
+    orca_scratch_carve(s, smem + (size_t)(mine ? lane : 0) * sb, L.cap_on, L.cap_stack);
+    RvoObstDev* l_obst = (RvoObstDev*)(smem + (size_t)L.G * sb);
+    RvoNodeDev* l_nodes = (RvoNodeDev*)(l_obst + L.stage_obst);
+    int* near_sorted = (int*)(l_nodes + L.stage_obst);
+    OrcaObst ob;
+    ob.obst = w.obst;
+    ob.onodes = w.onodes;
+    ob.n_obst = w.n_obst;
+    ob.oroot = w.oroot;
+    if (w.W > 1) {  // this world's slices
+        ob.obst += w.obst_base[wld];
+        ob.onodes += w.node_base[wld];
+        ob.n_obst = w.n_obst_w[wld];
+        ob.oroot = w.oroot_w[wld];
     }
-    // pref velocity: every lane computes the same (uniform) values
-    int idx = w.ptraj_idx[j];
-    const int len = w.ptraj_len[j];
-    const double px = w.ppx[j], py = w.ppy[j];
-    if (idx < len) {  // an index past the end (UB in the reference) never "arrives"
-        const double* tp = w.ptraj + ((size_t)j * w.traj_cap + idx) * 3;
-        if ((tp[0] - px) * (tp[0] - px) + (tp[1] - py) * (tp[1] - py) < 0.04) idx++;
+    if (ob.n_obst > 0 && ob.n_obst <= L.stage_obst) {  // (every obstacle vertex sits in exactly one tree node: as many nodes as vertices)
+        const uint32_t* so = (const uint32_t*)ob.obst;
+        const uint32_t* sn = (const uint32_t*)ob.onodes;
+        uint32_t *dobs = (uint32_t*)l_obst, *dn = (uint32_t*)l_nodes;
+        for (int t = lane; t < ob.n_obst * (int)(sizeof(RvoObstDev) / 4); t += WAVE) dobs[t] = so[t];
+        for (int t = lane; t < ob.n_obst * (int)(sizeof(RvoNodeDev) / 4); t += WAVE) dn[t] = sn[t];
+        ob.obst = l_obst;
+        ob.onodes = l_nodes;
     }
-    const double* g = w.ptraj + ((size_t)j * w.traj_cap + (len > 0 ? idx % len : 0)) * 3;
-    const f2 pos = F2(w.apx[j], w.apy[j]);
-    f2 pref = F2((float)g[0], (float)g[1]) - pos;
-    if (abs_sq(pref) > 1.0f) pref = normalize(pref);
-    if (lane == 0) {
-        w.ptraj_idx[j] = idx;
-        s.n_an = 0;
-        s.n_on = 0;
-    }
-    __syncthreads();
-    // agent neighbours (Agent::computeNeighbors over the kd-tree = the maxNeighbors nearest within neighborDist): scan in
-    // agent index order, 64 agents per round -- every pedestrian, then the robots k_side_robots found near this one
-    // (sorted by index; the full robot range if that list overflowed)
-    __shared__ int near_sorted[ORCA_NEAR_CAP];
-    float range_sq = sqr(0.5f);  // neighborDist (rvoscene.h:57)
-    const int n_near = w.NA > w.P ? w.near_n[j] : 0;
-    const bool listed = n_near <= ORCA_NEAR_CAP;
-    if (listed && n_near > 0) {
-        const int mine = lane < n_near ? w.near_list[(size_t)j * ORCA_NEAR_CAP + lane] : 0x7FFFFFFF;
-        int rank = 0;
-        for (int q = 0; q < n_near; q++) rank += __shfl(mine, q) < mine ? 1 : 0;
-        if (lane < n_near) near_sorted[rank] = mine;
-    }
-    __syncthreads();
-    const int n_rob = w.NA > w.P ? (w.W > 1 ? w.Rw : w.R) : 0, rob_lo = w.P + wld * n_rob;  // the robot agents of its world
-    const int n_scan = listed ? n_p + n_near : n_p + n_rob;
-    for (int base = 0; base < n_scan; base += WAVE) {
-        const int t = base + lane;
-        int a = p_lo + t;
-        if (t >= n_p && t < n_scan) a = listed ? near_sorted[t - n_p] : rob_lo + (t - n_p);
-        float dist_sq = 0.0f;
-        bool cand = false;
-        if (t < n_scan && a != j) {
-            dist_sq = abs_sq(pos - F2(w.apx[a], w.apy[a]));
-            cand = dist_sq < range_sq;
+    // waypoint + pref velocity, one agent per lane
+    f2 pos = F2(0.0f, 0.0f), pref = F2(0.0f, 0.0f);
+    if (mine) {
+        int idx = w.ptraj_idx[j];
+        const int len = w.ptraj_len[j];
+        const double px = w.ppx[j], py = w.ppy[j];
+        if (idx < len) {  // an index past the end (UB in the reference) never "arrives"
+            const double* tp = w.ptraj + ((size_t)j * w.traj_cap + idx) * 3;
+            if ((tp[0] - px) * (tp[0] - px) + (tp[1] - py) * (tp[1] - py) < 0.04) idx++;
         }
-        unsigned long long mask = __ballot(cand);
-        if (mask != 0ull) {  // rare: resolve in index order on lane 0 with the shrinking range
-            while (mask) {
+        const double* g = w.ptraj + ((size_t)j * w.traj_cap + (len > 0 ? idx % len : 0)) * 3;
+        pos = F2(w.apx[j], w.apy[j]);
+        pref = F2((float)g[0], (float)g[1]) - pos;
+        if (abs_sq(pref) > 1.0f) pref = normalize(pref);
+        w.ptraj_idx[j] = idx;
+    }
+    __syncthreads();
+    // agent neighbours (Agent::computeNeighbors over the kd-tree = the maxNeighbors nearest within neighborDist): candidates in
+    // agent index order, 64 per round, each tested against every agent of the group; an agent's hits are inserted in index
+    // order by its lane, with the reference's shrinking range -- first every pedestrian of the world ...
+    float range_sq = sqr(0.5f);  // neighborDist (rvoscene.h:57)
+    for (int base = 0; base < n_p; base += WAVE) {
+        const int t = base + lane, a = p_lo + min(t, n_p - 1);
+        const f2 cp = F2(w.apx[a], w.apy[a]);
+        for (int g = 0; g < G; g++) {
+            const f2 pg = F2(__shfl(pos.x, g), __shfl(pos.y, g));
+            const float dist_sq = abs_sq(pg - cp), rg = __shfl(range_sq, g);  // (every lane takes part in the shuffles)
+            const bool cand = t < n_p && t != a0 + g && dist_sq < rg;
+            unsigned long long mask = __ballot(cand);
+            while (mask) {  // rare
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const float d = __shfl(dist_sq, src);
                 const int who = __shfl(a, src);
-                if (lane == 0) insert_agent_neighbor(s, d, who, range_sq);
+                if (lane == g) insert_agent_neighbor(s, d, who, range_sq);
             }
-            range_sq = __shfl(range_sq, 0);
         }
     }
-    if (lane == 0 && w.NA > w.P) w.near_n[j] = 0;  // re-armed for the next step's k_side_robots
-    if (lane == 0) {
-        if (w.n_obst > 0) {
-            const float obst_range_sq = sqr(5.0f * w.amax_speed[j] + 0.5f);  // timeHorizonObst*maxSpeed + radius
-            query_obstacle_tree(w, s, pos, obst_range_sq);
+    // ... then the robots k_side_robots found near each agent (sorted by index; the full robot range if that list overflowed)
+    if (w.NA > w.P) {
+        const int n_near_mine = mine ? w.near_n[j] : 0;
+        const int n_rob = w.W > 1 ? w.Rw : w.R, rob_lo = w.P + wld * n_rob;  // the robot agents of the world
+        for (int g = 0; g < G; g++) {
+            const int n_near = __shfl(n_near_mine, g);
+            if (n_near == 0) continue;
+            const int jg = p_lo + a0 + g;
+            const bool listed = n_near <= ORCA_NEAR_CAP;
+            if (listed) {
+                const int nm = lane < n_near ? w.near_list[(size_t)jg * ORCA_NEAR_CAP + lane] : 0x7FFFFFFF;
+                int rank = 0;
+                for (int e = 0; e < n_near; e++) rank += __shfl(nm, e) < nm ? 1 : 0;
+                __syncthreads();
+                if (lane < n_near) near_sorted[rank] = nm;
+                __syncthreads();
+            }
+            const f2 pg = F2(__shfl(pos.x, g), __shfl(pos.y, g));
+            const int n_scan = listed ? n_near : n_rob;
+            for (int base = 0; base < n_scan; base += WAVE) {
+                const int t = base + lane;
+                int a = rob_lo;
+                if (t < n_scan) a = listed ? near_sorted[t] : rob_lo + t;
+                const float dist_sq = abs_sq(pg - F2(w.apx[a], w.apy[a])), rg = __shfl(range_sq, g);
+                const bool cand = t < n_scan && dist_sq < rg;
+                unsigned long long mask = __ballot(cand);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const float d = __shfl(dist_sq, src);
+                    const int who = __shfl(a, src);
+                    if (lane == g) insert_agent_neighbor(s, d, who, range_sq);
+                }
+            }
         }
-        const f2 nv = compute_new_velocity(w, s, j, pref);
+        if (mine) w.near_n[j] = 0;  // re-armed for the next step's k_side_robots
+    }
+    __syncthreads();
+    if (mine) {
+        if (ob.n_obst > 0) {
+            const float obst_range_sq = sqr(5.0f * w.amax_speed[j] + 0.5f);  // timeHorizonObst*maxSpeed + radius
+            query_obstacle_tree(ob, w.err, s, pos, obst_range_sq);
+        }
+        const f2 nv = compute_new_velocity(w, ob, s, j, pref);
         // ERVO's evacuation term (Agent.cpp:63-69, 430-432) is added by k_evac once the step's actions -- and with them the
         // beep sources -- exist; through the reference's Python API there never are any (yaml_env.py:183-200).
         w.anvx[j] = nv.x;

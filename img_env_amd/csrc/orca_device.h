@@ -5,13 +5,15 @@
 // (795-838), linearProgram1/2/3 (845-1001), KdTree::queryObstacleTreeRecursive (src/KdTree.cpp:
 // 310-353), helpers in include/ervo_ros/Vector2.h and Definitions.h.
 //
-// MI355X mapping: the agent-neighbour search is a coalesced brute-force scan of the SoA agent
-// arrays by all 64 lanes (chunks in index order, ballot + ordered insertion by lane 0, with the
-// reference's shrinking range) -- equivalent to the kd-tree query up to the order of exactly
-// equidistant neighbours.  The obstacle BSP tree (built on the host at reset with the reference's
-// algorithm) is walked iteratively in the reference's traversal order.  Half-plane construction
-// and the 2-D linear programs are inherently sequential and tiny (<= 10 agent lines): lane 0 runs
-// them out of LDS.  Every float operation is kept in the reference's order (-ffp-contract=off).
+// MI355X mapping: a wavefront takes a GROUP of up to 8 pedestrians of one world.  The agent-neighbour search is a coalesced
+// brute-force scan of the SoA agent arrays by all 64 lanes -- each candidate is loaded once and tested against every agent
+// of the group (ballot + ordered insertion by the agent's lane, with the reference's shrinking range) -- equivalent to the
+// kd-tree query up to the order of exactly equidistant neighbours.  The world's obstacle segments and their BSP tree (built at
+// reset with the reference's algorithm) are staged into LDS once per wavefront; the tree is walked iteratively in the
+// reference's traversal order.  Half-plane construction and the 2-D linear programs are sequential and tiny (<= 10 agent
+// lines): one LANE per agent of the group runs them out of its own LDS scratch (divergent, but 4-8 times the lane use of one
+// agent per wavefront, and every pointer chase is an LDS access instead of an HBM round trip).  Every float operation is kept
+// in the reference's order (-ffp-contract=off).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -55,16 +57,40 @@ struct OrcaLine {
     f2 point, direction;
 };
 
-// LDS scratch of one wave
+// LDS scratch of one agent (one lane of a group): pointers into the workgroup's dynamic LDS, capacities chosen at launch from
+// the handle's largest obstacle table (at most ORCA_MAX_ON obstacle neighbours, ORCA_STACK tree levels)
 struct OrcaScratch {
-    OrcaLine lines[ORCA_MAX_LINES];
-    OrcaLine proj[ORCA_MAX_LINES];
-    float on_dist[ORCA_MAX_ON];
-    int on_idx[ORCA_MAX_ON];
-    float an_dist[ORCA_MAX_AN];
-    int an_idx[ORCA_MAX_AN];
-    int stack[ORCA_STACK];
-    int n_an, n_on;
+    OrcaLine* lines;   // [cap_on + ORCA_MAX_AN]
+    OrcaLine* proj;    // [cap_on + ORCA_MAX_AN]
+    float* on_dist;    // [cap_on]
+    int* on_idx;       // [cap_on]
+    float* an_dist;    // [ORCA_MAX_AN]
+    int* an_idx;       // [ORCA_MAX_AN]
+    int* stack;        // [cap_stack]
+    int n_an, n_on, cap_on, cap_stack;
+};
+__host__ __device__ inline size_t orca_scratch_bytes(int cap_on, int cap_stack) {
+    return (size_t)(cap_on + ORCA_MAX_AN) * 2 * sizeof(OrcaLine) + (size_t)cap_on * 8 + ORCA_MAX_AN * 8 + (size_t)cap_stack * 4;
+}
+__device__ __forceinline__ void orca_scratch_carve(OrcaScratch& s, unsigned char* base, int cap_on, int cap_stack) {
+    const int nl = cap_on + ORCA_MAX_AN;
+    s.lines = (OrcaLine*)base;
+    s.proj = s.lines + nl;
+    s.on_dist = (float*)(s.proj + nl);
+    s.on_idx = (int*)(s.on_dist + cap_on);
+    s.an_dist = (float*)(s.on_idx + cap_on);
+    s.an_idx = (int*)(s.an_dist + ORCA_MAX_AN);
+    s.stack = s.an_idx + ORCA_MAX_AN;
+    s.n_an = s.n_on = 0;
+    s.cap_on = cap_on;
+    s.cap_stack = cap_stack;
+}
+
+// the obstacle segments and BSP nodes of the agent's world: in LDS when they fit the staging area, else in HBM (generic pointers)
+struct OrcaObst {
+    const RvoObstDev* obst;
+    const RvoNodeDev* onodes;
+    int n_obst, oroot;
 };
 
 __device__ float dist_sq_point_segment(f2 a, f2 b, f2 c) {
@@ -78,10 +104,10 @@ __device__ float dist_sq_point_segment(f2 a, f2 b, f2 c) {
     }
 }
 
-__device__ __forceinline__ f2 opoint(const DevWorld& w, int i) { return F2(w.obst[i].px, w.obst[i].py); }
-__device__ __forceinline__ f2 ounit(const DevWorld& w, int i) { return F2(w.obst[i].ux, w.obst[i].uy); }
+__device__ __forceinline__ f2 opoint(const OrcaObst& w, int i) { return F2(w.obst[i].px, w.obst[i].py); }
+__device__ __forceinline__ f2 ounit(const OrcaObst& w, int i) { return F2(w.obst[i].ux, w.obst[i].uy); }
 
-// Agent::insertAgentNeighbor (lane 0)
+// Agent::insertAgentNeighbor (the agent's lane)
 __device__ void insert_agent_neighbor(OrcaScratch& s, float dist_sq, int other, float& range_sq) {
     if (dist_sq < range_sq) {
         if (s.n_an < ORCA_MAX_AN) {
@@ -101,13 +127,13 @@ __device__ void insert_agent_neighbor(OrcaScratch& s, float dist_sq, int other, 
     }
 }
 
-// Agent::insertObstacleNeighbor (lane 0)
-__device__ __forceinline__ void insert_obstacle_neighbor(const DevWorld& w, OrcaScratch& s, f2 pos, int ob, float range_sq) {
+// Agent::insertObstacleNeighbor (the agent's lane)
+__device__ __forceinline__ void insert_obstacle_neighbor(const OrcaObst& w, int* err, OrcaScratch& s, f2 pos, int ob, float range_sq) {
     const int nx = w.obst[ob].next;
     const float dist_sq = dist_sq_point_segment(opoint(w, ob), opoint(w, nx), pos);
     if (dist_sq < range_sq) {
-        if (s.n_on >= ORCA_MAX_ON) {
-            w.err[0] = 1;  // more visible obstacle segments than the scratch holds
+        if (s.n_on >= s.cap_on) {
+            err[0] = 1;  // more visible obstacle segments than the scratch holds
             return;
         }
         s.on_dist[s.n_on] = dist_sq;
@@ -124,8 +150,8 @@ __device__ __forceinline__ void insert_obstacle_neighbor(const DevWorld& w, Orca
     }
 }
 
-// KdTree::queryObstacleTreeRecursive, iteratively, same visiting order (lane 0)
-__device__ __forceinline__ void query_obstacle_tree(const DevWorld& w, OrcaScratch& s, f2 pos, float range_sq) {
+// KdTree::queryObstacleTreeRecursive, iteratively, same visiting order (the agent's lane)
+__device__ __forceinline__ void query_obstacle_tree(const OrcaObst& w, int* err, OrcaScratch& s, f2 pos, float range_sq) {
     int sp = 0;
     if (w.oroot < 0) return;
     s.stack[sp++] = w.oroot << 1;  // (node << 1) | stage
@@ -139,8 +165,8 @@ __device__ __forceinline__ void query_obstacle_tree(const DevWorld& w, OrcaScrat
             s.stack[sp - 1] = top | 1;
             const int child = (agent_left >= 0.0f ? w.onodes[node].left : w.onodes[node].right);
             if (child >= 0) {
-                if (sp >= ORCA_STACK) {
-                    w.err[1] = 1;
+                if (sp >= s.cap_stack) {
+                    err[1] = 1;
                     return;
                 }
                 s.stack[sp++] = child << 1;
@@ -149,7 +175,7 @@ __device__ __forceinline__ void query_obstacle_tree(const DevWorld& w, OrcaScrat
             sp--;
             const float dist_sq_line = sqr(agent_left) / abs_sq(opoint(w, o2) - opoint(w, o1));
             if (dist_sq_line < range_sq) {
-                if (agent_left < 0.0f) insert_obstacle_neighbor(w, s, pos, o1, range_sq);
+                if (agent_left < 0.0f) insert_obstacle_neighbor(w, err, s, pos, o1, range_sq);
                 const int child = (agent_left >= 0.0f ? w.onodes[node].right : w.onodes[node].left);
                 if (child >= 0) s.stack[sp++] = child << 1;
             }
@@ -255,12 +281,13 @@ __device__ void linear_program3(OrcaScratch& s, int n, int num_obst_lines, int b
     }
 }
 
-// Agent::computeNewVelocity for agent `self` given its neighbour lists in the scratch (lane 0)
-__device__ __forceinline__ f2 compute_new_velocity(const DevWorld& w, OrcaScratch& s, int self, f2 pref) {
-    const f2 pos = F2(w.apx[self], w.apy[self]);
-    const f2 vel = F2(w.avx[self], w.avy[self]);
+// Agent::computeNewVelocity for agent `self` given its neighbour lists in the scratch (the agent's lane); ob: its world's
+// obstacle segments
+__device__ __forceinline__ f2 compute_new_velocity(const DevWorld& dw, const OrcaObst& w, OrcaScratch& s, int self, f2 pref) {
+    const f2 pos = F2(dw.apx[self], dw.apy[self]);
+    const f2 vel = F2(dw.avx[self], dw.avy[self]);
     const float radius = 0.5f, time_horizon = 5.0f, time_horizon_obst = 5.0f;  // rvoscene.h:57,63
-    const float max_speed = w.amax_speed[self];
+    const float max_speed = dw.amax_speed[self];
     const float inv_tho = 1.0f / time_horizon_obst;
     int nl = 0;
     OrcaLine* L = s.lines;
@@ -377,8 +404,8 @@ __device__ __forceinline__ f2 compute_new_velocity(const DevWorld& w, OrcaScratc
     const float inv_th = 1.0f / time_horizon;
     for (int i = 0; i < s.n_an; ++i) {
         const int other = s.an_idx[i];
-        const f2 rel_pos = F2(w.apx[other], w.apy[other]) - pos;
-        const f2 rel_vel = vel - F2(w.avx[other], w.avy[other]);
+        const f2 rel_pos = F2(dw.apx[other], dw.apy[other]) - pos;
+        const f2 rel_vel = vel - F2(dw.avx[other], dw.avy[other]);
         const float dist_sq = abs_sq(rel_pos);
         const float comb = radius + 0.5f;  // every agent has radius 0.5
         const float comb_sq = sqr(comb);
@@ -403,7 +430,7 @@ __device__ __forceinline__ f2 compute_new_velocity(const DevWorld& w, OrcaScratc
                 u = dp2 * dir - rel_vel;
             }
         } else {
-            const float inv_ts = 1.0f / (float)w.step_hz;
+            const float inv_ts = 1.0f / (float)dw.step_hz;
             const f2 ww = rel_vel - inv_ts * rel_pos;
             const float wl = vabs(ww);
             const f2 unit_w = vdiv(ww, wl);
@@ -413,7 +440,7 @@ __device__ __forceinline__ f2 compute_new_velocity(const DevWorld& w, OrcaScratc
         PUSH(vel + 0.5f * u, dir);
     }
 #undef PUSH
-    f2 nv = F2(w.anvx[self], w.anvy[self]);
+    f2 nv = F2(dw.anvx[self], dw.anvy[self]);
     const int fail = linear_program2(L, nl, max_speed, pref, false, nv);
     if (fail < nl) linear_program3(s, nl, num_obst_lines, fail, max_speed, nv);
     return nv;
