@@ -1250,15 +1250,15 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         k_side_robots<<<dim3((n_g + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
         h->launches += 1;
         if (h->NA > 0) {
-            // groups of up to 8 pedestrians of one world per wavefront; an agent's LDS scratch sized by the largest obstacle table
+            // groups of up to 4 pedestrians of one world per wavefront; an agent's LDS scratch sized by the largest obstacle table
             // any world of the handle can hold, the table itself staged into LDS when it fits 256 segments
             OrcaLaunch L;
             const int per_world = h->W > 1 ? h->Pw : h->P, cap = std::max(std::max(h->cap_obst, d.n_obst), 1);
-            L.G = per_world >= 8 ? 8 : per_world > 2 ? 4 : per_world;
+            L.G = per_world > 2 ? 4 : per_world;  // a row of 16 lanes per agent
             L.groups = (per_world + L.G - 1) / L.G;
-            L.cap_on = std::min(ORCA_MAX_ON, cap);
+            L.cap_on = std::max(std::min(ORCA_MAX_ON, cap), ORCA_ROW - ORCA_MAX_AN);  // (a round's 16 candidate lines borrow the projection area)
             L.cap_stack = std::min(ORCA_STACK, cap + 1);
-            L.stage_obst = cap <= 256 ? cap : 0;
+            L.stage_obst = std::min(cap, 256);  // (a world with more segments than that is solved out of HBM: the kernel checks its count)
             const unsigned blocks = (unsigned)((n_p / per_world) * L.groups);
             TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(blocks), dim3(WAVE), orca_lds_bytes(L), s_orca>>>(d, L)));
             h->launches += 1;

@@ -294,42 +294,60 @@ __device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l,
 // Pedestrian advance (ORCA)
 
 // PedAgent::arrive + _get_cur_goal + RVOScene::step pref velocity (img_env.cpp:306-319, rvoscene.h:36-46),
-// then Agent::computeNeighbors + computeNewVelocity -- for a GROUP of up to ORCA_GROUP_MAX pedestrians of one world per
-// wavefront (workgroup = (listed world, group); lane g < G owns agent g of the group, all 64 lanes share the scans):
+// then Agent::computeNeighbors + computeNewVelocity -- for a GROUP of up to 4 pedestrians of one world per wavefront
+// (workgroup = (listed world, group)): agent g of the group owns ROW g of the wavefront, lanes 16 g .. 16 g + 15; lane 16 g is
+// its home lane.
 //   * the world's obstacle segments + BSP nodes are copied into LDS once (a pedestrian's tree walk and half-plane construction
 //     are chains of dependent loads: ~100 HBM round trips per agent before, LDS accesses now);
-//   * every candidate neighbour is loaded once and tested against each agent of the group;
-//   * tree walk, half-planes and the linear programs run on one lane per agent.
-// (Before: one pedestrian per wavefront, everything serial on lane 0 out of HBM -- 129 us at 2048 shipped envs x 4 pedestrians,
-// where its 8192 wavefronts also took k_crop_big's issue slots.)
+//   * agent neighbours: every candidate is loaded once and tested against each agent of the group (positions and ranges in
+//     scalar registers), hits inserted in index order by the agent's home lane;
+//   * obstacle neighbours (KdTree::queryObstacleTreeRecursive): the row evaluates every tree node at once (which side the
+//     agent is on, whether the far side gets visited, whether the node's segment is inserted and at what distance); the home
+//     lane then only replays the traversal on those flags to get the visiting order, and the row sorts the inserted
+//     segments by (distance, visiting order) by rank -- what the reference's insertion sort leaves behind;
+//   * ORCA lines: one obstacle neighbour per lane (everything but the "already covered" test is independent of the other
+//     lines: Agent.cpp:479-671), coverage of i by the candidate lines j < i as a 16 x 16 bit matrix, the accepted lines
+//     settled in order on those bits; one agent neighbour per lane;
+//   * the linear programs stay on the home lane (sequential and tiny).
+// (History: one pedestrian per wavefront with everything on lane 0 out of HBM took 129 us at 2048 shipped envs x 4 pedestrians,
+// one lane per agent out of LDS 62 us alone -- a single agent's chain of ~9000 dependent instructions.)
 struct OrcaLaunch {
-    int G;          // agents per wavefront
+    int G;          // agents per wavefront (1, 2 or 4: one row of 16 lanes each)
     int groups;     // wavefronts per world
     int cap_on;     // obstacle neighbours an agent's scratch holds (the handle's largest obstacle table, at most ORCA_MAX_ON)
     int cap_stack;  // tree levels its walk may stack up
-    int stage_obst; // obstacle segments / nodes the LDS staging area holds (0: read them from HBM)
+    int stage_obst; // obstacle segments / nodes the LDS staging area holds (0: read them from HBM, everything on the home lane)
 };
-#define ORCA_GROUP_MAX 8
+#define ORCA_GROUP_MAX 4
+#define ORCA_ROW 16
+__host__ __device__ inline size_t orca_row_bytes(const OrcaLaunch& L) {  // an agent's scratch + per-node records + the row's exchange words
+    return orca_scratch_bytes(L.cap_on, L.cap_stack) + (size_t)L.stage_obst * 16 + ORCA_ROW * 4;
+}
 __host__ __device__ inline size_t orca_lds_bytes(const OrcaLaunch& L) {
-    return ((size_t)L.G * orca_scratch_bytes(L.cap_on, L.cap_stack) + (size_t)L.stage_obst * (sizeof(RvoObstDev) + sizeof(RvoNodeDev)) +
-            ORCA_NEAR_CAP * sizeof(int) + 15) & ~(size_t)15;
+    return ((size_t)L.G * orca_row_bytes(L) + (size_t)L.stage_obst * (sizeof(RvoObstDev) + sizeof(RvoNodeDev)) + ORCA_NEAR_CAP * sizeof(int) + 15) &
+           ~(size_t)15;
 }
 __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = lane_id();
+    const int lane = lane_id(), row = lane >> 4, li = lane & (ORCA_ROW - 1);
     const int n_p = w.W > 1 ? w.Pw : w.P;  // the pedestrians of one world
     const int q = (int)blockIdx.x / L.groups, gi = (int)blockIdx.x - q * L.groups;
     if (q * n_p >= act_count_p(w)) return;
     const int wld = w.W > 1 ? (w.act_list ? w.act_list[q] : q) : 0;
     const int p_lo = wld * n_p, a0 = gi * L.G;
-    const int G = min(L.G, n_p - a0);  // agents of this group
-    const bool mine = lane < G;
-    const int j = p_lo + a0 + (mine ? lane : 0);
-    // LDS: G scratches | staged obstacles | staged nodes | near_sorted
-    const size_t sb = orca_scratch_bytes(L.cap_on, L.cap_stack);
+    PHASE_BEGIN();
+    const int G = min(L.G, n_p - a0);    // agents of this group
+    const bool row_ok = row < G, mine = row_ok && li == 0;
+    const int home = min(row, G - 1) * ORCA_ROW;
+    const int j = p_lo + a0 + min(row, G - 1);  // the row's agent
+    // LDS: per row (scratch | node records | exchange words), then staged obstacles | staged nodes | near_sorted
+    const size_t rb = orca_row_bytes(L);
+    unsigned char* row_base = smem + (size_t)min(row, L.G - 1) * rb;
     OrcaScratch s;
-    orca_scratch_carve(s, smem + (size_t)(mine ? lane : 0) * sb, L.cap_on, L.cap_stack);
-    RvoObstDev* l_obst = (RvoObstDev*)(smem + (size_t)L.G * sb);
+    orca_scratch_carve(s, row_base, L.cap_on, L.cap_stack);
+    uint4* node_rec = (uint4*)(row_base + orca_scratch_bytes(L.cap_on, L.cap_stack));  // flags | obstacle << 8, distance, near child, far child
+    uint32_t* xch = (uint32_t*)(node_rec + L.stage_obst);
+    RvoObstDev* l_obst = (RvoObstDev*)(smem + (size_t)L.G * rb);
     RvoNodeDev* l_nodes = (RvoNodeDev*)(l_obst + L.stage_obst);
     int* near_sorted = (int*)(l_nodes + L.stage_obst);
     OrcaObst ob;
@@ -343,7 +361,8 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
         ob.n_obst = w.n_obst_w[wld];
         ob.oroot = w.oroot_w[wld];
     }
-    if (ob.n_obst > 0 && ob.n_obst <= L.stage_obst) {  // (every obstacle vertex sits in exactly one tree node: as many nodes as vertices)
+    const bool staged = ob.n_obst > 0 && ob.n_obst <= L.stage_obst;
+    if (staged) {  // (every obstacle vertex sits in exactly one tree node: as many nodes as vertices)
         const uint32_t* so = (const uint32_t*)ob.obst;
         const uint32_t* sn = (const uint32_t*)ob.onodes;
         uint32_t *dobs = (uint32_t*)l_obst, *dn = (uint32_t*)l_nodes;
@@ -352,51 +371,113 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
         ob.obst = l_obst;
         ob.onodes = l_nodes;
     }
-    // waypoint + pref velocity, one agent per lane
-    f2 pos = F2(0.0f, 0.0f), pref = F2(0.0f, 0.0f);
-    if (mine) {
-        int idx = w.ptraj_idx[j];
-        const int len = w.ptraj_len[j];
-        const double px = w.ppx[j], py = w.ppy[j];
-        if (idx < len) {  // an index past the end (UB in the reference) never "arrives"
-            const double* tp = w.ptraj + ((size_t)j * w.traj_cap + idx) * 3;
-            if ((tp[0] - px) * (tp[0] - px) + (tp[1] - py) * (tp[1] - py) < 0.04) idx++;
-        }
-        const double* g = w.ptraj + ((size_t)j * w.traj_cap + (len > 0 ? idx % len : 0)) * 3;
-        pos = F2(w.apx[j], w.apy[j]);
-        pref = F2((float)g[0], (float)g[1]) - pos;
+    // everything the solve reads of its agent, requested at once (one HBM round trip instead of a dozen along the way)
+    const int idx0 = w.ptraj_idx[j], len = w.ptraj_len[j];
+    const double ppx = w.ppx[j], ppy = w.ppy[j];
+    f2 pos = F2(w.apx[j], w.apy[j]);
+    const f2 vel = F2(w.avx[j], w.avy[j]), nv0 = F2(w.anvx[j], w.anvy[j]);
+    const float max_speed = w.amax_speed[j];
+    const int n_near_row = w.NA > w.P ? w.near_n[j] : 0;
+    const int near_ent = w.NA > w.P ? w.near_list[(size_t)j * ORCA_NEAR_CAP + li] : 0;  // (the row's first 16 entries, whatever the count)
+    // waypoint + pref velocity: the waypoint in question and the one behind it, both in flight
+    f2 pref;
+    int idx = idx0;
+    {
+        const double* tr = w.ptraj + (size_t)j * w.traj_cap * 3;
+        const int e0 = idx0 < len ? idx0 : 0, e1 = len > 0 ? (idx0 + 1) % len : 0, e2 = len > 0 ? idx0 % len : 0;
+        const double t0x = tr[3 * e0], t0y = tr[3 * e0 + 1], t1x = tr[3 * e1], t1y = tr[3 * e1 + 1], t2x = tr[3 * e2], t2y = tr[3 * e2 + 1];
+        bool arrived = false;
+        if (idx0 < len) arrived = (t0x - ppx) * (t0x - ppx) + (t0y - ppy) * (t0y - ppy) < 0.04;  // an index past the end (UB in the reference) never "arrives"
+        if (arrived) idx++;
+        const double gx = arrived ? t1x : t2x, gy = arrived ? t1y : t2y;  // trajectory_[idx % len] (agent.cpp:839-843)
+        pref = F2((float)gx, (float)gy) - pos;
         if (abs_sq(pref) > 1.0f) pref = normalize(pref);
-        w.ptraj_idx[j] = idx;
+        if (mine) w.ptraj_idx[j] = idx;
     }
+    PHASE_MARK(5);  // staging, the agent's scalars, waypoint
     __syncthreads();
     // agent neighbours (Agent::computeNeighbors over the kd-tree = the maxNeighbors nearest within neighborDist): candidates in
     // agent index order, 64 per round, each tested against every agent of the group; an agent's hits are inserted in index
-    // order by its lane, with the reference's shrinking range -- first every pedestrian of the world ...
+    // order by its home lane, with the reference's shrinking range -- first every pedestrian of the world ...
     float range_sq = sqr(0.5f);  // neighborDist (rvoscene.h:57)
-    for (int base = 0; base < n_p; base += WAVE) {
-        const int t = base + lane, a = p_lo + min(t, n_p - 1);
-        const f2 cp = F2(w.apx[a], w.apy[a]);
-        for (int g = 0; g < G; g++) {
-            const f2 pg = F2(__shfl(pos.x, g), __shfl(pos.y, g));
-            const float dist_sq = abs_sq(pg - cp), rg = __shfl(range_sq, g);  // (every lane takes part in the shuffles)
-            const bool cand = t < n_p && t != a0 + g && dist_sq < rg;
-            unsigned long long mask = __ballot(cand);
-            while (mask) {  // rare
-                const int src = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const float d = __shfl(dist_sq, src);
-                const int who = __shfl(a, src);
-                if (lane == g) insert_agent_neighbor(s, d, who, range_sq);
+    {
+        // the group's positions and ranges live in scalar registers (v_readlane with a constant lane): a (round, agent) test is
+        // two subtractions, the squares, a compare and a ballot -- no shuffles through LDS in the loop
+        float gx[ORCA_GROUP_MAX], gy[ORCA_GROUP_MAX], gr[ORCA_GROUP_MAX];
+#pragma unroll
+        for (int g = 0; g < ORCA_GROUP_MAX; g++) {
+            gx[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pos.x), g * ORCA_ROW));
+            gy[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pos.y), g * ORCA_ROW));
+            gr[g] = range_sq;
+        }
+        // the robots near each agent (rows of up to 16 list entries): their positions requested before the pedestrian scan starts
+        f2 near_pos = F2(0.0f, 0.0f);
+        if (row_ok && li < min(n_near_row, ORCA_ROW)) near_pos = F2(w.apx[near_ent], w.apy[near_ent]);
+        constexpr int SCAN_BATCH = 8;  // rounds whose candidates are loaded together: one HBM / L2 round trip per 512 pedestrians
+        for (int base0 = 0; base0 < n_p; base0 += WAVE * SCAN_BATCH) {
+            f2 cps[SCAN_BATCH];
+#pragma unroll
+            for (int u = 0; u < SCAN_BATCH; u++) {
+                const int a = p_lo + min(base0 + u * WAVE + lane, n_p - 1);
+                cps[u] = F2(w.apx[a], w.apy[a]);
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_BATCH; u++) {
+                const int base = base0 + u * WAVE;
+                if (base >= n_p) break;  // uniform
+                const int t = base + lane, a = p_lo + min(t, n_p - 1);
+                const f2 cp = cps[u];
+#pragma unroll
+                for (int g = 0; g < ORCA_GROUP_MAX; g++) {
+                    if (g >= G) break;  // uniform
+                    const float dist_sq = abs_sq(F2(gx[g], gy[g]) - cp);
+                    const bool cand = t < n_p && t != a0 + g && dist_sq < gr[g];
+                    unsigned long long mask = __ballot(cand);
+                    if (mask != 0ull) {  // rare
+                        while (mask) {
+                            const int src = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            const float d = __shfl(dist_sq, src);
+                            const int who = __shfl(a, src);
+                            if (lane == g * ORCA_ROW) insert_agent_neighbor(s, d, who, range_sq);
+                        }
+                        gr[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(range_sq), g * ORCA_ROW));
+                    }
+                }
+            }
+        }
+        // ... then the robots k_side_robots found near each agent, in index order.  Up to 16 of them (nearly always): the row sorts
+        // its list by rank, the home lane inserts
+        {
+            int any_fast = (row_ok && n_near_row > 0 && n_near_row <= ORCA_ROW) ? 1 : 0;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) any_fast |= __shfl_xor(any_fast, off);
+            if (any_fast) {  // uniform
+                const bool fast = row_ok && n_near_row > 0 && n_near_row <= ORCA_ROW, have = fast && li < n_near_row;
+                float* nd = (float*)s.proj;       // (the projection area is free until the lines are built)
+                int* ni = (int*)(nd + ORCA_ROW);
+                if (fast) xch[li] = have ? (uint32_t)near_ent : 0x7FFFFFFFu;
+                __syncthreads();
+                if (have) {
+                    int rank = 0;
+                    for (int e = 0; e < ORCA_ROW; e++) rank += (int)xch[e] < near_ent ? 1 : 0;
+                    nd[rank] = abs_sq(pos - near_pos);
+                    ni[rank] = near_ent;
+                }
+                __syncthreads();
+                if (mine && fast)
+                    for (int e = 0; e < n_near_row; e++) insert_agent_neighbor(s, nd[e], ni[e], range_sq);
+                __syncthreads();
             }
         }
     }
-    // ... then the robots k_side_robots found near each agent (sorted by index; the full robot range if that list overflowed)
+    // ... lists of more than 16 robots one agent at a time (sorted by index; the full robot range if the list overflowed)
     if (w.NA > w.P) {
-        const int n_near_mine = mine ? w.near_n[j] : 0;
+        const int n_near_mine = mine ? n_near_row : 0;
         const int n_rob = w.W > 1 ? w.Rw : w.R, rob_lo = w.P + wld * n_rob;  // the robot agents of the world
         for (int g = 0; g < G; g++) {
-            const int n_near = __shfl(n_near_mine, g);
-            if (n_near == 0) continue;
+            const int n_near = __shfl(n_near_mine, g * ORCA_ROW);
+            if (n_near <= ORCA_ROW) continue;  // (none, or done above)
             const int jg = p_lo + a0 + g;
             const bool listed = n_near <= ORCA_NEAR_CAP;
             if (listed) {
@@ -407,13 +488,13 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
                 if (lane < n_near) near_sorted[rank] = nm;
                 __syncthreads();
             }
-            const f2 pg = F2(__shfl(pos.x, g), __shfl(pos.y, g));
+            const f2 pg = F2(__shfl(pos.x, g * ORCA_ROW), __shfl(pos.y, g * ORCA_ROW));
             const int n_scan = listed ? n_near : n_rob;
             for (int base = 0; base < n_scan; base += WAVE) {
                 const int t = base + lane;
                 int a = rob_lo;
                 if (t < n_scan) a = listed ? near_sorted[t] : rob_lo + t;
-                const float dist_sq = abs_sq(pg - F2(w.apx[a], w.apy[a])), rg = __shfl(range_sq, g);
+                const float dist_sq = abs_sq(pg - F2(w.apx[a], w.apy[a])), rg = __shfl(range_sq, g * ORCA_ROW);
                 const bool cand = t < n_scan && dist_sq < rg;
                 unsigned long long mask = __ballot(cand);
                 while (mask) {
@@ -421,24 +502,156 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
                     mask &= mask - 1;
                     const float d = __shfl(dist_sq, src);
                     const int who = __shfl(a, src);
-                    if (lane == g) insert_agent_neighbor(s, d, who, range_sq);
+                    if (lane == g * ORCA_ROW) insert_agent_neighbor(s, d, who, range_sq);
                 }
             }
         }
         if (mine) w.near_n[j] = 0;  // re-armed for the next step's k_side_robots
     }
     __syncthreads();
-    if (mine) {
-        if (ob.n_obst > 0) {
-            const float obst_range_sq = sqr(5.0f * w.amax_speed[j] + 0.5f);  // timeHorizonObst*maxSpeed + radius
-            query_obstacle_tree(ob, w.err, s, pos, obst_range_sq);
+    PHASE_MARK(6);  // neighbour scans
+    if (!staged && ob.n_obst > 0) {  // an obstacle table too large for LDS: the whole solve on the home lane, out of HBM
+        if (mine) {
+            query_obstacle_tree(ob, w.err, s, pos, sqr(5.0f * max_speed + 0.5f));
+            const f2 nv = compute_new_velocity(w, ob, s, j, pref);
+            w.anvx[j] = nv.x;
+            w.anvy[j] = nv.y;
         }
-        const f2 nv = compute_new_velocity(w, ob, s, j, pref);
+        return;
+    }
+    const int n_an = __shfl(s.n_an, home);
+    // ---- obstacle neighbours: every node of the tree at once, then the traversal replayed on the flags
+    int n_on = 0;
+    if (staged) {
+        const float obst_range_sq = sqr(5.0f * max_speed + 0.5f);  // timeHorizonObst*maxSpeed + radius
+        const int n_nodes = ob.n_obst;
+        for (int k = li; k < n_nodes; k += ORCA_ROW) {
+            const RvoNodeDev nd = ob.onodes[k];
+            const int o1 = min(max(nd.obstacle, 0), n_nodes - 1);
+            const int o2 = min(max(ob.obst[o1].next, 0), n_nodes - 1);
+            const float agent_left = left_of(opoint(ob, o1), opoint(ob, o2), pos);
+            const float dist_sq_line = sqr(agent_left) / abs_sq(opoint(ob, o2) - opoint(ob, o1));
+            uint32_t f = (agent_left >= 0.0f ? 1u : 0u) | (dist_sq_line < obst_range_sq ? 2u : 0u);
+            float dseg = 0.0f;
+            if ((f & 2u) != 0u && agent_left < 0.0f) {  // insertObstacleNeighbor(node->obstacle): Agent.cpp:813-838
+                dseg = dist_sq_point_segment(opoint(ob, o1), opoint(ob, o2), pos);
+                if (dseg < obst_range_sq) f |= 4u;
+            }
+            // the side the agent is on is walked first; the other one only if the node's line is within range (KdTree.cpp:325-349)
+            const int near_child = (f & 1u) ? nd.left : nd.right, far_child = (f & 2u) ? ((f & 1u) ? nd.right : nd.left) : -1;
+            if (row_ok) node_rec[k] = make_uint4(f | ((uint32_t)o1 << 8), __float_as_uint(dseg), (uint32_t)near_child, (uint32_t)far_child);
+        }
+        __syncthreads();
+        PHASE_MARK(7);  // tree nodes
+        // the traversal itself (near side, the node, far side) on those records alone, one LDS read per node: inserted segments in
+        // visiting order into the (still unused) projection area
+        float* vis_dist = (float*)s.proj;
+        int* vis_idx = (int*)(vis_dist + L.cap_on);
+        int nv = 0;
+        if (mine) {
+            int sp = 0, cur = ob.oroot;
+            for (;;) {
+                bool overflow = false;
+                while (cur >= 0) {  // down the near side
+                    if (sp >= s.cap_stack) {
+                        overflow = true;
+                        break;
+                    }
+                    s.stack[sp++] = cur;
+                    cur = (int)node_rec[cur].z;
+                }
+                if (overflow) {
+                    w.err[1] = 1;
+                    break;
+                }
+                if (sp == 0) break;
+                const uint4 rec = node_rec[s.stack[--sp]];
+                if (rec.x & 4u) {
+                    if (nv >= s.cap_on) {
+                        w.err[0] = 1;  // more visible obstacle segments than the scratch holds
+                    } else {
+                        vis_dist[nv] = __uint_as_float(rec.y);
+                        vis_idx[nv] = (int)(rec.x >> 8);
+                        nv++;
+                    }
+                }
+                cur = (int)rec.w;
+            }
+        }
+        __syncthreads();
+        PHASE_MARK(12);  // traversal replay
+        n_on = __shfl(nv, home);
+        // insertion in visiting order with a strict "<" (Agent.cpp:824-833) = sorted by (distance, visiting order): by rank
+        for (int e = li; e < n_on; e += ORCA_ROW) {
+            const float d = vis_dist[e];
+            int rank = 0;
+            for (int k = 0; k < n_on; k++) {
+                const float dk = vis_dist[k];
+                rank += (dk < d || (dk == d && k < e)) ? 1 : 0;
+            }
+            if (row_ok) {
+                s.on_dist[rank] = d;
+                s.on_idx[rank] = vis_idx[e];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- ORCA lines of the obstacle neighbours, 16 per round and row
+    int nl = 0;
+    {
+        const float inv_tho = 1.0f / ORCA_TIME_HORIZON_OBST;
+        int n_on_max = n_on;  // trip counts are wavefront-uniform: the rows run in lockstep, barriers included
+#pragma unroll
+        for (int off = 16; off < WAVE; off <<= 1) n_on_max = max(n_on_max, __shfl_xor(n_on_max, off));
+        OrcaLine* cand = s.proj;
+        for (int base = 0; base < n_on_max; base += ORCA_ROW) {
+            const int i = base + li;
+            const bool valid = row_ok && i < n_on;
+            const int o1 = valid ? s.on_idx[i] : 0;
+            OrcaLine ln;
+            ln.point = ln.direction = F2(0.0f, 0.0f);
+            bool has = false;
+            f2 rel1s = F2(0.0f, 0.0f), rel2s = F2(0.0f, 0.0f);
+            if (valid) {
+                const int o2 = ob.obst[o1].next;
+                rel1s = inv_tho * (opoint(ob, o1) - pos);
+                rel2s = inv_tho * (opoint(ob, o2) - pos);
+                bool covered = false;  // ... by a line of an earlier round
+                for (int jj = 0; jj < nl; jj++) covered = covered || obstacle_covered_by(rel1s, rel2s, s.lines[jj]);
+                if (!covered) has = obstacle_line(ob, pos, vel, o1, ln);
+            }
+            if (row_ok) cand[li] = ln;  // (rows without an agent may share a row's scratch: they write nothing)
+            __syncthreads();
+            uint32_t cov = 0;  // bit jj: candidate line jj of this round covers obstacle i
+            if (valid)
+                for (int jj = 0; jj < li; jj++) cov |= obstacle_covered_by(rel1s, rel2s, cand[jj]) ? (1u << jj) : 0u;
+            if (row_ok) xch[li] = (has ? 1u : 0u) | (cov << 1);
+            __syncthreads();
+            uint32_t acc = 0;  // the lines of this round that really get pushed, settled in order (every lane of the row alike)
+            for (int jj = 0; jj < ORCA_ROW; jj++) {
+                const uint32_t x = xch[jj];
+                if ((x & 1u) != 0u && ((x >> 1) & acc) == 0u) acc |= 1u << jj;
+            }
+            if (row_ok && ((acc >> li) & 1u) != 0u) s.lines[nl + __popc(acc & ((1u << li) - 1u))] = ln;
+            nl += __popc(acc);
+            __syncthreads();
+        }
+    }
+    PHASE_MARK(13);  // rank sort + obstacle lines
+    const int num_obst_lines = nl;
+    // ---- one agent neighbour per lane
+    if (row_ok && li < n_an) s.lines[nl + li] = agent_line(w, pos, vel, s.an_idx[li]);
+    nl += n_an;
+    __syncthreads();
+    PHASE_MARK(14);  // agent lines
+    if (mine) {
+        const f2 nv = solve_velocity(s, max_speed, nv0, nl, num_obst_lines, pref);
         // ERVO's evacuation term (Agent.cpp:63-69, 430-432) is added by k_evac once the step's actions -- and with them the
         // beep sources -- exist; through the reference's Python API there never are any (yaml_env.py:183-200).
         w.anvx[j] = nv.x;
         w.anvy[j] = nv.y;
     }
+    PHASE_MARK(15);  // linear programs
 }
 
 // Beep lottery (img_env.cpp:323-342), one workgroup per world: `rand() / double(RAND_MAX) < ped_ca_p` once per robot in

@@ -281,167 +281,190 @@ __device__ void linear_program3(OrcaScratch& s, int n, int num_obst_lines, int b
     }
 }
 
-// Agent::computeNewVelocity for agent `self` given its neighbour lists in the scratch (the agent's lane); ob: its world's
-// obstacle segments
+// ---- Agent::computeNewVelocity (Agent.cpp:437-793) in pieces, so that a group of lanes can share one agent's work ----
+#define ORCA_RADIUS 0.5f        // rvoscene.h:57,63
+#define ORCA_TIME_HORIZON 5.0f
+#define ORCA_TIME_HORIZON_OBST 5.0f
+
+// "already covered" (Agent.cpp:466-477): both end points of the obstacle segment, scaled by 1 / timeHorizonObst, lie behind line L
+__device__ __forceinline__ bool obstacle_covered_by(f2 rel1s, f2 rel2s, const OrcaLine& L) {
+    const float inv_tho = 1.0f / ORCA_TIME_HORIZON_OBST, radius = ORCA_RADIUS;
+    return det(rel1s - L.point, L.direction) - inv_tho * radius >= -RVO_EPS && det(rel2s - L.point, L.direction) - inv_tho * radius >= -RVO_EPS;
+}
+
+// The ORCA line of obstacle neighbour o1 (the segment o1 -> next) for an agent at pos moving with vel, if it yields one
+// (Agent.cpp:479-671): everything behind the covered test, which is the only part that looks at the lines pushed so far
+__device__ __forceinline__ bool obstacle_line(const OrcaObst& w, f2 pos, f2 vel, int o1, OrcaLine& out) {
+    const float radius = ORCA_RADIUS;
+    const float inv_tho = 1.0f / ORCA_TIME_HORIZON_OBST;
+#define EMIT(P_, D_)            \
+    do {                        \
+        out.point = (P_);       \
+        out.direction = (D_);   \
+        return true;            \
+    } while (0)
+    int o2 = w.obst[o1].next;
+    const f2 rel1 = opoint(w, o1) - pos;
+    const f2 rel2 = opoint(w, o2) - pos;
+    const float dsq1 = abs_sq(rel1), dsq2 = abs_sq(rel2);
+    const float rsq = sqr(radius);
+    const f2 ovec = opoint(w, o2) - opoint(w, o1);
+    const float sp = dot(-rel1, ovec) / abs_sq(ovec);
+    const float dsq_line = abs_sq(-rel1 - sp * ovec);
+    const f2 u1 = ounit(w, o1);
+    if (sp < 0.0f && dsq1 <= rsq) {
+        if (w.obst[o1].is_convex) EMIT(F2(0.0f, 0.0f), normalize(F2(-rel1.y, rel1.x)));
+        return false;
+    } else if (sp > 1.0f && dsq2 <= rsq) {
+        if (w.obst[o2].is_convex && det(rel2, ounit(w, o2)) >= 0.0f) EMIT(F2(0.0f, 0.0f), normalize(F2(-rel2.y, rel2.x)));
+        return false;
+    } else if (sp >= 0.0f && sp < 1.0f && dsq_line <= rsq) {
+        EMIT(F2(0.0f, 0.0f), -u1);
+    }
+    f2 left_leg, right_leg;
+    if (sp < 0.0f && dsq_line <= rsq) {
+        if (!w.obst[o1].is_convex) return false;
+        o2 = o1;
+        const float leg1 = sqrtf(dsq1 - rsq);
+        left_leg = vdiv(F2(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), dsq1);
+        right_leg = vdiv(F2(rel1.x * leg1 + rel1.y * radius, -rel1.x * radius + rel1.y * leg1), dsq1);
+    } else if (sp > 1.0f && dsq_line <= rsq) {
+        if (!w.obst[o2].is_convex) return false;
+        o1 = o2;
+        const float leg2 = sqrtf(dsq2 - rsq);
+        left_leg = vdiv(F2(rel2.x * leg2 - rel2.y * radius, rel2.x * radius + rel2.y * leg2), dsq2);
+        right_leg = vdiv(F2(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), dsq2);
+    } else {
+        if (w.obst[o1].is_convex) {
+            const float leg1 = sqrtf(dsq1 - rsq);
+            left_leg = vdiv(F2(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), dsq1);
+        } else {
+            left_leg = -u1;
+        }
+        if (w.obst[o2].is_convex) {
+            const float leg2 = sqrtf(dsq2 - rsq);
+            right_leg = vdiv(F2(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), dsq2);
+        } else {
+            right_leg = u1;
+        }
+    }
+    const f2 uo1 = ounit(w, o1), uo2 = ounit(w, o2);
+    const f2 uln = ounit(w, w.obst[o1].prev);
+    bool left_foreign = false, right_foreign = false;
+    if (w.obst[o1].is_convex && det(left_leg, -uln) >= 0.0f) {
+        left_leg = -uln;
+        left_foreign = true;
+    }
+    if (w.obst[o2].is_convex && det(right_leg, uo2) <= 0.0f) {
+        right_leg = uo2;
+        right_foreign = true;
+    }
+    const f2 left_cutoff = inv_tho * (opoint(w, o1) - pos);
+    const f2 right_cutoff = inv_tho * (opoint(w, o2) - pos);
+    const f2 cutoff_vec = right_cutoff - left_cutoff;
+    const float t = (o1 == o2 ? 0.5f : dot(vel - left_cutoff, cutoff_vec) / abs_sq(cutoff_vec));
+    const float t_left = dot(vel - left_cutoff, left_leg);
+    const float t_right = dot(vel - right_cutoff, right_leg);
+    if ((t < 0.0f && t_left < 0.0f) || (o1 == o2 && t_left < 0.0f && t_right < 0.0f)) {
+        const f2 unit_w = normalize(vel - left_cutoff);
+        EMIT(left_cutoff + radius * inv_tho * unit_w, F2(unit_w.y, -unit_w.x));
+    } else if (t > 1.0f && t_right < 0.0f) {
+        const f2 unit_w = normalize(vel - right_cutoff);
+        EMIT(right_cutoff + radius * inv_tho * unit_w, F2(unit_w.y, -unit_w.x));
+    }
+    const float inf = __builtin_huge_valf();
+    const float dsq_cutoff = ((t < 0.0f || t > 1.0f || o1 == o2) ? inf : abs_sq(vel - (left_cutoff + t * cutoff_vec)));
+    const float dsq_left = ((t_left < 0.0f) ? inf : abs_sq(vel - (left_cutoff + t_left * left_leg)));
+    const float dsq_right = ((t_right < 0.0f) ? inf : abs_sq(vel - (right_cutoff + t_right * right_leg)));
+    if (dsq_cutoff <= dsq_left && dsq_cutoff <= dsq_right) {
+        const f2 d = -uo1;
+        EMIT(left_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
+    } else if (dsq_left <= dsq_right) {
+        if (left_foreign) return false;
+        const f2 d = left_leg;
+        EMIT(left_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
+    } else {
+        if (right_foreign) return false;
+        const f2 d = -right_leg;
+        EMIT(right_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
+    }
+#undef EMIT
+}
+
+// The ORCA line against agent neighbour `other` (Agent.cpp:676-770)
+__device__ __forceinline__ OrcaLine agent_line(const DevWorld& dw, f2 pos, f2 vel, int other) {
+    const float radius = ORCA_RADIUS;
+    const float inv_th = 1.0f / ORCA_TIME_HORIZON;
+    const f2 rel_pos = F2(dw.apx[other], dw.apy[other]) - pos;
+    const f2 rel_vel = vel - F2(dw.avx[other], dw.avy[other]);
+    const float dist_sq = abs_sq(rel_pos);
+    const float comb = radius + 0.5f;  // every agent has radius 0.5
+    const float comb_sq = sqr(comb);
+    f2 dir, u;
+    if (dist_sq > comb_sq) {
+        const f2 ww = rel_vel - inv_th * rel_pos;
+        const float wl_sq = abs_sq(ww);
+        const float dp1 = dot(ww, rel_pos);
+        if (dp1 < 0.0f && sqr(dp1) > comb_sq * wl_sq) {
+            const float wl = sqrtf(wl_sq);
+            const f2 unit_w = vdiv(ww, wl);
+            dir = F2(unit_w.y, -unit_w.x);
+            u = (comb * inv_th - wl) * unit_w;
+        } else {
+            const float leg = sqrtf(dist_sq - comb_sq);
+            if (det(rel_pos, ww) > 0.0f) {
+                dir = vdiv(F2(rel_pos.x * leg - rel_pos.y * comb, rel_pos.x * comb + rel_pos.y * leg), dist_sq);
+            } else {
+                dir = vdiv(-F2(rel_pos.x * leg + rel_pos.y * comb, -rel_pos.x * comb + rel_pos.y * leg), dist_sq);
+            }
+            const float dp2 = dot(rel_vel, dir);
+            u = dp2 * dir - rel_vel;
+        }
+    } else {
+        const float inv_ts = 1.0f / (float)dw.step_hz;
+        const f2 ww = rel_vel - inv_ts * rel_pos;
+        const float wl = vabs(ww);
+        const f2 unit_w = vdiv(ww, wl);
+        dir = F2(unit_w.y, -unit_w.x);
+        u = (comb * inv_ts - wl) * unit_w;
+    }
+    OrcaLine L;
+    L.point = vel + 0.5f * u;
+    L.direction = dir;
+    return L;
+}
+
+// the two linear programs on the lines in s.lines[0, nl): the new velocity (Agent.cpp:772-792)
+__device__ __forceinline__ f2 solve_velocity(OrcaScratch& s, float max_speed, f2 nv /* newVelocity_ as the last step left it */, int nl,
+                                             int num_obst_lines, f2 pref) {
+    const int fail = linear_program2(s.lines, nl, max_speed, pref, false, nv);
+    if (fail < nl) linear_program3(s, nl, num_obst_lines, fail, max_speed, nv);
+    return nv;
+}
+
+// Agent::computeNewVelocity for agent `self` given its neighbour lists in the scratch, all on the agent's own lane
 __device__ __forceinline__ f2 compute_new_velocity(const DevWorld& dw, const OrcaObst& w, OrcaScratch& s, int self, f2 pref) {
     const f2 pos = F2(dw.apx[self], dw.apy[self]);
     const f2 vel = F2(dw.avx[self], dw.avy[self]);
-    const float radius = 0.5f, time_horizon = 5.0f, time_horizon_obst = 5.0f;  // rvoscene.h:57,63
-    const float max_speed = dw.amax_speed[self];
-    const float inv_tho = 1.0f / time_horizon_obst;
+    const float inv_tho = 1.0f / ORCA_TIME_HORIZON_OBST;
     int nl = 0;
     OrcaLine* L = s.lines;
-#define PUSH(P_, D_)              \
-    do {                          \
-        L[nl].point = (P_);       \
-        L[nl].direction = (D_);   \
-        nl++;                     \
-    } while (0)
     for (int i = 0; i < s.n_on; ++i) {
-        int o1 = s.on_idx[i];
-        int o2 = w.obst[o1].next;
-        const f2 rel1 = opoint(w, o1) - pos;
-        const f2 rel2 = opoint(w, o2) - pos;
+        const int o1 = s.on_idx[i];
+        const int o2 = w.obst[o1].next;
+        const f2 rel1s = inv_tho * (opoint(w, o1) - pos), rel2s = inv_tho * (opoint(w, o2) - pos);
         bool covered = false;
         for (int j = 0; j < nl; ++j) {
-            if (det(inv_tho * rel1 - L[j].point, L[j].direction) - inv_tho * radius >= -RVO_EPS &&
-                det(inv_tho * rel2 - L[j].point, L[j].direction) - inv_tho * radius >= -RVO_EPS) {
+            if (obstacle_covered_by(rel1s, rel2s, L[j])) {
                 covered = true;
                 break;
             }
         }
         if (covered) continue;
-        const float dsq1 = abs_sq(rel1), dsq2 = abs_sq(rel2);
-        const float rsq = sqr(radius);
-        const f2 ovec = opoint(w, o2) - opoint(w, o1);
-        const float sp = dot(-rel1, ovec) / abs_sq(ovec);
-        const float dsq_line = abs_sq(-rel1 - sp * ovec);
-        const f2 u1 = ounit(w, o1);
-        if (sp < 0.0f && dsq1 <= rsq) {
-            if (w.obst[o1].is_convex) PUSH(F2(0.0f, 0.0f), normalize(F2(-rel1.y, rel1.x)));
-            continue;
-        } else if (sp > 1.0f && dsq2 <= rsq) {
-            if (w.obst[o2].is_convex && det(rel2, ounit(w, o2)) >= 0.0f) PUSH(F2(0.0f, 0.0f), normalize(F2(-rel2.y, rel2.x)));
-            continue;
-        } else if (sp >= 0.0f && sp < 1.0f && dsq_line <= rsq) {
-            PUSH(F2(0.0f, 0.0f), -u1);
-            continue;
-        }
-        f2 left_leg, right_leg;
-        if (sp < 0.0f && dsq_line <= rsq) {
-            if (!w.obst[o1].is_convex) continue;
-            o2 = o1;
-            const float leg1 = sqrtf(dsq1 - rsq);
-            left_leg = vdiv(F2(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), dsq1);
-            right_leg = vdiv(F2(rel1.x * leg1 + rel1.y * radius, -rel1.x * radius + rel1.y * leg1), dsq1);
-        } else if (sp > 1.0f && dsq_line <= rsq) {
-            if (!w.obst[o2].is_convex) continue;
-            o1 = o2;
-            const float leg2 = sqrtf(dsq2 - rsq);
-            left_leg = vdiv(F2(rel2.x * leg2 - rel2.y * radius, rel2.x * radius + rel2.y * leg2), dsq2);
-            right_leg = vdiv(F2(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), dsq2);
-        } else {
-            if (w.obst[o1].is_convex) {
-                const float leg1 = sqrtf(dsq1 - rsq);
-                left_leg = vdiv(F2(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), dsq1);
-            } else {
-                left_leg = -u1;
-            }
-            if (w.obst[o2].is_convex) {
-                const float leg2 = sqrtf(dsq2 - rsq);
-                right_leg = vdiv(F2(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), dsq2);
-            } else {
-                right_leg = u1;
-            }
-        }
-        const f2 uo1 = ounit(w, o1), uo2 = ounit(w, o2);
-        const f2 uln = ounit(w, w.obst[o1].prev);
-        bool left_foreign = false, right_foreign = false;
-        if (w.obst[o1].is_convex && det(left_leg, -uln) >= 0.0f) {
-            left_leg = -uln;
-            left_foreign = true;
-        }
-        if (w.obst[o2].is_convex && det(right_leg, uo2) <= 0.0f) {
-            right_leg = uo2;
-            right_foreign = true;
-        }
-        const f2 left_cutoff = inv_tho * (opoint(w, o1) - pos);
-        const f2 right_cutoff = inv_tho * (opoint(w, o2) - pos);
-        const f2 cutoff_vec = right_cutoff - left_cutoff;
-        const float t = (o1 == o2 ? 0.5f : dot(vel - left_cutoff, cutoff_vec) / abs_sq(cutoff_vec));
-        const float t_left = dot(vel - left_cutoff, left_leg);
-        const float t_right = dot(vel - right_cutoff, right_leg);
-        if ((t < 0.0f && t_left < 0.0f) || (o1 == o2 && t_left < 0.0f && t_right < 0.0f)) {
-            const f2 unit_w = normalize(vel - left_cutoff);
-            PUSH(left_cutoff + radius * inv_tho * unit_w, F2(unit_w.y, -unit_w.x));
-            continue;
-        } else if (t > 1.0f && t_right < 0.0f) {
-            const f2 unit_w = normalize(vel - right_cutoff);
-            PUSH(right_cutoff + radius * inv_tho * unit_w, F2(unit_w.y, -unit_w.x));
-            continue;
-        }
-        const float inf = __builtin_huge_valf();
-        const float dsq_cutoff = ((t < 0.0f || t > 1.0f || o1 == o2) ? inf : abs_sq(vel - (left_cutoff + t * cutoff_vec)));
-        const float dsq_left = ((t_left < 0.0f) ? inf : abs_sq(vel - (left_cutoff + t_left * left_leg)));
-        const float dsq_right = ((t_right < 0.0f) ? inf : abs_sq(vel - (right_cutoff + t_right * right_leg)));
-        if (dsq_cutoff <= dsq_left && dsq_cutoff <= dsq_right) {
-            const f2 d = -uo1;
-            PUSH(left_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
-            continue;
-        } else if (dsq_left <= dsq_right) {
-            if (left_foreign) continue;
-            const f2 d = left_leg;
-            PUSH(left_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
-            continue;
-        } else {
-            if (right_foreign) continue;
-            const f2 d = -right_leg;
-            PUSH(right_cutoff + radius * inv_tho * F2(-d.y, d.x), d);
-            continue;
-        }
+        OrcaLine ln;
+        if (obstacle_line(w, pos, vel, o1, ln)) L[nl++] = ln;
     }
     const int num_obst_lines = nl;
-    const float inv_th = 1.0f / time_horizon;
-    for (int i = 0; i < s.n_an; ++i) {
-        const int other = s.an_idx[i];
-        const f2 rel_pos = F2(dw.apx[other], dw.apy[other]) - pos;
-        const f2 rel_vel = vel - F2(dw.avx[other], dw.avy[other]);
-        const float dist_sq = abs_sq(rel_pos);
-        const float comb = radius + 0.5f;  // every agent has radius 0.5
-        const float comb_sq = sqr(comb);
-        f2 dir, u;
-        if (dist_sq > comb_sq) {
-            const f2 ww = rel_vel - inv_th * rel_pos;
-            const float wl_sq = abs_sq(ww);
-            const float dp1 = dot(ww, rel_pos);
-            if (dp1 < 0.0f && sqr(dp1) > comb_sq * wl_sq) {
-                const float wl = sqrtf(wl_sq);
-                const f2 unit_w = vdiv(ww, wl);
-                dir = F2(unit_w.y, -unit_w.x);
-                u = (comb * inv_th - wl) * unit_w;
-            } else {
-                const float leg = sqrtf(dist_sq - comb_sq);
-                if (det(rel_pos, ww) > 0.0f) {
-                    dir = vdiv(F2(rel_pos.x * leg - rel_pos.y * comb, rel_pos.x * comb + rel_pos.y * leg), dist_sq);
-                } else {
-                    dir = vdiv(-F2(rel_pos.x * leg + rel_pos.y * comb, -rel_pos.x * comb + rel_pos.y * leg), dist_sq);
-                }
-                const float dp2 = dot(rel_vel, dir);
-                u = dp2 * dir - rel_vel;
-            }
-        } else {
-            const float inv_ts = 1.0f / (float)dw.step_hz;
-            const f2 ww = rel_vel - inv_ts * rel_pos;
-            const float wl = vabs(ww);
-            const f2 unit_w = vdiv(ww, wl);
-            dir = F2(unit_w.y, -unit_w.x);
-            u = (comb * inv_ts - wl) * unit_w;
-        }
-        PUSH(vel + 0.5f * u, dir);
-    }
-#undef PUSH
-    f2 nv = F2(dw.anvx[self], dw.anvy[self]);
-    const int fail = linear_program2(L, nl, max_speed, pref, false, nv);
-    if (fail < nl) linear_program3(s, nl, num_obst_lines, fail, max_speed, nv);
-    return nv;
+    for (int i = 0; i < s.n_an; ++i) L[nl++] = agent_line(dw, pos, vel, s.an_idx[i]);
+    return solve_velocity(s, dw.amax_speed[self], F2(dw.anvx[self], dw.anvy[self]), nl, num_obst_lines, pref);
 }

@@ -46,6 +46,12 @@ CASES = {
     "no_laser_tiled": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "no_laser": dict(n_robots=5, n_peds=3, seed=8, use_laser=False),
     "time_limit": dict(n_robots=4, n_peds=2, seed=9, time_max=6),
+    # k_orca's obstacle phases: more than 16 obstacle neighbours per pedestrian (several rounds of candidate lines per row, lines
+    # of earlier rounds covering later segments), a pedestrian count that leaves rows of the last group empty; and an obstacle
+    # table beyond the LDS staging area (280 segments: the whole solve on the home lane, out of HBM)
+    "orca_many_obstacle_segments": dict(n_robots=5, n_peds=14, seed=28, n_obstacles=24, grid_size=112, clearance=0.6),
+    "orca_obstacle_table_beyond_lds": dict(n_robots=6, n_peds=9, seed=29, n_obstacles=70, clearance=0.6, ped_shape="leg",
+                                           scene="ervoscene"),
 }
 
 
@@ -143,6 +149,39 @@ def test_resampled_maps_and_large_views_match_oracle(worlds, case, view_maps):
             assert not gpu.snapshot()["view_maps"].any()  # never written
         sm = cpu.snapshot()["sensor_maps"].astype(np.float32)
         assert sm.min() >= 0.0 and sm.max() <= 1.0 and len(np.unique(sm)) > 3  # the shrink really interpolated
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_orca_pedestrians_inside_an_obstacle_lattice(worlds):
+    """38 small obstacles on a 1.1 m lattice around the pedestrians: 50-90 obstacle segments within a pedestrian's 3 m range, i.e.
+    several 16-wide rounds of candidate ORCA lines per row of k_orca, lines of earlier rounds covering later segments, ties in the
+    distance order (two segments meeting at the nearest corner) settled by the tree's visiting order (Agent.cpp:437-671, 813-838;
+    KdTree.cpp:310-353)"""
+    World, OracleWorld = worlds
+    from img_env_amd import _cabi
+    n, P = 4, 10
+    grid, params, layout = small_world(n, P, seed=33, grid_size=96, n_obstacles=0, clearance=0.7)
+    pts = np.vstack([layout.robot_pose[:, :2], layout.ped_pose[:, :2], layout.robot_goal, layout.ped_goal])
+    obs = []
+    for a in np.arange(2.6, 9.6, 1.1):
+        for b in np.arange(2.6, 9.6, 1.1):
+            if np.linalg.norm(pts - (a, b), axis=1).min() > 0.55:
+                obs.append((a, b))
+    obs = np.array(obs[:60])
+    assert 30 <= len(obs) <= 64  # <= 256 segments: staged in LDS
+    rng = np.random.default_rng(33)
+    yaw = rng.uniform(-3.14, 3.14, len(obs))
+    layout.obs_shape = np.where(np.arange(len(obs)) % 2 == 0, _cabi.SHAPE_CIRCLE, _cabi.SHAPE_RECTANGLE).astype(np.int32)
+    layout.obs_size = np.where((np.arange(len(obs)) % 2 == 0)[:, None], np.float32([0, 0, 0.12, 0]), np.float32([-0.1, 0.1, -0.08, 0.08])).astype(np.float32)
+    layout.obs_pose = np.zeros((len(obs), 4))
+    layout.obs_pose[:, :2], layout.obs_pose[:, 2], layout.obs_pose[:, 3] = obs, np.sin(yaw / 2), np.cos(yaw / 2)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(40)])
+        assert not fails, fails[:3]
+        assert np.abs(cpu.snapshot()["ped_state"][:, 2:]).max() > 0.02  # the crowd moves between the obstacles
     finally:
         gpu.close()
         cpu.close()
