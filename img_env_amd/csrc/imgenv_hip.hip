@@ -2281,8 +2281,13 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     const int na = cfg->n_robots + cfg->n_peds, nob = cfg->n_obstacles;
     if (na > SPAWN_MAX_AGENTS || nob > SPAWN_MAX_OBST)
         FAIL(IMGENV_EINVAL, "device-side auto-reset places at most %d agents and %d obstacles per world", SPAWN_MAX_AGENTS, SPAWN_MAX_OBST);
-    if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET)
-        FAIL(IMGENV_EINVAL, "device-side auto-reset: pedsim and dataset scenes are reset by the host (imgenv_step_autoreset)");
+    if (h->cfg.ped_scene_type == IMGENV_SCENE_DATASET)
+        FAIL(IMGENV_EINVAL, "device-side auto-reset: dataset scenes (recorded crowds come with the reset call) are reset by the host (imgenv_step_autoreset)");
+    const bool sfm = h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0;
+    if (sfm && (h->W < 2 || !h->d.sfm.n_obs_w))
+        FAIL(IMGENV_EINVAL, "device-side auto-reset of a pedscene world needs a handle of several worlds (n_worlds > 1: the per-world crowd tables)");
+    if (sfm && !cfg->ignore_obstacle && nob > h->sfm_cap_obs)
+        FAIL(IMGENV_EINVAL, "device-side auto-reset: %d obstacles, a pedscene world of this handle has room for %d", nob, h->sfm_cap_obs);
     if (h->Pw > 0 && (h->traj_cap < 2 || !h->d_traj)) FAIL(IMGENV_ESTATE, "device-side auto-reset: reset every world once first (trajectories of two points)");
     if (!h->sd_storage) {
         h->sd_storage = new SpawnDev();
@@ -2292,6 +2297,7 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     memset(&c, 0, sizeof(c));
     c.n_robots = cfg->n_robots; c.n_peds = cfg->n_peds; c.n_obstacles = nob; c.go_back = cfg->go_back; c.ignore_obstacle = cfg->ignore_obstacle;
     c.rvo = h->NA > 0 ? 1 : 0;
+    c.sfm = sfm ? 1 : 0;
     c.clearance = cfg->clearance; c.target_min_dist = cfg->target_min_dist; c.circle0 = cfg->circle_ranges[0]; c.circle1 = cfg->circle_ranges[1];
     std::vector<DevSpawnAgent> ag((size_t)(na ? na : 1));
     std::vector<double> multi;
@@ -2337,6 +2343,7 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     RTRY(dev_alloc(h, &c.s_rvo, (size_t)S * c.cap_o));
     RTRY(dev_alloc(h, &c.s_nodes, (size_t)S * c.cap_n));
     RTRY(dev_alloc(h, &c.s_rvo_n, (size_t)S * 4));
+    RTRY(dev_alloc(h, &c.s_seg, (size_t)S * (nob ? nob : 1) * 4));
     RTRY(dev_alloc(h, &c.fin_list, (size_t)W));
     RTRY(dev_alloc(h, &c.fin_n, 1));
     RTRY(dev_alloc(h, &c.inst_out, (size_t)W * (nob ? nob : 1)));
@@ -2353,16 +2360,22 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
         RvoNodeDev* nn = nullptr;
         RTRY(dev_alloc(h, &no, (size_t)co * W));
         RTRY(dev_alloc(h, &nn, (size_t)cn * W));
+        // every world's slice laid out on the host, then ONE copy per table (two blocking copies per world were 4 144 copies and
+        // 21 ms for the 2048 envs of the shipped geometry)
+        std::vector<RvoObstHost> all_o((size_t)co * W);
+        std::vector<RvoNodeHost> all_n((size_t)cn * W);
         for (int q = 0; q < W; q++) {
             const RvoObstacles& rq = h->rvos[q];
             if ((int)rq.ob.size() > co || (int)rq.nodes.size() > cn) FAIL(IMGENV_ESTATE, "world %d holds more RVO obstacle vertices than a placement can have", q);
-            if (!rq.ob.empty()) HIPCHK(hipMemcpy(no + (size_t)q * co, rq.ob.data(), sizeof(RvoObstDev) * rq.ob.size(), hipMemcpyHostToDevice));
-            if (!rq.nodes.empty()) HIPCHK(hipMemcpy(nn + (size_t)q * cn, rq.nodes.data(), sizeof(RvoNodeDev) * rq.nodes.size(), hipMemcpyHostToDevice));
+            std::copy(rq.ob.begin(), rq.ob.end(), all_o.begin() + (size_t)q * co);
+            std::copy(rq.nodes.begin(), rq.nodes.end(), all_n.begin() + (size_t)q * cn);
             h->wobst[q] = q * co;
             h->wobst[h->W + q] = q * cn;
             h->wobst[2 * h->W + q] = (int)rq.ob.size();
             h->wobst[3 * h->W + q] = rq.root;
         }
+        HIPCHK(hipMemcpy(no, all_o.data(), sizeof(RvoObstDev) * all_o.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(nn, all_n.data(), sizeof(RvoNodeDev) * all_n.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size(), hipMemcpyHostToDevice));
         h->d_obst = no; h->d_nodes = nn; h->cap_obst = co; h->cap_nodes = cn;
         h->d.obst = no; h->d.onodes = nn;

@@ -18,7 +18,7 @@
 // imgenv_spawn_slot() reads a placement back for checkers.
 #pragma once
 
-#define SPAWN_MAX_AGENTS 64   // robots + pedestrians of one world
+#define SPAWN_MAX_AGENTS 256  // robots + pedestrians of one world (the distance tests take them 64 at a time)
 #define SPAWN_MAX_OBST 24     // obstacles of one world
 #define SPAWN_BSP_CAP 256     // RVO obstacle vertices of one world, splits included
 #define SPAWN_LIST_CAP 6144   // arena of the BSP's per-node vertex lists
@@ -62,6 +62,8 @@ struct SpawnDev {
     RvoObstDev* s_rvo;                 // [S][cap_o]
     RvoNodeDev* s_nodes;               // [S][cap_n]
     int* s_rvo_n;                      // [S][4] obstacles, nodes, root
+    double* s_seg;                     // [S][n_obstacles][4] pedscene: the obstacles as PedScene::addObs takes them, a segment pa -> pb each (pedscene.h:24-30)
+    int sfm;                           // the worlds run libpedsim crowds
     int cap_o, cap_n;
     int* fin_list;                     // [W] finished worlds of this step, ascending
     int* fin_n;                        // [1]
@@ -134,13 +136,14 @@ struct SpawnScratch {  // LDS of one k_spawn_fill workgroup
 };
 
 // The whole wavefront runs the placement in lockstep -- every lane draws the same numbers -- so that the distance tests can use
-// the lanes: lane q looks at agent / obstacle q (at most 64 of either), one ballot answers.
+// the lanes: lane q looks at agents q, q + 64, ... / obstacle q (at most 24 of those), one ballot answers.
 __device__ inline bool sp_free_of_all(const double (*pose)[3], const unsigned char* has, int n, double x, double y, double d) {
-    const int q = lane_id();  // free_check_robo_ped (reset_helper.py:35-43)
-    bool hit = false;
-    if (q < n && has[q]) {
-        const double dx = x - pose[q][0], dy = y - pose[q][1];
-        hit = sqrt(dx * dx + dy * dy) <= d;
+    bool hit = false;  // free_check_robo_ped (reset_helper.py:35-43)
+    for (int q = lane_id(); q < n; q += WAVE) {
+        if (has[q]) {
+            const double dx = x - pose[q][0], dy = y - pose[q][1];
+            hit = hit || sqrt(dx * dx + dy * dy) <= d;
+        }
     }
     return !__any(hit);
 }
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(WAVE) void k_spawn_fill(SpawnDev c) {
             oi.n0 = (int)floor(sizes[2] / 0.01); oi.n1 = (int)ceil(sizes[3] / 0.01);
         }
         c.s_inst[(size_t)s * c.n_obstacles + q] = oi;
-        if (c.rvo && !c.ignore_obstacle) {
+        if ((c.rvo || c.sfm) && !c.ignore_obstacle) {
             const Tf2 bw = tf_from_pose_sc(o.x, o.y, oi.sh, oi.ch);
             double pax, pay, pbx, pby;
             if (o.shape == IMGENV_SHAPE_CIRCLE) {  // Agent::get_corners
@@ -537,8 +540,14 @@ __global__ __launch_bounds__(WAVE) void k_spawn_fill(SpawnDev c) {
                 tf_apply(bw, sizes[0], sizes[2], pax, pay);
                 tf_apply(bw, sizes[1], sizes[3], pbx, pby);
             }
-            const float v[8] = {(float)pax, (float)pay, (float)pax, (float)pby, (float)pbx, (float)pby, (float)pbx, (float)pay};
-            if (!sp_rvo_add(L, v, 4)) L.status = 15;
+            if (c.sfm) {  // PedScene::addObs: the segment pa -> pb (pedscene.h:24-30)
+                double* g = c.s_seg + ((size_t)s * c.n_obstacles + q) * 4;
+                g[0] = pax; g[1] = pay; g[2] = pbx; g[3] = pby;
+            }
+            if (c.rvo) {
+                const float v[8] = {(float)pax, (float)pay, (float)pax, (float)pby, (float)pbx, (float)pby, (float)pbx, (float)pay};
+                if (!sp_rvo_add(L, v, 4)) L.status = 15;
+            }
         }
     }
     if (L.status == 0 && L.n_ob > 0) root = sp_rvo_build(L);
@@ -646,6 +655,31 @@ __global__ __launch_bounds__(WAVE) void k_respawn(DevWorld w, SpawnDev c, int el
                 w.apx[j] = (float)o.x;
                 w.apy[j] = (float)o.y;
             }
+            if (w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setPedPos + setWayPoint (pedscene.h:34-46): position (velocity persists), then
+                const size_t m = (size_t)world * w.sfm.n + (size_t)(a - nr);  // the waypoint deque [goal r = 1, trajectory r = z], destination its front
+                double* p = w.sfm.p + 3 * m;
+                p[0] = o.x;
+                p[1] = o.y;
+                p[2] = 0.0;
+                double *wx = w.sfm.wpx + m * SFM_MAX_WP, *wy = w.sfm.wpy + m * SFM_MAX_WP, *wr = w.sfm.wpr + m * SFM_MAX_WP;
+                int* dq = w.sfm.dq + m * SFM_MAX_WP;
+                wx[0] = o.gx;
+                wy[0] = o.gy;
+                wr[0] = 1.0;
+                int nw = 1;
+                for (int e = 0; e < o.traj_len && nw < SFM_MAX_WP; e++, nw++) {
+                    wx[nw] = o.traj[e][0];
+                    wy[nw] = o.traj[e][1];
+                    wr[nw] = o.traj[e][2];
+                }
+                for (int e = 0; e < SFM_MAX_WP; e++) {
+                    dq[e] = e < nw ? e : 0;
+                    if (e >= nw) wx[e] = wy[e] = wr[e] = 0.0;
+                }
+                w.sfm.dq_n[m] = nw;
+                w.sfm.dest[m] = 0;
+                w.sfm.last[m] = -1;
+            }
             w.ped_state[4 * j] = o.x;
             w.ped_state[4 * j + 1] = o.y;
             w.ped_state[4 * j + 2] = w.pvx[j];
@@ -663,6 +697,12 @@ __global__ __launch_bounds__(WAVE) void k_respawn(DevWorld w, SpawnDev c, int el
         ObstInst oi = c.s_inst[(size_t)s * c.n_obstacles + e];
         oi.world = world;
         c.inst_out[(size_t)q * c.n_obstacles + e] = oi;
+    }
+    if (c.sfm) {  // the crowd's obstacle segments
+        const int nseg = c.ignore_obstacle ? 0 : c.n_obstacles;
+        double* dst = w.sfm.obs + (size_t)world * w.sfm.cap_obs * 4;
+        for (int e = tid; e < nseg * 4; e += WAVE) dst[e] = c.s_seg[(size_t)s * c.n_obstacles * 4 + e];
+        if (tid == 0) const_cast<int*>(w.sfm.n_obs_w)[world] = nseg;
     }
     const int n_ob = c.s_rvo_n[4 * s], n_nodes = c.s_rvo_n[4 * s + 1];
     for (int e = tid; e < n_ob; e += WAVE) c.w_obst[(size_t)world * c.cap_o + e] = c.s_rvo[(size_t)s * c.cap_o + e];

@@ -384,7 +384,7 @@ int imgenv_step_autoreset(imgenv_t* h, const float* actions, const imgenv_spawn_
  * soon as everything is queued on `stream`: no synchronisation, nothing read back.  The FIRST call with a given spawn cfg
  * fixes seed0: the k-th world reset from then on (in step order, ascending world index within a step) takes placement
  * seed0 + k, as a loop of imgenv_step_autoreset() calls fed seed0 + (worlds reset so far) would hand them out.  RVO, ERVO and
- * empty scenes; at most 64 agents and 24 obstacles per world. */
+ * empty scenes, and social-force crowds (pedscene) in handles of several worlds; at most 256 agents and 24 obstacles per world. */
 int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, const imgenv_spawn_cfg* cfg, uint64_t seed0, void* stream);
 /* What the last such call did, for checkers and hosts that do want to know (synchronises `stream`): the worlds it reset
  * (ascending, up to cap), their number, and the placement number of the first of them. */

@@ -308,3 +308,84 @@ def test_host_reset_with_longer_waypoint_lists_between_device_side_steps():
         vec.close()
         for c in cpus:
             c.close()
+
+
+def _device_reset_against_oracles(cfg, E, steps, fields, seed=9, min_resets=None):
+    """``VecImageEnv(device_reset=True)`` from ``cfg`` with one oracle per env fed the placements the device reports; every field
+    of ``fields`` after every step, the step's own rewards / dones too"""
+    import torch
+    from img_env_amd import spawn
+    from img_env_amd.vec_env import VecImageEnv
+    from oracle_binding import OracleWorld, build_oracle
+    build_oracle()
+    R, P, n_obs = int(cfg["robot"]["total"]), int(cfg["ped_sim"]["total"]), int(cfg["object"]["total"])
+    vec = VecImageEnv(copy.deepcopy(cfg), env_num=E, seed=seed, device_reset=True)
+    cpus = [OracleWorld(vec.params, vec.grid) for _ in range(E)]
+
+    def check(where):
+        snap = vec.world.snapshot()
+        for k, c in enumerate(cpus):
+            mine = {f: (snap[f][k * P:(k + 1) * P] if f == "ped_state" else snap[f][k * R:(k + 1) * R]) for f in fields}
+            bad = compare(mine, c.snapshot(), fields)
+            assert not bad, (where, k, bad)
+
+    try:
+        vec.reset()
+        for k in range(E):
+            cpus[k].reset(spawn.native_spawn(cfg, vec._spawn_seed + k))
+        check("reset")
+        rng = np.random.default_rng(2)
+        resets, expect_serial = 0, 0
+        for s in range(steps):
+            a = np.zeros((E * R, 3), np.float32)
+            a[:, 0], a[:, 1] = rng.uniform(0, 0.6, E * R), rng.uniform(-0.9, 0.9, E * R)
+            _, rew, done, info = vec.step(torch.as_tensor(a, device="cuda"))
+            worlds, first = vec.world.autoreset_last()
+            rew, done = rew.cpu().numpy(), done.cpu().numpy()
+            assert first == expect_serial, s
+            for k, c in enumerate(cpus):
+                c.step(a[k * R:(k + 1) * R])
+                ref = c.snapshot()
+                assert np.array_equal(rew[k * R:(k + 1) * R], ref["rewards"]), (s, k)
+                assert np.array_equal(done[k * R:(k + 1) * R], ref["dones"]), (s, k)
+            for q, k in enumerate(worlds):
+                lay, serial = vec.world.world_placement(k, n_obs)
+                assert serial == first + q, (s, k)
+                lay.ignore_obstacle = bool(cfg["ped_sim"].get("ignore_obstacle", False))
+                cpus[k].reset(lay)
+            expect_serial += len(worlds)
+            resets += len(worlds)
+            check(s)
+        assert resets >= (2 * E if min_resets is None else min_resets), resets
+    finally:
+        vec.close()
+        for c in cpus:
+            c.close()
+
+
+DEVICE_RESET_FIELDS = ("is_collisions", "is_arrives", "view_maps", "sensor_maps", "vector_states", "lasers", "ped_maps", "ped_vector_states",
+                       "rewards", "dones", "dones_info", "robot_pose", "ped_state")
+
+
+def test_device_side_reset_of_worlds_with_more_than_64_agents():
+    """worlds of 20 robots + 60 pedestrians: the device-side sampler's distance tests take the agents placed so far 64 at a time
+    (csrc/spawn_device.h: up to 256 agents per world); reset_helper.py:35-55, 189-345"""
+    from img_env_amd import worldgen
+    grid = worldgen.make_grid(200, 3)
+    cfg = worldgen.make_yaml_cfg(20, 60, grid, time_max=3, n_obstacles=3, seed=9)
+    _device_reset_against_oracles(cfg, 3, 10, DEVICE_RESET_FIELDS, min_resets=6)
+
+
+def test_device_side_reset_of_pedscene_worlds():
+    """social-force crowds (pedscene.h:17-91) reset by the device: a finished world's pedestrians get their new positions
+    (velocities persist), their waypoint deques [goal, trajectory], the crowd its new obstacle segments; robots are crowd members
+    (relation_ped_robo = 1).  One oracle per env fed the placements the device drew."""
+    from img_env_amd import worldgen
+    from oracle_binding import set_cr_atan2
+    grid = worldgen.make_grid(88, 3)
+    cfg = worldgen.make_yaml_cfg(2, 5, grid, time_max=4, n_obstacles=2, seed=9, scene="pedscene")
+    set_cr_atan2(True)  # the oracle's atan2 correctly rounded, like the device's (tests/test_gpu_parity.py::cr_atan2_oracle)
+    try:
+        _device_reset_against_oracles(cfg, 5, 16, DEVICE_RESET_FIELDS)
+    finally:
+        set_cr_atan2(False)
