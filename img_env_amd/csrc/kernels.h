@@ -2220,6 +2220,46 @@ __device__ __forceinline__ void sort_pairs_in_registers(double (&key)[E], uint32
     }
 }
 
+// The same network on ONE 64-bit integer per slot: float32(key) bits << 32 | index.  float32 rounding is monotone, so this
+// order is the order by (key, index) unless two slots share their float32 surrogate with different float64 keys -- the caller
+// looks for equal surrogates in neighbouring slots afterwards and falls back to the exact comparator (about one wavefront per
+// step at 8192 robots x 200 pedestrians).  A compare-exchange is one 64-bit compare + two selects (+ two lane shuffles across
+// lanes) instead of three compares + three selects (+ three shuffles); two registers per slot instead of three.
+template <int E>
+__device__ __forceinline__ void sort_packed_in_registers(unsigned long long (&kv)[E], int lane) {
+#pragma unroll
+    for (int size = 2; size <= WAVE * E; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= E) {
+                const int lm = stride / E;
+                const bool lower = (lane & lm) == 0;
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const bool up = ((lane * E + r) & size) == 0;
+                    const unsigned long long pk = __shfl_xor(kv[r], lm);
+                    const bool self_gt = kv[r] > pk;
+                    const bool take = (lower == up) ? self_gt : !self_gt;  // the lower slot keeps the smaller value when ascending (equal values: either)
+                    kv[r] = take ? pk : kv[r];
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < E; a++) {
+                    const int b = a ^ stride;
+                    if (b > a) {
+                        const bool up = ((lane * E + a) & size) == 0;
+                        const bool gt = kv[a] > kv[b];
+                        const bool sw = gt == up;
+                        const unsigned long long ka = kv[a], kb = kv[b];
+                        kv[a] = sw ? kb : ka;
+                        kv[b] = sw ? ka : kb;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // E > 0: PP = 64 * E sort slots held in registers; E == 0: any PP = 2^k, sorted in LDS (more than 1024 pedestrians)
 template <int E>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8 : 4, 8))) void k_obs(DevWorld w, int PP) {
@@ -2255,27 +2295,62 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
         wb.ox = uniform_f64(wb.ox);
         wb.oy = uniform_f64(wb.oy);
         if (E > 0) {
-            double skey[E > 0 ? E : 1];
-            uint32_t sid[E > 0 ? E : 1];
+            constexpr int EE = E > 0 ? E : 1;
+            unsigned long long kv[EE];  // float32(key) << 32 | index: see sort_packed_in_registers
 #pragma unroll
-            for (int q = 0; q < (E > 0 ? E : 1); q++) {
+            for (int q = 0; q < EE; q++) {
                 const int j = lane + WAVE * q;
-                skey[q] = __builtin_huge_val();
-                sid[q] = 0xFFFFu;
+                kv[q] = ((unsigned long long)0x7F800000u << 32) | 0xFFFFull;  // padding: +inf, sorts behind everyone
                 if (j < P) {
                     double px, py;
                     tf_apply(wb, g_ppx[j], g_ppy[j], px, py);
                     const float fx = (float)px, fy = (float)py;
                     info[j] = make_float2(fx, fy);
-                    skey[q] = (double)fx * (double)fx + (double)fy * (double)fy;
-                    sid[q] = (uint32_t)j;
+                    const double key = (double)fx * (double)fx + (double)fy * (double)fy;
+                    kv[q] = ((unsigned long long)__float_as_uint((float)key) << 32) | (unsigned long long)(uint32_t)j;
                 }
             }
             PHASE_MARK(8);
-            sort_pairs_in_registers<(E > 0 ? E : 1)>(skey, sid, lane);
+            sort_packed_in_registers<EE>(kv, lane);
+            // two neighbouring slots with one surrogate (and a pedestrian in the later one): their float64 keys may differ
+            uint32_t clash = 0;  // bit q: slots lane * E + q and its successor
 #pragma unroll
-            for (int q = 0; q < (E > 0 ? E : 1); q++) ord[lane * (E > 0 ? E : 1) + q] = (uint16_t)sid[q];
+            for (int q = 0; q + 1 < EE; q++)
+                clash |= ((uint32_t)(kv[q] >> 32) == (uint32_t)(kv[q + 1] >> 32) && (uint32_t)kv[q + 1] != 0xFFFFu) ? (1u << q) : 0u;
+            {
+                const unsigned long long nxt = __shfl_down(kv[0], 1);
+                clash |= (lane < WAVE - 1 && (uint32_t)(kv[EE - 1] >> 32) == (uint32_t)(nxt >> 32) && (uint32_t)nxt != 0xFFFFu) ? (1u << (EE - 1)) : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < EE; q++) ord[lane * EE + q] = (uint16_t)(uint32_t)kv[q];
             __syncthreads();
+            if (__builtin_expect(__any(clash != 0u), 0)) {
+                // rare.  Slots with different surrogates are in their final order (rounding is monotone); inside a run of equal
+                // surrogates the exact (float64 key, index) order is restored by odd-even transposition over the flagged
+                // neighbours, until nothing moves (runs are two or three slots long)
+                bool again = true;
+                while (again) {
+                    bool swapped = false;
+                    for (int parity = 0; parity < 2; parity++) {
+                        for (int q = 0; q < EE; q++) {
+                            const int e = lane * EE + q;
+                            if (((clash >> q) & 1u) != 0u && (e & 1) == parity) {
+                                const uint32_t ja = ord[e], jb = ord[e + 1];
+                                const float2 fa = info[ja], fb = info[jb];
+                                const double ka = (double)fa.x * (double)fa.x + (double)fa.y * (double)fa.y;
+                                const double kb = (double)fb.x * (double)fb.x + (double)fb.y * (double)fb.y;
+                                if (ka > kb || (ka == kb && ja > jb)) {
+                                    ord[e] = (uint16_t)jb;
+                                    ord[e + 1] = (uint16_t)ja;
+                                    swapped = true;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    again = __any(swapped);
+                }
+            }
         } else {
             for (int j = lane; j < PP; j += WAVE) {
                 if (j < P) {
@@ -2331,7 +2406,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
                 const double dpx = f.x, dpy = f.y;
                 const double ped_r = g_ped_r_round[j];
                 const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
-                float* o = stage + lane * 7;
+                // seven dwords per lane, 28 bytes from the neighbour lane's: the seven store instructions of a round fill
+                // the same cache lines between them (no staging through LDS, no barriers)
+                float* o = pt + 1 + 7 * (size_t)q;
                 o[0] = f.x;
                 o[1] = f.y;
                 o[2] = fvx;
@@ -2345,11 +2422,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             const unsigned long long mask = __ballot(in_box);
             if (in_box) inbox[n_in + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)q;
             n_in += __popcll(mask);
-            __syncthreads();
-            const int nf = min(WAVE, P - q0) * 7;
-            for (int e = lane; e < nf; e += WAVE) pt[1 + 7 * q0 + e] = stage[e];
-            __syncthreads();
         }
+        __syncthreads();
         min_dist = __shfl(min_dist, 0);
         PHASE_MARK(10);
 

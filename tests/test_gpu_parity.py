@@ -782,6 +782,41 @@ def test_equidistant_pedestrians_keep_index_order(worlds):
         cpu.close()
 
 
+@pytest.mark.parametrize("n_peds", [5, 70, 300])
+def test_pedestrian_distances_that_differ_below_float32_keep_the_float64_order(worlds, n_peds):
+    """the register sort of k_obs orders float32(key) << 32 | index and repairs runs of equal surrogates with the exact comparator:
+    pedestrians whose squared distances (float64, yaml_env.py:451) differ by less than a float32 ulp -- 1 + 2^-26 against 1, and a
+    run of three -- must come out in float64 order, against their index order; plus exact ties inside the same run"""
+    from test_oracle_known_answers import _layout, _open_world
+    from parity import compare
+    World, OracleWorld = worlds
+    grid, params = _open_world(n_robots=2, n_peds=n_peds, scene="rvoscene")
+    e = 2.0 ** -13
+    # robot 0 at (10, 10) heading 0: its frame is the world shifted.  Squared distances: 1 + 4 e^2, 1 + e^2, 1, 1 (tie), then far ones
+    ped_xy = [(11.0, 10.0 + 2 * e), (11.0, 10.0 - e), (11.0, 10.0), (9.0, 10.0), (13.0, 11.0)]
+    rng = np.random.default_rng(5)
+    while len(ped_xy) < n_peds:
+        ped_xy.append((float(rng.uniform(3, 21)), float(rng.uniform(14, 21))))
+    lay = _layout([(10.0, 10.0, 0.0), (14.0, 18.0, 1.5707963267948966)], [(16.0, 10.0), (14.0, 20.0)], ped_xy=ped_xy)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        gpu.reset(lay)
+        cpu.reset(lay)
+        a, b = gpu.snapshot(), cpu.snapshot()
+        assert not compare(a, b)
+        pv = b["ped_vector_states"][0][1:].reshape(n_peds, 7)
+        assert np.allclose(pv[:4, :2], [(1.0, 0.0), (-1.0, 0.0), (1.0, -e), (1.0, 2 * e)], atol=1e-7)  # float64 order, ties by index
+        assert np.array_equal(a["ped_vector_states"], b["ped_vector_states"])
+        for s in range(2):
+            act = np.zeros((2, 3), np.float32)
+            gpu.step(act)
+            cpu.step(act)
+            assert not compare(gpu.snapshot(), cpu.snapshot())
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def _fuzz_case(seed):
     """a random but valid configuration of the same path: geometry, sensor, kinematics, crowd, footprints"""
     from img_env_amd import _cabi
