@@ -1628,7 +1628,7 @@ __device__ __forceinline__ void angular_bins(const DevWorld& w, const RobotClass
 // NW: wavefronts per robot.  1 when a launch fills the machine (instruction issue bounds it); 4 for small launches (a reset of
 // a few worlds), where the single wavefront's latency is all there is: the cells and beams are then spread over 256 lanes.
 template <bool POW2, bool A4, bool STAMP, int NW>
-__global__ __launch_bounds__(WAVE * NW) void k_view(DevWorld w) {
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_view(DevWorld w) {
     constexpr int NT = WAVE * NW;
     const int tid = threadIdx.x;
     // A4: Wv % 4 == 0 (a lane's 4 consecutive cells share their row and nothing runs over the end of the view)

@@ -14,6 +14,7 @@ from img_env_amd.world import World  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 32: views through the tiled kernels, 64: through k_view
+SHORT = len(sys.argv) > 3 and sys.argv[3] == "short"  # counter passes: a handful of steps (the profiler serialises every dispatch)
 P = 1000
 grid = worldgen.make_grid(800, 0)
 layout = worldgen.make_layout(grid, 0.125, R, P, seed=100, clearance=0.7)
@@ -21,12 +22,12 @@ w = World(dict(worldgen.make_params(R, P, res=0.125, view_cells=96, beams=720, s
 w.reset(layout)
 a = torch.zeros(R, 3, device="cuda")
 a[:, 1] = torch.rand(R, device="cuda") * 1.8 - 0.9
-for s in range(50):
+for s in range(3 if SHORT else 50):
     w.step(a)
 w.timing(1)
 prev = w.timing_read()
 samples = {k: [] for k in prev}
-for s in range(20):
+for s in range(2 if SHORT else 20):
     w.step(a)
     cur = w.timing_read()
     for k in cur:
@@ -37,8 +38,9 @@ w.timing(0)
 print(" ".join("%s %.1f" % (k[2:], np.median(v)) for k, v in samples.items() if v))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for s in range(100):
+N = 4 if SHORT else 100
+for s in range(N):
     w.step(a)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 100
+dt = (time.perf_counter() - t0) / N
 print("%d robots: %.1f us/step, %.2f M robot-steps/s" % (R, 1e6 * dt, R / dt / 1e6))

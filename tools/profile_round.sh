@@ -43,6 +43,8 @@ python3 bench.py 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
 bash tools/profile_shipped.sh ${tag}_shipped256 256
 bash tools/profile_shipped.sh ${tag}_shipped2048 2048
 PMC_CMD="python3 /root/repo/tools/shipped_probe.py --envs 2048 --steps 6" bash tools/profile_pmc.sh ${tag}_shipped2048
+# BASELINE cfg-5 (96 x 96 views, 720 beams, 1000 ERVO pedestrians): FETCH / WRITE / SQ passes of a handful of steps
+PMC_CMD="python3 /root/repo/tools/cfg5_probe.py 8192 0 short" bash tools/profile_pmc.sh ${tag}_cfg5
 # (profile_pmc.sh averages a kernel over ALL its launches, the reset chain's few-robot ones included; the step's own launches alone:)
 bash tools/pmc_mem.sh ${tag}_shipped2048
 # keep the returned directory small: the raw traces stay on the box
