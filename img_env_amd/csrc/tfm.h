@@ -155,13 +155,29 @@ TFM_HD int w2m_t(double v, double res, double inv_res) {
 // both cell indices of a world point, one (rarely taken) branch for the pair
 template <bool POW2>
 __device__ __forceinline__ void w2m_pair(double wx, double wy, double res, double inv_res, int& m, int& n) {
-    const double tx = w2m_scale<POW2>(wx, res, inv_res), ty = w2m_scale<POW2>(wy, res, inv_res);
-    bool tie = false;
-    m = round_even_i(tx, tie);
-    n = round_even_i(ty, tie);
-    if (__builtin_expect(tie, 0)) {
-        m = round_tie_fix(tx);
-        n = round_tie_fix(ty);
+    if (POW2) {
+        const double tx = wx * inv_res, ty = wy * inv_res;
+        bool tie = false;
+        m = round_even_i(tx, tie);
+        n = round_even_i(ty, tie);
+        if (__builtin_expect(tie, 0)) {
+            m = round_tie_fix(tx);
+            n = round_tie_fix(ty);
+        }
+    } else {
+        // The reference divides (grid_map.cpp:40-44), and a float64 division is ~22 instructions on this chip.  v * (1 / res)
+        // differs from the correctly rounded v / res by at most 1.5 * 2^-52 |v / res| (two roundings against one), so both round
+        // to the same integer unless the product lies within that distance of a half-integer; the test below leaves a margin of
+        // 8 x (2^-49 |t|) and sends those values -- exact .5 ties included -- through the reference's own division.
+        const double tx = wx * inv_res, ty = wy * inv_res;
+        const double rx = rint(tx), ry = rint(ty);
+        const double ex = fabs(fabs(tx - rx) - 0.5), ey = fabs(fabs(ty - ry) - 0.5);  // distance to the nearest half-integer (t - r is exact)
+        m = (int)rx;
+        n = (int)ry;
+        if (__builtin_expect(ex <= fabs(tx) * 0x1p-49 || ey <= fabs(ty) * 0x1p-49, 0)) {
+            m = round_tie_fix(wx / res);
+            n = round_tie_fix(wy / res);
+        }
     }
 }
 #endif
