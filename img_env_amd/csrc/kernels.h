@@ -289,6 +289,21 @@ __device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l,
 #define PHASE_BEGIN() WAVE_T0()
 #define PHASE_MARK(slot) (void)0
 #endif
+// -DIMGENV_PHASE_PROFILE -DIMGENV_PROFILE_RASTER: the marks inside k_raster's robot blocks instead of k_orca's (they share slots)
+#if defined(IMGENV_PHASE_PROFILE) && defined(IMGENV_PROFILE_RASTER)
+#define RASTER_MARK_BEGIN() long long rm_t_ = clock64()
+#define RASTER_MARK(slot)                                                                 \
+    do {                                                                                  \
+        const long long now_ = clock64();                                                 \
+        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&w.prof[slot], (unsigned long long)(now_ - rm_t_)); \
+        rm_t_ = now_;                                                                     \
+    } while (0)
+#define ORCA_MARK(slot) (void)0
+#else
+#define RASTER_MARK_BEGIN() (void)0
+#define RASTER_MARK(slot) (void)0
+#define ORCA_MARK(slot) PHASE_MARK(slot)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Pedestrian advance (ORCA)
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
         if (abs_sq(pref) > 1.0f) pref = normalize(pref);
         if (mine) w.ptraj_idx[j] = idx;
     }
-    PHASE_MARK(5);  // staging, the agent's scalars, waypoint
+    ORCA_MARK(5);  // staging, the agent's scalars, waypoint
     __syncthreads();
     // agent neighbours (Agent::computeNeighbors over the kd-tree = the maxNeighbors nearest within neighborDist): candidates in
     // agent index order, 64 per round, each tested against every agent of the group; an agent's hits are inserted in index
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
         if (mine) w.near_n[j] = 0;  // re-armed for the next step's k_side_robots
     }
     __syncthreads();
-    PHASE_MARK(6);  // neighbour scans
+    ORCA_MARK(6);  // neighbour scans
     if (!staged && ob.n_obst > 0) {  // an obstacle table too large for LDS: the whole solve on the home lane, out of HBM
         if (mine) {
             query_obstacle_tree(ob, w.err, s, pos, sqr(5.0f * max_speed + 0.5f));
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
             if (row_ok) node_rec[k] = make_uint4(f | ((uint32_t)o1 << 8), __float_as_uint(dseg), (uint32_t)near_child, (uint32_t)far_child);
         }
         __syncthreads();
-        PHASE_MARK(7);  // tree nodes
+        ORCA_MARK(7);  // tree nodes
         // the traversal itself (near side, the node, far side) on those records alone, one LDS read per node: inserted segments in
         // visiting order into the (still unused) projection area
         float* vis_dist = (float*)s.proj;
@@ -579,7 +594,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
             }
         }
         __syncthreads();
-        PHASE_MARK(12);  // traversal replay
+        ORCA_MARK(12);  // traversal replay
         n_on = __shfl(nv, home);
         // insertion in visiting order with a strict "<" (Agent.cpp:824-833) = sorted by (distance, visiting order): by rank
         for (int e = li; e < n_on; e += ORCA_ROW) {
@@ -637,13 +652,13 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
             __syncthreads();
         }
     }
-    PHASE_MARK(13);  // rank sort + obstacle lines
+    ORCA_MARK(13);  // rank sort + obstacle lines
     const int num_obst_lines = nl;
     // ---- one agent neighbour per lane
     if (row_ok && li < n_an) s.lines[nl + li] = agent_line(w, pos, vel, s.an_idx[li]);
     nl += n_an;
     __syncthreads();
-    PHASE_MARK(14);  // agent lines
+    ORCA_MARK(14);  // agent lines
     if (mine) {
         const f2 nv = solve_velocity(s, max_speed, nv0, nl, num_obst_lines, pref);
         // ERVO's evacuation term (Agent.cpp:63-69, 430-432) is added by k_evac once the step's actions -- and with them the
@@ -651,7 +666,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
         w.anvx[j] = nv.x;
         w.anvy[j] = nv.y;
     }
-    PHASE_MARK(15);  // linear programs
+    ORCA_MARK(15);  // linear programs
 }
 
 // Beep lottery (img_env.cpp:323-342), one workgroup per world: `rand() / double(RAND_MAX) < ped_ca_p` once per robot in
@@ -1245,6 +1260,7 @@ template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const RobotClassDev& k, uint32_t* box, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
     constexpr int UB = NW > 1 ? 4 : 1;   // cells a lane stamps at once (stamp_robot_batch)
+    RASTER_MARK_BEGIN();
     const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
     const int lane = lane_id(), tid = threadIdx.x;
     const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
@@ -1306,6 +1322,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         }
     }
     uint32_t* stray_flag = box + w.box_cells;  // NW > 1: "some sample fell outside the box", seen by any wavefront
+    RASTER_MARK(5);  // pose, cached-list test
     if (use_box) {
         for (int q = tid; q < ncell; q += NT) box[q] = 0;
         if (NW > 1 && tid == 0) *stray_flag = 0;
@@ -1346,6 +1363,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             if (b >= 0 && (lane == WAVE - 1 || b_next != b)) atomicMax(&box[b], (uint32_t)q + 1);
         }
     }
+    RASTER_MARK(6);  // footprint samples into the LDS box
     if (use_box) {
         uint32_t* n_sh = stray_flag + 1;  // NW > 1: entries of the cell list so far
         if (NW > 1 && stray) *stray_flag = 1;
@@ -1401,6 +1419,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
             __syncthreads();
             n_out = (int)*n_sh;
         }
+        RASTER_MARK(7);  // box -> stamps + cell list
         const bool any_stray = NW > 1 ? *stray_flag != 0 : __any(stray);
         if (local && tid == 0) w.fp_n[l] = (n_out <= w.fp_cap && !any_stray) ? n_out : -1;
     } else if (local && tid == 0) {
@@ -1427,8 +1446,10 @@ __global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel, 
     }
     const int bp = split > 0 ? b - split : b;
     if (bp >= 0 && bp < act_count_p(w)) {
+        RASTER_MARK_BEGIN();
         const int j = act_member(w, w.Pw, bp);
         raster_ped<POW2, STAMP, NW>(w, j, w.pc[w.ped_cls[j]], g);
+        RASTER_MARK(12);  // the block's pedestrian
     }
     if (b < w.RL) WAVE_DONE(2);
 }
