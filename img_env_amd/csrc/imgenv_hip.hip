@@ -1282,14 +1282,15 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // four wavefronts per robot / pedestrian when the launch cannot fill the machine (device-side auto-reset: by the expected
         // number of robots, the grid itself is sized for every world)
         const bool small = (d.act_n_dev ? std::min(n_blocks, h->act_hint) : n_blocks) <= 1024;
-        const int split = small && n_g > 0 && n_p > 0 ? n_g : 0;  // small launches: robots and pedestrians in blocks of their own
+        static const int force_split = getenv("IMGENV_RASTER_SPLIT") ? atoi(getenv("IMGENV_RASTER_SPLIT")) : 0;  // (measurement switch)
+        const int split = (small || force_split) && n_g > 0 && n_p > 0 ? n_g : 0;  // small launches: robots and pedestrians in blocks of their own
         const dim3 gr(split ? n_g + n_p : n_blocks), br(small ? 4 * WAVE : WAVE);
         const size_t lds = 4 * (size_t)d.box_cells + 16;
         const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
 #define RASTER_CASE(N, P2, ST)                                                                                    \
     case N:                                                                                                       \
         if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
-        else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, is_reset, 0)));               \
+        else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
         break;
         switch (variant) {
             RASTER_CASE(3, true, true)

@@ -1273,6 +1273,11 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
     const int world = world_of_robot(w, i);
     const uint32_t cell0 = (uint32_t)world * w.Gs;  // this world's copy of the layers
     const int cm = w2m_t<POW2>(r[0], res, inv), cn = w2m_t<POW2>(r[1], res, inv);
+    // view_robot (img_env.cpp:620-629) draws every OTHER robot of the world into a robot's map: the only robot of its world has
+    // nobody to be drawn for, so it leaves no stamps (the shipped configs: one robot per env -- its 27 x 27-cell footprint at
+    // 0.015 m was 54 lines of class words + crop_map + segment tags fetched and written back per step for nothing); what it still
+    // needs is its own (cell, last sample) list for the collision test
+    const bool alone = (w.W > 1 ? w.Rw : w.R) == 1;
     // _step_robot tail: setRobotPos for every robot (img_env.cpp:411-417); the RVO scenes get theirs from k_side_robots
     if (tid == 0 && w.relation == 1 && w.scene == IMGENV_SCENE_PEDSIM) {  // PedScene::setRobotPos: setPosition(px, py, 1)
         double* p = w.sfm.p + 3 * ((size_t)world * w.sfm.n + w.sfm.n_peds + (size_t)(i - world * w.Rw));  // the world's crowd: pedestrians, then robots
@@ -1290,6 +1295,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         double* cached = w.fp_pose + 3 * (size_t)l;
         const int n_cached = w.fp_n[l];
         if (n_cached >= 0 && cached[0] == r[0] && cached[1] == r[1] && cached[2] == r[2]) {
+            if (alone) return;  // (the list stands, and there is nobody to stamp for)
             const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
             for (int e0 = 0; e0 < n_cached; e0 += NT * UB) {
                 uint32_t c[UB];
@@ -1347,7 +1353,8 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                     b = dm * side + dn;
                 } else {
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
-                    if (STAMP) {
+                    if (alone) {
+                    } else if (STAMP) {
                         stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w), world);
                     } else {
                         atomicMin(&w.own_lo[c], id);
@@ -1389,7 +1396,8 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c[u] = go[u] ? cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n : 0u;
             }
-            if (STAMP) {
+            if (alone) {
+            } else if (STAMP) {
                 stamp_robot_batch<UB>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
             } else {
 #pragma unroll
