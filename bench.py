@@ -493,12 +493,17 @@ def main():
     vec_env = None
     if world_size == 1 and args.config == "cfg3" and not args.no_multi_world and not args.force_dist:
         # secondary: the trainer's end-to-end loop -- 1024 reference envs of 4 robots behind VecImageEnv (the wrapper stack's
-        # outputs, NeverStopWrapper-style resets inside the library: imgenv_step_autoreset), Python call to Python return
+        # outputs, NeverStopWrapper-style resets inside the library), Python call to Python return: with the device-side reset
+        # (the value) and with the host in the loop
         try:
             from vec_env_probe import measure as measure_vec
-            v = measure_vec(1024, 4, 3, 2, steps=args.steps, natives=(True,))
-            vec_env = dict(value=v["native_spawn"]["robot_steps_per_s"], unit="robot-steps/s", envs=1024, robots_per_env=4,
-                           peds_per_env=3, **{k: v["native_spawn"][k] for k in ("us_per_step", "env_resets_per_step")})
+            v = measure_vec(1024, 4, 3, 2, steps=args.steps, natives=(True, "device"))
+            dv, hv = v["device_reset"], v["native_spawn"]
+            vec_env = dict(value=dv["robot_steps_per_s"], unit="robot-steps/s", envs=1024, robots_per_env=4, peds_per_env=3,
+                           mode="imgenv_step_autoreset_device: finished envs found, placed and reset by kernels alone",
+                           **{k: dv[k] for k in ("us_per_step", "env_resets_per_step")},
+                           host_in_the_loop=dict(value=hv["robot_steps_per_s"], us_per_step=hv["us_per_step"],
+                                                 mode="imgenv_step_autoreset: placements drawn on the host while the device steps"))
         except Exception as e:
             vec_env = {"error": repr(e)}
 

@@ -121,6 +121,7 @@ struct imgenv {
     long trace_calls = 0, trace_resets = 0;
     // device-side auto-reset (csrc/spawn_device.h): pool of placements drawn ahead on a side stream
     bool sd_ready = false, dev_reset_used = false;
+    int fill_due = 0;  // calls until the placement pool is refilled again (SPAWN_FILL_PERIOD)
     bool wobst_all = false;  // the per-world RVO table has to be uploaded as a whole (its slices moved)
     // ... and, on request (IMGENV_GRAPH=1), the whole step + reset chain as one hipGraph: per-step values then live in device
     // memory (DevWorld::step_vars), the actions are copied into a buffer of the handle, and a step costs the host one copy and
@@ -2330,7 +2331,7 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     RTRY(dev_upload(h, &c.agents, ag));
     RTRY(dev_upload(h, &c.obstacles, ob));
     RTRY(dev_upload(h, &c.multi, multi));
-    const int W = h->W, S = std::max(64, W);  // one placement per world can be needed in a single step
+    const int W = h->W, S = (SPAWN_FILL_PERIOD + 2) * std::max(64, W);  // every world can need a placement in a single step; see SPAWN_FILL_PERIOD
     c.S = S;
     c.seed0 = seed0;
     c.cap_o = std::max(16, std::min(SPAWN_BSP_CAP, 16 * std::max(nob, 1)));
@@ -2443,6 +2444,7 @@ static int spawn_dev_refresh(imgenv* h, hipStream_t st) {
         RTRY(dev_alloc(h, &c.s_rvo, (size_t)c.S * c.cap_o));
         RTRY(dev_alloc(h, &c.s_nodes, (size_t)c.S * c.cap_n));
         HIPCHK(hipMemset(c.slot_serial, 0xFF, sizeof(unsigned long long) * (size_t)c.S));  // every slot is drawn again (the chain's own fill)
+        h->fill_due = 0;
     }
     c.w_obst = h->d_obst;
     c.w_nodes = h->d_nodes;
@@ -2464,14 +2466,20 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
     SpawnDev& c = *(SpawnDev*)h->sd_storage;
     DevWorld& d = h->d;
     const int W = h->W, nob = c.n_obstacles;
-    // the pool, underneath the step: the slots whose placements the previous step handed out
-    HIPCHK(hipEventRecord(h->ev_consumed, st));
-    HIPCHK(hipStreamWaitEvent(h->side3, h->ev_consumed, 0));
-    k_spawn_fill<<<dim3(c.S), dim3(WAVE), 0, h->side3>>>(c);
-    HIPCHK(hipEventRecord(h->ev_fill, h->side3));
+    // the pool, underneath the step: the slots whose placements earlier steps handed out -- on every SPAWN_FILL_PERIOD-th call
+    // (two event operations and a launch less on the others: each costs the caller's stream a dependency bubble and the host a call)
+    const bool fill = h->fill_due <= 0 || !h->no_graph;  // (a captured chain is replayed as it was captured: with the refill)
+    if (fill) {
+        HIPCHK(hipEventRecord(h->ev_consumed, st));
+        HIPCHK(hipStreamWaitEvent(h->side3, h->ev_consumed, 0));
+        k_spawn_fill<<<dim3(c.S), dim3(WAVE), 0, h->side3>>>(c);
+        HIPCHK(hipEventRecord(h->ev_fill, h->side3));
+        h->fill_due = SPAWN_FILL_PERIOD;
+    }
+    h->fill_due -= 1;
     if (int rc = imgenv_step(h, actions, st)) return rc;
     k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
-    HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
+    if (fill) HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
     k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
     // grids for a guess of the finished worlds (four times the last count; the kernels stride over the rest if there are more)
     const int last_n = h->finished_host[0];  // (page-locked, written by k_finished_dev: stale by a step or two)

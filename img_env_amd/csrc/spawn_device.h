@@ -23,6 +23,8 @@
 #define SPAWN_BSP_CAP 256     // RVO obstacle vertices of one world, splits included
 #define SPAWN_LIST_CAP 6144   // arena of the BSP's per-node vertex lists
 #define SPAWN_GUARD 200000    // draws before a placement is given up (the host gives up after 2e7: a kernel must not spin that long)
+#define SPAWN_FILL_PERIOD 2    // the pool is refilled on every second call; it holds 4 W placements: a refill sees the count of
+                              // two steps ago at worst, and up to W worlds can finish on each of the steps until the next one
 
 struct DevSpawnAgent {
     int begin_type, target_type;
@@ -490,10 +492,14 @@ __device__ int sp_rvo_build(SpawnScratch& L) {
 }
 
 // One pool slot: placement number n = the smallest n >= consumed with n % S == slot, unless the slot holds it already.
+// "consumed" is the count BEFORE the worlds of the last completed step took theirs (consumed[1]): this kernel runs beside a
+// step on its own stream, and with the up-to-date count it could recycle a slot whose placement that very step's k_respawn has
+// been handed (k_finished_dev advances consumed[0] before k_respawn reads the slots) -- one step's worth of placements is
+// redrawn into slots that are not read any more, which the pool's size allows for (SPAWN_FILL_PERIOD).
 __global__ __launch_bounds__(WAVE) void k_spawn_fill(SpawnDev c) {
     __shared__ SpawnScratch L;
     const int s = blockIdx.x;
-    const unsigned long long done = c.consumed[0];
+    const unsigned long long done = c.consumed[1];
     const unsigned long long S = (unsigned long long)c.S;
     unsigned long long n = done - done % S + (unsigned long long)s;
     if (n < done) n += S;
