@@ -1235,12 +1235,17 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // observation stream finally waits for the solve, so its join event covers both.
         // (IMGENV_SERIAL=1 in the environment keeps everything on the caller's stream: clean per-kernel timings.)
         const bool overlap = !h->serial;
-        hipStream_t s_orca = overlap ? h->side : st;
+        // Handles of at most 4096 robots keep ONE side stream: observation, robot records and the solve one behind the other (they
+        // fit underneath the rasters + views with room to spare: 31 us against 72 at 1024 envs x (4 + 3)), which saves three of the
+        // seven event operations of a phase -- such shapes are bound by the host's call rate (tools/host_issue_probe.py:
+        // ~6 us per launch or event call, ~30 calls per step with a device-side reset)
+        const bool one_side = overlap && !d.sharded && h->RL <= 4096;
+        hipStream_t s_orca = overlap ? (one_side ? h->side2 : h->side) : st;
         if (!h->obs_forked)
             if (int rc = launch_obs(h, st)) return rc;
         h->obs_forked = false;
         hipStream_t s_obs = overlap ? h->side2 : st;
-        if (overlap) {
+        if (overlap && !one_side) {
             if (d.sharded) {  // the solve needs every rank's robots: a second fork behind the exchange
                 HIPCHK(hipEventRecord(h->ev_fork2, st));
                 HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork2, 0));
@@ -1265,8 +1270,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             h->launches += 1;
         }
         if (overlap) {
-            HIPCHK(hipEventRecord(h->ev_join, s_orca));
-            HIPCHK(hipStreamWaitEvent(s_obs, h->ev_join, 0));
+            if (!one_side) {
+                HIPCHK(hipEventRecord(h->ev_join, s_orca));
+                HIPCHK(hipStreamWaitEvent(s_obs, h->ev_join, 0));
+            }
             HIPCHK(hipEventRecord(h->ev_join2, s_obs));
         }
     }
