@@ -1253,8 +1253,12 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
                 HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
             }
         }
-        k_side_robots<<<dim3((n_g + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
-        h->launches += 1;
+        // handles of several worlds with RVO crowds: k_orca does k_side_robots' part for its world itself (one launch less per phase)
+        const bool fold_side = h->W > 1 && h->NA > 0;
+        if (!fold_side) {
+            k_side_robots<<<dim3((n_g + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
+            h->launches += 1;
+        }
         if (h->NA > 0) {
             // groups of up to 4 pedestrians of one world per wavefront; an agent's LDS scratch sized by the largest obstacle table
             // any world of the handle can hold, the table itself staged into LDS when it fits 256 segments
@@ -1264,6 +1268,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             L.groups = (per_world + L.G - 1) / L.G;
             L.cap_on = std::max(std::min(ORCA_MAX_ON, cap), ORCA_ROW - ORCA_MAX_AN);  // (a round's 16 candidate lines borrow the projection area)
             L.cap_stack = std::min(ORCA_STACK, cap + 1);
+            L.fold_side = fold_side ? 1 : 0;
+            L.zero_vel = is_reset;
             L.stage_obst = std::min(cap, 256);  // (a world with more segments than that is solved out of HBM: the kernel checks its count)
             const unsigned blocks = (unsigned)((n_p / per_world) * L.groups);
             TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(blocks), dim3(WAVE), orca_lds_bytes(L), s_orca>>>(d, L)));

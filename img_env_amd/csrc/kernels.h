@@ -326,12 +326,17 @@ __device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l,
 //   * the linear programs stay on the home lane (sequential and tiny).
 // (History: one pedestrian per wavefront with everything on lane 0 out of HBM took 129 us at 2048 shipped envs x 4 pedestrians,
 // one lane per agent out of LDS 62 us alone -- a single agent's chain of ~9000 dependent instructions.)
+__device__ __forceinline__ void state_robot(const DevWorld& w, int l);  // Agent::get_state, below
 struct OrcaLaunch {
     int G;          // agents per wavefront (1, 2 or 4: one row of 16 lanes each)
     int groups;     // wavefronts per world
     int cap_on;     // obstacle neighbours an agent's scratch holds (the handle's largest obstacle table, at most ORCA_MAX_ON)
     int cap_stack;  // tree levels its walk may stack up
     int stage_obst; // obstacle segments / nodes the LDS staging area holds (0: read them from HBM, everything on the home lane)
+    int fold_side;  // handles of several worlds: this kernel also does k_side_robots' part for its world (a launch less per phase):
+                    // the world's robot agents out of the robot records (setRobotPos, img_env.cpp:411-417), Agent::get_state of
+                    // its robots (group 0), and the robots taken as neighbour candidates directly instead of through near lists
+    int zero_vel;   // (with fold_side) a reset: robot agents start at rest
 };
 #define ORCA_GROUP_MAX 4
 #define ORCA_ROW 16
@@ -392,8 +397,27 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
     f2 pos = F2(w.apx[j], w.apy[j]);
     const f2 vel = F2(w.avx[j], w.avy[j]), nv0 = F2(w.anvx[j], w.anvy[j]);
     const float max_speed = w.amax_speed[j];
-    const int n_near_row = w.NA > w.P ? w.near_n[j] : 0;
-    const int near_ent = w.NA > w.P ? w.near_list[(size_t)j * ORCA_NEAR_CAP + li] : 0;  // (the row's first 16 entries, whatever the count)
+    const int n_rob_w = w.W > 1 ? w.Rw : w.R, rob_lo_w = w.P + wld * n_rob_w;  // the robot agents of the world
+    // fold_side: every robot of the world is a candidate (in index order, as a sorted near list would hold them); more than 16 of
+    // them go through the full scan below (a count beyond ORCA_NEAR_CAP asks for it)
+    const int n_near_row = w.NA > w.P ? (L.fold_side ? (n_rob_w <= ORCA_ROW ? n_rob_w : ORCA_NEAR_CAP + 1) : w.near_n[j]) : 0;
+    const int near_ent = w.NA > w.P ? (L.fold_side ? rob_lo_w + min(li, n_rob_w - 1) : w.near_list[(size_t)j * ORCA_NEAR_CAP + li]) : 0;  // (the row's first 16 entries, whatever the count)
+    if (L.fold_side) {  // k_side_robots' part for this world: every group writes the same robot agents (it reads them back below)
+        for (int q = lane; q < n_rob_w; q += WAVE) {
+            const int i = wld * n_rob_w + q;
+            const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+            if (w.NA > w.P) {  // (relation_ped_robo = 1: the robots are agents of the crowd)
+                const int a = w.P + i;
+                w.apx[a] = (float)r[0];
+                w.apy[a] = (float)r[1];
+                w.avx[a] = L.zero_vel ? 0.0f : (float)r[3];
+                w.avy[a] = L.zero_vel ? 0.0f : (float)r[4];
+            }
+            const int l = i - w.r0;
+            if (gi == 0 && l >= 0 && l < w.RL) state_robot(w, l);
+        }
+        __syncthreads();
+    }
     // waypoint + pref velocity: the waypoint in question and the one behind it, both in flight
     f2 pref;
     int idx = idx0;
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
     // ... lists of more than 16 robots one agent at a time (sorted by index; the full robot range if the list overflowed)
     if (w.NA > w.P) {
         const int n_near_mine = mine ? n_near_row : 0;
-        const int n_rob = w.W > 1 ? w.Rw : w.R, rob_lo = w.P + wld * n_rob;  // the robot agents of the world
+        const int n_rob = n_rob_w, rob_lo = rob_lo_w;
         for (int g = 0; g < G; g++) {
             const int n_near = __shfl(n_near_mine, g * ORCA_ROW);
             if (n_near <= ORCA_ROW) continue;  // (none, or done above)
@@ -521,7 +545,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
                 }
             }
         }
-        if (mine) w.near_n[j] = 0;  // re-armed for the next step's k_side_robots
+        if (mine && !L.fold_side) w.near_n[j] = 0;  // re-armed for the next step's k_side_robots
     }
     __syncthreads();
     ORCA_MARK(6);  // neighbour scans
