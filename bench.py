@@ -591,10 +591,18 @@ def main():
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
-        print(json.dumps(out))
     world.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, whose buffer would otherwise
+        # only be flushed at exit, behind the line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
