@@ -577,6 +577,159 @@ class ObsLaserStateTmp(ObservationWrapper):
         return [states.lasers, states.vector_states, states.ped_maps]
 
 
+class PedTrajectoryDatasetWrapper(Wrapper):
+    """The feeder of the ``dataset`` pedestrian scene (envs/wrapper/evaluation_wrapper/PedTrajectoryDatasetWrapper.py:15-291): a file
+    of recorded pedestrian tracks (ETH / UCY world coordinates: four rows frame, pedestrian, y, x) is cut into "worlds" -- ranges
+    of pedestrians -- and every ``reset`` hands the env the current world's tracks as ``cur_ped_pos_v_datas``, one series of
+    [x, y, theta, vx, vy] per pedestrian every ``control_hz`` seconds (img_env.cpp:361-386 replays them).  After
+    ``repeated_time_per_env`` episodes the next world is up; every finished episode appends one line to ``output_file`` (how it
+    ended + the path figures of its (v, w) commands); after the last world the process exits, as in the reference.
+
+    numpy only (the reference goes through pandas and builds scipy interpolators it never evaluates).  The path figures follow
+    envs/wrapper/evaluation_wrapper/utils.py:60-129 on the stored commands of robot 0 ("suppose only one agent here")."""
+
+    def __init__(self, env, cfg):
+        super().__init__(env)
+        import os
+        self.cfg = cfg
+        self.dt = cfg.get("control_hz", 0.4)
+        if cfg.get("ped_traj_dataset") is None:
+            raise ValueError("PedTrajectoryDatasetWrapper needs cfg['ped_traj_dataset']")
+        self._read_dataset(cfg["ped_traj_dataset"])
+        self.repeated_time_per_env = cfg.get("repeated_time_per_env", 10)
+        self.cur_repeated_time_per_env = 0
+        self.ped_dataset_worlds = cfg.get("ped_dataset_worlds", [[0, 10]])
+        self.max_worlds = len(self.ped_dataset_worlds)
+        self.cur_world = 0
+        lo, hi = self.ped_dataset_worlds[self.cur_world]
+        cfg["ped_sim"]["total"] = self.cur_world_max_peds = hi - lo + 1
+        self.node_id = cfg.get("node_id", 0)
+        self.output_file = cfg.get("output_file", "../output/ped_dataset_{}/ppo_{}.txt".format(self.dataset_name, self.node_id))
+        self.output_dir = "/".join(self.output_file.split("/")[:-1])
+        if self.output_dir != "" and not os.path.exists(self.output_dir):
+            os.mkdir(self.output_dir)
+        self._v, self._w = [], []  # this episode's commands of robot 0
+
+    # ---- the recorded tracks
+    def _read_dataset(self, path):
+        import os
+        import sys
+        if not os.path.exists(path):  # (run from the trainer's directory)
+            path = sys.argv[0].split("runner")[0] + "env/drlnav_env/" + path
+        rows = np.loadtxt(path, delimiter=",", ndmin=2)
+        self._frame, self._ped = rows[0].astype(np.int64), rows[1].astype(np.int64)
+        self._y, self._x = rows[2], rows[3]  # the file's third row is "y", its fourth "x"
+        self.max_peds = int(self._ped.max())
+        c = self.cfg
+        self.dataset_name = c.get("ped_dataset_name", "eth")
+        self.swapxy = c.get("swapxy", True)
+        self.spawn_delay_s = c.get("spawn_delay_s", 0)
+        self.offset = c.get("offset", [1.4, 14.4, 0])
+        self.fps = c.get("fps", 15)
+        if (self.dt * self.fps) % 1 != 0:
+            raise ValueError("control_hz * fps must be a whole number of frames")
+        self.skip_frame = int(self.dt * self.fps)
+        self.start_t = c.get("start_t", 0)
+        self.max_time = c.get("max_time", 20)
+        self.scale_x, self.scale_y = c.get("scale_x", 1), c.get("scale_y", 1)
+
+    def _track(self, ped_id, start_frame):
+        """one pedestrian's series: times (with the spawn instant in front), poses with the heading of each move, finite-
+        difference speeds along that heading; the first pose held until the pedestrian's first frame; every skip_frame-th kept"""
+        sel = self._ped == ped_id
+        frames, xs, ys = self._frame[sel], self._x[sel], self._y[sel]
+        times = (frames - start_frame) * (1.0 / self.fps) + (self.spawn_delay_s + self.start_t)
+        times = np.concatenate([[times[0] - self.start_t], times])
+        a, b = (ys, xs) if self.swapxy else (xs, ys)
+        sa, sb = (self.scale_y, self.scale_x) if self.swapxy else (self.scale_x, self.scale_y)
+        a, b = sa * a, sb * b
+        s, c = np.sin(self.offset[2]), np.cos(self.offset[2])
+        px, py = a * c - b * s + self.offset[0], a * s + b * c + self.offset[1]
+        th = np.arctan2(py[1:] - py[:-1], px[1:] - px[:-1])
+        th = np.append(th, th[-1])
+        pose = np.stack([px, py, th], 1)
+        pose = np.insert(pose, [0], pose[0], axis=0)  # the spawn instant
+        out = []
+        for j in range(len(pose)):
+            if j > 1:
+                speed = np.sqrt((pose[j, 0] - pose[j - 1, 0]) ** 2 + (pose[j, 1] - pose[j - 1, 1]) ** 2) / (times[j] - times[j - 1])
+                out.append([pose[j, 0], pose[j, 1], pose[j, 2], speed * np.cos(pose[j, 2]), speed * np.sin(pose[j, 2])])
+            else:
+                out.append([pose[j, 0], pose[j, 1], pose[j, 2], 0, 0])
+        out = [out[0]] * int(frames[0] - start_frame) + out
+        return out[::self.skip_frame], frames
+
+    def _generate_humans(self, start_idx, max_agents):
+        series, longest, start_frame = [], 0, None
+        for i in range(max_agents):
+            ped_id = i + start_idx + 1
+            if not ped_id < self.max_peds + 1:
+                raise AssertionError("PedTrajectoryDatasetWrapper: pedestrian %d is beyond the file's %d" % (ped_id, self.max_peds))
+            first = int(self._frame[self._ped == ped_id][0])
+            if i == 0:
+                start_frame = first
+            if (first - start_frame) / self.fps > self.max_time:
+                break
+            one, _ = self._track(ped_id, start_frame)
+            longest = max(longest, len(one))
+            series.append(one)
+        for i in range(max_agents):  # (IndexError when the max_time cut dropped a pedestrian, as in the reference)
+            series[i] = series[i] + (longest - len(series[i])) * [series[i][-1]]
+        return series
+
+    def change_world(self):
+        return self._generate_humans(self.ped_dataset_worlds[self.cur_world][0], self.cur_world_max_peds)
+
+    # ---- the env
+    def step(self, action):
+        states, reward, done, info = self.env.step(action)
+        speeds = info.get("speeds")[0]  # robot 0
+        self._v.append(float(speeds[0]))
+        self._w.append(float(speeds[1]))
+        return states, reward, done, info
+
+    def reset(self, **kwargs):
+        import sys
+        self.out2logfile(kwargs.get("dones_info"))
+        print("PedTrajectoryDatasetWrapper Reset ", flush=True)
+        if self.cur_world == self.max_worlds:
+            print("[PedTrajectoryDatasetWrapper]: Run Over.", flush=True)
+            sys.exit()
+        kwargs["cur_ped_pos_v_datas"] = self.change_world()
+        return self.env.reset(**kwargs)
+
+    def _metrics(self):
+        v, w, dt = np.asarray(self._v, np.float64), np.asarray(self._w, np.float64), self.dt
+        tmp, w_zero = 0, 0
+        for x in w:  # sign changes of w (a zero after a turn counts)
+            if x == 0:
+                w_zero += 1 if tmp != 0 else 0
+            elif (x > 0 and tmp < 0) or (x < 0 and tmp > 0):
+                w_zero += 1
+            tmp = x
+        v_acc, w_acc = np.diff(v) / dt, np.diff(w) / dt
+        return dict(v_avg=round(float(np.average(v)), 4), w_avg=round(float(np.average(np.abs(w))), 4),
+                    v_acc=round(float(np.average(np.abs(v_acc))), 4), w_acc=round(float(np.average(np.abs(w_acc))), 4),
+                    v_jerk=round(float(np.average(np.abs(np.diff(v_acc) / dt))), 4), w_jerk=round(float(np.average(np.abs(np.diff(w_acc) / dt))), 4),
+                    w_zero=w_zero, path_time=round(len(v) * dt, 4), steps=len(v))
+
+    def out2logfile(self, dones):
+        if dones is None:
+            return
+        self.cur_repeated_time_per_env += 1
+        code = int(dones[0])
+        m = self._metrics()
+        m.update(arrive=1 if code == 5 else 0, ped_collision=1 if code == 2 else 0, stuck=1 if code == 10 else 0, cur_world=self.cur_world)
+        with open(self.output_file, "a") as f:
+            f.write("{cur_world}, {arrive}, {ped_collision}, {stuck}, {v_avg}, {w_avg}, {v_acc}, {w_acc}, {v_jerk}, {w_jerk}, {w_zero}, "
+                    "{path_time}, {steps}".format_map(m))
+            f.write("\n")
+        self._v, self._w = [], []
+        if self.cur_repeated_time_per_env == self.repeated_time_per_env:
+            self.cur_world += 1
+            self.cur_repeated_time_per_env = 0
+
+
 wrapper_dict = {
     "StatePedVectorWrapper": StatePedVectorWrapper,
     "VelActionWrapper": VelActionWrapper,
@@ -589,6 +742,7 @@ wrapper_dict = {
     "InfoLogWrapper": InfoLogWrapper,
     "ObsLaserStateTmp": ObsLaserStateTmp,
     "TestEpisodeWrapper": TestEpisodeWrapper,
+    "PedTrajectoryDatasetWrapper": PedTrajectoryDatasetWrapper,
 }
 
 

@@ -449,3 +449,52 @@ def test_device_side_placements_follow_the_host_sampler():
         assert seen >= 3 * E and same >= 0.98 * seen, (seen, same)
     finally:
         vec.close()
+
+
+def test_ped_trajectory_dataset_wrapper_feeds_the_dataset_scene(tmp_path):
+    """make_env with ``ped_sim.type: dataset`` and PedTrajectoryDatasetWrapper in the wrapper list: every reset hands the env the
+    current world's recorded tracks (cur_ped_pos_v_datas), the pedestrians replay them step by step (img_env.cpp:361-386), the next
+    world is up after repeated_time_per_env episodes, and each finished episode leaves its line in the output file"""
+    import torch
+    from img_env_amd import make_env, worldgen
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ped_dataset_ref.npz"))
+    path = str(tmp_path / "world.csv")
+    np.savetxt(path, z["csv"], delimiter=",", fmt="%.17g")
+    grid = worldgen.make_grid(200, 3)
+    cfg = worldgen.make_yaml_cfg(1, 4, grid, scene="dataset", time_max=6, dt=0.4, n_obstacles=0, seed=4,
+                                 wrappers=["VelActionWrapper", "TimeLimitWrapper", "SensorsPaperRewardWrapper", "InfoLogWrapper",
+                                           "PedTrajectoryDatasetWrapper", "NeverStopWrapper"])
+    cfg.update(ped_traj_dataset=path, repeated_time_per_env=2, ped_dataset_worlds=[[0, 3], [3, 6]], offset=[12.0, 12.0, 0.3], fps=15,
+               output_file=str(tmp_path / "log.txt"), max_time=100)
+    env = make_env(cfg)
+    try:
+        wr = env
+        while type(wr).__name__ != "PedTrajectoryDatasetWrapper":
+            wr = wr.env
+        base = wr
+        while not hasattr(base, "world"):
+            base = base.env
+        env.reset()
+        series = np.array(wr.change_world())  # the world the reset just fed
+        assert np.allclose(base.world.out["ped_state"][:, :2].cpu().numpy(), series[:, 0, :2])
+        episodes, k = 0, 0
+        for s in range(30):
+            a = torch.tensor([[0.2, 0.1]], device="cuda")
+            _, _, done, info = env.step(a)
+            k += 1
+            if bool(info["all_down"][0]):  # NeverStopWrapper has reset the env: a new episode, maybe a new world
+                episodes += 1
+                k = 0
+                series = np.array(wr.change_world())
+                assert np.allclose(base.world.out["ped_state"][:, :2].cpu().numpy(), series[:, 0, :2])
+            else:
+                want = series[:, min(k - 1, series.shape[1] - 1), :]
+                got = base.world.out["ped_state"].cpu().numpy()
+                assert np.allclose(got[:, :2], want[:, :2]) and np.allclose(got[:, 2:], want[:, 3:5]), (s, k)
+            if episodes == 3:
+                break
+        assert episodes == 3 and wr.cur_world == 1  # two episodes in world 0, then world 1
+        lines = open(cfg["output_file"]).read().strip().splitlines()
+        assert len(lines) == 3 and lines[0].startswith("0, ") and len(lines[0].split(", ")) == 13
+    finally:
+        env.close()
