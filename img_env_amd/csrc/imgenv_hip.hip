@@ -1327,14 +1327,18 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // 155 us at 2048 robots, i.e. worse -- the prologue's cost is its loads, not its arithmetic.)
         const int n_eff = d.act_n_dev ? std::min(n_l, h->act_hint) : n_l;
         const int tpw = n_eff >= 1024 ? 64 : n_eff >= 48 ? 32 : 8, crop_chunks = (h->big_max_crop + (VBC_T / WAVE) * tpw - 1) / ((VBC_T / WAVE) * tpw);
-        const dim3 gc((unsigned)((n_l + 7) / 8 * 8) * (unsigned)crop_chunks), gb((unsigned)n_l * (unsigned)quarters);
+        static const int force_qpw = getenv("IMGENV_BEAMS_QPW") ? atoi(getenv("IMGENV_BEAMS_QPW")) : 0;  // (measurement switch)
+        // (2048 robots x 1000 beams: one block of 256 beams per workgroup 98 us, two 87, four 87 -- but end to end two win: 3.85 M robot-steps/s
+        // against 3.79 / 3.78: the first workgroup of a robot also hands the collision code to the step's tail)
+        const int qpw = force_qpw ? std::min(force_qpw, quarters) : (n_eff >= 1024 ? std::min(2, quarters) : 1);
+        const dim3 gc((unsigned)((n_l + 7) / 8 * 8) * (unsigned)crop_chunks), gb((unsigned)n_l * (unsigned)((quarters + qpw - 1) / qpw));
         const dim3 gt((unsigned)n_l * (unsigned)tap_chunks), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
         if (h->stamp && d.crop_map) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true, true><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
         else if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true, false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
         else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false, false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
         const int variant = (h->pow2 ? 4 : 0) | (h->stamp ? 2 : 0) | (h->big_bits_in_lds ? 1 : 0);
 #define BEAMS_CASE(N, P2, ST, LB) \
-    case N: TIMED(h, IMGENV_K_VIEW, st, (k_beams_big<P2, ST, LB><<<gb, dim3(VBB_T), h->lds_view_big, st>>>(d, quarters))); break;
+    case N: TIMED(h, IMGENV_K_VIEW, st, (k_beams_big<P2, ST, LB><<<gb, dim3(VBB_T), h->lds_view_big, st>>>(d, quarters, qpw))); break;
         switch (variant) {
             BEAMS_CASE(7, true, true, true)
             BEAMS_CASE(6, true, true, false)

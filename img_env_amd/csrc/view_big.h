@@ -294,10 +294,15 @@ __device__ __forceinline__ uint32_t big_cell_value(const RobotClassDev& rc, cons
 // Every beam walks its static path 32 steps at a time (eight 16-byte loads of bit addresses in flight, consecutive lanes
 // contiguous), one LDS bit lookup per step; a wavefront leaves as soon as all its beams have hit or ended.
 template <bool POW2, bool STAMP, bool LDSBM>
-__global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
+__global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters, int qpw) {
+    // qpw: blocks of 256 beams one workgroup walks one after the other over ONE copy of the bitmap.  A launch that fills the chip
+    // takes two (the 20 KB bitmap leaves a compute unit 8 workgroups: with a workgroup per 256 beams the 8192 workgroups of
+    // 2048 robots x 1000 beams passed in four generations, each loading the robot's bitmap again: 98 -> 87 us); a handful of robots
+    // (a reset of a few worlds) keeps one block per workgroup: there the single workgroup's latency is the launch's
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the bitmap at LDS address 0 (a path entry >> 5 IS its word's address), one word behind it
     const int tid = threadIdx.x;
-    const int t = (int)blockIdx.x / quarters, quarter = (int)blockIdx.x - t * quarters;
+    const int groups = (quarters + qpw - 1) / qpw;
+    const int t = (int)blockIdx.x / groups, quarter0 = ((int)blockIdx.x - t * groups) * qpw, quarter = quarter0;
     uint32_t& best_sh = *(uint32_t*)(smem + (LDSBM ? 4 * (size_t)w.big_words : 0));
     if (t >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, t);
@@ -363,7 +368,8 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
     if (w.use_laser == 0) return;
     const uint32_t* plane0 = LDSBM ? (const uint32_t*)bm : plane0_g;
     const int stride = rc.ray_stride, kpad = rc.ray_kpad;
-    const int b = quarter * VBB_T + tid, bb = min(b, B - 1);
+    for (int qq = quarter0; qq < min(quarter0 + qpw, quarters); qq++) {
+    const int b = qq * VBB_T + tid, bb = min(b, B - 1);
     const int len = b < B ? (int)rc.ray_len[bb] : 0;
     uint32_t hk = 0xFFFFFFFFu;
     const uint4* col = (const uint4*)k.cells + bb;  // [kpad / 4][stride] four steps per entry (host_tables.h big_bit_entry)
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters) {
             w.hits_x[(size_t)l * B + b] = rc.ray_hx[hx];
             w.hits_y[(size_t)l * B + b] = rc.ray_hy[hx];
         }
+    }
     }
 }
 
