@@ -782,7 +782,7 @@ def test_equidistant_pedestrians_keep_index_order(worlds):
         cpu.close()
 
 
-@pytest.mark.parametrize("n_peds", [5, 70, 300])
+@pytest.mark.parametrize("n_peds", [5, 70, 300, 700])
 def test_pedestrian_distances_that_differ_below_float32_keep_the_float64_order(worlds, n_peds):
     """the register sort of k_obs orders float32(key) << 32 | index and repairs runs of equal surrogates with the exact comparator:
     pedestrians whose squared distances (float64, yaml_env.py:451) differ by less than a float32 ulp -- 1 + 2^-26 against 1, and a
