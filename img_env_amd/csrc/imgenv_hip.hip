@@ -117,6 +117,9 @@ struct imgenv {
     uint64_t spawn_ahead_cfg = 0;  // fingerprint of the spawn cfg the placements were drawn from
     int spawn_ahead_n = 8;
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
+    // imgenv_step on a handle of at most 4096 robots, all local: the move is left to the raster launch (k_move_raster)
+    bool in_step = false, move_pending = false;
+    const float* move_actions = nullptr;
     double trace_acc[4] = {0, 0, 0, 0};  // IMGENV_TRACE_RESET: host time inside imgenv_step_autoreset
     long trace_calls = 0, trace_resets = 0;
     // device-side auto-reset (csrc/spawn_device.h): pool of placements drawn ahead on a side stream
@@ -1228,6 +1231,50 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     if (h->P == 0)
         if (int rc = chain_begin(h, st)) return rc;
     const unsigned compose_blocks = d.act_list ? (unsigned)(((h->Gs / 4 + 255) / 256) * d.act_nw) : (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
+    // the rasters (in front of them, in STAMP mode, every STAMP_TAGS steps the sweep): in a step whose move was left to them
+    // (imgenv_step_begin: k_move_raster) they come first and the side stream forks behind them, otherwise behind the side launches
+    const bool moved = h->move_pending;
+    h->move_pending = false;
+    auto rasters = [&]() -> int {
+        // STAMP mode: no compose.  A reset has given the worlds it covers their base classes together with their obstacle maps
+        // (k_reset_apply, k_reset_obstacles); every STAMP_TAGS steps one sweep drops all stamps before their tags come round again.
+        if (h->stamp && !is_reset && h->stamp_seq % STAMP_TAGS == 0)
+            TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
+        {
+            const int n_blocks = n_p > n_g ? n_p : n_g;
+            // four wavefronts per robot / pedestrian when the launch cannot fill the machine (device-side auto-reset: by the expected
+            // number of robots, the grid itself is sized for every world)
+            const bool small = (d.act_n_dev ? std::min(n_blocks, h->act_hint) : n_blocks) <= 1024;
+            static const int force_split = getenv("IMGENV_RASTER_SPLIT") ? atoi(getenv("IMGENV_RASTER_SPLIT")) : 0;  // (measurement switch)
+            // robots and pedestrians in blocks of their own while all of them fit the chip at once (8192 wavefronts): a robot and a
+            // pedestrian one behind the other in one block is twice a block's chain of memory round trips
+            // (1024 envs x (4 + 3): k_raster 34 -> 22 us; the headline's 8192 + 200 stay as they are: a second, nearly empty round)
+            const bool roomy = !small && n_g + n_p <= 8192 && force_split >= 0;
+            const int split = (small || roomy || force_split > 0) && n_g > 0 && n_p > 0 ? n_g : 0;
+            const dim3 gr(split || moved ? n_g + n_p : n_blocks), br(small ? 4 * WAVE : WAVE);
+            const size_t lds = 4 * (size_t)d.box_cells + 16;
+            const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
+            // (k_move_raster: the step's move in the same launch -- the RVO / recorded pedestrians' too; a social-force crowd has moved in k_sfm)
+            const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = h->elapsed - 1;
+#define RASTER_CASE(N, P2, ST)                                                                                    \
+        case N:                                                                                                       \
+            if (moved && small) TIMED(h, IMGENV_K_RASTER, st, (k_move_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            else if (moved) TIMED(h, IMGENV_K_RASTER, st, (k_move_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
+            else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
+            break;
+            switch (variant) {
+                RASTER_CASE(3, true, true)
+                RASTER_CASE(2, true, false)
+                RASTER_CASE(1, false, true)
+                RASTER_CASE(0, false, false)
+            }
+#undef RASTER_CASE
+        }
+        return 0;
+    };
+    if (moved)
+        if (int rc = rasters()) return rc;
     if (h->P > 0) {
         // One fork and one join per step on the caller's stream (every event operation costs it a ~6 us dependency
         // bubble).  Beside the rasters, compose and view run, on two side streams, the pedestrian half of the
@@ -1287,33 +1334,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         k_state<<<dim3((n_l + 127) / 128), dim3(128), 0, st>>>(d);
         h->launches += 1;
     }
-    // STAMP mode: no compose.  A reset has given the worlds it covers their base classes together with their obstacle maps
-    // (k_reset_apply, k_reset_obstacles); every STAMP_TAGS steps one sweep drops all stamps before their tags come round again.
-    if (h->stamp && !is_reset && h->stamp_seq % STAMP_TAGS == 0)
-        TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
-    {
-        const int n_blocks = n_p > n_g ? n_p : n_g;
-        // four wavefronts per robot / pedestrian when the launch cannot fill the machine (device-side auto-reset: by the expected
-        // number of robots, the grid itself is sized for every world)
-        const bool small = (d.act_n_dev ? std::min(n_blocks, h->act_hint) : n_blocks) <= 1024;
-        static const int force_split = getenv("IMGENV_RASTER_SPLIT") ? atoi(getenv("IMGENV_RASTER_SPLIT")) : 0;  // (measurement switch)
-        const int split = (small || force_split) && n_g > 0 && n_p > 0 ? n_g : 0;  // small launches: robots and pedestrians in blocks of their own
-        const dim3 gr(split ? n_g + n_p : n_blocks), br(small ? 4 * WAVE : WAVE);
-        const size_t lds = 4 * (size_t)d.box_cells + 16;
-        const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
-#define RASTER_CASE(N, P2, ST)                                                                                    \
-    case N:                                                                                                       \
-        if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
-        else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
-        break;
-        switch (variant) {
-            RASTER_CASE(3, true, true)
-            RASTER_CASE(2, true, false)
-            RASTER_CASE(1, false, true)
-            RASTER_CASE(0, false, false)
-        }
-#undef RASTER_CASE
-    }
+    if (!moved)
+        if (int rc = rasters()) return rc;
     if (!h->stamp) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     if (h->big_view) {  // view_big.h: crop (tiles of every robot spread over the chip) -> beams (a workgroup per robot and 256
                         // beams) -> the shrunk sensor_map (a thread per pixel) -> the full view, only where it is an output
@@ -1364,11 +1386,15 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         static const int force_nw = getenv("IMGENV_VIEW_NW") ? atoi(getenv("IMGENV_VIEW_NW")) : 0;  // (measurement switch)
         const bool lds_bound = (160 * 1024) / ((h->lds_view + 1279) / 1280 * 1280) <= 16;
         const bool small = force_nw ? force_nw == 4 : (lds_bound || (d.act_n_dev ? std::min(n_l, h->act_hint) : n_l) <= 1024);
-        const dim3 gv(n_l), bv(small ? 4 * WAVE : WAVE);
+        // two wavefronts per robot in between (1025-4096 robots: every wavefront still resident at once; 1024 envs x 4: 39 -> 28 us)
+        const int n_view = d.act_n_dev ? std::min(n_l, h->act_hint) : n_l;
+        const bool two = force_nw ? force_nw == 2 : (!small && n_view <= 4096);
+        const dim3 gv(n_l), bv(small ? 4 * WAVE : two ? 2 * WAVE : WAVE);
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
     case N:                                                                                                                     \
         if (small) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 4><<<gv, bv, h->lds_view, st>>>(d)));                        \
+        else if (two) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 2><<<gv, bv, h->lds_view, st>>>(d)));                     \
         else TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 1><<<gv, bv, h->lds_view, st>>>(d)));                              \
         break;
         switch (variant) {
@@ -2137,6 +2163,14 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         h->launches += 2;
     }
     // _step_robot (img_env.cpp:388-410)
+    static const int force_fuse = getenv("IMGENV_FUSE_MOVE") ? atoi(getenv("IMGENV_FUSE_MOVE")) : -1;  // (measurement switch)
+    const bool fuse_move = h->in_step && !d.sharded && !h->comm && h->RL == h->R && h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS &&
+                           (force_fuse >= 0 ? force_fuse != 0 : (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024));
+    if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
+        h->move_pending = true;
+        h->move_actions = actions;
+        return IMGENV_OK;
+    }
     {   // ... and the pedestrians' move (img_env.cpp:343-358) in the same launch
         const bool peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET);
         if (h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS) {
@@ -2167,7 +2201,10 @@ extern "C" int imgenv_step_end(imgenv_t* h, void* stream) {
 }
 
 extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) {
-    if (int rc = imgenv_step_begin(h, actions, stream)) return rc;
+    if (h) h->in_step = true;  // (begin and end in one call: the actions outlive the move whoever launches it)
+    const int rc_begin = imgenv_step_begin(h, actions, stream);
+    if (h) h->in_step = false;
+    if (rc_begin) return rc_begin;
     if (h->comm) {  // the one exchange of a robot-sharded world: records of all robots, in place
         const size_t count = (size_t)h->RL * IMGENV_RECORD_DOUBLES;
         const ncclResult_t e = rccl_api()->all_gather(h->d.rec + (size_t)h->r0 * IMGENV_RECORD_DOUBLES, h->d.rec, count,

@@ -782,23 +782,27 @@ __device__ __forceinline__ void ped_leg_gait(const DevWorld& w, int j, double x,
     w.prem[j] = move + w.prem[j] - (st - last) * step_len;
     st %= 7;
     w.pstate[j] = st;
+    // (the array pointers fetched once, in front of the branches: merged behind them, the stores would pick the FIELD by a phi of
+    // addresses inside the kernel argument -- and a kernel whose argument has its address taken keeps all 3.5 KB of it in scratch
+    // memory: k_move_raster, 34 -> 200 us)
+    double *const llx = w.llx, *const lly = w.lly, *const rlx = w.rlx, *const rly = w.rly;
     if (st == 0 || st == 4) {
-        w.llx[j] = k.sizes[0];
-        w.lly[j] = k.sizes[1];
-        w.rlx[j] = k.sizes[3];
-        w.rly[j] = k.sizes[4];
+        llx[j] = k.sizes[0];
+        lly[j] = k.sizes[1];
+        rlx[j] = k.sizes[3];
+        rly[j] = k.sizes[4];
     } else if (st == 1 || st == 3) {
-        w.llx[j] = -step_len / 2;
-        w.rlx[j] = step_len / 2;
+        llx[j] = -step_len / 2;
+        rlx[j] = step_len / 2;
     } else if (st == 2) {
-        w.llx[j] = -step_len;
-        w.rlx[j] = step_len;
+        llx[j] = -step_len;
+        rlx[j] = step_len;
     } else if (st == 5) {
-        w.llx[j] = step_len / 2;
-        w.rlx[j] = -step_len / 2;
+        llx[j] = step_len / 2;
+        rlx[j] = -step_len / 2;
     } else if (st == 6) {
-        w.llx[j] = step_len;
-        w.rlx[j] = -step_len;
+        llx[j] = step_len;
+        rlx[j] = -step_len;
     }
 }
 
@@ -1484,6 +1488,51 @@ __global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel, 
         RASTER_MARK(12);  // the block's pedestrian
     }
     if (b < w.RL) WAVE_DONE(2);
+}
+
+// k_integrate and k_raster as ONE launch, for steps of handles that leave the chip room (imgenv_step on at most 4096 robots, all of
+// them local): a robot's footprint needs nothing but its own new pose, a pedestrian's nothing but its own move, so the robot's
+// block integrates it first -- the headings one per lane (integrate_heading), the position recurrence on lane 0 -- and the
+// pedestrian's block moves it first.  One launch and one stream dependency less in front of the views; the side stream's fork
+// moves behind this kernel, the observation and the solve then run underneath k_view.  (At 8192 robots that placement loses --
+// k_obs and k_view are both bound by vector issue, DESIGN.md section 4 -- so the big launches keep the two kernels.)
+// Blocks [0, R): robots, [R, R + P): pedestrians.
+template <bool POW2, bool STAMP, int NW>
+__global__ __launch_bounds__(WAVE * NW) void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int step, int move_peds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double2 trig[INT_ITEMS];  // (cos, sin)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (STAMP && b == 0 && tid == 0) w.counters[1] = 0;  // (as k_raster)
+    const Region g = grid_region(w);
+    if (b < w.R) {
+        const int l = b;  // (every robot is local: r0 = 0)
+        // (the class index in a scalar register: behind the stores below the compiler would fetch it per lane, and a per-lane index
+        // into the class records of the kernel argument sends the whole argument through scratch memory)
+        const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[l]);
+        double* r = w.rec + (size_t)l * IMGENV_RECORD_DOUBLES;
+        if (!w.py_done[l]) {  // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
+            double v, wv, v_y;
+            integrate_command(w, actions, l, v, wv, v_y);
+            const double theta = r[2];
+            if (tid < n_sub + 2) trig[tid] = integrate_heading(theta, wv, w.step_hz, tid, n_sub);
+            __syncthreads();
+            if (tid == 0) integrate_finish(w, l, r, v, wv, v_y, theta, trig, n_sub);
+        }
+        if (w.state_in_integrate && tid == 0) state_robot(w, l);  // no pedestrians, no side stream: get_state right behind the move
+        __syncthreads();  // the new record, for every lane
+        raster_robot<POW2, STAMP, NW>(w, l, robot_class(w, cls), (uint32_t*)smem, g);
+    } else if (b - w.R < w.P) {
+        const int j = b - w.R;
+        const int cls = __builtin_amdgcn_readfirstlane(w.ped_cls[j]);
+        if (move_peds) {
+            if (tid == 0) {
+                if (w.scene == IMGENV_SCENE_DATASET) ped_dataset_one(w, j, step - w.world_epoch[world_of_ped(w, j)]);
+                else ped_update_one(w, j);
+            }
+            __syncthreads();
+        }
+        raster_ped<POW2, STAMP, NW>(w, j, w.pc[cls], g);
+    }
 }
 
 // `cell` of the cells [c0, min(c0 + 4, G)) from the map and the raster layers; re-arms the raster layers

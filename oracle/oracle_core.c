@@ -494,9 +494,9 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     Hg = w->Hg;
     Wg = w->Wg;
     w->obs_map = (uint8_t*)malloc(G);
-    memcpy(w->obs_map, static_map, G);
+    memcpy(w->obs_map, w->static_map, G); /* (the resized map: the caller's buffer holds Hg x Wg cells of the SOURCE resolution) */
     w->peds_map = (uint8_t*)malloc(G);
-    memcpy(w->peds_map, static_map, G);
+    memcpy(w->peds_map, w->static_map, G);
     w->priv = (uint8_t*)malloc(G);
     w->own_lo = (uint32_t*)malloc(G * 4);
     w->own_hi = (uint32_t*)malloc(G * 4);
@@ -585,7 +585,7 @@ int oracle_create(const imgenv_cfg* cfg, const uint8_t* static_map, int32_t Hg, 
     ALLOC(o->rewards, double, RL); ALLOC(o->paper_rewards, double, RL); ALLOC(o->dones, uint8_t, RL); ALLOC(o->dones_info, int32_t, RL);
     ALLOC(o->is_clean, uint8_t, RL);
     ALLOC(o->robot_pose, double, (size_t)RL * 3);
-    ALLOC(o->ped_state, double, (size_t)P * 4);
+    ALLOC(o->ped_state, double, (size_t)(P > 0 ? P : 1) * 4); /* (the bindings view one zero row when there are no pedestrians) */
     ALLOC(o->counters, int32_t, 4);
     for (int l = 0; l < RL; l++) {
         o->ped_min_dists[l] = INFINITY; /* NearbyPed (reset_helper.py:85-99), never re-initialised */

@@ -1,8 +1,10 @@
 """The kernel variants only LARGE launches select, against the oracle.
 
 The library picks kernel variants by launch size (csrc/imgenv_hip.hip, launch_views): one wavefront per robot / pedestrian
-instead of four in `k_raster` / `k_view` above 1024 blocks, 32 / 64 instead of 8 tiles per `k_crop_big` wavefront from 48 / 1024
-robots on, strided instead of one-to-one grids in the device-side reset chain.  The other GPU suites stay below those
+instead of four in `k_raster` above 1024 blocks (robots and pedestrians in blocks of their own up to 8192 blocks, one block for a
+robot AND a pedestrian beyond), four / two / one wavefronts per `k_view` up to 1024 / up to 4096 / more robots, the step's move
+inside the raster launch (`k_move_raster`) for pedestrian-free handles up to 4096 robots, 32 / 64 instead of 8 tiles per
+`k_crop_big` wavefront from 48 / 1024 robots on, strided instead of one-to-one grids in the device-side reset chain.  The other GPU suites stay below those
 thresholds (a dozen robots per oracle); here the handles are big enough to cross them, with one oracle per world as the checker:
 
 * STAMP-mode many-world handles above 1024 robots (what `bench.py`'s `multi_world` / `vec_env` figures run);
@@ -37,9 +39,10 @@ def worlds():
 
 @pytest.mark.parametrize("res,legs", [(0.125, False), (0.1, True)], ids=["pow2_cells", "tenth_cells_legs"])
 def test_stamped_worlds_above_1024_robots_match_one_oracle_each(worlds, res, legs):
-    """300 worlds x (4 robots + 3 pedestrians) = 1200 robots, STAMP mode: the step's rasters and views are the one-wavefront
-    variants (`k_raster<.., true, 1>`, `k_view<.., true, 1>`), the resets of a few worlds in mid-flight the four-wavefront ones,
-    the reset of 250 worlds at once (1000 robots + ...) sits just below the threshold, the one of all 300 above it"""
+    """300 worlds x (4 robots + 3 pedestrians) = 1200 robots, STAMP mode: the step's rasters are the one-wavefront variant with
+    robots and pedestrians in blocks of their own (`k_raster<.., true, 1>`, split), its views the two-wavefront one
+    (`k_view<.., true, 2>`), the resets of a few worlds in mid-flight the four-wavefront ones, the reset of 250 worlds at once
+    (1000 robots + ...) sits just below the threshold, the one of all 300 above it"""
     World, OracleWorld = worlds
     W = 300
     resets = {1: [7, 150, 299], 3: list(range(0, W, 7)), 4: [1], 5: list(range(250)), 7: list(range(W))}
@@ -50,9 +53,22 @@ def test_stamped_worlds_above_1024_robots_match_one_oracle_each(worlds, res, leg
     assert snap["is_collisions"].shape[0] == 1200
 
 
+def test_stamped_worlds_above_4096_robots_match_one_oracle_each(worlds):
+    """1400 worlds x (4 robots + 3 pedestrians) = 5600 robots + 4200 pedestrians, STAMP mode: beyond 4096 robots the views are the
+    one-wavefront variant (`k_view<.., true, 1>`), beyond 8192 raster blocks a block draws a robot AND a pedestrian; the reset of
+    900 worlds at once (3600 robots) takes the two-wavefront views and the split rasters"""
+    World, OracleWorld = worlds
+    W = 1400
+    resets = {1: [3, 700, 1399], 3: list(range(900)), 4: list(range(0, W, 5))}
+    fails, snap, _ = _run(World, OracleWorld, W, 4, 3, 6, resets, seed=87, n_obstacles=2, grid_size=120, res=0.125, flags=4,
+                          time_max=4, clearance=0.8, view_cells=48)
+    assert not fails, fails[:3]
+    assert snap["is_collisions"].shape[0] == 5600
+
+
 def test_stamped_worlds_without_pedestrians_above_1024_robots(worlds):
-    """1100 one-robot worlds (the `8192 x 1` row of the many-worlds table in small): no side streams, `k_state` / `k_integrate` do
-    get_state, the views are `k_view<.., true, 1>`"""
+    """1100 one-robot worlds (the `8192 x 1` row of the many-worlds table in small): no side streams, the step's move and
+    get_state inside the raster launch (`k_move_raster<.., true, 1>`), `k_state` after a reset, the views are `k_view<.., true, 2>`"""
     World, OracleWorld = worlds
     W = 1100
     fails, _, _ = _run(World, OracleWorld, W, 1, 0, 7, {2: [0, 500, 1099], 4: list(range(0, W, 3))}, seed=83, n_obstacles=2,

@@ -69,8 +69,10 @@ def main():
     ap.add_argument("--obstacles", type=int, default=2)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--time-max", type=int, default=100)
+    ap.add_argument("--device-only", action="store_true", help="only the device-side auto-reset variant")
     args = ap.parse_args()
-    print(json.dumps(measure(args.envs, args.robots, args.peds, args.obstacles, args.steps, args.time_max)))
+    natives = ("device",) if args.device_only else (False, True, "device")
+    print(json.dumps(measure(args.envs, args.robots, args.peds, args.obstacles, args.steps, args.time_max, natives)))
 
 
 if __name__ == "__main__":
