@@ -572,15 +572,18 @@ def test_cfg5_world_matches_oracle(worlds):
         cpu.close()
 
 
-def test_cfg2_world_matches_oracle(worlds):
-    """BASELINE cfg-2 at full size: 1024 robots, no pedestrians, 400 x 400 map at 0.125 m"""
+@pytest.mark.parametrize("layer", ["default", "composed"])
+def test_cfg2_world_matches_oracle(worlds, layer):
+    """BASELINE cfg-2 at full size: 1024 robots, no pedestrians, 400 x 400 map at 0.125 m -- with the class layer the library
+    picks for it (stamped: a launch-bound handle, csrc/imgenv_hip.hip) and with the composed one (`k_compose`)"""
     World, OracleWorld = worlds
-    from img_env_amd import worldgen
+    from img_env_amd import _cabi, worldgen
     n = 1024
     grid = worldgen.make_grid(400, 0)
     params = worldgen.make_params(n, 0, res=0.125, view_cells=48, beams=360, scene="", time_max=100)
     layout = worldgen.make_layout(grid, 0.125, n, 0, seed=100, clearance=1.0)
-    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    gpu = World(dict(params, flags=_cabi.FLAG_COMPOSE_DENSE if layer == "composed" else 0), grid)
+    cpu = OracleWorld(params, grid)
     try:
         rng = np.random.default_rng(12)
         fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(12)])
