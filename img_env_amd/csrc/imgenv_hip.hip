@@ -591,6 +591,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         d.wv_magic = (uint32_t)((0x100000000ull + (uint64_t)g.Wv - 1) / (uint64_t)g.Wv);
     }
     d.step_hz = (double)cfg->step_hz; d.laser_max = cfg->laser_max;
+    d.laser_out_nohit = cfg->laser_norm ? (double)6.0f / (double)cfg->laser_max : (double)6.0f;
     d.ped_safety_space = cfg->ped_safety_space; d.ped_image_r = cfg->ped_image_r;
     d.ped_image_r2 = pow(cfg->ped_image_r, 2.0);        // self.ped_image_r ** 2 (yaml_env.py:425)
     {   // while (cur_control <= step_hz) { ...; cur_control += 0.05; } with the loop's own fp64 accumulation
@@ -682,6 +683,19 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.ray_rows, k.ray_rows));
             TRY(dev_upload(h, &o.ray_len, k.ray_len));
             TRY(dev_upload(h, &o.ray_dist, k.ray_dist));
+            if (!k.big) {  // what k_view needs of a beam's first hit, per (step, beam): the host's IEEE division = the device's
+                std::vector<uint32_t> fin(4 * k.ray_dist.size());
+                for (size_t q = 0; q < k.ray_dist.size(); q++) {
+                    const float hd = k.ray_dist[q];
+                    const double out = cfg->laser_norm ? (double)hd / (double)cfg->laser_max : (double)hd;
+                    fin[4 * q] = k.ray_run[q];
+                    memcpy(&fin[4 * q + 1], &hd, 4);
+                    memcpy(&fin[4 * q + 2], &out, 8);
+                }
+                const uint32_t* fin_dev = nullptr;
+                TRY(dev_upload(h, &fin_dev, fin));
+                o.ray_fin = (const uint4*)fin_dev;
+            }
             TRY(dev_upload(h, &o.ray_run, k.ray_run));
             if (!k.ray_hx.empty()) {
                 TRY(dev_upload(h, &o.ray_hx, k.ray_hx));

@@ -1913,11 +1913,13 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
                 const bool has = first < 0x0100u;  // value 0 in the key's top byte
                 const uint32_t hk = first & 0xFFu;
                 // how far behind the hit the beam stays in the hit cell's row or column: static per (step, beam)
-                const uint32_t run = has ? k.ray_run[(size_t)hk * k.ray_stride + b] : 0u;
-                const float hd = has ? k.ray_dist[(size_t)hk * k.ray_stride + b] : 6.0f;  // agent.cpp:513
+                // ... and its distance, as float32 and as the `lasers` value (hd / laser_max when laser_norm): one 16-byte record
+                const uint4 fin = k.ray_fin[(size_t)(has ? hk : 0u) * k.ray_stride + b];
+                const uint32_t run = has ? fin.x : 0u;
+                const float hd = has ? __uint_as_float(fin.y) : 6.0f;  // agent.cpp:513
                 hit[b] = has ? ((hk << 16) | (hk + run)) : 0xFFFFFFFFu;
                 w.lasers_raw[(size_t)l * w.B + b] = hd;
-                w.lasers[(size_t)l * w.B + b] = w.laser_norm ? (double)hd / w.laser_max : (double)hd;
+                w.lasers[(size_t)l * w.B + b] = has ? __hiloint2double((int)fin.w, (int)fin.z) : w.laser_out_nohit;
                 if (w.hits_x) {  // hit_points_x_ / _y_ (agent.cpp:434-435), static per (step, beam); row ray_maxlen: no hit
                     const size_t at = (size_t)(has ? hk : (uint32_t)k.ray_maxlen) * k.ray_stride + b;
                     w.hits_x[(size_t)l * w.B + b] = k.ray_hx[at];

@@ -52,6 +52,9 @@ struct RobotClassDev {
                                  // chunk per lane, consecutive lanes contiguous; padding points at a free dummy cell
     const uint16_t* ray_len;     // [ray_stride] number of in-map steps before the ray leaves / ends
     const float* ray_dist;       // [ray_maxlen][ray_stride] float32(hit distance) if the hit is at step k
+    const uint4* ray_fin;        // [ray_maxlen][ray_stride] everything k_view stores for a beam whose first hit is at step k, in ONE 16-byte load:
+                                 // {ray_run, float bits of ray_dist, the `lasers` value as a double = (double)ray_dist / laser_max when laser_norm
+                                 // (divided on the host: an fp64 division per beam less)}; null for big views
     const uint8_t* ray_run;      // [ray_maxlen][ray_stride] steps right behind step k that share its row or column (left alone by a hit at k)
     const uint32_t* inv_pack;    // [Hv*Wv] rays through a view cell: first entry | count << 20 ...
     const uint32_t* inv_ent;     // ... entries (beam << 16 | k), beam descending
@@ -131,6 +134,7 @@ struct DevWorld {
     int Hg, Wg, Hv, Wv, B, Hp, Wp, SD, PV;
     int scene, relation, ktype, use_laser, laser_norm, time_max;
     double res, inv_res, step_hz, laser_max, ped_safety_space, ped_image_r, ped_image_r2, ped_res;
+    double laser_out_nohit;  // the `lasers` value of a beam without a hit: 6.0 (agent.cpp:513), over laser_max when laser_norm
     double ped_inv_res;  // 1 / ped_res when ped_res is a power of two (v // ped_res == floor(v * ped_inv_res) exactly), else 0
     uint32_t wv_magic;  // ceil(2^32 / Wv): c / Wv == __umulhi(c, wv_magic) for c < 65536
     Tf2 view_base, base_view;
