@@ -19,6 +19,12 @@
 #define EXP_STOP_AFTER(n) (void)0
 #endif
 
+#ifdef IMGENV_EXP_EVERY_CELL  // k_view's final pass over every cell in the steps too (what it did until round 4): A/B builds
+#define EXP_EVERY_CELL true
+#else
+#define EXP_EVERY_CELL false
+#endif
+
 #ifdef IMGENV_EXP_TINY_RESOLVE
 #define EXP_RESOLVE_CAP(product, tiny) (tiny)
 #else

@@ -114,6 +114,10 @@ struct RobotClassHost {
     std::vector<uint16_t> bin_start;    // [73] first beam of each of the 72 angular_map bins (a beam's bin never decreases)
     std::vector<uint32_t> inv_pack, inv_ent, top_ent;
     std::vector<uint32_t> inv_cell;  // [NC][2] k_view's step (5): filter word, inv_pack
+    // k_view's final pass in a STEP: the groups of 4 view cells (first cell c4, c4 % 4 == 0) in which a step can change anything -- a
+    // cell no beam crosses (no laser: a cell outside the field of view) is 200, or 100 under the own footprint, for the whole
+    // episode: the pass of a reset writes every cell, the passes of the steps only these groups
+    std::vector<uint16_t> dyn_c4;
 };
 
 static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_big = false, bool extras = false) {
@@ -342,6 +346,15 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
             k.top_ent[c] = inv[c][0];
         }
     if (k.inv_ent.empty()) k.inv_ent.push_back(0);
+    k.dyn_c4.clear();
+    if (!k.big)
+        for (int c4 = 0; c4 < NC; c4 += 4) {
+            bool dyn = false;
+            for (int c = c4; c < std::min(c4 + 4, NC); c++)
+                dyn = dyn || (B > 0 ? !inv[c].empty() : ((k.fov_bits[c >> 5] >> (c & 31)) & 1u) != 0u);
+            if (dyn) k.dyn_c4.push_back((uint16_t)c4);
+        }
+    if (k.dyn_c4.empty()) k.dyn_c4.push_back(0);
     // k_view's step (5) for the cells a top beam leaves alone.  Such a cell keeps its 200 unless one of the lower beams through
     // it gets as far as the cell, so the kernel keeps the largest first-hit step of overlapping blocks of beams -- level v:
     // 16 << v beams starting every 8 << v, v = 0, 1, 2, stored back to back -- and compares the one block around the cell's

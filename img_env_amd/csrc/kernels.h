@@ -1815,7 +1815,14 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     if (tid < 16) src[NC + tid] = 255;  // dummy free cells behind the view (padded path entries)
     if (tid < 3) skip_cnt[tid] = 0;
     __syncthreads();
-    for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
+    // Which groups of four cells?  A reset takes every cell; a step only the groups in which a beam crosses a cell (no laser: a cell
+    // inside the field of view) -- static list per class, host_tables.h.  Nobody reads the crop of another cell (the beams walk
+    // their paths, the final pass without a laser reads the cells of the field of view), and in the outputs the other cells hold
+    // their 200, or the own footprint's 100, since the reset.  (48 x 48 cells, 360 beams over 180 degrees: 241 of 576 groups.)
+    const bool every_cell = w.tail_is_reset != 0 || EXP_EVERY_CELL;
+    const int n_groups = every_cell ? (NC + 3) >> 2 : k.n_dyn;
+    for (int gi = tid; gi < n_groups; gi += NT) {
+        const int c4 = every_cell ? 4 * gi : (int)k.dyn_c4[gi];
         const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds the 4 bits
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
         if (fov) {
@@ -1958,7 +1965,8 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     uint32_t* skip_list = (uint32_t*)src;  // the crop is dead once the beams have their hits
     const uint32_t no_beam = ((uint32_t)w.B << 16) | 0xFFFFu;  // top_ent of a cell no beam crosses
     int n_skip = 0;
-    for (int c4 = tid * 4; c4 < NC; c4 += NT * 4) {
+    for (int gi = tid; gi < n_groups; gi += NT) {  // (the groups of the crop)
+        const int c4 = every_cell ? 4 * gi : (int)k.dyn_c4[gi];
         uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
         if (laser) {
             uint32_t top[4] = {no_beam, no_beam, no_beam, no_beam};

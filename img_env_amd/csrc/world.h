@@ -59,6 +59,8 @@ struct RobotClassDev {
     const uint32_t* inv_pack;    // [Hv*Wv] rays through a view cell: first entry | count << 20 ...
     const uint32_t* inv_ent;     // ... entries (beam << 16 | k), beam descending
     const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or B << 16 | 0xFFFF
+    const uint16_t* dyn_c4;      // [n_dyn] first cells of the groups of 4 view cells a step can change (a beam crosses one of them): what k_view's final
+    int n_dyn;                   // pass walks in a step; the pass of a reset writes every cell (the others hold 200 / 100 for the whole episode)
     const uint2* inv_cell;       // [Hv*Wv] k_view's step (5): {block of the reach table | none << 13 | own footprint << 14 | smallest step << 24, inv_pack}
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
     // AgentState.hits_x / hits_y / angular_map (IMGENV_FLAG_AGENT_STATE_EXTRAS; null otherwise)
