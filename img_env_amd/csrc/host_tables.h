@@ -106,6 +106,10 @@ struct RobotClassHost {
     std::vector<uint64_t> crop_masks; // ... and their cells inside it (bit = (a % 8) * 8 + b % 8), + 8 zero entries
     int n_crop = 0;
     std::vector<uint32_t> tap_top, tap_inv, tap_addr;  // [16][image_h * image_w] the 4 x 4 source cells of every pixel of the shrunk sensor_map (build_big_taps)
+    // k_taps_big in a STEP: the chunks of TAP_CHUNK_PIXELS pixels in which some pixel has a source cell that a beam crosses -- a pixel
+    // whose 16 source cells see no beam is a mix of 200 and the own footprint's 100 for the whole episode (the launch of a reset
+    // covers every chunk, the launches of the steps only these)
+    std::vector<uint16_t> tap_chunks;
     std::vector<uint16_t> ray_rows, ray_len;
     std::vector<float> ray_dist;
     std::vector<uint8_t> ray_run;  // [ray_maxlen][ray_stride] steps behind step k of beam b that share a row or column with it
@@ -395,8 +399,10 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
 // by), and two cold ones -- the cell's ray list {first entry, count} and its bit address in the tiled crop bitmap -- for the
 // taps a top beam leaves alone or the own footprint covers.  xofs / yofs: source index of tap 1 per destination column / row
 // (csrc/cv_resize.h), borders replicated as OpenCV does.
+#define TAP_CHUNK_PIXELS 256  // (= VBT_T, k_taps_big's workgroup)
 static void build_big_taps(RobotClassHost& k, const ViewGeom& g, const std::vector<int>& xofs, const std::vector<int>& yofs) {
     const int IW = (int)xofs.size(), IH = (int)yofs.size(), NP = IW * IH;
+    std::vector<char> chunk_dyn((size_t)(NP + TAP_CHUNK_PIXELS - 1) / TAP_CHUNK_PIXELS, g.B > 0 ? 0 : 1);  // (no laser: the crop decides everywhere)
     k.tap_top.assign((size_t)16 * NP, 0);
     k.tap_inv.assign((size_t)16 * NP * 2, 0);
     k.tap_addr.assign((size_t)16 * NP, 0);
@@ -409,10 +415,15 @@ static void build_big_taps(RobotClassHost& k, const ViewGeom& g, const std::vect
                     const uint32_t st = (k.stamp_bits[c >> 5] >> (c & 31)) & 1u;
                     const size_t at = (size_t)(kr * 4 + j) * NP + (size_t)dy * IW + dx;
                     k.tap_top[at] = k.top_ent[c] | (st << 31);  // fewer than 32768 beams in a big view
+                    if ((k.top_ent[c] >> 16) != (uint32_t)g.B) chunk_dyn[(size_t)(dy * IW + dx) / TAP_CHUNK_PIXELS] = 1;  // some beam crosses the cell
                     k.tap_inv[2 * at] = k.big_inv[2 * (size_t)c];
                     k.tap_inv[2 * at + 1] = k.big_inv[2 * (size_t)c + 1];
                     k.tap_addr[at] = (((uint32_t)a >> 3) * (uint32_t)k.big_tb + ((uint32_t)b >> 3)) * 64u + ((uint32_t)a & 7u) * 8u + ((uint32_t)b & 7u);
                 }
+    k.tap_chunks.clear();
+    for (size_t q = 0; q < chunk_dyn.size(); q++)
+        if (chunk_dyn[q]) k.tap_chunks.push_back((uint16_t)q);
+    if (k.tap_chunks.empty()) k.tap_chunks.push_back(0);  // (the robot's first workgroup also commits the collision code)
 }
 
 struct PedClassHost {

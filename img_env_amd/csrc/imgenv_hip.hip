@@ -85,6 +85,7 @@ struct imgenv {
     size_t cap_oinst = 0;
     int* d_act_list = nullptr;
     bool big_view = false;   // the view is beyond k_view's packing, or shrunk by cv2.resize: the kernels of view_big.h
+    int big_tap_chunks_dyn = 0;  // k_taps_big workgroups per robot in a step (the largest list of any class: BigClassDev::tap_chunks)
     size_t lds_view_big = 0;
     bool big_bits_in_lds = true;  // the crop bitmap of one robot fits the LDS next to the hit words
     int big_max_crop = 1, big_full_chunks = 1;
@@ -824,6 +825,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
                 TRY(dev_upload(h, &p2i, k.tap_inv));
                 o.tap_inv = (const uint2*)p2i;
                 TRY(dev_upload(h, &o.tap_addr, k.tap_addr));
+                TRY(dev_upload(h, &o.tap_chunks, k.tap_chunks));
+                o.n_tap_chunks = (int)k.tap_chunks.size();
+                h->big_tap_chunks_dyn = std::max(h->big_tap_chunks_dyn, o.n_tap_chunks);
                 std::vector<uint32_t>().swap(k.tap_top);
                 std::vector<uint32_t>().swap(k.tap_inv);
                 std::vector<uint32_t>().swap(k.tap_addr);
@@ -1374,7 +1378,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // against 3.79 / 3.78: the first workgroup of a robot also hands the collision code to the step's tail)
         const int qpw = force_qpw ? std::min(force_qpw, quarters) : (n_eff >= 1024 ? std::min(2, quarters) : 1);
         const dim3 gc((unsigned)((n_l + 7) / 8 * 8) * (unsigned)crop_chunks), gb((unsigned)n_l * (unsigned)((quarters + qpw - 1) / qpw));
-        const dim3 gt((unsigned)n_l * (unsigned)tap_chunks), gf((unsigned)n_l * (unsigned)h->big_full_chunks);
+        const dim3 gf((unsigned)n_l * (unsigned)h->big_full_chunks);
+        static_assert(VBT_T == TAP_CHUNK_PIXELS, "host_tables.h lists k_taps_big's chunks");
         if (h->stamp && d.crop_map) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true, true><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
         else if (h->stamp) TIMED(h, IMGENV_K_CROP, st, (k_crop_big<true, false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
         else TIMED(h, IMGENV_K_CROP, st, (k_crop_big<false, false><<<gc, dim3(VBC_T), 0, st>>>(d, crop_chunks, n_l, tpw)));
@@ -1393,7 +1398,11 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         }
 #undef BEAMS_CASE
         // the last kernel of the chain commits the robots' new is_collision_
-        if (d.resize) TIMED(h, IMGENV_K_TAPS, st, (k_taps_big<<<gt, dim3(VBT_T), taps_lds_bytes(d.B), st>>>(d, tap_chunks, full ? 0 : 1)));
+        // (a step only runs the chunks of pixels a beam can reach: static list per class; the chunks behind the sensor hold their
+        // 200 / 100 since the reset)
+        const bool listed = !is_reset && h->big_tap_chunks_dyn > 0 && h->big_tap_chunks_dyn < tap_chunks;
+        const int tap_wgs = listed ? h->big_tap_chunks_dyn : tap_chunks;
+        if (d.resize) TIMED(h, IMGENV_K_TAPS, st, (k_taps_big<<<dim3((unsigned)n_l * (unsigned)tap_wgs), dim3(VBT_T), taps_lds_bytes(d.B), st>>>(d, tap_wgs, full ? 0 : 1, listed ? 1 : 0)));
         if (full) TIMED(h, IMGENV_K_FULLVIEW, st, (k_fullview_big<<<gf, dim3(VBF_T), 16 * (size_t)((d.B + 4) / 4), st>>>(d, h->big_full_chunks, 1)));
         h->launches += (d.resize ? 1 : 0) + (full ? 1 : 0);
     } else {

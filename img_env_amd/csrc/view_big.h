@@ -416,20 +416,24 @@ __global__ __launch_bounds__(VBB_T) void k_beams_big(DevWorld w, int quarters, i
 //   pass 2  the list, spread evenly over the workgroup: crop bit, ray list walk;
 //   pass 3  the two resize passes from the 16 values of the pixel.
 // LDS: hit[B + 1 .. pad] | vals[VBT_T][16] u8 | list[VBT_T * 16] u16 | counter
-__global__ __launch_bounds__(VBT_T) void k_taps_big(DevWorld w, int chunks, int commit) {
+// listed: a step -- workgroup `slot` of a robot takes chunk tap_chunks[slot] of its class (the chunks a beam can reach; the others
+// hold what the reset's launch, which covers every chunk, left in them)
+__global__ __launch_bounds__(VBT_T) void k_taps_big(DevWorld w, int chunks, int commit, int listed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = lane_id();
-    const int t = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x - t * chunks;
+    const int t = (int)blockIdx.x / chunks, slot = (int)blockIdx.x - t * chunks;
     if (t >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, t);
     const int B = w.B;
     const uint32_t* hit_g = w.big_hit + (size_t)l * w.big_hit_stride;
     if (hit_g[B + 1] == 0u) return;  // frozen
-    if (commit && chunk == 0 && tid == 0) w.is_coll[l] = (int)hit_g[B + 2];
+    if (commit && slot == 0 && tid == 0) w.is_coll[l] = (int)hit_g[B + 2];
     const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[w.r0 + l]);
     const RobotClassDev rc = w.rc[cls];
     const BigClassDev k = w.big[cls];
-    if (commit && chunk == 0 && w.angular_map && w.use_laser) angular_bins(w, rc, hit_g, l, tid, VBT_T);
+    if (commit && slot == 0 && w.angular_map && w.use_laser) angular_bins(w, rc, hit_g, l, tid, VBT_T);
+    if (listed && slot >= k.n_tap_chunks) return;
+    const int chunk = listed ? (int)k.tap_chunks[slot] : slot;
     const int n_hit4 = (B + 4) / 4;  // B words + the dummy beam, in 16-byte units
     uint32_t* hit = (uint32_t*)smem;
     uint32_t* vals = hit + 4 * n_hit4;                  // [VBT_T][4]: the pixel's 16 tap values, one byte each

@@ -84,6 +84,8 @@ struct BigClassDev {
     const uint32_t* tap_top;     // the cell's top beam entry | own footprint << 31
     const uint2* tap_inv;        // its ray list {first entry of inv_ent, count}
     const uint32_t* tap_addr;    // its bit address in the crop bitmap
+    const uint16_t* tap_chunks;  // [n_tap_chunks] the chunks of 256 pixels a step can change (some source cell is crossed by a beam): what k_taps_big covers
+    int n_tap_chunks;            // in a step; a reset covers every chunk
 };
 
 struct PedClassDev {
