@@ -8,6 +8,9 @@
 //                               "no room" fallbacks; the parity suites run on such a build (tools/check_k_view.sh)
 //   -DIMGENV_EXP_RESOLVE_STATS  device-side counts of the cells a top beam leaves alone and of the ray lists behind them
 //                               (tools/resolve_stats.py)
+//   -DIMGENV_EXP_EVERY_CELL     k_view's crop and final pass over every cell in the steps too (what they did until round 4)
+//   -DIMGENV_EXP_SKEW=n         every second k_view workgroup starts n x 64 clocks late: a timing experiment ("do the wavefronts suffer
+//                               from all being in the same phase at the same time?" -- no: the kernel gets longer by the delay)
 #pragma once
 
 #ifdef IMGENV_EXP_STOP_AFTER
@@ -17,6 +20,16 @@
     } while (0)
 #else
 #define EXP_STOP_AFTER(n) (void)0
+#endif
+
+#ifdef IMGENV_EXP_SKEW
+#define EXP_SKEW()                                                                          \
+    do {                                                                                    \
+        if (blockIdx.x & 1)                                                                 \
+            for (int q_ = 0; q_ < IMGENV_EXP_SKEW; q_++) __builtin_amdgcn_s_sleep(1);       \
+    } while (0)
+#else
+#define EXP_SKEW() (void)0
 #endif
 
 #ifdef IMGENV_EXP_EVERY_CELL  // k_view's final pass over every cell in the steps too (what it did until round 4): A/B builds

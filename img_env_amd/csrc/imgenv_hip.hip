@@ -277,7 +277,8 @@ extern "C" int imgenv_timing_read(imgenv_t* h, double* total_ms, int64_t* launch
 // profiling instrumentation says so, so that a number measured on it can never pass for the product's
 #if defined(IMGENV_EXP_STOP_AFTER)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-EXPERIMENT-work-skipped"; }
-#elif defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE) || defined(IMGENV_EXP_RESOLVE_STATS) || defined(IMGENV_EXP_TINY_RESOLVE)
+#elif defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE) || defined(IMGENV_EXP_RESOLVE_STATS) || defined(IMGENV_EXP_TINY_RESOLVE) || \
+    defined(IMGENV_EXP_SKEW) || defined(IMGENV_EXP_EVERY_CELL)
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950-profile-instrumented"; }
 #else
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950"; }

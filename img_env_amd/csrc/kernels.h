@@ -1767,6 +1767,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     int* skip_cnt = (int*)(colt + Wv);  // [0] list entries (NW > 1), [1] chunk descriptors, [2] result slots of the final pass
     uint32_t* reach_tab = (uint32_t*)(skip_cnt + 4);  // largest hit word of overlapping blocks of 16 / 32 / 64 beams (filter of (5))
     PHASE_BEGIN();
+    EXP_SKEW();
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
     //     the code (agent.cpp:294-326) -> max over (last sample index in the cell, code) of the covered cells
