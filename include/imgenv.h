@@ -24,7 +24,11 @@
  *    `actions` of the step functions and `records` (see below) which are DEVICE pointers.
  *  - all *output* pointers handed out by imgenv_outputs() are DEVICE pointers owned by the
  *    handle, valid until imgenv_destroy(); their contents are valid after the stream work of
- *    the last reset/step has completed and are overwritten by the next step.
+ *    the last reset/step has completed and are overwritten by the next step.  They are the
+ *    library's working copies, READ-ONLY for the caller: a step only rewrites what can change
+ *    (a view cell no laser beam crosses holds its 200, or the footprint's 100, from the reset on;
+ *    a frozen robot's rows keep their last values, agent.cpp:358-360), so whatever a caller
+ *    wrote into them would stay there.
  *  - one handle is one world (one ImgEnv node, img_env.h:171-172) -- or imgenv_cfg.n_worlds of them,
  *    the reference's env_num nodes batched into one set of launches -- and is single-threaded
  *    like the node (ros::spin, img_env_node.cpp:8); distinct handles are independent.
