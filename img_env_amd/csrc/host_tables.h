@@ -122,6 +122,10 @@ struct RobotClassHost {
     // cell no beam crosses (no laser: a cell outside the field of view) is 200, or 100 under the own footprint, for the whole
     // episode: the pass of a reset writes every cell, the passes of the steps only these groups
     std::vector<uint16_t> dyn_c4;
+    // ... as k_view reads them: one word per group = c4 | the group's four field-of-view bits << 16 | its four own-footprint bits
+    // << 20 (what the kernel would otherwise fetch from fov_bits / stamp_bits once it knows c4: two dependent round trips a round);
+    // all_groups: the same for every group of the view (the pass of a reset)
+    std::vector<uint32_t> dyn_groups, all_groups;
 };
 
 static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_big = false, bool extras = false) {
@@ -359,6 +363,23 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
             if (dyn) k.dyn_c4.push_back((uint16_t)c4);
         }
     if (k.dyn_c4.empty()) k.dyn_c4.push_back(0);
+    {
+        auto word = [&](int c4) {
+            uint32_t fov = 0, st = 0;
+            for (int q = 0; q < 4 && c4 + q < NC; q++) {
+                const int c = c4 + q;
+                fov |= ((k.fov_bits[c >> 5] >> (c & 31)) & 1u) << q;
+                st |= ((k.stamp_bits[c >> 5] >> (c & 31)) & 1u) << q;
+            }
+            return (uint32_t)c4 | (fov << 16) | (st << 20);
+        };
+        k.dyn_groups.clear();
+        k.all_groups.clear();
+        for (uint16_t c4 : k.dyn_c4) k.dyn_groups.push_back(word((int)c4));
+        if (!k.big)
+            for (int c4 = 0; c4 < NC; c4 += 4) k.all_groups.push_back(word(c4));
+        if (k.all_groups.empty()) k.all_groups.push_back(0);
+    }
     // k_view's step (5) for the cells a top beam leaves alone.  Such a cell keeps its 200 unless one of the lower beams through
     // it gets as far as the cell, so the kernel keeps the largest first-hit step of overlapping blocks of beams -- level v:
     // 16 << v beams starting every 8 << v, v = 0, 1, 2, stored back to back -- and compares the one block around the cell's

@@ -707,8 +707,9 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.inv_pack, k.inv_pack));
             TRY(dev_upload(h, &o.inv_ent, k.inv_ent));
             TRY(dev_upload(h, &o.top_ent, k.top_ent));
-            TRY(dev_upload(h, &o.dyn_c4, k.dyn_c4));
-            o.n_dyn = (int)k.dyn_c4.size();
+            TRY(dev_upload(h, &o.dyn_groups, k.dyn_groups));
+            o.n_dyn = (int)k.dyn_groups.size();
+            TRY(dev_upload(h, &o.all_groups, k.all_groups));
             {
                 const uint32_t* cells2 = nullptr;
                 TRY(dev_upload(h, &cells2, k.inv_cell));

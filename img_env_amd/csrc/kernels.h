@@ -1822,9 +1822,15 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     // their 200, or the own footprint's 100, since the reset.  (48 x 48 cells, 360 beams over 180 degrees: 241 of 576 groups.)
     const bool every_cell = w.tail_is_reset != 0 || EXP_EVERY_CELL;
     const int n_groups = every_cell ? (NC + 3) >> 2 : k.n_dyn;
+    // (a group's word -- c4, field-of-view bits, own-footprint bits -- is fetched a round ahead: a wavefront's lifetime is its chain
+    // of dependent round trips, and list -> bits -> cells were three of them per round)
+    const uint32_t* glist = every_cell ? k.all_groups : k.dyn_groups;
+    uint32_t g_next = tid < n_groups ? glist[tid] : 0u;
     for (int gi = tid; gi < n_groups; gi += NT) {
-        const int c4 = every_cell ? 4 * gi : (int)k.dyn_c4[gi];
-        const uint32_t fov = (k.fov_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;  // c4 % 4 == 0: one word holds the 4 bits
+        const uint32_t g_cur = g_next;
+        if (gi + NT < n_groups) g_next = glist[gi + NT];
+        const int c4 = (int)(g_cur & 0xFFFFu);
+        const uint32_t fov = (g_cur >> 16) & 0xFu;
         uint32_t packed = 200u | (200u << 8) | (200u << 16) | (200u << 24);
         if (fov) {
             const int a0 = (int)__umulhi((uint32_t)c4, wv_magic), b0 = c4 - a0 * Wv;
@@ -1966,8 +1972,11 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     uint32_t* skip_list = (uint32_t*)src;  // the crop is dead once the beams have their hits
     const uint32_t no_beam = ((uint32_t)w.B << 16) | 0xFFFFu;  // top_ent of a cell no beam crosses
     int n_skip = 0;
+    g_next = tid < n_groups ? glist[tid] : 0u;
     for (int gi = tid; gi < n_groups; gi += NT) {  // (the groups of the crop)
-        const int c4 = every_cell ? 4 * gi : (int)k.dyn_c4[gi];
+        const uint32_t g_cur = g_next;
+        if (gi + NT < n_groups) g_next = glist[gi + NT];
+        const int c4 = (int)(g_cur & 0xFFFFu);
         uint32_t I = 0x02020202u;  // four class indices, one per byte; no beam through a cell: 200
         if (laser) {
             uint32_t top[4] = {no_beam, no_beam, no_beam, no_beam};
@@ -2017,7 +2026,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
             }
         }
         // own footprint: class 1 wherever the stamp bit is set and the cell is not 0 (agent.cpp:307-312 skips 0 / 1 / 2)
-        const uint32_t stamp = (k.stamp_bits[c4 >> 5] >> (c4 & 31)) & 0xFu;
+        const uint32_t stamp = (g_cur >> 20) & 0xFu;
         const uint32_t st = (stamp * 0x00204081u) & 0x01010101u;  // bit q -> bit 8q
         const uint32_t sel = st & (I | (I >> 1));                   // ... and class != 0
         I = (I & ~(sel | (sel << 1))) | sel;

@@ -59,8 +59,9 @@ struct RobotClassDev {
     const uint32_t* inv_pack;    // [Hv*Wv] rays through a view cell: first entry | count << 20 ...
     const uint32_t* inv_ent;     // ... entries (beam << 16 | k), beam descending
     const uint32_t* top_ent;     // [Hv*Wv] first entry of each cell's list (highest beam) or B << 16 | 0xFFFF
-    const uint16_t* dyn_c4;      // [n_dyn] first cells of the groups of 4 view cells a step can change (a beam crosses one of them): what k_view's final
-    int n_dyn;                   // pass walks in a step; the pass of a reset writes every cell (the others hold 200 / 100 for the whole episode)
+    const uint32_t* dyn_groups;  // [n_dyn] the groups of 4 view cells a step can change (a beam crosses one of them), one word each: first cell c4 |
+    int n_dyn;                   // field-of-view bits << 16 | own-footprint bits << 20: what k_view's crop and final pass walk in a step;
+    const uint32_t* all_groups;  // [ceil(Hv*Wv / 4)] the same for every group: the pass of a reset (the other cells hold 200 / 100 for the whole episode)
     const uint2* inv_cell;       // [Hv*Wv] k_view's step (5): {block of the reach table | none << 13 | own footprint << 14 | smallest step << 24, inv_pack}
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
     // AgentState.hits_x / hits_y / angular_map (IMGENV_FLAG_AGENT_STATE_EXTRAS; null otherwise)
