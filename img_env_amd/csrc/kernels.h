@@ -1052,7 +1052,9 @@ __device__ __forceinline__ double2 integrate_heading(double theta, double wv, do
         a = theta + wv * step_hz;
         if (it == n_sub + 1) a = a * 0.5;
     }
-    return make_double2(cos(a), sin(a));
+    double sn, cs;
+    sincos(a, &sn, &cs);  // (one argument reduction for both)
+    return make_double2(cs, sn);
 }
 // ... and the position recurrence with the arrive tests plus the exact arc, over that table (one lane)
 __device__ __forceinline__ void integrate_finish(const DevWorld& w, int l, double* r, double v, double wv, double v_y, double theta,
