@@ -13,6 +13,7 @@
 
 #define WAVE_SZ 64
 #include "../../img_env_amd/csrc/host_tables.h"
+#include "../../img_env_amd/csrc/cv_resize.h"
 
 static int fail(const char* what, long a = 0, long b = 0, long c = 0) {
     printf("FAIL %s (%ld %ld %ld)\n", what, a, b, c);
@@ -122,6 +123,31 @@ int main(int argc, char** argv) {
             const unsigned long long cl = (unsigned long long)m * Wg + n;
             if ((uint32_t)((cl * magic) >> 40) != m) return fail("multiply-shift row", m, n);
         }
-    printf("OK %d x %d view, %d beams, %d crop tiles, %zu path steps\n", Hv, Wv, B, k.n_crop, steps);
+    // 5. the chunks of pixels k_taps_big covers in a STEP (round 4; 48 x 48 pixels shrunk with INTER_CUBIC as the shipped config
+    //    does): a pixel one of whose 4 x 4 source cells is crossed by a beam lies in a listed chunk, a listed chunk holds such
+    //    a pixel, the chunks are listed once, in ascending order
+    size_t n_chunks_listed = 0;
+    {
+        const int IW = 48, IH = 48, NP = IW * IH;
+        const CvAxis ax = cv_axis(Wv, IW, true, true), ay = cv_axis(Hv, IH, true, false);
+        build_big_taps(k, g, ax.ofs, ay.ofs);
+        const int n_chunks = (NP + TAP_CHUNK_PIXELS - 1) / TAP_CHUNK_PIXELS;
+        std::vector<char> want(n_chunks, 0), got(n_chunks, 0);
+        for (int p = 0; p < NP; p++)
+            for (int j = 0; j < 16; j++)
+                if (((k.tap_top[(size_t)j * NP + p] >> 16) & 0x7FFFu) != (uint32_t)B) want[p / TAP_CHUNK_PIXELS] = 1;
+        int prev = -1;
+        for (uint16_t q : k.tap_chunks) {
+            if ((int)q <= prev || (int)q >= n_chunks) return fail("tap_chunks: order / range", q, prev);
+            prev = q;
+            got[q] = 1;
+        }
+        bool any = false;
+        for (int q = 0; q < n_chunks; q++) any = any || want[q];
+        for (int q = 0; q < n_chunks; q++)
+            if (want[q] != got[q] && !(!any && q == 0)) return fail("tap_chunks: chunk", q, want[q], got[q]);
+        n_chunks_listed = k.tap_chunks.size();
+    }
+    printf("OK %d x %d view, %d beams, %d crop tiles, %zu path steps, %zu pixel chunks in a step\n", Hv, Wv, B, k.n_crop, steps, n_chunks_listed);
     return 0;
 }

@@ -146,6 +146,46 @@ int main(int argc, char** argv) {
             if (v != ref[cidx]) return fail("laser_map", trial, cidx, v * 1000 + ref[cidx]);
         }
     }
-    printf("OK %d x %d cells, %d beams\n", Hv, Wv, B);
+    // 6. the static lists of a STEP's crop / final pass (round 4): every cell on a beam's path lies in a listed group, no beam
+    //    crosses a cell of a group that is not listed, the groups are listed once and in ascending order, a group's word carries
+    //    its field-of-view and own-footprint bits, and all_groups holds every group
+    {
+        std::vector<char> listed((NC + 3) / 4, 0);
+        uint32_t prev = 0;
+        for (size_t q = 0; q < k.dyn_groups.size(); q++) {
+            const uint32_t wd = k.dyn_groups[q], c4 = wd & 0xFFFFu;
+            if (c4 % 4 != 0 || (int)c4 >= NC) return fail("dyn_groups: first cell", (long)q, c4);
+            if (q > 0 && c4 <= prev) return fail("dyn_groups: order", (long)q, c4, prev);
+            prev = c4;
+            listed[c4 / 4] = 1;
+        }
+        for (int b = 0; b < B; b++)
+            for (int c : path[b])
+                if (!listed[c / 4]) return fail("a beam crosses a cell outside the listed groups", b, c);
+        std::vector<char> crossed(NC, 0);
+        for (int b = 0; b < B; b++)
+            for (int c : path[b]) crossed[c] = 1;
+        if (B > 0)
+            for (int gq = 0; gq < (NC + 3) / 4; gq++) {
+                bool any = false;
+                for (int c = 4 * gq; c < std::min(4 * gq + 4, NC); c++) any = any || crossed[c];
+                if (any != (listed[gq] != 0) && !(k.dyn_groups.size() == 1 && !any && gq == 0)) return fail("dyn_groups: listed without a beam", gq);
+            }
+        if ((int)k.all_groups.size() != (NC + 3) / 4) return fail("all_groups: size", (long)k.all_groups.size());
+        auto check_word = [&](uint32_t wd) {
+            const int c4 = (int)(wd & 0xFFFFu);
+            for (int q = 0; q < 4 && c4 + q < NC; q++) {
+                const int c = c4 + q;
+                if (((wd >> (16 + q)) & 1u) != ((k.fov_bits[c >> 5] >> (c & 31)) & 1u)) return false;
+                if (((wd >> (20 + q)) & 1u) != ((k.stamp_bits[c >> 5] >> (c & 31)) & 1u)) return false;
+            }
+            return true;
+        };
+        for (size_t q = 0; q < k.all_groups.size(); q++)
+            if ((k.all_groups[q] & 0xFFFFu) != 4u * (uint32_t)q || !check_word(k.all_groups[q])) return fail("all_groups: word", (long)q);
+        for (uint32_t wd : k.dyn_groups)
+            if (!check_word(wd)) return fail("dyn_groups: word", wd & 0xFFFFu);
+    }
+    printf("OK %d x %d cells, %d beams, %zu of %d cell groups in a step\n", Hv, Wv, B, k.dyn_groups.size(), (NC + 3) / 4);
     return 0;
 }

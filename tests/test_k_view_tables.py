@@ -5,7 +5,10 @@ builds a robot class with the library's own host code (img_env_amd/csrc/host_tab
   * that the per-cell ray lists, their heads, the 8-byte cell records and the reach-table blocks agree with each other;
   * that the table-driven composition the kernel performs -- the top beam's verdict, else the first deciding entry of the
     cell's list, behind the reach filter -- gives the laser_map of the reference's sequential beam-after-beam algorithm on
-    random occupancies with and without axis-parallel walls."""
+    random occupancies with and without axis-parallel walls;
+  * that the static lists a STEP walks instead of every cell (round 4: `dyn_groups` of k_view, `tap_chunks` of k_taps_big) hold
+    exactly the groups of cells / chunks of pixels a beam can reach, and that a group's word carries its field-of-view and
+    own-footprint bits."""
 import os
 import subprocess
 
