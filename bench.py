@@ -437,6 +437,14 @@ def main():
     dom_ms, dom_n = tm[dominant]
     value = R * args.steps / dt
     pass_values = [R * args.steps / p[0] for p in passes]
+    # ... and the same passes once more WITHOUT the two HIP events around the dominant kernel (an event operation is a dependency
+    # bubble on its stream: the timed region above pays ~4 % for carrying the roofline's measurement inside it).  Reported beside
+    # `value`, never instead of it.
+    uninstrumented = None
+    if args.timing_mode != 0 and world_size == 1:
+        d0 = sorted(run("active", args.steps, min(args.warmup, 5), timing_mode=0)[0] for _ in range(3))[1]
+        uninstrumented = dict(value=R * args.steps / d0, ms_per_step=1e3 * d0 / args.steps,
+                              what="median of 3 more passes of the same %d steps with no HIP event in the timed region" % args.steps)
     # SURVEY 8(d) wants the auto-reset inside the timed region; a run shorter than an episode (the driver's 20 steps) never meets
     # one, so it is timed separately: the same N steps + ONE full imgenv_reset of the world
     with_reset = None
@@ -568,6 +576,7 @@ def main():
                        if use_dist else "single GPU"},
             "resets_in_timed_region": resets_timed,
             "passes": {"n": len(passes), "value_is": "median", "values": pass_values, "min": min(pass_values), "max": max(pass_values)},
+            "uninstrumented": uninstrumented,
             "with_reset": with_reset,
             "shipped": shipped,
             "frozen_fraction": frozen_active,
