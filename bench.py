@@ -437,9 +437,9 @@ def main():
     dom_ms, dom_n = tm[dominant]
     value = R * args.steps / dt
     pass_values = [R * args.steps / p[0] for p in passes]
-    # ... and the same passes once more WITHOUT the two HIP events around the dominant kernel (an event operation is a dependency
-    # bubble on its stream: the timed region above pays ~4 % for carrying the roofline's measurement inside it).  Reported beside
-    # `value`, never instead of it.
+    # ... and the same passes once more WITHOUT the HIP events around the dominant kernel (every 8th launch carries a pair, and an
+    # event operation is a dependency bubble on its stream: the timed region above pays just under 1 % for carrying the roofline's
+    # measurement inside it).  Reported beside `value`, never instead of it.
     uninstrumented = None
     if args.timing_mode != 0 and world_size == 1:
         d0 = sorted(run("active", args.steps, min(args.warmup, 5), timing_mode=0)[0] for _ in range(3))[1]
