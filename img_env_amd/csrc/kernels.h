@@ -1365,10 +1365,19 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         __syncthreads();
     }
     bool stray = false;
+    // (the next four samples are requested before these four are used: the static table's round trip is then underneath the
+    // transforms instead of in front of them, four times per robot)
+    double2 fp_next[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) fp_next[u] = k.fp[min(u * NT + tid, k.n_fp - 1)];
     for (int q0 = 0; q0 < k.n_fp; q0 += NT * 4) {  // wave-uniform trip count (lane shuffles inside), 4 loads in flight
         double2 fp[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) fp[u] = k.fp[min(q0 + u * NT + tid, k.n_fp - 1)];
+        for (int u = 0; u < 4; u++) fp[u] = fp_next[u];
+        if (q0 + NT * 4 < k.n_fp) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) fp_next[u] = k.fp[min(q0 + NT * 4 + u * NT + tid, k.n_fp - 1)];
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int q = q0 + u * NT + tid;
