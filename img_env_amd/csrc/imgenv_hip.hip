@@ -1420,11 +1420,15 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // two wavefronts per robot in between (1025-4096 robots: every wavefront still resident at once; 1024 envs x 4: 39 -> 28 us)
         const int n_view = d.act_n_dev ? std::min(n_l, h->act_hint) : n_l;
         const bool two = force_nw ? force_nw == 2 : (!small && n_view <= 4096);
-        const dim3 gv(n_l), bv(small ? 4 * WAVE : two ? 2 * WAVE : WAVE);
+        // ... and eight where a launch is at most 1024 robots and the view small (48 x 48 cells and 360 beams are then ONE round of groups
+        // and ONE round of beams per wavefront: cfg-2 k_view 21.6 -> 20.4 us)
+        const bool eight = force_nw ? force_nw == 8 : (small && !lds_bound);
+        const dim3 gv(n_l), bv(eight ? 8 * WAVE : small ? 4 * WAVE : two ? 2 * WAVE : WAVE);
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
     case N:                                                                                                                     \
-        if (small) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 4><<<gv, bv, h->lds_view, st>>>(d)));                        \
+        if (eight) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 8><<<gv, bv, h->lds_view, st>>>(d)));                        \
+        else if (small) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 4><<<gv, bv, h->lds_view, st>>>(d)));                   \
         else if (two) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 2><<<gv, bv, h->lds_view, st>>>(d)));                     \
         else TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 1><<<gv, bv, h->lds_view, st>>>(d)));                              \
         break;

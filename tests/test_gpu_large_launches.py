@@ -2,7 +2,8 @@
 
 The library picks kernel variants by launch size (csrc/imgenv_hip.hip, launch_views): one wavefront per robot / pedestrian
 instead of four in `k_raster` above 1024 blocks (robots and pedestrians in blocks of their own up to 8192 blocks, one block for a
-robot AND a pedestrian beyond), four / two / one wavefronts per `k_view` up to 1024 / up to 4096 / more robots, the step's move
+robot AND a pedestrian beyond), eight / two / one wavefronts per `k_view` up to 1024 / up to 4096 / more robots (four where the
+view's LDS bounds the occupancy: cfg-5), the step's move
 inside the raster launch (`k_move_raster`) for pedestrian-free handles up to 4096 robots, 32 / 64 instead of 8 tiles per
 `k_crop_big` wavefront from 48 / 1024 robots on, strided instead of one-to-one grids in the device-side reset chain.  The other GPU suites stay below those
 thresholds (a dozen robots per oracle); here the handles are big enough to cross them, with one oracle per world as the checker:
