@@ -193,7 +193,9 @@ def cpu_baseline(cfg_name, params, grid, layout, peds, seconds=6.0, all_core_sec
                 sample="all cores: %d single-threaded oracle processes side by side (one per hardware thread, the reference's env_num "
                        "idiom), each its own world + %d %s peds on the 400x400 map @%.2f m, v=0 policy: %d robots per world (the "
                        "benchmark's %d split over the cores, %.1f s) and 1024 robots per world (%.1f s); value = the better of the two; "
-                       "single_thread_value: 1 thread, %d steps of the same %d-robot shared world the GPU ran, %.1f s"
+                       "single_thread_value: 1 thread, %d steps of the same %d-robot shared world the GPU ran, %.1f s.  kind \"port\": the "
+                       "oracle keeps ONE shared owner layer per world where the reference copies the whole map once per robot and step "
+                       "(img_env.cpp:623) -- the reference itself would be slower than this figure, which therefore flatters the CPU"
                        % (max(ok1, ok2), peds, WORKLOADS[cfg_name]["scene"], WORKLOADS[cfg_name]["res"], per, R, t1, t2, steps, R, dt))
 
 
@@ -417,9 +419,15 @@ def main():
         return {k: (float(np.median(v)) if v else 0.0) for k, v in samples.items()}
 
     per_kernel_us = kernel_breakdown()
+    # every rank's kernel times (and the exchange's duration) travel with the line: a scaling curve then explains itself
+    per_rank_kernel_us = None
+    if use_dist:
+        gathered = [None] * world_size
+        dist.all_gather_object(gathered, {k: round(v, 2) for k, v in per_kernel_us.items() if v})
+        per_rank_kernel_us = gathered
     # dominant = the per-robot kernel with the longest launch.  k_orca is left out: it is 200 single-wave workgroups of
     # serial LP code that idle along on a side stream underneath k_view (latency, not work) and moves no per-robot bytes
-    dominant = max((k for k in per_kernel_us if k != "k_orca"), key=per_kernel_us.get)
+    dominant = max((k for k in per_kernel_us if k not in ("k_orca", "rccl_all_gather")), key=per_kernel_us.get)
     dom_id = list(per_kernel_us).index(dominant)
     # untimed spin-up: the first ~second of sustained work after start-up runs at lower clocks than steady state
     if args.spinup > 0:
@@ -532,16 +540,24 @@ def main():
         achieved = kernel_bytes / dur_s / 1e9
         traffic, path_traffic, traffic_source = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        build_id = world.lib.imgenv_build_id().decode()
+        counters_ok = False  # the committed counters describe THIS library (same sources + flags), or they are not quoted
         if os.path.exists(pmc) and args.config == "cfg3" and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
             try:
                 counters = json.load(open(pmc))
-                traffic = counters.get(dominant, {}).get("hbm_bytes_per_launch")
-                # every kernel of a step once (k_reset_apply is not part of a step)
-                path_traffic = sum(v["hbm_bytes_per_launch"] for k, v in counters.items()
-                                   if k.startswith("k_") and not k.startswith("k_reset") and k != "k_cell_base")
-                traffic_source = ("profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, "
-                                  "gfx950 corrections) over this same bench command, committed with the build -- NOT collected "
-                                  "during this run")
+                pmc_id = counters.get("build_id")
+                counters_ok = pmc_id == build_id
+                if counters_ok:
+                    traffic = counters.get(dominant, {}).get("hbm_bytes_per_launch")
+                    # every kernel of a step once (k_reset_apply is not part of a step)
+                    path_traffic = sum(v["hbm_bytes_per_launch"] for k, v in counters.items()
+                                       if k.startswith("k_") and not k.startswith("k_reset") and k != "k_cell_base" and isinstance(v, dict))
+                    traffic_source = ("profiles/pmc_latest.json, collected on build %s = the library of this run: rocprofv3 --pmc FETCH_SIZE and "
+                                      "--pmc WRITE_SIZE passes (separate runs, gfx950 corrections) over this same bench command -- committed "
+                                      "with the build, NOT collected during this run" % pmc_id)
+                else:
+                    traffic_source = ("none: profiles/pmc_latest.json was collected on build %s, this run's library is %s (imgenv_build_id) -- "
+                                      "counters of another build are not quoted" % (pmc_id, build_id))
             except Exception:
                 traffic = None
         # instruction-issue ceiling of the dominant kernel: wavefronts x vector instructions per wavefront (SQ_INSTS_VALU of the
@@ -549,7 +565,7 @@ def main():
         # but plain add / and, which take 2.4) over 1024 SIMDs
         issue = None
         try:
-            cnt = json.load(open(pmc)).get(dominant, {}) if os.path.exists(pmc) else {}
+            cnt = json.load(open(pmc)).get(dominant, {}) if (os.path.exists(pmc) and counters_ok) else {}
             if cnt.get("valu_per_wave") and args.config == "cfg3" and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
                 waves, vpw = cnt["waves_per_launch"], cnt["valu_per_wave"]
                 lo, hi = (waves * vpw * c / (1024 * 2.4e9) * 1e6 for c in (2.4, 4.2))
@@ -584,6 +600,8 @@ def main():
             "vec_env": vec_env,
             "episode_policy": episode,
             "kernel_us": per_kernel_us,
+            "per_rank_kernel_us": per_rank_kernel_us,  # N > 1: every rank's kernels and `rccl_all_gather`, the in-library exchange
+            "build_id": build_id,
             "launches_per_step": launches_per_step,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,

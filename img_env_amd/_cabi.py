@@ -21,6 +21,8 @@ FLAG_NO_VIEW_MAPS = 8  # imgenv_out.view_maps not wanted (include/imgenv.h)
 FLAG_VIEW_TILED = 32  # views through the tiled kernels (csrc/view_big.h) / through k_view, where both can run
 FLAG_VIEW_WAVE = 64
 FLAG_AGENT_STATE_EXTRAS = 16  # AgentState.hits_x / hits_y / angular_map as well
+FLAG_CHECK_OUTPUTS = 128  # debug: checksum every output array between calls, EINVAL "the caller wrote into imgenv_out.<field>"
+FLAG_FULL_REWRITE = 256   # the outputs are copies rewritten in full by every call (the reference's value-copy ownership)
 ANGULAR_BINS = 72
 
 SHAPES = {"circle": SHAPE_CIRCLE, "rectangle": SHAPE_RECTANGLE, "leg": SHAPE_LEG}
@@ -256,8 +258,8 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
            "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_step_autoreset_device", "imgenv_autoreset_last",
-           "imgenv_world_placement", "imgenv_cv_resize_u8")
-K_COUNT = 11
+           "imgenv_world_placement", "imgenv_cv_resize_u8", "imgenv_build_id")
+K_COUNT = 13
 
 
 def library_path():
@@ -270,6 +272,7 @@ _LIB = None
 def bind(lib):
     """Attach argtypes / restypes of include/imgenv.h to a loaded CDLL."""
     lib.imgenv_backend.restype = C.c_char_p
+    lib.imgenv_build_id.restype = C.c_char_p
     lib.imgenv_abi_version.restype = C.c_int32
     lib.imgenv_last_error.restype = C.c_char_p
     lib.imgenv_create.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]

@@ -126,6 +126,7 @@ struct imgenv {
     // device-side auto-reset (csrc/spawn_device.h): pool of placements drawn ahead on a side stream
     bool sd_ready = false, dev_reset_used = false;
     int fill_due = 0;  // calls until the placement pool is refilled again (SPAWN_FILL_PERIOD)
+    bool fill_pending = false;  // ev_fill has been recorded behind a k_spawn_fill that nothing has waited for yet
     bool wobst_all = false;  // the per-world RVO table has to be uploaded as a whole (its slices moved)
     // ... and, on request (IMGENV_GRAPH=1), the whole step + reset chain as one hipGraph: per-step values then live in device
     // memory (DevWorld::step_vars), the actions are copied into a buffer of the handle, and a step costs the host one copy and
@@ -143,6 +144,16 @@ struct imgenv {
     hipEvent_t ev_fill = nullptr, ev_consumed = nullptr;
     void* sd_storage = nullptr;  // SpawnDev (defined behind the kernels)
     void (*sd_delete)(void*) = nullptr;
+    // output guards (include/imgenv.h: IMGENV_FLAG_CHECK_OUTPUTS / IMGENV_FLAG_FULL_REWRITE)
+    unsigned char* pub_arena = nullptr;  // FULL_REWRITE: what imgenv_outputs hands out -- a copy of the working arena made at the end of every chain
+    bool own_pub = false;
+    size_t arena_bytes = 0;
+    imgenv_out pub_out;
+    bool guard_check = false, guard_sealed = false;
+    OutSpan* d_spans = nullptr;          // CHECK_OUTPUTS: the output arrays as (pointer, bytes, first block) ...
+    int n_spans = 0, span_blocks = 0;
+    unsigned long long* d_sums = nullptr;  // ... and their checksums: [2][n_spans], sealed | found at the next call
+    const char* span_name[40];
     bool chain_open = false;  // a chain of launches that hands over through tail_sig / tail_cnt has started and not been completed
     std::vector<RvoObstacles> rvos;  // one obstacle set per world
     int sfm_cap_obs = 0;
@@ -192,7 +203,7 @@ static RcclApi* rccl_api() {
 }
 
 static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster", "k_compose",
-                                                         "k_view", "k_obs", "k_tail", "k_crop_big", "k_fullview_big", "k_taps_big"};
+                                                         "k_view", "k_obs", "k_tail", "k_crop_big", "k_fullview_big", "k_taps_big", "k_move_raster", "rccl_all_gather"};
 extern "C" const char* imgenv_kernel_name(int id) { return (id >= 0 && id < IMGENV_K_COUNT) ? KERNEL_NAMES[id] : ""; }
 
 static int timing_flush(imgenv* h) {
@@ -283,6 +294,12 @@ extern "C" const char* imgenv_backend(void) { return "hip-gfx950-profile-instrum
 #else
 extern "C" const char* imgenv_backend(void) { return "hip-gfx950"; }
 #endif
+// which sources + flags this library was compiled from (__graft_entry__.source_id): counter files under profiles/ name the
+// build they were collected on, and bench.py only quotes them for the library it is running
+#ifndef IMGENV_BUILD_ID
+#define IMGENV_BUILD_ID "unstamped"
+#endif
+extern "C" const char* imgenv_build_id(void) { return IMGENV_BUILD_ID; }
 extern "C" int32_t imgenv_abi_version(void) { return IMGENV_ABI_VERSION; }
 extern "C" const char* imgenv_last_error(void) { return g_err; }
 
@@ -373,6 +390,19 @@ static int dev_alloc(imgenv* h, T** out, size_t n, int fill = 0) {
     *out = (T*)p;
     return 0;
 }
+// hands one dev_alloc'd block back before the handle dies (the caller has made sure nothing in flight uses it)
+template <typename T>
+static void dev_free(imgenv* h, T*& p) {
+    if (!p) return;
+    for (size_t q = 0; q < h->allocs.size(); q++)
+        if (h->allocs[q] == (void*)p) {
+            h->allocs[q] = h->allocs.back();
+            h->allocs.pop_back();
+            (void)hipFree((void*)p);
+            break;
+        }
+    p = nullptr;
+}
 template <typename T>
 static int dev_upload(imgenv* h, const T** out, const std::vector<T>& v) {
     T* p = nullptr;
@@ -433,6 +463,7 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->own_arena && h->arena) (void)hipFree(h->arena);
+    if (h->own_pub && h->pub_arena) (void)hipFree(h->pub_arena);
     delete h;
 }
 
@@ -991,11 +1022,31 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     // output arena
     ArenaPlan plan;
     plan_arena(*cfg, g, RL, plan);
-    if (cfg->out_arena) {
-        if (cfg->out_arena_bytes < (int64_t)plan.total) {
-            imgenv_destroy(h);
-            FAIL(IMGENV_EINVAL, "out_arena too small: %lld < %zu", (long long)cfg->out_arena_bytes, plan.total);
+    const bool full_rewrite = (cfg->flags & IMGENV_FLAG_FULL_REWRITE) != 0;
+    h->arena_bytes = plan.total;
+    if (full_rewrite && RL != R) {  // (a shard's caller all-gathers the records in place: that buffer cannot be a copy)
+        imgenv_destroy(h);
+        FAIL(IMGENV_EINVAL, "IMGENV_FLAG_FULL_REWRITE is not available in a robot shard");
+    }
+    if (cfg->out_arena && cfg->out_arena_bytes < (int64_t)plan.total) {
+        imgenv_destroy(h);
+        FAIL(IMGENV_EINVAL, "out_arena too small: %lld < %zu", (long long)cfg->out_arena_bytes, plan.total);
+    }
+    if (full_rewrite) {  // the caller's arena (or a second allocation) only ever receives copies; the kernels work on a private one
+        if (cfg->out_arena) {
+            h->pub_arena = (unsigned char*)cfg->out_arena;
+        } else {
+            void* p = nullptr;
+            if (hipMalloc(&p, plan.total) != hipSuccess) {
+                imgenv_destroy(h);
+                FAIL(IMGENV_ENOMEM, "hipMalloc(%zu) for the public output arena failed", plan.total);
+            }
+            h->pub_arena = (unsigned char*)p;
+            h->own_pub = true;
         }
+        HIPCHK_H(hipMemset(h->pub_arena, 0, plan.total));
+    }
+    if (cfg->out_arena && !full_rewrite) {
         h->arena = (unsigned char*)cfg->out_arena;
     } else {
         void* p = nullptr;
@@ -1065,6 +1116,46 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         std::vector<double> inf(RL, INFINITY);
         HIPCHK_H(hipMemcpy(o.ped_min_dists, inf.data(), sizeof(double) * RL, hipMemcpyHostToDevice));
         HIPCHK_H(hipMemset(o.is_clean, 1, RL));
+    }
+    if (full_rewrite) {  // the same struct with every pointer moved into the public arena
+        h->pub_out = o;
+        const ptrdiff_t shift = h->pub_arena - h->arena;
+        for (void** f : {(void**)&h->pub_out.vector_states, (void**)&h->pub_out.view_maps, (void**)&h->pub_out.sensor_maps, (void**)&h->pub_out.lasers_raw,
+                         (void**)&h->pub_out.lasers, (void**)&h->pub_out.ped_vector_states, (void**)&h->pub_out.ped_maps, (void**)&h->pub_out.is_collisions,
+                         (void**)&h->pub_out.is_arrives, (void**)&h->pub_out.step_ds, (void**)&h->pub_out.ped_min_dists, (void**)&h->pub_out.base_rewards,
+                         (void**)&h->pub_out.base_dones, (void**)&h->pub_out.rewards, (void**)&h->pub_out.paper_rewards, (void**)&h->pub_out.dones,
+                         (void**)&h->pub_out.dones_info, (void**)&h->pub_out.is_clean, (void**)&h->pub_out.robot_pose, (void**)&h->pub_out.ped_state,
+                         (void**)&h->pub_out.counters, (void**)&h->pub_out.step_rewards, (void**)&h->pub_out.step_dones, (void**)&h->pub_out.step_dones_info,
+                         (void**)&h->pub_out.step_is_clean, (void**)&h->pub_out.step_is_arrives, (void**)&h->pub_out.step_is_collisions,
+                         (void**)&h->pub_out.step_all_down, (void**)&h->pub_out.hits_x, (void**)&h->pub_out.hits_y, (void**)&h->pub_out.angular_map})
+            if (*f) *f = (unsigned char*)*f + shift;
+    }
+    if (cfg->flags & IMGENV_FLAG_CHECK_OUTPUTS) {  // every array of imgenv_out (not the records: the caller's exchange writes those)
+        static const char* const names[32] = {"vector_states", "view_maps", "sensor_maps", "lasers_raw", "lasers", "ped_vector_states", "ped_maps",
+                                              "is_collisions", "is_arrives", "step_ds", "ped_min_dists", "base_rewards", "base_dones", "rewards", "dones",
+                                              "dones_info", "is_clean", "robot_pose", "ped_state", "counters", "records", "paper_rewards", "step_rewards",
+                                              "step_dones", "step_dones_info", "step_is_clean", "step_is_arrives", "step_is_collisions", "step_all_down",
+                                              "hits_x", "hits_y", "angular_map"};
+        std::vector<OutSpan> spans;
+        int blocks = 0;
+        for (int q = 0; q < plan.n; q++) {
+            const size_t bytes = (q + 1 < plan.n ? plan.off[q + 1] : plan.total) - plan.off[q];  // (the padding up to the next array is zero and stays zero)
+            if (q == 20 || (q >= 29 && !o.hits_x)) continue;
+            OutSpan sp;
+            sp.p = A + plan.off[q];
+            sp.bytes = bytes;
+            sp.first_block = blocks;
+            blocks += (int)((bytes + OUT_SUM_CHUNK - 1) / OUT_SUM_CHUNK);
+            h->span_name[spans.size()] = names[q];
+            spans.push_back(sp);
+        }
+        h->n_spans = (int)spans.size();
+        h->span_blocks = blocks;
+        const OutSpan* up = nullptr;
+        TRY(dev_upload(h, &up, spans));
+        h->d_spans = const_cast<OutSpan*>(up);
+        TRY(dev_alloc(h, &h->d_sums, 2 * (size_t)h->n_spans));
+        h->guard_check = true;
     }
     h->PP = WAVE;  // sort slots of k_obs: a power of two, 64 * E of them in registers up to 1024 pedestrians
     while (h->PP < h->Pw) h->PP <<= 1;
@@ -1226,6 +1317,39 @@ static int chain_begin(imgenv* h, hipStream_t st) {
     return 0;
 }
 
+// ---- output guards.  The arrays behind imgenv_outputs() are the kernels' incremental working copies (a step rewrites what can
+// change), so a caller that writes into them -- an in-place normalisation in a trainer -- would corrupt every later observation
+// silently, where the reference hands out fresh copies (ROS responses, img_env.cpp:745-749).  Two opt-in answers:
+// IMGENV_FLAG_CHECK_OUTPUTS seals every array with a checksum at the end of a chain of launches and verifies it at the start
+// of the next call (debug: it synchronises); IMGENV_FLAG_FULL_REWRITE hands out a second arena that receives a complete copy
+// of every array at the end of every chain, so nothing the caller does to it can reach the kernels.
+static int outputs_seal(imgenv* h, hipStream_t st) {
+    if (h->pub_arena) HIPCHK(hipMemcpyAsync(h->pub_arena, h->arena, h->arena_bytes, hipMemcpyDeviceToDevice, st));
+    if (h->guard_check) {
+        HIPCHK(hipMemsetAsync(h->d_sums, 0, sizeof(unsigned long long) * (size_t)h->n_spans, st));
+        k_out_sum<<<dim3(h->span_blocks), dim3(256), 0, st>>>(h->d_spans, h->n_spans, h->d_sums);
+        h->guard_sealed = true;
+    }
+    return 0;
+}
+static int outputs_verify(imgenv* h, hipStream_t st) {
+    if (!h->guard_check || !h->guard_sealed) return 0;
+    unsigned long long* found = h->d_sums + h->n_spans;
+    HIPCHK(hipMemsetAsync(found, 0, sizeof(unsigned long long) * (size_t)h->n_spans, st));
+    k_out_sum<<<dim3(h->span_blocks), dim3(256), 0, st>>>(h->d_spans, h->n_spans, found);
+    k_out_verify<<<dim3(1), dim3(64), 0, st>>>(h->d_sums, found, h->n_spans, h->d.err);
+    HIPCHK(hipStreamSynchronize(st));
+    const int f = h->err_host ? h->err_host[5] : 0;
+    if (f) {
+        h->err_host[5] = 0;
+        h->guard_sealed = false;  // (the next chain seals what it finds; the caller has been told)
+        FAIL(IMGENV_EINVAL, "the caller wrote into imgenv_out.%s since the last call: the output arrays are the library's working copies "
+                            "and read-only (include/imgenv.h); create the handle with IMGENV_FLAG_FULL_REWRITE to receive copies instead",
+             h->span_name[f - 1]);
+    }
+    return 0;
+}
+
 static int launch_obs(imgenv* h, hipStream_t st) {
     if (int rc = chain_begin(h, st)) return rc;
     DevWorld& d = h->d;
@@ -1284,8 +1408,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = h->elapsed - 1;
 #define RASTER_CASE(N, P2, ST)                                                                                    \
         case N:                                                                                                       \
-            if (moved && small) TIMED(h, IMGENV_K_RASTER, st, (k_move_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
-            else if (moved) TIMED(h, IMGENV_K_RASTER, st, (k_move_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
             else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
             else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
             break;
@@ -1450,7 +1574,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     h->launches += 3;
     HIPCHK(hipGetLastError());
     h->chain_open = false;
-    return 0;
+    return outputs_seal(h, st);
 }
 
 // ---- pinned staging for reset: everything a reset uploads goes through page-locked chunks owned by the handle and
@@ -2024,6 +2148,7 @@ static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int w
 extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stream) {
     if (int rc = reset_checks(h, 1, b, h ? h->P : 0)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = outputs_verify(h, st)) return rc;
     RTRY(stage_begin(h));
     RTRY(reset_blocks(h, h->W, nullptr));
     h->oinst.clear();
@@ -2072,6 +2197,7 @@ extern "C" int imgenv_reset_worlds(imgenv_t* h, int32_t n, const int32_t* worlds
         seen[worlds[q]] = 1;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = outputs_verify(h, st)) return rc;
     static const bool trace = getenv("IMGENV_TRACE_RESET") != nullptr;
     std::chrono::steady_clock::time_point tp[4];
     if (trace) tp[0] = std::chrono::steady_clock::now();
@@ -2168,6 +2294,7 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     if (h->obs_forked) FAIL(IMGENV_ESTATE, "imgenv_step_begin twice without imgenv_step_end (reset the handle to recover from an aborted step)");
     if (int rc = check_device_flags(h)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = outputs_verify(h, st)) return rc;
     DevWorld& d = h->d;
     h->launches = 0;
     if (d.step_vars) {  // the device-side twins of h->elapsed / h->stamp_seq (advanced here; the host's in imgenv_step_end)
@@ -2242,8 +2369,9 @@ extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) {
     if (rc_begin) return rc_begin;
     if (h->comm) {  // the one exchange of a robot-sharded world: records of all robots, in place
         const size_t count = (size_t)h->RL * IMGENV_RECORD_DOUBLES;
-        const ncclResult_t e = rccl_api()->all_gather(h->d.rec + (size_t)h->r0 * IMGENV_RECORD_DOUBLES, h->d.rec, count,
-                                                      ncclDouble, h->comm, (hipStream_t)stream);
+        ncclResult_t e = ncclSuccess;
+        TIMED(h, IMGENV_K_EXCHANGE, (hipStream_t)stream,
+              e = rccl_api()->all_gather(h->d.rec + (size_t)h->r0 * IMGENV_RECORD_DOUBLES, h->d.rec, count, ncclDouble, h->comm, (hipStream_t)stream));
         if (e != ncclSuccess) FAIL(IMGENV_EDEVICE, "ncclAllGather: %s", rccl_api()->err(e));
     }
     return imgenv_step_end(h, stream);
@@ -2296,6 +2424,7 @@ extern "C" int imgenv_step_autoreset(imgenv_t* h, const float* actions, const im
     if (int rc = imgenv_step(h, actions, stream)) return rc;
     hipStream_t st = (hipStream_t)stream;
     k_finished<<<dim3(1), dim3(1024), 0, st>>>(h->d);
+    if (int rc = outputs_seal(h, st)) return rc;  // (k_finished writes imgenv_out.step_all_down behind the step's own seal)
     HIPCHK(hipGetLastError());
     {   // while the device works: the placements of the next seeds (a placement depends on its seed alone, not on the world)
         const uint64_t fp = spawn_cfg_fingerprint(*cfg);
@@ -2385,6 +2514,19 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
         h->sd_delete = [](void* p) { delete (SpawnDev*)p; };
     }
     SpawnDev& c = *(SpawnDev*)h->sd_storage;
+    if (h->sd_ready) {  // another spawn cfg: the old pool goes (a curriculum that alternates cfgs would otherwise grow until imgenv_destroy)
+        HIPCHK(hipStreamSynchronize(h->side3));
+        HIPCHK(hipStreamSynchronize(st));
+        h->sd_ready = false;
+        h->fill_pending = false;
+        SpawnDev o = c;
+        DevSpawnAgent* oa = (DevSpawnAgent*)o.agents; DevSpawnObstacle* oo = (DevSpawnObstacle*)o.obstacles; double* om = (double*)o.multi;
+        dev_free(h, oa); dev_free(h, oo); dev_free(h, om);
+        dev_free(h, o.slot_serial); dev_free(h, o.consumed); dev_free(h, o.slot_status); dev_free(h, o.s_agents); dev_free(h, o.s_obst);
+        dev_free(h, o.s_inst); dev_free(h, o.s_rvo); dev_free(h, o.s_nodes); dev_free(h, o.s_rvo_n); dev_free(h, o.s_seg);
+        dev_free(h, o.fin_list); dev_free(h, o.fin_n); dev_free(h, o.inst_out); dev_free(h, o.place_agents); dev_free(h, o.place_obst);
+        dev_free(h, o.place_serial); dev_free(h, o.w_inst); dev_free(h, o.w_inst_valid);
+    }
     memset(&c, 0, sizeof(c));
     c.n_robots = cfg->n_robots; c.n_peds = cfg->n_peds; c.n_obstacles = nob; c.go_back = cfg->go_back; c.ignore_obstacle = cfg->ignore_obstacle;
     c.rvo = h->NA > 0 ? 1 : 0;
@@ -2468,12 +2610,16 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
         HIPCHK(hipMemcpy(no, all_o.data(), sizeof(RvoObstDev) * all_o.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(nn, all_n.data(), sizeof(RvoNodeDev) * all_n.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_wobst, h->wobst.data(), sizeof(int) * h->wobst.size(), hipMemcpyHostToDevice));
+        dev_free(h, h->d_obst);  // (st was synchronised above and every side stream is joined to it at the end of a step)
+        dev_free(h, h->d_nodes);
         h->d_obst = no; h->d_nodes = nn; h->cap_obst = co; h->cap_nodes = cn;
         h->d.obst = no; h->d.onodes = nn;
     }
     c.cap_o = h->NA > 0 ? h->cap_obst : c.cap_o;  // the worlds' slices and the slots' share one stride
     c.cap_n = h->NA > 0 ? h->cap_nodes : c.cap_n;
     if (h->NA > 0) {  // (slot arrays were sized with the smaller capacity: again with the handle's)
+        dev_free(h, c.s_rvo);
+        dev_free(h, c.s_nodes);
         RTRY(dev_alloc(h, &c.s_rvo, (size_t)S * c.cap_o));
         RTRY(dev_alloc(h, &c.s_nodes, (size_t)S * c.cap_n));
     }
@@ -2510,6 +2656,8 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     HIPCHK(hipStreamSynchronize(st));  // (set-up only: the uploads above were synchronous copies)
     k_spawn_fill<<<dim3(S), dim3(WAVE), 0, h->side3>>>(c);
     HIPCHK(hipEventRecord(h->ev_fill, h->side3));
+    h->fill_pending = true;  // the next chain waits for this fill in front of its k_respawn, whatever fill_due says
+    h->fill_due = 0;
     h->sd_ready = true;
     return 0;
 }
@@ -2530,9 +2678,11 @@ static int spawn_dev_refresh(imgenv* h, hipStream_t st) {
         HIPCHK(hipStreamSynchronize(st));
         c.cap_o = h->cap_obst;
         c.cap_n = h->cap_nodes;
+        dev_free(h, c.s_rvo);  // (both streams are idle: nothing reads the old slot arrays any more)
+        dev_free(h, c.s_nodes);
         RTRY(dev_alloc(h, &c.s_rvo, (size_t)c.S * c.cap_o));
         RTRY(dev_alloc(h, &c.s_nodes, (size_t)c.S * c.cap_n));
-        HIPCHK(hipMemset(c.slot_serial, 0xFF, sizeof(unsigned long long) * (size_t)c.S));  // every slot is drawn again (the chain's own fill)
+        HIPCHK(hipMemsetAsync(c.slot_serial, 0xFF, sizeof(unsigned long long) * (size_t)c.S, st));  // every slot is drawn again (the chain's own fill, behind this on st's event)
         h->fill_due = 0;
     }
     c.w_obst = h->d_obst;
@@ -2563,12 +2713,15 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
         HIPCHK(hipStreamWaitEvent(h->side3, h->ev_consumed, 0));
         k_spawn_fill<<<dim3(c.S), dim3(WAVE), 0, h->side3>>>(c);
         HIPCHK(hipEventRecord(h->ev_fill, h->side3));
+        h->fill_pending = true;
         h->fill_due = SPAWN_FILL_PERIOD;
     }
     h->fill_due -= 1;
     if (int rc = imgenv_step(h, actions, st)) return rc;
     k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
-    if (fill) HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
+    // (also the set-up's fill, which runs on the side stream whatever this call's fill_due was: k_respawn must not meet half-drawn slots)
+    if (h->fill_pending || !h->no_graph) HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
+    h->fill_pending = false;
     k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
     // grids for a guess of the finished worlds (four times the last count; the kernels stride over the rest if there are more)
     const int last_n = h->finished_host[0];  // (page-locked, written by k_finished_dev: stale by a step or two)
@@ -2630,7 +2783,7 @@ extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, c
     // The chain as a graph: captured on the third call (the first ones have loaded every kernel), replayed from then on --
     // except while per-kernel timing is on and on the steps that sweep the stamped class layer (every STAMP_TAGS-th)
     const bool sweep = h->stamp && ((h->stamp_seq + 1) % STAMP_TAGS == 0 || (h->stamp_seq + 2) % STAMP_TAGS == 0);
-    const bool graphable = !h->no_graph && h->t_mode == 0 && !sweep && !h->comm && !h->serial;
+    const bool graphable = !h->no_graph && h->t_mode == 0 && !sweep && !h->comm && !h->serial && !h->guard_check;  // (the guard's verification synchronises)
     if (graphable && !h->gexec && h->dev_calls >= 2) {
         if (int rc = check_device_flags(h)) return rc;
         // (the capture runs nothing: the host's counters, which the chain advances as it is issued, are put back)
@@ -2786,10 +2939,11 @@ extern "C" int imgenv_outputs(imgenv_t* h, imgenv_out* out) {
     // (fields are only ever appended); 0 = the caller's struct is this library's
     const int32_t want = out->struct_size;
     if (want < 0 || want > (int32_t)sizeof(imgenv_out)) FAIL(IMGENV_EINVAL, "imgenv_out.struct_size %d (this library's is %d)", want, (int)sizeof(imgenv_out));
+    const imgenv_out& src = h->pub_arena ? h->pub_out : h->out;
     if (want == 0) {
-        *out = h->out;
+        *out = src;
     } else {
-        memcpy(out, &h->out, (size_t)want);
+        memcpy(out, &src, (size_t)want);
         out->struct_size = want;  // what the caller really holds, not this library's larger size
     }
     return IMGENV_OK;

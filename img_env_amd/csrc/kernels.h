@@ -205,6 +205,37 @@ __device__ __forceinline__ uint32_t cell_seen_class(uint32_t v, uint32_t self, u
 // per-step values: kernel arguments, or (replayed chains) the device-side counters k_tick advances
 __device__ __forceinline__ int tail_elapsed_of(const DevWorld& w) { return w.step_vars ? w.step_vars[0] : w.tail_elapsed; }
 __device__ __forceinline__ uint32_t stamp_tag_of(const DevWorld& w) { return w.step_vars ? (uint32_t)w.step_vars[1] % STAMP_TAGS + 1u : w.stamp_tag; }
+// ---- output guard (IMGENV_FLAG_CHECK_OUTPUTS): a position-weighted 64-bit sum per output array
+#define OUT_SUM_CHUNK 65536  // bytes one workgroup sums
+struct OutSpan {
+    const unsigned char* p;  // 256-byte aligned (arena carve-outs)
+    unsigned long long bytes;
+    int first_block, pad_;
+};
+__global__ __launch_bounds__(256) void k_out_sum(const OutSpan* spans, int n, unsigned long long* sums) {
+    int f = 0;
+    while (f + 1 < n && spans[f + 1].first_block <= (int)blockIdx.x) f++;  // (at most 32 spans)
+    const OutSpan sp = spans[f];
+    const unsigned long long lo = (unsigned long long)((int)blockIdx.x - sp.first_block) * OUT_SUM_CHUNK;
+    const unsigned long long hi = lo + OUT_SUM_CHUNK < sp.bytes ? lo + OUT_SUM_CHUNK : sp.bytes;
+    unsigned long long acc = 0;
+    for (unsigned long long b = lo + 4ull * threadIdx.x; b < hi; b += 4ull * 256) {
+        uint32_t v = 0;
+        if (b + 4 <= hi) {
+            v = *(const uint32_t*)(sp.p + b);
+        } else {
+            for (unsigned long long q = b; q < hi; q++) v |= (uint32_t)sp.p[q] << (8 * (q - b));
+        }
+        acc += ((unsigned long long)v + 0x9E3779B97F4A7C15ull) * (2ull * (b >> 2) + 1ull);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane_id() == 0 && acc) atomicAdd(&sums[f], acc);
+}
+__global__ void k_out_verify(const unsigned long long* sealed, const unsigned long long* found, int n, int* err) {
+    const int f = threadIdx.x;
+    if (f < n && sealed[f] != found[f]) err[5] = f + 1;  // (page-locked host memory: a plain store; any of the changed arrays names the problem)
+}
+
 __global__ void k_tick(int* vars, int stamp) {
     vars[0] += 1;  // TimeLimitWrapper._elapsed_steps (base.py:224)
     if (stamp) vars[1] += 1;  // this step's stamps get a new tag
@@ -341,6 +372,7 @@ struct OrcaLaunch {
 #define ORCA_GROUP_MAX 4
 #define ORCA_ROW 16
 __host__ __device__ inline size_t orca_row_bytes(const OrcaLaunch& L) {  // an agent's scratch + per-node records + the row's exchange words
+    static_assert(ORCA_ROW * 4 % 16 == 0 && sizeof(RvoObstDev) % 4 == 0, "k_orca's LDS carving keeps its uint4 records 16-byte aligned");
     return orca_scratch_bytes(L.cap_on, L.cap_stack) + (size_t)L.stage_obst * 16 + ORCA_ROW * 4;
 }
 __host__ __device__ inline size_t orca_lds_bytes(const OrcaLaunch& L) {

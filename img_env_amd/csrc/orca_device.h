@@ -70,7 +70,8 @@ struct OrcaScratch {
     int n_an, n_on, cap_on, cap_stack;
 };
 __host__ __device__ inline size_t orca_scratch_bytes(int cap_on, int cap_stack) {
-    return (size_t)(cap_on + ORCA_MAX_AN) * 2 * sizeof(OrcaLine) + (size_t)cap_on * 8 + ORCA_MAX_AN * 8 + (size_t)cap_stack * 4;
+    // (a multiple of 16: the per-node records behind the scratch are uint4, and so is every later row's base)
+    return ((size_t)(cap_on + ORCA_MAX_AN) * 2 * sizeof(OrcaLine) + (size_t)cap_on * 8 + ORCA_MAX_AN * 8 + (size_t)cap_stack * 4 + 15) & ~(size_t)15;
 }
 __device__ __forceinline__ void orca_scratch_carve(OrcaScratch& s, unsigned char* base, int cap_on, int cap_stack) {
     const int nl = cap_on + ORCA_MAX_AN;

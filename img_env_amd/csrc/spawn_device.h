@@ -621,8 +621,10 @@ __global__ __launch_bounds__(WAVE) void k_respawn(DevWorld w, SpawnDev c, int el
     const int s = (int)(n % (unsigned long long)c.S);
     if (c.slot_serial[s] != n || c.slot_status[s] != 0) {  // the pool did not hold this placement, or it could not be placed
         if (tid == 0) w.err[2] = c.slot_serial[s] != n ? 100 : c.slot_status[s];
-        // the world keeps its episode (the error surfaces at the next synchronising call): nothing of the chain behind may
-        // take this list entry for a reset -- no obstacle instances to draw, no map to restore
+        // The error surfaces at the next API call and the handle is then to be reset by its owner.  Until then the world keeps its
+        // poses and its map (no obstacle instances to draw, no map to restore: world = -1 below); it does stay on the finished
+        // list, so the chain's rasters / views / solve still treat it as freshly reset (robot agents at rest, every view cell
+        // rewritten) -- its outputs between here and the error are those of a reset of the OLD placement, not of a running episode
         for (int e = tid; e < c.n_obstacles; e += WAVE) c.inst_out[(size_t)q * c.n_obstacles + e].world = -1;
         return;
     }

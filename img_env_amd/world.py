@@ -35,6 +35,18 @@ class World:
         self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
         self.params = dict(params)
         self.params["device"] = self.device.index
+        # Output ownership.  The reference hands out fresh copies with every step (ROS responses); this library hands out its
+        # working copies, read-only by contract (include/imgenv.h).  params["output_guard"] (or IMGENV_OUTPUT_GUARD in the
+        # environment, which wins): "check" = IMGENV_FLAG_CHECK_OUTPUTS, a write by the caller fails the next call;
+        # "copy" = IMGENV_FLAG_FULL_REWRITE, `out` is then a second arena rewritten in full by every call.  Default: neither.
+        guard = os.environ.get("IMGENV_OUTPUT_GUARD") or self.params.pop("output_guard", None)
+        self.params.pop("output_guard", None)
+        if guard not in (None, "", "none", "check", "copy"):
+            raise ValueError("output_guard: none | check | copy")
+        if guard == "check":
+            self.params["flags"] = int(self.params.get("flags", 0)) | _cabi.FLAG_CHECK_OUTPUTS
+        elif guard == "copy":
+            self.params["flags"] = int(self.params.get("flags", 0)) | _cabi.FLAG_FULL_REWRITE
         self.grid = np.ascontiguousarray(grid, np.uint8)
         cfg, self._keep = _cabi.make_cfg(self.params)
         nbytes = self.lib.imgenv_arena_bytes(C.byref(cfg))
@@ -70,7 +82,9 @@ class World:
         self._check(self.lib.imgenv_records(self.h, C.byref(rec), C.byref(bpr)), "imgenv_records")
         off = rec.value - base
         n = self.n_robots * _cabi.RECORD_DOUBLES * 8
-        self.records = self.arena[off:off + n].view(torch.float64).view(self.n_robots, _cabi.RECORD_DOUBLES)
+        # (output_guard "copy": the records stay in the library's private arena -- no tensor for them; such a handle is never a shard)
+        self.records = (self.arena[off:off + n].view(torch.float64).view(self.n_robots, _cabi.RECORD_DOUBLES)
+                        if 0 <= off and off + n <= int(nbytes) else None)
         self.robot_begin = cfg.robot_begin
         self.robot_end = cfg.robot_end if cfg.robot_end else cfg.n_robots
 

@@ -28,7 +28,8 @@
  *    library's working copies, READ-ONLY for the caller: a step only rewrites what can change
  *    (a view cell no laser beam crosses holds its 200, or the footprint's 100, from the reset on;
  *    a frozen robot's rows keep their last values, agent.cpp:358-360), so whatever a caller
- *    wrote into them would stay there.
+ *    wrote into them would stay there.  IMGENV_FLAG_CHECK_OUTPUTS detects such writes,
+ *    IMGENV_FLAG_FULL_REWRITE hands out copies the caller may do anything to (below).
  *  - one handle is one world (one ImgEnv node, img_env.h:171-172) -- or imgenv_cfg.n_worlds of them,
  *    the reference's env_num nodes batched into one set of launches -- and is single-threaded
  *    like the node (ros::spin, img_env_node.cpp:8); distinct handles are independent.
@@ -176,6 +177,17 @@ typedef struct imgenv_cfg {
  * same. */
 #define IMGENV_FLAG_VIEW_TILED 32
 #define IMGENV_FLAG_VIEW_WAVE 64  /* (reserved: k_view is the default) */
+/* Guards for the read-only output arrays (see "Conventions": imgenv_outputs() hands out the kernels' incremental working copies,
+ * where the reference returns fresh copies with every service response, img_env.cpp:745-749).
+ * IMGENV_FLAG_CHECK_OUTPUTS (debug): every output array is sealed with a checksum when a reset / step has been queued and
+ * verified at the start of the next reset / step call; a mismatch fails that call with IMGENV_EINVAL "the caller wrote into
+ * imgenv_out.<field>".  The verification synchronises the stream once per call.
+ * IMGENV_FLAG_FULL_REWRITE: for callers that cannot promise to leave the arrays alone (in-place normalisation, ...).
+ * imgenv_outputs() then hands out a SECOND arena (imgenv_cfg.out_arena if given) whose every byte is rewritten from the
+ * kernels' private working copy at the end of every reset / step; whatever the caller does to it never reaches the kernels.
+ * Costs one device-to-device copy of imgenv_arena_bytes() per call. */
+#define IMGENV_FLAG_CHECK_OUTPUTS 128
+#define IMGENV_FLAG_FULL_REWRITE 256
 
 /* ResetEnv.srv:1-6 (img_env.cpp:162-292).  Poses are (x, y, qz, qw): geometry_msgs/Pose with a
  * planar orientation; yaw is recovered with tf::Matrix3x3(q).getRPY as the node does. */
@@ -257,6 +269,9 @@ typedef struct imgenv imgenv_t;
 
 /* library / build identification: "hip-gfx950" for the product library */
 const char* imgenv_backend(void);
+/* which build: a hash of the extension's sources and compiler flags (__graft_entry__.source_id), "unstamped" for a library
+ * compiled by hand.  profiles/pmc_latest.json carries the id of the library its counters were collected on. */
+const char* imgenv_build_id(void);
 int32_t imgenv_abi_version(void);
 const char* imgenv_last_error(void);
 
@@ -419,7 +434,9 @@ int imgenv_step_launches(imgenv_t* h);
 #define IMGENV_K_CROP 8      /* big views (csrc/view_big.h): k_crop_big; IMGENV_K_VIEW is then k_beams_big */
 #define IMGENV_K_FULLVIEW 9  /* k_fullview_big */
 #define IMGENV_K_TAPS 10     /* k_taps_big */
-#define IMGENV_K_COUNT 11
+#define IMGENV_K_MOVE_RASTER 11 /* k_move_raster: K_INTEGRATE + K_RASTER as one launch (small / pedestrian-free handles) */
+#define IMGENV_K_EXCHANGE 12    /* the in-library ncclAllGather of the robot records (imgenv_comm_init), between K_INTEGRATE and K_RASTER */
+#define IMGENV_K_COUNT 13
 int imgenv_timing(imgenv_t* h, int mode, int which);
 /* synchronises the recorded events and returns accumulated milliseconds / launch counts per kernel
  * id since the last imgenv_timing() call; arrays of IMGENV_K_COUNT entries */

@@ -1,0 +1,117 @@
+"""The workload `bench.py` TIMES, under the oracle: the cfg-3 world (8192 robots, 200 ORCA pedestrians, 400 x 400 at 0.25 m),
+episodes of `time_max` = 100 steps with the full reset that follows them (NeverStopWrapper, /root/reference/envs/wrapper/base.py:198-231),
+for longer than one episode -- so the kernels' incremental paths (a step only rewrites the view cells a beam crosses, the sparse
+ped_map update of k_obs, k_raster's cached cell lists of robots that did not move; agent.cpp:358-360 freezes a robot's outputs
+after a collision) are held to the oracle across 100 steps and across the reset, not only over the first handful.
+
+Both action policies of the bench line: "active" (v = 0: `value`) and the reference's random policy (env_test.py:8-19:
+`episode_policy`, most robots frozen within a few steps).  The oracle steps every step (~0.6 s each); every field is compared on
+every 10th step, on the three steps around the reset and on the reset's own observation.  BASELINE cfg-5 the same way over 20 steps."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from parity import CLOSE, EXACT, compare
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def worlds():
+    import torch
+    assert torch.cuda.is_available()
+    from img_env_amd.world import World
+    from oracle_binding import OracleWorld, build_oracle
+    build_oracle()
+    return World, OracleWorld
+
+
+def _actions(rng, n, policy):
+    v = rng.uniform(0.0, 0.6, n) if policy == "episode" else np.zeros(n)
+    return np.stack([v, rng.uniform(-0.9, 0.9, n), np.zeros(n)], 1).astype(np.float32)
+
+
+def _bench_loop(gpu, cpu, layouts, n, policy, steps, time_max, every, seed):
+    """bench.py's do_step / do_reset loop on both worlds; returns (failures, steps compared, resets)"""
+    rng = np.random.default_rng(seed)
+    fails, compared, resets = [], 0, 0
+
+    def check(tag):
+        nonlocal compared
+        bad = compare(gpu.snapshot(), cpu.snapshot(), EXACT + CLOSE)
+        compared += 1
+        if bad:
+            fails.append((tag, bad))
+
+    gpu.reset(layouts[0])
+    cpu.reset(layouts[0])
+    check("reset 0")
+    elapsed, episode = 0, 1
+    for s in range(steps):
+        a = _actions(rng, n, policy)
+        gpu.step(a)
+        cpu.step(a)
+        elapsed += 1
+        near_limit = elapsed >= time_max - 1  # the two steps in front of the limit and the one that trips it
+        if s % every == every - 1 or near_limit or elapsed <= 1 or s == steps - 1:
+            check("step %d (elapsed %d)" % (s, elapsed))
+        if elapsed > time_max:  # TimeLimitWrapper has set done for every robot: NeverStopWrapper resets (bench.py do_step)
+            lay = layouts[episode % len(layouts)]
+            gpu.reset(lay)
+            cpu.reset(lay)
+            episode += 1
+            resets += 1
+            elapsed = 0
+            check("reset %d behind step %d" % (resets, s))
+        if len(fails) > 3:
+            break
+    return fails, compared, resets
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("policy", ["active", "episode"])
+def test_timed_workload_matches_oracle_across_an_episode_and_its_reset(worlds, policy):
+    World, OracleWorld = worlds
+    import bench
+    n, P = bench.ROBOTS, bench.N_PEDS
+    grid, params, layouts = bench.make_workload("cfg3", n, P, 2)
+    assert params["time_max"] == bench.TIME_MAX == 100
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        fails, compared, resets = _bench_loop(gpu, cpu, layouts, n, policy, steps=106, time_max=bench.TIME_MAX, every=10, seed=41)
+        assert not fails, fails[:2]
+        assert resets == 1 and compared >= 18
+        snap = cpu.snapshot()
+        assert snap["counters"][0] == 5  # five steps into the second episode
+        frozen = ((snap["is_collisions"] != 0) | (snap["is_arrives"] != 0)).mean()
+        if policy == "active":
+            assert frozen == 0.0  # v = 0: nobody collides or arrives, every robot-step runs the full view path (bench.py's `value`)
+        print("cfg-3 %s policy: %d comparisons over 106 steps and one reset, %.1f %% of the robots frozen at the end" % (policy, compared, 100 * frozen))
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+@pytest.mark.timeout(1500)
+def test_cfg5_matches_oracle_over_twenty_steps(worlds):
+    """BASELINE cfg-5 (8192 robots, 1000 ERVO pedestrians, 800 x 800 at 0.125 m, 96 x 96 views, 720 beams), random policy"""
+    World, OracleWorld = worlds
+    from img_env_amd import worldgen
+    n, P = 8192, 1000
+    grid = worldgen.make_grid(800, 0)
+    params = worldgen.make_params(n, P, res=0.125, view_cells=96, beams=720, scene="ervoscene", time_max=100)
+    layouts = [worldgen.make_layout(grid, 0.125, n, P, seed=100, clearance=0.7)]
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        fails, compared, _ = _bench_loop(gpu, cpu, layouts, n, "episode", steps=20, time_max=100, every=5, seed=43)
+        assert not fails, fails[:2]
+        assert compared >= 6
+    finally:
+        gpu.close()
+        cpu.close()

@@ -20,3 +20,5 @@ python3 tools/pmc_to_json.py $out/${tag}_fetch $out/${tag}_write $out/${tag}_pmc
 python3 tools/pmc_summary.py $out/${tag}_fetch $out/${tag}_write > $out/${tag}_pmc_hbm.txt
 python3 tools/pmc_summary.py $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 > $out/${tag}_pmc_sq.txt
 rm -rf $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 $out/${tag}_fetch $out/${tag}_write
+# which library the set describes (imgenv_build_id = hash of the sources + flags; bench.py compares it with the library it runs)
+python3 -c "import ctypes;l=ctypes.CDLL('/root/repo/img_env_amd/csrc/libimgenv_hip.so');l.imgenv_build_id.restype=ctypes.c_char_p;print(l.imgenv_build_id().decode())" > $out/${tag}_build_id.txt

@@ -11,3 +11,5 @@ db=$(ls $out/${tag}_trace/*/*.db $out/${tag}_trace/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python3 tools/timeline.py $db > $out/${tag}_timeline.txt 2>/dev/null
 python3 bench.py 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
 rm -rf $out/${tag}_trace
+# which library the set describes (imgenv_build_id = hash of the sources + flags; bench.py compares it with the library it runs)
+python3 -c "import ctypes;l=ctypes.CDLL('/root/repo/img_env_amd/csrc/libimgenv_hip.so');l.imgenv_build_id.restype=ctypes.c_char_p;print(l.imgenv_build_id().decode())" > $out/${tag}_build_id.txt

@@ -50,3 +50,5 @@ bash tools/pmc_mem.sh ${tag}_shipped2048
 # keep the returned directory small: the raw traces stay on the box
 rm -rf $out/${tag}_trace $out/${tag}_mw $out/${tag}_cfg2 $out/${tag}_cfg4 $out/${tag}_cfg5 $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 $out/${tag}_fetch $out/${tag}_write
 du -sh $out
+# which library the set describes (imgenv_build_id = hash of the sources + flags; bench.py compares it with the library it runs)
+python3 -c "import ctypes;l=ctypes.CDLL('/root/repo/img_env_amd/csrc/libimgenv_hip.so');l.imgenv_build_id.restype=ctypes.c_char_p;print(l.imgenv_build_id().decode())" > $out/${tag}_build_id.txt
