@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/imgenv.h"
+#include "fp_rows.h"
 #include "tfm.h"
 
 struct Pts {
@@ -51,6 +52,34 @@ static Pts shape_rectangle(const double* s) {
             p.y.push_back(n * resolution);
         }
     return p;
+}
+
+// The lattice rows of a sample list (fp_rows.h): runs of consecutive samples (px, cy + 0.01 n), n = n_lo .. n_hi.  Empty when
+// the list is not of that form -- it always is for the reference's discs and rectangles; this re-derives the rows from the list
+// itself and checks every sample, so a mismatch can only switch the shortcut off -- or when a row can take more steps than
+// fp_rows.h handles at this resolution (FPR_MAXC: then nearly every robot would fall back to the sample walk anyway).
+static std::vector<FpRow> build_fp_rows(const Pts& p, double cy, double res) {
+    std::vector<FpRow> rows;
+    const double pitch = FPR_PITCH;
+    int q = 0;
+    double longest = 0;
+    while (q < p.n()) {
+        int e = q;
+        while (e + 1 < p.n() && p.x[e + 1] == p.x[q]) e++;
+        FpRow r;
+        r.px = p.x[q];
+        r.n_lo = (int)lrint((p.y[q] - cy) / pitch);
+        r.n_hi = r.n_lo + (e - q);
+        r.q0 = q;
+        for (int t = q; t <= e; t++)
+            if (p.y[t] != (r.n_lo + (t - q)) * pitch + cy) return {};  // (the generating expression, agent.cpp:26, 58)
+        if (!rows.empty() && !(r.px > rows.back().px)) return {};
+        longest = std::max(longest, (r.n_hi - r.n_lo) * pitch);
+        rows.push_back(r);
+        q = e + 1;
+    }
+    if ((int)floor(longest / res) + 1 > FPR_MAXC) return {};
+    return rows;
 }
 
 struct ViewGeom {
@@ -91,6 +120,8 @@ struct RobotClassHost {
     float size[4], sensor[2];
     double sizes[4], sx, sy;
     Pts fp;
+    std::vector<FpRow> fp_rows;  // lattice rows of fp (fp_rows.h), empty: the rasters walk the samples
+    double fp_cy = 0;
     std::vector<uint32_t> fov_bits, stamp_bits;
     int ray_maxlen = 0, ray_stride = 0, ray_kpad = 8, box_rad = 0;
     bool ok = true;  // false: a table field overflowed its packing
@@ -133,6 +164,8 @@ static void build_robot_class(RobotClassHost& k, const ViewGeom& g, bool force_b
     k.sx = (double)k.sensor[0];
     k.sy = (double)k.sensor[1];
     k.fp = k.shape == IMGENV_SHAPE_CIRCLE ? shape_circle(k.sizes[0], k.sizes[1], k.sizes[2]) : shape_rectangle(k.sizes);
+    k.fp_cy = k.shape == IMGENV_SHAPE_CIRCLE ? k.sizes[1] : 0.0;
+    k.fp_rows = build_fp_rows(k.fp, k.fp_cy, g.res);
     const int Hv = g.Hv, Wv = g.Wv, NC = Hv * Wv, NW = (NC + 31) / 32;
     const double res = g.res;
     // crop gate (agent.cpp:373-386)
@@ -452,18 +485,26 @@ struct PedClassHost {
     float size[6];
     double sizes[6];
     Pts bbox, left, right;
+    std::vector<FpRow> bbox_rows, left_rows, right_rows;  // lattice rows (fp_rows.h) of the three sample lists
+    double bbox_cy = 0;
 };
 
 // PedAgent::init_shape (agent.cpp:666-685)
-static void build_ped_class(PedClassHost& k) {
+static void build_ped_class(PedClassHost& k, double res) {
     for (int j = 0; j < 6; j++) k.sizes[j] = (double)k.size[j];
     if (k.shape == IMGENV_SHAPE_LEG) {
         k.left = shape_circle(0, 0, k.sizes[2]);
         k.right = shape_circle(0, 0, k.sizes[5]);
+        k.left_rows = build_fp_rows(k.left, 0.0, res);
+        k.right_rows = build_fp_rows(k.right, 0.0, res);
+        if (k.left_rows.empty() || k.right_rows.empty()) k.left_rows.clear(), k.right_rows.clear();
     } else if (k.shape == IMGENV_SHAPE_CIRCLE) {
         k.bbox = shape_circle(k.sizes[0], k.sizes[1], k.sizes[2]);
+        k.bbox_cy = k.sizes[1];
+        k.bbox_rows = build_fp_rows(k.bbox, k.bbox_cy, res);
     } else {
         k.bbox = shape_rectangle(k.sizes);
+        k.bbox_rows = build_fp_rows(k.bbox, 0.0, res);
     }
 }
 

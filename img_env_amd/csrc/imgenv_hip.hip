@@ -593,7 +593,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             PedClassHost k;
             k.shape = cfg->ped_shape[j];
             memcpy(k.size, cfg->ped_size + 6 * j, 24);
-            build_ped_class(k);
+            build_ped_class(k, g.res);
             h->pcls.push_back(std::move(k));
             found = (int)h->pcls.size() - 1;
         }
@@ -749,6 +749,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             o.big = k.big ? 1 : 0;
             h->big_view = h->big_view || k.big;
             o.box_rad = k.box_rad;
+            static const bool no_rows = getenv("IMGENV_FP_ROWS") && getenv("IMGENV_FP_ROWS")[0] == '0';  // (measurement switch: the literal sample walk)
+            o.n_rows = no_rows ? 0 : (int)k.fp_rows.size();
+            o.rows = nullptr;
+            o.fp_cy = k.fp_cy;
+            if (o.n_rows) TRY(dev_upload(h, &o.rows, k.fp_rows));
             max_stride = std::max(max_stride, (size_t)k.ray_stride);
         }
         if (rc.size() > RC_INLINE || h->pcls.size() > PC_INLINE) {
@@ -773,6 +778,12 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.rx, k.right.x));
             TRY(dev_upload(h, &o.ry, k.right.y));
             memcpy(o.sizes, k.sizes, sizeof(o.sizes));
+            static const bool no_rows = getenv("IMGENV_FP_ROWS") && getenv("IMGENV_FP_ROWS")[0] == '0';
+            o.n_brows = no_rows ? 0 : (int)k.bbox_rows.size(); o.n_lrows = no_rows ? 0 : (int)k.left_rows.size(); o.n_rrows = no_rows ? 0 : (int)k.right_rows.size();
+            o.bbox_cy = k.bbox_cy;
+            if (o.n_brows) TRY(dev_upload(h, &o.brows, k.bbox_rows));
+            if (o.n_lrows) TRY(dev_upload(h, &o.lrows, k.left_rows));
+            if (o.n_rrows) TRY(dev_upload(h, &o.rrows, k.right_rows));
         }
         for (size_t c = 0; c < pc.size(); c++) d.pc[c] = pc[c];
         if (pc.empty()) pc.resize(1);

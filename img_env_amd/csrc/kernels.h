@@ -1247,33 +1247,87 @@ __device__ __forceinline__ void ped_samples(const DevWorld& w, const bool (&in)[
     stamp_ped_batch<PB>(w, c, go, v, stamp_tag_of(w), world);
 }
 
+// the literal walk over one sample list of a pedestrian (Agent::draw / PedAgent::draw_leg): thread `first` of `stride` takes
+// every stride-th sample, PB rounds at a time (ped_samples)
+template <bool POW2, bool STAMP>
+__device__ __forceinline__ void ped_walk(const DevWorld& w, const Tf2& bw, const Tf2* lb, const double* sx, const double* sy, int n_s, int rule,
+                                         int first, int stride, const Region& g, uint32_t cell0, int world) {
+    constexpr int PB = 4;  // rounds of samples per batch (ped_samples)
+    const double res = w.res, inv = w.inv_res;
+    const int lane = lane_id();
+    for (int q0 = 0; q0 < n_s; q0 += stride * PB) {  // wave-uniform trip count (lane shuffles inside)
+        uint32_t cc[PB];
+        bool in[PB];
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            in[u] = false;
+            cc[u] = 0u;
+            if (q0 + u * stride >= n_s) continue;  // uniform
+            const int q = min(q0 + u * stride + first, n_s - 1);
+            double bx = sx[q], by = sy[q], wx, wy;
+            if (lb) tf_apply(*lb, sx[q], sy[q], bx, by);
+            tf_apply(bw, bx, by, wx, wy);
+            int m, n;
+            w2m_pair<POW2>(wx, wy, res, inv, m, n);
+            in[u] = q0 + u * stride + first < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+            cc[u] = cell0 + (uint32_t)(m * w.Wg + n);
+        }
+        ped_samples<STAMP, PB>(w, in, cc, rule, lane, world);
+    }
+}
+
+// ... and the same cells from the list's lattice rows, one row per lane (fp_rows.h; raster_robot has the story).  px_off / cy: a
+// leg disc's rows are shifted by the leg's offset in the pedestrian's frame.  Returns false when some row of THIS wavefront could
+// not be certified: the wavefront then walks the whole list itself (the layer is order independent and idempotent).
+template <bool STAMP, int NW>
+__device__ __forceinline__ bool ped_rows(const DevWorld& w, const Tf2& bw, const FpRow* rows, int n_rows, double px_off, double cy, int rule,
+                                         const Region& g, uint32_t cell0, int world) {
+    constexpr int NT = WAVE * NW;
+    const int lane = lane_id(), tid = threadIdx.x;
+    const FpRowsPose P = fpr_pose(bw.m00, bw.m01, bw.m10, bw.m11, bw.ox, bw.oy, cy, w.res);
+    bool bad = false;
+    for (int r0 = 0; r0 < n_rows; r0 += NT) {  // wave-uniform trip count
+        const int ri = r0 + tid;
+        const bool act = ri < n_rows;
+        FpRow row = rows[min(ri, n_rows - 1)];
+        row.px = row.px + px_off;
+        FpAxis ax, ay;
+        const bool ok = fpr_row(P, row, ax, ay);
+        bad |= act & !ok;
+        const bool use = act & ok;
+        const int cx = use ? ax.cnt : 0, cyn = use ? ay.cnt : 0;
+        const int cxw = (int)__any(cx >= 1) + (int)__any(cx >= 2) + (int)__any(cx >= 3) + (int)__any(cx >= 4);
+        const int cyw = (int)__any(cyn >= 1) + (int)__any(cyn >= 2) + (int)__any(cyn >= 3) + (int)__any(cyn >= 4);
+#pragma unroll
+        for (int i = 0; i <= FPR_MAXC; i++) {
+            if (i > cxw) break;
+#pragma unroll
+            for (int j = 0; j <= FPR_MAXC; j++) {
+                if (j > cyw) break;
+                int m, n;
+                uint32_t last;
+                const bool has = fpr_piece(row, ax, ay, i, j, m, n, last) & use;
+                const bool in = has && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
+                ped_sample<STAMP>(w, in, cell0 + (uint32_t)(m * w.Wg + n), rule, lane, world);  // (neighbouring rows mostly share the cell: one stamp per run)
+            }
+        }
+    }
+    return !__any(bad);
+}
+
 template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
-    constexpr int PB = 4;  // rounds of samples per batch (ped_samples)
     const int world = world_of_ped(w, j);
     const uint32_t cell0 = (uint32_t)world * w.Gs;  // this world's copy of the layers
     const Tf2 bw = tf_from_pose(w.ppx[j], w.ppy[j], w.pyaw[j]);
     const int lane = lane_id(), tid = threadIdx.x;
-    const double res = w.res, inv = w.inv_res;
     if (k.shape == IMGENV_SHAPE_CIRCLE) {
-        for (int q0 = 0; q0 < k.n_bbox; q0 += NT * PB) {  // wave-uniform trip count (lane shuffles inside)
-            uint32_t cc[PB];
-            bool in[PB];
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                in[u] = false;
-                cc[u] = 0u;
-                if (q0 + u * NT >= k.n_bbox) continue;  // uniform
-                const int q = min(q0 + u * NT + tid, k.n_bbox - 1);
-                double wx, wy;
-                tf_apply(bw, k.bx[q], k.by[q], wx, wy);
-                int m, n;
-                w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                in[u] = q0 + u * NT + tid < k.n_bbox && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
-                cc[u] = cell0 + (uint32_t)(m * w.Wg + n);
-            }
-            ped_samples<STAMP, PB>(w, in, cc, 0, lane, world);
+        if (k.n_brows > 0) {
+            if (!ped_rows<STAMP, NW>(w, bw, k.brows, k.n_brows, 0.0, k.bbox_cy, 0, g, cell0, world))
+                ped_walk<POW2, STAMP>(w, bw, nullptr, k.bx, k.by, k.n_bbox, 0, lane, WAVE, g, cell0, world);
+        } else {
+            ped_walk<POW2, STAMP>(w, bw, nullptr, k.bx, k.by, k.n_bbox, 0, tid, NT, g, cell0, world);
         }
     } else if (k.shape == IMGENV_SHAPE_LEG) {
         for (int leg = 0; leg < 2; leg++) {
@@ -1284,24 +1338,14 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
             const int n_s = leg == 0 ? k.n_left : k.n_right;
             const double* sx = leg == 0 ? k.lx : k.rx;
             const double* sy = leg == 0 ? k.ly : k.ry;
-            for (int q0 = 0; q0 < n_s; q0 += NT * PB) {
-                uint32_t cc[PB];
-                bool in[PB];
-#pragma unroll
-                for (int u = 0; u < PB; u++) {
-                    in[u] = false;
-                    cc[u] = 0u;
-                    if (q0 + u * NT >= n_s) continue;  // uniform
-                    const int q = min(q0 + u * NT + tid, n_s - 1);
-                    double bx, by, wx, wy;
-                    tf_apply(lb, sx[q], sy[q], bx, by);
-                    tf_apply(bw, bx, by, wx, wy);
-                    int m, n;
-                    w2m_pair<POW2>(wx, wy, res, inv, m, n);
-                    in[u] = q0 + u * NT + tid < n_s && m >= g.m0 && m < g.m1 && n >= g.n0 && n < g.n1;
-                    cc[u] = cell0 + (uint32_t)(m * w.Wg + n);
-                }
-                ped_samples<STAMP, PB>(w, in, cc, leg + 1, lane, world);
+            const FpRow* rows = leg == 0 ? k.lrows : k.rrows;
+            const int n_rows = leg == 0 ? k.n_lrows : k.n_rrows;
+            if (n_rows > 0) {
+                // (the leg frame is a pure translation: a disc sample (x, y) sits at (x + leg x, y + leg y) in the pedestrian's frame, exactly)
+                if (!ped_rows<STAMP, NW>(w, bw, rows, n_rows, lb.ox, lb.oy, leg + 1, g, cell0, world))
+                    ped_walk<POW2, STAMP>(w, bw, &lb, sx, sy, n_s, leg + 1, lane, WAVE, g, cell0, world);
+            } else {
+                ped_walk<POW2, STAMP>(w, bw, &lb, sx, sy, n_s, leg + 1, tid, NT, g, cell0, world);
             }
         }
     }
@@ -1393,16 +1437,64 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
     RASTER_MARK(5);  // pose, cached-list test
     if (use_box) {
         for (int q = tid; q < ncell; q += NT) box[q] = 0;
-        if (NW > 1 && tid == 0) *stray_flag = 0;
+        if (NW > 1 && tid == 0) stray_flag[0] = stray_flag[2] = 0;
         __syncthreads();
     }
     bool stray = false;
+    // The lattice rows of the footprint, one per lane (fp_rows.h): the cells a row covers and the last sample in each are PREDICTED
+    // from the real-arithmetic model and certified against the rounding boundaries -- a dozen instructions per cell of a row
+    // instead of ~50 per sample of it (901 samples on a dozen cells at 0.25 m).  Any row that cannot be certified sends the whole
+    // robot through the literal sample walk below, which adds the same values to the box again (atomicMax: idempotent).
+    bool rows_done = false;
+    if (use_box && k.n_rows > 0) {
+        uint32_t* rows_bad = stray_flag + 2;
+        const FpRowsPose P = fpr_pose(bw.m00, bw.m01, bw.m10, bw.m11, bw.ox, bw.oy, k.fp_cy, res);
+        bool bad = false;
+        for (int r0 = 0; r0 < k.n_rows; r0 += NT) {  // wave-uniform trip count
+            const int ri = r0 + tid;
+            const bool act = ri < k.n_rows;
+            const FpRow row = k.rows[min(ri, k.n_rows - 1)];
+            FpAxis ax, ay;
+            const bool ok = fpr_row(P, row, ax, ay);
+            bad |= act & !ok;
+            const bool use = act & ok;
+            const int cx = use ? ax.cnt : 0, cy = use ? ay.cnt : 0;
+            // (the pieces of a row are walked up to the wavefront's largest step counts: scalar loop bounds, constant register indices)
+            const int cxw = (int)__any(cx >= 1) + (int)__any(cx >= 2) + (int)__any(cx >= 3) + (int)__any(cx >= 4);
+            const int cyw = (int)__any(cy >= 1) + (int)__any(cy >= 2) + (int)__any(cy >= 3) + (int)__any(cy >= 4);
+            static_assert(FPR_MAXC == 4, "the wavefront's largest step count is gathered with four ballots");
+#pragma unroll
+            for (int i = 0; i <= FPR_MAXC; i++) {
+                if (i > cxw) break;
+#pragma unroll
+                for (int j = 0; j <= FPR_MAXC; j++) {
+                    if (j > cyw) break;
+                    int m, n;
+                    uint32_t last;
+                    const bool has = fpr_piece(row, ax, ay, i, j, m, n, last) & use;
+                    if (has && m >= lo_m && m < hi_m && n >= lo_n && n < hi_n) {
+                        const int dm = m - cm + rad, dn = n - cn + rad;
+                        if (dm >= 0 && dm < side && dn >= 0 && dn < side) atomicMax(&box[dm * side + dn], last);
+                        else bad = true;  // (cannot happen: the box is the footprint's extent + 2 cells; the walk below would stamp it)
+                    }
+                }
+            }
+        }
+        if (NW > 1) {
+            if (bad) *rows_bad = 1;
+            __syncthreads();
+            rows_done = *rows_bad == 0;
+        } else {
+            rows_done = !__any(bad);
+        }
+    }
     // (the next four samples are requested before these four are used: the static table's round trip is then underneath the
     // transforms instead of in front of them, four times per robot)
     double2 fp_next[4];
+    const int n_walk = rows_done ? 0 : k.n_fp;  // the literal walk: classes without rows, boxes too small, uncertified poses
 #pragma unroll
-    for (int u = 0; u < 4; u++) fp_next[u] = k.fp[min(u * NT + tid, k.n_fp - 1)];
-    for (int q0 = 0; q0 < k.n_fp; q0 += NT * 4) {  // wave-uniform trip count (lane shuffles inside), 4 loads in flight
+    for (int u = 0; u < 4; u++) fp_next[u] = rows_done ? make_double2(0.0, 0.0) : k.fp[min(u * NT + tid, k.n_fp - 1)];
+    for (int q0 = 0; q0 < n_walk; q0 += NT * 4) {  // wave-uniform trip count (lane shuffles inside), 4 loads in flight
         double2 fp[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) fp[u] = fp_next[u];
@@ -1509,7 +1601,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
 // NW: wavefronts per workgroup.  1 when a launch fills the machine; 4 in small launches (a reset of a few worlds), where the
 // 15 rounds of footprint samples of one wavefront are pure latency.
 template <bool POW2, bool STAMP, int NW>
-__global__ __launch_bounds__(WAVE * NW) void k_raster(DevWorld w, int zero_vel, int split) {
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((STAMP || !POW2) ? 6 : 8, 8))) void k_raster(DevWorld w, int zero_vel, int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 
+#include "fp_rows.h"
 #include "sfm.h"
 #include "tfm.h"
 
@@ -64,6 +65,9 @@ struct RobotClassDev {
     const uint32_t* all_groups;  // [ceil(Hv*Wv / 4)] the same for every group: the pass of a reset (the other cells hold 200 / 100 for the whole episode)
     const uint2* inv_cell;       // [Hv*Wv] k_view's step (5): {block of the reach table | none << 13 | own footprint << 14 | smallest step << 24, inv_pack}
     int box_rad;                 // half-size (cells) of the LDS de-duplication box of the robot raster
+    int n_rows;                  // lattice rows of fp (fp_rows.h): the rasters find the covered cells row by row instead of sample
+    const FpRow* rows;           // by sample; 0: this class walks its samples (cells much smaller than the footprint)
+    double fp_cy;
     // AgentState.hits_x / hits_y / angular_map (IMGENV_FLAG_AGENT_STATE_EXTRAS; null otherwise)
     const float *ray_hx, *ray_hy;   // [ray_maxlen + 1][ray_stride] float32(hit * cos / sin(beam angle)) for a hit at step k; last row: no hit
     const uint16_t* bin_start;      // [73] first beam of each angular_map bin
@@ -97,6 +101,9 @@ struct PedClassDev {
     int n_left, n_right;  // leg samples (circles of radius lr / rr around 0,0)
     const double *lx, *ly, *rx, *ry;
     double sizes[6];
+    int n_brows, n_lrows, n_rrows;           // lattice rows (fp_rows.h) of the three sample lists; 0: walk the samples
+    const FpRow *brows, *lrows, *rrows;
+    double bbox_cy;
 };
 
 struct RvoObstDev {  // RVO::Obstacle (Obstacle.h) with index links

@@ -36,6 +36,7 @@ int oracle_grids(oracle_world* w, const uint8_t** obs_map, const uint8_t** peds_
 /* unit-test hooks: Agent::bresenhamLine (agent.cpp:511-624) and the planar tf operations of tfmath.h on hand-made inputs */
 double oracle_test_bresenham(int x1, int y1, int x2, int y2, const uint8_t* src, uint8_t* dst, int Hv, int Wv, double res);
 void oracle_test_tf(int op, const double* in, double* out);
+void oracle_test_corners(int shape, const double* sizes, double x, double y, double yaw, double* out);
 /* the first n values of glibc's rand() after srand(seed), from the oracle's restatement (the beep lottery's stream) */
 void oracle_test_glibc_rand(unsigned int seed, int n, int32_t* out);
 

@@ -1480,6 +1480,11 @@ int oracle_outputs(oracle_world* w, imgenv_out* out) {
 double oracle_test_bresenham(int x1, int y1, int x2, int y2, const uint8_t* src, uint8_t* dst, int Hv, int Wv, double res) {
     return bresenham(x1, y1, x2, y2, src, dst, Hv, Wv, res);
 }
+/* Agent::get_corners (agent.cpp:626-651) of a footprint (shape, sizes[4]) at pose (x, y, yaw): out = pax, pay, pbx, pby */
+void oracle_test_corners(int shape, const double* sizes, double x, double y, double yaw, double* out) {
+    tf2d bw = tf_from_pose(x, y, yaw);
+    get_corners(shape, sizes, &bw, &out[0], &out[1], &out[2], &out[3]);
+}
 /* op 0: from_pose(x, y, yaw) -> tf | 1: apply(tf[6], x, y) -> (x, y) | 2: inverse(tf) -> tf | 3: mul(tf a, tf b) -> tf
  * | 4: basis yaw via quaternion (tf) -> yaw | 5: yaw from quaternion (z, w) -> yaw | 6: set_rotation_zw(z, w) -> tf (origin 0) */
 void oracle_test_tf(int op, const double* in, double* out) {

@@ -86,7 +86,7 @@ def test_timed_workload_matches_oracle_across_an_episode_and_its_reset(worlds, p
     try:
         fails, compared, resets = _bench_loop(gpu, cpu, layouts, n, policy, steps=106, time_max=bench.TIME_MAX, every=10, seed=41)
         assert not fails, fails[:2]
-        assert resets == 1 and compared >= 18
+        assert resets == 1 and compared >= 15
         snap = cpu.snapshot()
         assert snap["counters"][0] == 5  # five steps into the second episode
         frozen = ((snap["is_collisions"] != 0) | (snap["is_arrives"] != 0)).mean()

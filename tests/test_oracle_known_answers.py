@@ -354,3 +354,203 @@ def test_beep_pushes_an_ervo_pedestrian_away(oracle_lib):
                 assert abs(ps[2]) < 1e-6 and abs(ps[3]) < 1e-6 and abs(ps[1] - 10.8) < 1e-6
         finally:
             w.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: the parts of the unpinned core that had no hand-derived answer yet.  Every expected value below is
+# derived in the docstring from the reference's source alone; worlds use 0.5 m cells so that a footprint falls into cells that can
+# be named on paper: cell index = round(world / 0.5) (grid_map.cpp:40-44), i.e. cell k covers [0.5 k - 0.25, 0.5 k + 0.25).
+def _coarse_world(n_robots, n_peds, cells=60, **kw):
+    grid = np.full((cells, cells), 255, np.uint8)
+    params = worldgen.make_params(n_robots, n_peds, res=0.5, view_cells=8, beams=8, **kw)
+    return grid, params
+
+
+def test_leg_raster_left_leg_skips_obstacles_right_leg_overwrites_them(oracle_lib):
+    """PedAgent::draw_leg (agent.cpp:737-774): left-leg samples skip cells that hold 0 (`== 0 -> is_collision`), right-leg samples
+    skip cells that hold 1 ONLY -- so a right leg standing on an obstacle turns the obstacle cell into a pedestrian cell.
+
+    Legs [lx, ly, lr, rx, ry, rr] = [0, 0.15, 0.1, 0, -0.15, 0.1], pedestrian at (x, 10.25), yaw 0, gait state 0 (legs at their
+    sizes, agent.cpp:705-712).  Left leg: disc of radius 0.1 around (x, 10.40): y in [10.30, 10.50] -> y / 0.5 in [20.6, 21.0]
+    -> column 21; right leg around (x, 10.10): y in [10.00, 10.20] -> [20.0, 20.4] -> column 20; x in [x - 0.1, x + 0.1] -> row
+    2 x for x = 10, 15, 20.  Pedestrian A (row 20) stands on two obstacle cells, B (row 30) on free floor, C (row 40) with its
+    left leg on a cell of value 100 and its right leg on a literal 2."""
+    grid, params = _coarse_world(1, 3, scene="rvoscene", ped_shape="leg", relation_ped_robo=0,
+                                 ped_size=np.tile(np.array([0, 0.15, 0.1, 0, -0.15, 0.1], np.float32), (3, 1)))
+    grid[20, 21] = 0
+    grid[20, 20] = 0
+    grid[40, 21] = 100
+    grid[40, 20] = 2
+    w = OracleWorld(params, grid)
+    try:
+        w.reset(_layout([(25.0, 25.0, 0.0)], [(27.0, 25.0)], ped_xy=[(10.0, 10.25), (15.0, 10.25), (20.0, 10.25)]))
+        w.step(np.zeros((1, 3), np.float32))  # update_bbox has run: state 0, legs at their sizes; nobody moved (goal = own position)
+        obs, ped = w.grids()
+        assert ped[20, 21] == 0        # A's left leg: the obstacle stays (agent.cpp:751)
+        assert ped[20, 20] == 1        # A's right leg: the obstacle BECOMES a pedestrian cell (agent.cpp:767 tests == 1 only)
+        assert ped[30, 21] == 1 and ped[30, 20] == 1   # B on free floor
+        assert ped[40, 21] == 1        # C's left leg over a 100: anything but 0 is overwritten
+        assert ped[40, 20] == 1        # C's right leg over a literal 2: anything but 1 is overwritten
+        diff = np.argwhere(ped != obs)
+        assert sorted(map(tuple, diff)) == [(20, 20), (30, 20), (30, 21), (40, 20), (40, 21)]  # and nothing else was touched
+    finally:
+        w.close()
+
+
+def test_view_ped_and_view_robot_never_overwrite_classes_0_1_2(oracle_lib):
+    """view_ped draws circle pedestrians with Agent::draw(peds_map, 1) and view_robot every OTHER robot with draw(map_i, 2)
+    (img_env.cpp:594-629); draw only writes where the cell holds none of 0 / 1 / 2 (agent.cpp:313-320).
+
+    Discs of radius 0.17 centred on cell centres (0.5 k) cover x, y in [0.5 k - 0.17, 0.5 k + 0.17] -> exactly cell k.  Pedestrians on
+    cells holding 0, 1, 2, 100, 255 leave 0, 1, 2, 1, 1.  Robots: R0 on free floor (20, 20), R1 on a 100 at (30, 30), R2 on the cell
+    of the pedestrian that stands on 255, R3 on an obstacle.  Robot i's private map shows every other robot as 2 where the cell held
+    anything but 0 / 1 / 2, and never itself."""
+    grid, params = _coarse_world(4, 5, scene="rvoscene", relation_ped_robo=0)
+    cells = {(10, 10): 0, (10, 12): 1, (10, 14): 2, (10, 16): 100, (10, 18): 255, (30, 30): 100, (44, 44): 0}
+    for (m, n), v in cells.items():
+        grid[m, n] = v
+    w = OracleWorld(params, grid)
+    try:
+        w.reset(_layout([(10.0, 10.0, 0.3), (15.0, 15.0, -1.0), (5.0, 9.0, 2.0), (22.0, 22.0, 0.0)],
+                        [(12.0, 10.0), (17.0, 15.0), (5.0, 11.0), (24.0, 22.0)],
+                        ped_xy=[(5.0, 5.0), (5.0, 6.0), (5.0, 7.0), (5.0, 8.0), (5.0, 9.0)]))
+        obs, ped = w.grids()
+        assert [int(ped[10, n]) for n in (10, 12, 14, 16, 18)] == [0, 1, 2, 1, 1]
+        assert sorted(map(tuple, np.argwhere(ped != obs))) == [(10, 16), (10, 18)]
+        g0, g1 = w.private_grid(0), w.private_grid(1)
+        assert g0[20, 20] == 255 and g1[20, 20] == 2      # R0: invisible to itself, a 2 for R1
+        assert g0[30, 30] == 2 and g1[30, 30] == 100      # R1 on a 100: a 2 for the others, the bare map for itself
+        assert g0[10, 18] == 1 and g1[10, 18] == 1        # R2 stands on a pedestrian cell: the 1 stays
+        assert g0[44, 44] == 0 and g1[44, 44] == 0        # R3 stands on an obstacle: the 0 stays
+        expect0 = ped.copy()
+        expect0[30, 30] = 2
+        assert np.array_equal(g0, expect0)                # nothing else differs from peds_map
+        s = w.snapshot()
+        assert list(s["is_collisions"]) == [0, 0, 2, 1]   # R2 on the pedestrian: code 2; R3 on the obstacle: code 1
+    finally:
+        w.close()
+
+
+def test_collision_code_is_that_of_the_last_footprint_sample_that_hits(oracle_lib):
+    """Agent::draw overwrites is_collision with every occupied cell a sample falls on and returns the LAST value (agent.cpp:294-326);
+    the samples of a disc are generated x-major, ascending (agent.cpp:18-30), the very last one being (+0.17, 0).
+
+    0.25 m cells, robot centre at x = 10.125 = the boundary between rows 40 and 41 (10.125 / 0.25 = 40.5 rounds away from zero to
+    41), y = 10.0 (column 40).  Row 40 column 40 holds a literal 1 ("pedestrian", code 2), row 41 column 40 a 0 (code 1).  Heading
+    0: the last sample lies at world (10.295, 10.0) -> row 41 -> code 1.  Heading pi (qz = 1, qw = 0: the rotation is exactly -I): it
+    lies at (9.955, 10.0) -> row 40 -> code 2, although the footprint covers the same cells."""
+    for (qz, qw), code in (((0.0, 1.0), 1), ((1.0, 0.0), 2)):
+        grid = np.full((80, 80), 255, np.uint8)
+        grid[40, 40] = 1
+        grid[41, 40] = 0
+        params = worldgen.make_params(1, 0, res=0.25)
+        w = OracleWorld(params, grid)
+        try:
+            lay = _layout([(10.125, 10.0, 0.0)], [(15.0, 10.0)])
+            lay.robot_pose[0, 2:] = (qz, qw)
+            w.reset(lay)
+            assert w.snapshot()["is_collisions"][0] == code, (qz, qw)
+        finally:
+            w.close()
+
+
+def test_crop_gate_of_a_seven_by_seven_view_cell_by_cell(oracle_lib):
+    """The crop of Agent::view (agent.cpp:366-404) with view_angle -+0.9 rad and view_min_dist 0.4 on a 7 x 7 view of 0.5 m cells,
+    no laser (the view_map is then the crop + the own footprint, agent.cpp:503).
+
+    T_view->base has its origin at (1.75, 1.75) and yaw 3.14159 (agent.cpp:84-88), so view cell (i, j) lies at base
+    (xb, yb) = (1.75 - 0.5 i, 1.75 - 0.5 j) up to 3e-6.  A cell passes iff -0.9 < atan2(yb, xb) < 0.9 (tan 0.9 = 1.26) and
+    0.4 <= xb <= 10:  row 0 (xb 1.75): |yb| <= 1.75 -> all seven;  row 1 (xb 1.25): |yb| < 1.575 -> j = 1 .. 6 (yb = 1.75 fails);
+    row 2 (xb 0.75): |yb| < 0.945 -> j = 2 .. 5;  rows 3 .. 6: xb <= 0.25 < 0.4 -> none.  Everything else keeps 200.
+    Robot at (10.25, 10.25), heading 0: view cell (i, j) looks at world (12 - 0.5 i, 12 - 0.5 j) = grid cell (24 - i, 24 - j); a grid
+    value < 250 gives 0, >= 250 gives 255 (agent.cpp:394-401).  Own footprint: base (x, y) -> view cell round(3.5 - 2 x), x in
+    [-0.17, 0.17] -> 3 or 4: the four centre cells become 100 (they hold 200, not 0 / 1 / 2)."""
+    grid = np.full((48, 48), 255, np.uint8)
+    grid[24, 24] = 0      # view (0, 0): passes -> 0
+    grid[23, 24] = 0      # view (1, 0): outside the angle gate -> stays 200
+    grid[22, 21] = 0      # view (2, 3): passes -> 0
+    grid[24, 20] = 100    # view (0, 4): < 250 -> 0
+    grid[24, 19] = 250    # view (0, 5): >= 250 -> 255
+    grid[24, 18] = 249    # view (0, 6): -> 0
+    grid[20, 24] = 0      # view (4, 0): behind the min-distance gate -> 200
+    grid[22, 18] = 0      # view (2, 6): outside the angle gate -> 200
+    params = worldgen.make_params(1, 0, res=0.5, view_cells=7, beams=0, use_laser=False, view_angle_begin=-0.9, view_angle_end=0.9,
+                                  view_min_dist=0.4)
+    w = OracleWorld(params, grid)
+    try:
+        w.reset(_layout([(10.25, 10.25, 0.0)], [(14.0, 10.25)]))
+        vm = w.snapshot()["view_maps"][0]
+        U, F, O, S = 200, 255, 0, 100
+        assert vm.tolist() == [[O, F, F, F, O, F, O],
+                               [U, F, F, F, F, F, F],
+                               [U, U, F, O, F, F, U],
+                               [U, U, U, S, S, U, U],
+                               [U, U, U, S, S, U, U],
+                               [U, U, U, U, U, U, U],
+                               [U, U, U, U, U, U, U]]
+        assert w.snapshot()["is_collisions"][0] == 0
+    finally:
+        w.close()
+
+
+def test_get_corners_of_both_shapes(oracle_lib):
+    """Agent::get_corners (agent.cpp:626-651): circle [cx, cy, r] -> base corners (cx - r, cy - r), (cx + r, cy + r); rectangle
+    [xmin, xmax, ymin, ymax] -> (xmin, ymin), (xmax, ymax); both through base -> world.
+    Circle [0.1, -0.2, 0.3] at (5, 7) heading pi / 2 ((x, y) -> (-y, x)): pa = (5 + 0.5, 7 - 0.2), pb = (5 - 0.1, 7 + 0.4).
+    Rectangle [-0.3, 0.5, -0.1, 0.2] at (1, 2) with the 3-4-5 rotation (cos 0.6, sin 0.8): pa = (1 - 0.18 + 0.08, 2 - 0.24 - 0.06),
+    pb = (1 + 0.30 - 0.16, 2 + 0.40 + 0.12)."""
+    import ctypes as C
+    oracle_lib.oracle_test_corners.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    oracle_lib.oracle_test_corners.restype = None
+    out = np.zeros(4)
+    sizes = np.array([0.1, -0.2, 0.3, 0.0])
+    oracle_lib.oracle_test_corners(_cabi.SHAPE_CIRCLE, sizes.ctypes.data, 5.0, 7.0, np.pi / 2, out.ctypes.data)
+    assert out == pytest.approx([5.5, 6.8, 4.9, 7.4], abs=1e-12)
+    sizes = np.array([-0.3, 0.5, -0.1, 0.2])
+    oracle_lib.oracle_test_corners(_cabi.SHAPE_RECTANGLE, sizes.ctypes.data, 1.0, 2.0, np.arctan2(0.8, 0.6), out.ctypes.data)
+    assert out == pytest.approx([0.9, 1.7, 1.14, 2.52], abs=1e-12)
+    oracle_lib.oracle_test_corners(_cabi.SHAPE_RECTANGLE, sizes.ctypes.data, 1.0, 2.0, 0.0, out.ctypes.data)
+    assert out.tolist() == [0.7, 1.9, 1.5, 2.2]
+
+
+def test_leg_gait_over_two_cycles_of_its_state_machine(oracle_lib):
+    """PedAgent::update_bbox (agent.cpp:696-735), step_len_ 0.3: state = int((move + remaining) / 0.3 + last), remaining carries
+    what is left, state %= 7; legs: states 0 / 4 at their sizes, 1 / 3 left -0.15 right +0.15, 2 left -0.3 right +0.3, 5 left
+    +0.15 right -0.15, 6 left +0.3 right -0.3 (only x changes; y keeps +-0.1).
+
+    A recorded walk (dataset scene, img_env.cpp:361-386) along +x, 7 / 32 m per record, heading atan2(0, vx) = 0.  Step s uses record
+    s - 1 (step_ counts from 0), so after step s the pedestrian has walked c = (s - 1) 7 / 32 and state = floor(c / 0.3) mod 7:
+      s      1  2       3       4        5      6        7       8        9     10       11      12       13      14
+      c      0  .21875  .4375   .65625   .875   1.09375  1.3125  1.53125  1.75  1.96875  2.1875  2.40625  2.625   2.84375
+      state  0  0       1       2        2      3        4       5        5     6        0       1        1       2
+    (no c is within 0.0125 of a multiple of 0.3, so rounding cannot move a state).  Checked through the raster: 1 / 16 m cells, the
+    left leg's cells lie in columns > y / res, the right leg's below, and each leg's mean row is its centre (x + leg x) / res."""
+    res, y0, x0, dx = 0.0625, 10.0, 10.0, 7.0 / 32.0
+    grid = np.full((400, 400), 255, np.uint8)
+    params = worldgen.make_params(1, 1, res=res, scene="dataset", ped_shape="leg", relation_ped_robo=0)
+    T = 16
+    data = np.zeros((1, T, 5))
+    data[0, :, 0] = x0 + dx * np.arange(T)
+    data[0, :, 1] = y0
+    data[0, :, 3] = 0.5
+    from img_env_amd import spawn
+    lay = _layout([(20.0, 20.0, 0.0)], [(22.0, 20.0)], ped_xy=[(x0, y0)])
+    spawn.init_ped_dataset(lay, data)
+    expect = [0, 0, 1, 2, 2, 3, 4, 5, 5, 6, 0, 1, 1, 2]
+    leg_x = {0: (0.0, 0.0), 4: (0.0, 0.0), 1: (-0.15, 0.15), 3: (-0.15, 0.15), 2: (-0.3, 0.3), 5: (0.15, -0.15), 6: (0.3, -0.3)}
+    w = OracleWorld(params, grid)
+    try:
+        w.reset(lay)
+        for s, st in enumerate(expect, start=1):
+            w.step(np.zeros((1, 3), np.float32))
+            _, ped = w.grids()
+            cells = np.argwhere(ped == 1)
+            x = x0 + dx * (s - 1)
+            left, right = cells[cells[:, 1] > y0 / res], cells[cells[:, 1] < y0 / res]
+            assert len(left) >= 6 and len(right) >= 6, s
+            lx, rx = leg_x[st]
+            assert abs(left[:, 0].mean() * res - (x + lx)) < 0.5 * res, (s, st, left[:, 0].mean() * res - x)
+            assert abs(right[:, 0].mean() * res - (x + rx)) < 0.5 * res, (s, st, right[:, 0].mean() * res - x)
+            assert abs(left[:, 1].mean() * res - (y0 + 0.1)) < 0.5 * res and abs(right[:, 1].mean() * res - (y0 - 0.1)) < 0.5 * res
+    finally:
+        w.close()
