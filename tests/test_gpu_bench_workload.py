@@ -91,7 +91,9 @@ def test_timed_workload_matches_oracle_across_an_episode_and_its_reset(worlds, p
         assert snap["counters"][0] == 5  # five steps into the second episode
         frozen = ((snap["is_collisions"] != 0) | (snap["is_arrives"] != 0)).mean()
         if policy == "active":
-            assert frozen == 0.0  # v = 0: nobody collides or arrives, every robot-step runs the full view path (bench.py's `value`)
+            assert frozen < 0.05  # v = 0: no robot drives into anything; the few frozen ones were walked into by a pedestrian (bench.py's `frozen_fraction`)
+        else:
+            assert frozen > 0.5   # the reference's random policy freezes most robots of a shared world within an episode
         print("cfg-3 %s policy: %d comparisons over 106 steps and one reset, %.1f %% of the robots frozen at the end" % (policy, compared, 100 * frozen))
     finally:
         gpu.close()
