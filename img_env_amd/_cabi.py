@@ -17,6 +17,7 @@ KTYPE_DIFF, KTYPE_OMNI = 0, 1
 FLAG_PRIVATE_GRIDS = 1
 FLAG_COMPOSE_DENSE = 2
 FLAG_COMPOSE_SPARSE = 4
+FLAG_LAYER_SUM = 512  # the counting class layer wherever it can run (include/imgenv.h)
 FLAG_NO_VIEW_MAPS = 8  # imgenv_out.view_maps not wanted (include/imgenv.h)
 FLAG_VIEW_TILED = 32  # views through the tiled kernels (csrc/view_big.h) / through k_view, where both can run
 FLAG_VIEW_WAVE = 64

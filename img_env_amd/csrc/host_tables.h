@@ -487,6 +487,7 @@ struct PedClassHost {
     Pts bbox, left, right;
     std::vector<FpRow> bbox_rows, left_rows, right_rows;  // lattice rows (fp_rows.h) of the three sample lists
     double bbox_cy = 0;
+    int box_rad = 0;  // cells around the pedestrian's own cell that hold its footprint whatever the gait state (SUM mode's LDS box)
 };
 
 // PedAgent::init_shape (agent.cpp:666-685)
@@ -506,6 +507,13 @@ static void build_ped_class(PedClassHost& k, double res) {
         k.bbox = shape_rectangle(k.sizes);
         k.bbox_rows = build_fp_rows(k.bbox, 0.0, res);
     }
+    double ext = 0;
+    for (int q = 0; q < k.bbox.n(); q++) ext = std::max(ext, sqrt(k.bbox.x[q] * k.bbox.x[q] + k.bbox.y[q] * k.bbox.y[q]));
+    if (k.shape == IMGENV_SHAPE_LEG) {  // leg centres: x in {sizes, -+0.15, -+0.3} (update_bbox, agent.cpp:696-735; step_len_ 0.3), y as given
+        const double lx = std::max(0.3, std::max(fabs(k.sizes[0]), fabs(k.sizes[3]))), ly = std::max(fabs(k.sizes[1]), fabs(k.sizes[4]));
+        ext = sqrt(lx * lx + ly * ly) + std::max(k.sizes[2], k.sizes[5]) + 0.01;
+    }
+    k.box_rad = (int)ceil(ext / res) + 2;
 }
 
 // Python round(x, 2) (float.__round__ is a correctly rounded decimal rounding)

@@ -89,6 +89,7 @@ struct imgenv {
     size_t lds_view_big = 0;
     bool big_bits_in_lds = true;  // the crop bitmap of one robot fits the LDS next to the hit words
     int big_max_crop = 1, big_full_chunks = 1;
+    bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
     std::vector<double> tmp_d1;  // scratch of stage_world
@@ -680,9 +681,29 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         if (cfg->flags & IMGENV_FLAG_COMPOSE_DENSE) h->stamp = false;
         if ((cfg->flags & IMGENV_FLAG_COMPOSE_SPARSE) && RL == R) h->stamp = true;
         if (h->stamp && R >= STAMP_MAX_ROBOTS) h->stamp = false;
+        // ... and where the owner layers + k_compose used to be the answer, the counting layer is (round 5: no pass over every cell
+        // of every world per step, a robot that covers the same cells as a step ago issues no atomic at all) -- wherever it can
+        // run: the handle owns every robot (another rank's robots have no list to take themselves off again), every footprint
+        // fits the rasters' LDS box, views through k_view, and the word has room for the counts: 3 bits of base class, as many
+        // pedestrian bits as a world has pedestrians, the robot's index within its world, and at least 6 bits of robot count
+        auto bits = [](int v) { int b = 0; while ((1 << b) <= v) b++; return b; };  // bits to count up to v
+        const int id_bits = std::max(1, bits(h->Rw - 1)), pc_bits = bits(h->Pw);
+        bool fits = G < ((size_t)1 << 24) && 3 + pc_bits + 6 + id_bits <= 32;
+        for (const RobotClassHost& k : h->rcls) fits = fits && !k.big && (2 * k.box_rad + 1) * (2 * k.box_rad + 1) <= RASTER_BOX_CELLS;
+        for (const PedClassHost& k : h->pcls) fits = fits && (2 * k.box_rad + 1) * (2 * k.box_rad + 1) <= RASTER_BOX_CELLS;
+        const bool want_sum = (cfg->flags & IMGENV_FLAG_LAYER_SUM) != 0 || (!h->stamp && !(cfg->flags & IMGENV_FLAG_COMPOSE_DENSE));
+        h->sum = want_sum && fits && RL == R;
+        if (h->sum) {
+            h->stamp = false;
+            d.layer_sum = 1;
+            d.sum_pc_mask = (1u << pc_bits) - 1u;
+            d.sum_rc_shift = 3u + (uint32_t)pc_bits;
+            d.sum_id_shift = 32u - (uint32_t)id_bits;
+            d.sum_wg_magic = (((unsigned long long)1 << 40) + (unsigned long long)Wg - 1) / (unsigned long long)Wg;
+        }
     }
     d.stamp_tag = 1;
-    if (!h->stamp) {
+    if (!h->stamp && !h->sum) {
         TRY(dev_alloc(h, &d.ped_layer, Gp));
         TRY(dev_alloc(h, &d.own_lo, Gp, 0xFF));
         TRY(dev_alloc(h, &d.own_hi, Gp));
@@ -906,6 +927,15 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             if (side * side > RASTER_BOX_CELLS) continue;
             box = std::max(box, side * side);
             cap = std::max(cap, std::min(side * side, k.fp.n()));
+        }
+        if (h->sum) {  // the pedestrians' boxes share the rasters' LDS, and every pedestrian keeps the list of the cells it counts itself on
+            int pbox = 1;
+            for (const PedClassHost& k : h->pcls) pbox = std::max(pbox, (2 * k.box_rad + 1) * (2 * k.box_rad + 1));
+            d.pd_cap = pbox;
+            d.ped_box_cells = pbox;
+            box = std::max(box, pbox);
+            TRY(dev_alloc(h, &d.pd_cells, (size_t)(P > 0 ? P : 1) * pbox));
+            TRY(dev_alloc(h, &d.pd_n, P > 0 ? P : 1));
         }
         d.box_cells = box;
         d.fp_cap = cap;
@@ -1299,6 +1329,7 @@ static int check_device_flags(imgenv* h) {
         FAIL(IMGENV_EDEVICE, "device-side auto-reset: a finished world could not be given its placement (code %d: 100 the pool did not hold it; "
                              "1 a fixed start with a random target; 2-4 no admissible placement within 200000 draws; 10-16 the RVO obstacle tree "
                              "outgrew its scratch)", e[2]);
+    if (e[6]) FAIL(IMGENV_EDEVICE, "class layer (counts): a pedestrian's footprint left its raster box or its cell list (code %d)", e[6]);
     if (e[4])
         FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth) -- more than "
                              "8 agents piled up outside the tree's 10 m x 10 m root square, where the reference recurses forever "
@@ -1414,21 +1445,23 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             const int split = (small || roomy || force_split > 0) && n_g > 0 && n_p > 0 ? n_g : 0;
             const dim3 gr(split || moved ? n_g + n_p : n_blocks), br(small ? 4 * WAVE : WAVE);
             const size_t lds = 4 * (size_t)d.box_cells + 16;
-            const int variant = (h->pow2 ? 2 : 0) | (h->stamp ? 1 : 0);
+            const int variant = (h->pow2 ? 3 : 0) + (h->stamp ? 1 : h->sum ? 2 : 0);
             // (k_move_raster: the step's move in the same launch -- the RVO / recorded pedestrians' too; a social-force crowd has moved in k_sfm)
             const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = h->elapsed - 1;
-#define RASTER_CASE(N, P2, ST)                                                                                    \
+#define RASTER_CASE(N, P2, LM)                                                                                    \
         case N:                                                                                                       \
-            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
-            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
-            else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
-            else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, ST, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
+            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
+            else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
             break;
             switch (variant) {
-                RASTER_CASE(3, true, true)
-                RASTER_CASE(2, true, false)
-                RASTER_CASE(1, false, true)
-                RASTER_CASE(0, false, false)
+                RASTER_CASE(5, true, 2)
+                RASTER_CASE(4, true, 1)
+                RASTER_CASE(3, true, 0)
+                RASTER_CASE(2, false, 2)
+                RASTER_CASE(1, false, 1)
+                RASTER_CASE(0, false, 0)
             }
 #undef RASTER_CASE
         }
@@ -1497,7 +1530,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     }
     if (!moved)
         if (int rc = rasters()) return rc;
-    if (!h->stamp) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
+    if (!h->stamp && !h->sum) TIMED(h, IMGENV_K_COMPOSE, st, (k_compose<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
     if (h->big_view) {  // view_big.h: crop (tiles of every robot spread over the chip) -> beams (a workgroup per robot and 256
                         // beams) -> the shrunk sensor_map (a thread per pixel) -> the full view, only where it is an output
         const int quarters = std::max(1, (d.B + VBB_T - 1) / VBB_T), tap_chunks = (d.img_w * d.img_h + VBT_T - 1) / VBT_T;
@@ -1730,15 +1763,17 @@ __global__ __launch_bounds__(256) void k_reset_apply(DevWorld w, ResetArgs a) {
         for (size_t e = (size_t)(b - q * MAP_BLOCKS) * blockDim.x + threadIdx.x; e < n16; e += (size_t)MAP_BLOCKS * blockDim.x) {
             const uint4 v = ((const uint4*)a.static_map)[e];
             dst[e] = v;
-            if (a.stamp) {  // base class of 16 cells, no stamp
+            if (a.stamp) {  // base class of 16 cells, no stamp (2, SUM mode: the counts on the cells stay -- their owners take them off)
                 const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     uint32_t c4[4];
+                    const uint4 old = a.stamp == 2 ? cls[4 * e + k] : make_uint4(0, 0, 0, 0);
+                    const uint32_t keep[4] = {old.x & ~7u, old.y & ~7u, old.z & ~7u, old.w & ~7u};
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t o = (wd[k] >> (8 * j)) & 0xFFu;
-                        c4[j] = o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH);
+                        c4[j] = (o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH)) | keep[j];
                     }
                     cls[4 * e + k] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
                 }
@@ -1806,7 +1841,8 @@ __global__ __launch_bounds__(256) void k_reset_obstacles(DevWorld w, const ObstI
                 const size_t at = (size_t)gm * w.Wg + gn;
                 if (map[at] > 2) {
                     map[at] = 0;
-                    if (stamp) w.cell[(size_t)o.world * w.Gs + at] = CLS_STATIC;  // the class layer's base class follows
+                    if (stamp == 1) w.cell[(size_t)o.world * w.Gs + at] = CLS_STATIC;  // the class layer's base class follows
+                    else if (stamp == 2) w.cell[(size_t)o.world * w.Gs + at] &= ~7u;        // (SUM mode: the counts stay; every writer of this cell writes the same word)
                     if (w.crop_map) w.crop_map[(size_t)o.world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = 0;  // ... and view_big.h's byte: not free, no stamp
                 }
             }
@@ -2136,15 +2172,15 @@ static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int w
         a.n_robots = d.act_ng;
         a.n_peds = d.act_np;
         a.whole = whole;
-        a.stamp = h->stamp ? 1 : 0;
+        a.stamp = h->stamp ? 1 : h->sum ? 2 : 0;
         const size_t blocks = (size_t)a.n_seg * a.per_seg + (size_t)a.n_worlds * MAP_BLOCKS + (a.n_robots + 255) / 256 + (a.n_peds + 255) / 256;
         k_reset_apply<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d, a);
         h->segs.clear();
         h->seg_max = 0;
     }
     if (n_inst) {
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0, 1, nullptr, nullptr);
-        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : 0, nullptr, 0, 1, nullptr, nullptr);
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : h->sum ? 2 : 0, nullptr, 0, 1, nullptr, nullptr);
+        else k_reset_obstacles<false><<<dim3((unsigned)n_inst), dim3(256), 0, st>>>(d, (const ObstInst*)h->d_oinst, h->stamp ? 1 : h->sum ? 2 : 0, nullptr, 0, 1, nullptr, nullptr);
     }
     if (d.sharded) k_reset_bbox<<<dim3((h->RL + 255) / 256), dim3(256), 0, st>>>(d, h->pin_rob3);
     HIPCHK(hipGetLastError());
@@ -2738,12 +2774,12 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
     const int last_n = h->finished_host[0];  // (page-locked, written by k_finished_dev: stale by a step or two)
     const int guess = std::min(W, std::max(16, 4 * std::max(last_n, 0)));
     const int restore_blocks = 4 * MAP_BLOCKS;  // per world
-    if (h->pow2) k_restore_maps_dev<true><<<dim3((unsigned)(guess * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
-    else k_restore_maps_dev<false><<<dim3((unsigned)(guess * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : 0, restore_blocks);
+    if (h->pow2) k_restore_maps_dev<true><<<dim3((unsigned)(guess * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : h->sum ? 2 : 0, restore_blocks);
+    else k_restore_maps_dev<false><<<dim3((unsigned)(guess * restore_blocks)), dim3(256), 0, st>>>(d, c, h->d_static_map, h->stamp ? 1 : h->sum ? 2 : 0, restore_blocks);
     if (nob > 0) {
         const int parts = 4;
-        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)(guess * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
-        else k_reset_obstacles<false><<<dim3((unsigned)(guess * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
+        if (h->pow2) k_reset_obstacles<true><<<dim3((unsigned)(guess * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : h->sum ? 2 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
+        else k_reset_obstacles<false><<<dim3((unsigned)(guess * nob * parts)), dim3(256), 0, st>>>(d, c.inst_out, h->stamp ? 1 : h->sum ? 2 : 0, c.fin_n, nob, parts, c.w_inst, c.w_inst_valid);
     }
     HIPCHK(hipGetLastError());
     if (h->stamp) {

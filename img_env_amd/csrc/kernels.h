@@ -202,6 +202,15 @@ __device__ __forceinline__ uint32_t cell_seen_class(uint32_t v, uint32_t self, u
     if (base >= CLS_LOW && (kind == STAMP_MANY || (kind == STAMP_ONE && (v >> STAMP_OWNER_SHIFT) != self))) return CLS_TWO;
     return base;
 }
+// ... and in SUM mode (world.h): counts instead of stamps.  self_w: the robot's index within its world
+__device__ __forceinline__ uint32_t cell_seen_class_sum(const DevWorld& w, uint32_t v, uint32_t self_w) {
+    const uint32_t base = v & 7u;
+    if ((v >> 3) & w.sum_pc_mask) return CLS_PED;
+    const uint32_t rx = v >> w.sum_rc_shift, mine = 1u | (self_w << (w.sum_id_shift - w.sum_rc_shift));
+    if (base >= CLS_LOW && rx != 0u && rx != mine) return CLS_TWO;
+    return base;
+}
+__device__ __forceinline__ uint32_t sum_robot_word(const DevWorld& w, uint32_t self_w) { return (1u << w.sum_rc_shift) + (self_w << w.sum_id_shift); }
 // per-step values: kernel arguments, or (replayed chains) the device-side counters k_tick advances
 __device__ __forceinline__ int tail_elapsed_of(const DevWorld& w) { return w.step_vars ? w.step_vars[0] : w.tail_elapsed; }
 __device__ __forceinline__ uint32_t stamp_tag_of(const DevWorld& w) { return w.step_vars ? (uint32_t)w.step_vars[1] % STAMP_TAGS + 1u : w.stamp_tag; }
@@ -1315,6 +1324,138 @@ __device__ __forceinline__ bool ped_rows(const DevWorld& w, const Tf2& bw, const
     return !__any(bad);
 }
 
+// SUM mode (world.h): the pedestrian's footprint goes into an LDS box around its cell -- which leg covers what (the legs' skip
+// rules differ, agent.cpp:751 / 767) --, the box cells that pass their rule are what view_ped would have drawn, and the
+// pedestrian's count comes off the cells it no longer draws on and goes onto the new ones.  A pedestrian that stands still
+// issues no atomic at all.
+template <bool POW2, int NW>
+__device__ __forceinline__ void raster_ped_sum(const DevWorld& w, int j, const PedClassDev& k, uint32_t* box) {
+    constexpr int NT = WAVE * NW;
+    const int world = world_of_ped(w, j), tid = threadIdx.x, lane = lane_id();
+    const uint32_t cell0 = (uint32_t)world * w.Gs;
+    const double res = w.res, inv = w.inv_res;
+    const double px = w.ppx[j], py = w.ppy[j];
+    const Tf2 bw = tf_from_pose(px, py, w.pyaw[j]);
+    const int rad = k.box_rad, side = 2 * rad + 1, ncell = side * side;
+    const int cm = w2m_t<POW2>(px, res, inv), cn = w2m_t<POW2>(py, res, inv);
+    uint32_t* n_sh = box + w.box_cells + 1;  // (the words behind the box: see raster_robot)
+    for (int q = tid; q < ncell; q += NT) box[q] = 0;
+    if (tid == 0) *n_sh = 0;
+    __syncthreads();
+    const int Hg = w.Hg, Wg = w.Wg;
+    int* err = w.err;
+    auto mark = [&](int m, int n, uint32_t bit) {
+        if (m < 0 || m >= Hg || n < 0 || n >= Wg) return;
+        const int dm = m - cm + rad, dn = n - cn + rad;
+        if (dm >= 0 && dm < side && dn >= 0 && dn < side) atomicOr(&box[dm * side + dn], bit);
+        else err[6] = 1;  // (cannot happen: the box is the footprint's extent in every gait state + 2 cells)
+    };
+    const bool leg_shape = k.shape == IMGENV_SHAPE_LEG;
+    for (int part = 0; part < (leg_shape ? 2 : 1); part++) {
+        if (!leg_shape && k.shape != IMGENV_SHAPE_CIRCLE) break;  // (view_ped draws discs and legs only, img_env.cpp:599-616)
+        Tf2 lb;  // get_leg_base (agent.cpp:815-821): a pure translation
+        tf_set_rotation_zw(lb, 0.0, 1.0);
+        lb.ox = !leg_shape ? 0.0 : part == 0 ? w.llx[j] : w.rlx[j];
+        lb.oy = !leg_shape ? 0.0 : part == 0 ? w.lly[j] : w.rly[j];
+        const FpRow* rows = !leg_shape ? k.brows : part == 0 ? k.lrows : k.rrows;
+        const int n_rows = !leg_shape ? k.n_brows : part == 0 ? k.n_lrows : k.n_rrows;
+        const double* sx = !leg_shape ? k.bx : part == 0 ? k.lx : k.rx;
+        const double* sy = !leg_shape ? k.by : part == 0 ? k.ly : k.ry;
+        const int n_s = !leg_shape ? k.n_bbox : part == 0 ? k.n_left : k.n_right;
+        const uint32_t bit = part == 0 ? 1u : 2u;
+        bool bad = n_rows == 0;
+        if (n_rows > 0) {  // lattice rows (fp_rows.h), one per lane
+            const FpRowsPose P = fpr_pose(bw.m00, bw.m01, bw.m10, bw.m11, bw.ox, bw.oy, leg_shape ? lb.oy : k.bbox_cy, res);
+            for (int r0 = 0; r0 < n_rows; r0 += NT) {
+                const int ri = r0 + tid;
+                FpRow row = rows[min(ri, n_rows - 1)];
+                row.px = row.px + lb.ox;
+                FpAxis ax, ay;
+                const bool ok = fpr_row(P, row, ax, ay);
+                bad |= ri < n_rows && !ok;
+                const bool use = ri < n_rows && ok;
+                const int cx = use ? ax.cnt : 0, cyn = use ? ay.cnt : 0;
+                const int cxw = (int)__any(cx >= 1) + (int)__any(cx >= 2) + (int)__any(cx >= 3) + (int)__any(cx >= 4);
+                const int cyw = (int)__any(cyn >= 1) + (int)__any(cyn >= 2) + (int)__any(cyn >= 3) + (int)__any(cyn >= 4);
+#pragma unroll
+                for (int a = 0; a <= FPR_MAXC; a++) {
+                    if (a > cxw) break;
+#pragma unroll
+                    for (int b = 0; b <= FPR_MAXC; b++) {
+                        if (b > cyw) break;
+                        int m, n;
+                        uint32_t last;
+                        if (fpr_piece(row, ax, ay, a, b, m, n, last) && use) mark(m, n, bit);
+                    }
+                }
+            }
+        }
+        if (__any(bad)) {  // this wavefront walks the whole list itself (marks are idempotent)
+            for (int q = lane; q < n_s; q += WAVE) {
+                double bx = sx[q], by = sy[q], wx, wy;
+                if (leg_shape) tf_apply(lb, sx[q], sy[q], bx, by);
+                tf_apply(bw, bx, by, wx, wy);
+                int m, n;
+                w2m_pair<POW2>(wx, wy, res, inv, m, n);
+                mark(m, n, bit);
+            }
+        }
+    }
+    __syncthreads();
+    // what view_ped draws: a disc skips cells holding 0 / 1 / 2, a left leg cells holding 0, a right leg nothing (agent.cpp:313-320, 751, 767)
+    for (int b = tid; b < ncell; b += NT) {
+        const uint32_t f = box[b];
+        if (f) {
+            const int bm = b / side;
+            const uint32_t c = cell0 + (uint32_t)(cm - rad + bm) * (uint32_t)Wg + (uint32_t)(cn - rad + (b - bm * side));
+            const uint32_t base = w.cell[c] & 7u;
+            const bool draws = leg_shape ? ((f & 2u) != 0u || base != CLS_STATIC) : base >= CLS_LOW;
+            if (draws) box[b] = f | 4u;
+        }
+    }
+    __syncthreads();
+    const uint32_t one = 1u << 3;
+    uint32_t* list = w.pd_cells + (size_t)j * w.pd_cap;
+    const int n_old = w.pd_n[j];
+    for (int e = tid; e < n_old; e += NT) {
+        const uint32_t c = list[e], rel = c - cell0;
+        const int m = (int)(((unsigned long long)rel * w.sum_wg_magic) >> 40), n = (int)rel - m * Wg;
+        const int dm = m - cm + rad, dn = n - cn + rad;
+        const bool inb = dm >= 0 && dm < side && dn >= 0 && dn < side;
+        const uint32_t f = inb ? box[dm * side + dn] : 0u;
+        if (f & 4u) atomicOr(&box[dm * side + dn], 8u);  // still drawn: the count stands
+        else atomicAdd(&w.cell[c], 0u - one);
+    }
+    __syncthreads();
+    int n_out = 0;
+    for (int b0 = 0; b0 < ncell; b0 += NT) {  // wave-uniform trip count (ballots inside)
+        const int b = b0 + tid;
+        const uint32_t f = b < ncell ? box[b] : 0u;
+        const bool go = (f & 4u) != 0u;
+        const int bm = b / side;
+        const uint32_t c = cell0 + (uint32_t)(cm - rad + bm) * (uint32_t)Wg + (uint32_t)(cn - rad + (b - bm * side));
+        if (go && !(f & 8u)) atomicAdd(&w.cell[c], one);
+        const unsigned long long mask = __ballot(go);
+        const int cnt = __popcll(mask);
+        int base = n_out;
+        if (NW > 1) {
+            if (lane == 0 && cnt) base = (int)atomicAdd(n_sh, (uint32_t)cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+        }
+        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (go && pos < w.pd_cap) list[pos] = c;
+        n_out += cnt;
+    }
+    if (NW > 1) {
+        __syncthreads();
+        n_out = (int)*n_sh;
+    }
+    if (tid == 0) {
+        w.pd_n[j] = min(n_out, w.pd_cap);
+        if (n_out > w.pd_cap) err[6] = 2;
+    }
+}
+
 template <bool POW2, bool STAMP, int NW>
 __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedClassDev& k, const Region& g) {
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
@@ -1362,8 +1503,10 @@ __device__ __forceinline__ void raster_ped(const DevWorld& w, int j, const PedCl
 // (cell, last sample) pairs go to fp_cells so that the collision test of k_view (agent.cpp:294-326:
 // the last footprint sample on an occupied cell decides) needs one gather per covered cell and no
 // second pass over the samples.
-template <bool POW2, bool STAMP, int NW>
+// LM: how the class layer is kept (world.h): 0 owner layers + k_compose, 1 stamps, 2 counts (SUM)
+template <bool POW2, int LM, int NW>
 __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const RobotClassDev& k, uint32_t* box, const Region& g) {
+    constexpr bool STAMP = LM == 1, SUM = LM == 2;
     constexpr int NT = WAVE * NW;  // NW wavefronts share the samples (see k_raster)
     constexpr int UB = NW > 1 ? 4 : 1;   // cells a lane stamps at once (stamp_robot_batch)
     RASTER_MARK_BEGIN();
@@ -1401,7 +1544,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         double* cached = w.fp_pose + 3 * (size_t)l;
         const int n_cached = w.fp_n[l];
         if (n_cached >= 0 && cached[0] == r[0] && cached[1] == r[1] && cached[2] == r[2]) {
-            if (alone) return;  // (the list stands, and there is nobody to stamp for)
+            if (alone || SUM) return;  // (the list stands, and there is nobody to stamp for -- or, SUM mode, the robot's counts stand with it)
             const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
             for (int e0 = 0; e0 < n_cached; e0 += NT * UB) {
                 uint32_t c[UB];
@@ -1516,7 +1659,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                     b = dm * side + dn;
                 } else {
                     const size_t c = (size_t)cell0 + (size_t)m * w.Wg + n;
-                    if (alone) {
+                    if (alone || SUM) {  // (SUM handles only have classes whose footprint fits the box: imgenv_create)
                     } else if (STAMP) {
                         stamp_robot(w, c, (uint32_t)i, stamp_tag_of(w), world);
                     } else {
@@ -1543,6 +1686,22 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         // of all four are read together and their compare-and-swaps go out together: stamp_robot_batch)
         uint2* list = w.fp_cells + (size_t)(local ? l : 0) * w.fp_cap;
         int n_out = 0;
+        const uint32_t sum_word = SUM ? sum_robot_word(w, (uint32_t)(i - world * w.Rw)) : 0u;
+        if (SUM && !alone) {
+            // the cells this robot counted itself on so far: still under its footprint -> marked in the box (top bit: nothing to add),
+            // left behind -> its word comes off again.  (Handles in SUM mode own every robot: `local` always holds.)
+            const int n_old = max(w.fp_n[l], 0);
+            for (int e = tid; e < n_old; e += NT) {
+                const uint32_t c = list[e].x, rel = c - cell0;
+                const int m = (int)(((unsigned long long)rel * w.sum_wg_magic) >> 40), n = (int)rel - m * w.Wg;
+                const int dm = m - cm + rad, dn = n - cn + rad;
+                const bool inb = dm >= 0 && dm < side && dn >= 0 && dn < side;
+                const uint32_t v = inb ? box[dm * side + dn] : 0u;
+                if (v) atomicOr(&box[dm * side + dn], 0x80000000u);
+                else atomicAdd(&w.cell[c], 0u - sum_word);
+            }
+            __syncthreads();
+        }
         for (int b0 = 0; b0 < ncell; b0 += NT * UB) {  // wave-uniform trip count (ballots inside)
             uint32_t c[UB], last[UB];
             bool go[UB];
@@ -1554,12 +1713,15 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 c[u] = 0u;
                 if (b0 + u * NT >= ncell) continue;  // uniform: a small box is one round
                 last[u] = b < ncell ? box[b] : 0u;
+                const bool counted = SUM && (last[u] >> 31) != 0u;
+                if (SUM) last[u] &= 0x7FFFFFFFu;
                 go[u] = last[u] != 0u;
                 const int bm = b / side;
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c[u] = go[u] ? cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n : 0u;
+                if (SUM && go[u] && !counted && !alone) atomicAdd(&w.cell[c[u]], sum_word);  // a cell the robot has just entered
             }
-            if (alone) {
+            if (alone || SUM) {
             } else if (STAMP) {
                 stamp_robot_batch<UB>(w, c, go, (uint32_t)i, stamp_tag_of(w), world);
             } else {
@@ -1600,26 +1762,32 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
 
 // NW: wavefronts per workgroup.  1 when a launch fills the machine; 4 in small launches (a reset of a few worlds), where the
 // 15 rounds of footprint samples of one wavefront are pure latency.
-template <bool POW2, bool STAMP, int NW>
-__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((STAMP || !POW2) ? 6 : 8, 8))) void k_raster(DevWorld w, int zero_vel, int split) {
+template <bool POW2, int LM, int NW>
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM == 1 || !POW2) ? 6 : 8, 8))) void k_raster(DevWorld w, int zero_vel, int split) {
+    constexpr bool STAMP = LM == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
     const int b = blockIdx.x;
     WAVE_T0();
-    if (STAMP && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // tail_group tallies this step's dones (k_compose does this otherwise)
+    if (LM != 0 && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // tail_group tallies this step's dones (k_compose does this otherwise)
     const Region g = grid_region(w);
     // split > 0 (small launches): the first `split` blocks draw robots, the ones behind them pedestrians -- a robot and a
     // pedestrian one after the other in the same block is twice one block's chain of memory round trips
     if (b < act_count_g(w) && (split == 0 || b < split)) {
         const int i = act_member(w, w.Rw, b);
-        raster_robot<POW2, STAMP, NW>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
+        raster_robot<POW2, LM, NW>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
     }
     const int bp = split > 0 ? b - split : b;
     if (bp >= 0 && bp < act_count_p(w)) {
         RASTER_MARK_BEGIN();
         const int j = act_member(w, w.Pw, bp);
-        raster_ped<POW2, STAMP, NW>(w, j, w.pc[w.ped_cls[j]], g);
+        if (LM == 2) {
+            if (split == 0) __syncthreads();  // (the robot of this block is done with the box)
+            raster_ped_sum<POW2, NW>(w, j, w.pc[w.ped_cls[j]], (uint32_t*)smem);
+        } else {
+            raster_ped<POW2, STAMP, NW>(w, j, w.pc[w.ped_cls[j]], g);
+        }
         RASTER_MARK(12);  // the block's pedestrian
     }
     if (b < w.RL) WAVE_DONE(2);
@@ -1632,12 +1800,13 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((STAM
 // moves behind this kernel, the observation and the solve then run underneath k_view.  (At 8192 robots that placement loses --
 // k_obs and k_view are both bound by vector issue, DESIGN.md section 4 -- so the big launches keep the two kernels.)
 // Blocks [0, R): robots, [R, R + P): pedestrians.
-template <bool POW2, bool STAMP, int NW>
+template <bool POW2, int LM, int NW>
 __global__ __launch_bounds__(WAVE * NW) void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int step, int move_peds) {
+    constexpr bool STAMP = LM == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double2 trig[INT_ITEMS];  // (cos, sin)
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (STAMP && b == 0 && tid == 0) w.counters[1] = 0;  // (as k_raster)
+    if (LM != 0 && b == 0 && tid == 0) w.counters[1] = 0;  // (as k_raster)
     const Region g = grid_region(w);
     if (b < w.R) {
         const int l = b;  // (every robot is local: r0 = 0)
@@ -1655,7 +1824,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_move_raster(DevWorld w, const flo
         }
         if (w.state_in_integrate && tid == 0) state_robot(w, l);  // no pedestrians, no side stream: get_state right behind the move
         __syncthreads();  // the new record, for every lane
-        raster_robot<POW2, STAMP, NW>(w, l, robot_class(w, cls), (uint32_t*)smem, g);
+        raster_robot<POW2, LM, NW>(w, l, robot_class(w, cls), (uint32_t*)smem, g);
     } else if (b - w.R < w.P) {
         const int j = b - w.R;
         const int cls = __builtin_amdgcn_readfirstlane(w.ped_cls[j]);
@@ -1666,7 +1835,8 @@ __global__ __launch_bounds__(WAVE * NW) void k_move_raster(DevWorld w, const flo
             }
             __syncthreads();
         }
-        raster_ped<POW2, STAMP, NW>(w, j, w.pc[cls], g);
+        if (LM == 2) raster_ped_sum<POW2, NW>(w, j, w.pc[cls], (uint32_t*)smem);
+        else raster_ped<POW2, STAMP, NW>(w, j, w.pc[cls], g);
     }
 }
 
@@ -1799,7 +1969,9 @@ __device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, co
         int m, n;
         w2m_pair<POW2>(wx, wy, res, inv, m, n);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
-            const uint32_t cc = cell_seen_class<STAMP>(w.cell[(size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n], self, stamp_tag_of(w));
+            const uint32_t v = w.cell[(size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n];
+            const uint32_t cc = (!STAMP && w.layer_sum) ? cell_seen_class_sum(w, v, self - (uint32_t)(world_of_robot(w, (int)self) * w.Rw))
+                                                        : cell_seen_class<STAMP>(v, self, stamp_tag_of(w));
             if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
         }
     }
@@ -1892,8 +2064,11 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     // (tested on the word with base and tag XORed against HIGH and our tag: a non-zero multiple of 32)
     const uint32_t tag = STAMP ? stamp_tag_of(w) : 0u;
     const uint32_t free_plain = CLS_HIGH;
+    const bool layer_sum = !STAMP && w.layer_sum != 0;  // (uniform) counts instead of owners: the same two compares per crop cell
+    const uint32_t self_w = self - (uint32_t)(world_of_robot(w, i) * (w.W > 1 ? w.Rw : 0));
     const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
-                                    : (CLS_HIGH | CLS_ROBOT | (self << 8));
+                              : layer_sum ? (CLS_HIGH + sum_robot_word(w, self_w))
+                                          : (CLS_HIGH | CLS_ROBOT | (self << 8));
     const uint32_t base_tag_mask = 7u | (0xFFu << STAMP_TAG_SHIFT), base_tag_ours = CLS_HIGH | (tag << STAMP_TAG_SHIFT);
     const uint32_t cell0 = (uint32_t)world_of_robot(w, i) * w.Gs;  // this world's copy of the layers
     uint8_t* src = smem;
@@ -1912,7 +2087,8 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
         const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
         for (int e = lane; e < n_cov; e += WAVE) {
             const uint2 ce = list[e];
-            const uint32_t cc = cell_seen_class<STAMP>(w.cell[ce.x], self, stamp_tag_of(w));
+            const uint32_t v = w.cell[ce.x];
+            const uint32_t cc = layer_sum ? cell_seen_class_sum(w, v, self_w) : cell_seen_class<STAMP>(v, self, stamp_tag_of(w));
             best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
         }
     } else {

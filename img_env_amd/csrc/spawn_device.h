@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c
                         const size_t at = (size_t)gm * w.Wg + gn;
                         const uint32_t v = static_map[at];
                         map[at] = (uint8_t)v;
-                        if (stamp) cell[at] = v <= 2 ? v : (v < 250 ? CLS_LOW : CLS_HIGH);
+                        if (stamp) cell[at] = (v <= 2 ? v : (v < 250 ? CLS_LOW : CLS_HIGH)) | (stamp == 2 ? cell[at] & ~7u : 0u);  // (SUM mode: the counts stay)
                         if (w.crop_map) w.crop_map[(size_t)world * w.crop_ws + crop_tiled(w, (uint32_t)gm, (uint32_t)gn)] = v >= 250 ? 128 : 0;  // (a stamp left on it has expired)
                     }
                 }
@@ -784,10 +784,12 @@ __global__ __launch_bounds__(256) void k_restore_maps_dev(DevWorld w, SpawnDev c
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     uint32_t c4[4];
+                    const uint4 old = stamp == 2 ? cls[4 * e + k] : make_uint4(0, 0, 0, 0);
+                    const uint32_t keep[4] = {old.x & ~7u, old.y & ~7u, old.z & ~7u, old.w & ~7u};
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t o = (wd[k] >> (8 * j)) & 0xFFu;
-                        c4[j] = o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH);
+                        c4[j] = (o <= 2 ? o : (o < 250 ? CLS_LOW : CLS_HIGH)) | keep[j];
                     }
                     cls[4 * e + k] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
                 }

@@ -38,6 +38,20 @@
 #define STAMP_MAX_ROBOTS (1 << 19)
 #define STAMP_TAGS 255
 
+// The same layer in SUM mode (round 5; dense worlds whose handle owns every robot): `cell` = the base class of the obstacle map
+// plus COUNTS of what stands on the cell, kept up to date by the agents themselves with fire-and-forget atomic adds -- every robot
+// and pedestrian remembers the cells it has added itself to (fp_cells / pd_cells) and, when it moves, subtracts itself from the
+// cells it left and adds itself to the ones it entered (nothing at all while it covers the same cells: a robot turning in
+// place, a frozen one, a pedestrian waiting at its goal).  No owner layers, no k_compose over every cell of every world per
+// step, no tags to expire.  Layout (field widths per handle: sum_rc_shift, sum_id_shift, sum_pc_mask):
+//   bits 0-2                      base class (written by the resets with read-modify-write: the counts stay)
+//   bits 3 .. rc_shift - 1        pedestrians on the cell that view_ped would have drawn there (at least bits(peds per world))
+//   bits rc_shift .. id_shift - 1 robots on the cell (at least 6 bits: 63 footprints on one cell)
+//   bits id_shift .. 31           sum of their indices within the world, modulo: THE robot when the count is 1
+// A robot adds (1 << rc_shift) + (index << id_shift); what it later subtracts is the same word, so the arithmetic is exact
+// modulo 2^32 whatever the index sums do.  The view's crop still decides a cell with one gather and two compares: free iff the
+// word is `CLS_HIGH` or `CLS_HIGH + this robot's own word`.
+
 // Everything of a robot class that does not depend on the pose: footprint samples
 // (agent.cpp:18-62), field-of-view mask of the crop (agent.cpp:373-386), Bresenham ray paths of
 // the laser (agent.cpp:405-438, 511-624) and the own-footprint stamp (agent.cpp:503).
@@ -101,6 +115,7 @@ struct PedClassDev {
     int n_left, n_right;  // leg samples (circles of radius lr / rr around 0,0)
     const double *lx, *ly, *rx, *ry;
     double sizes[6];
+    int box_rad;                             // SUM mode: half-size (cells) of the LDS box around the pedestrian's cell that holds its footprint in every gait state
     int n_brows, n_lrows, n_rrows;           // lattice rows (fp_rows.h) of the three sample lists; 0: walk the samples
     const FpRow *brows, *lrows, *rrows;
     double bbox_cy;
@@ -161,6 +176,12 @@ struct DevWorld {
     uint32_t* own_hi;        // max (robot index + 1) covering the cell, 0 = none
     uint32_t* cell;          // composed layer: class byte | (owning robot or OWNER_MULTI) << 8, one gather per lookup
                              // (STAMP mode: base class | this step's stamp, and the three layers above do not exist)
+    int layer_sum;           // SUM mode (above): ped_layer / own_lo / own_hi do not exist, k_compose never runs
+    uint32_t sum_rc_shift, sum_id_shift, sum_pc_mask;
+    unsigned long long sum_wg_magic;  // ceil(2^40 / Wg): row of a cell index below 2^24
+    uint32_t* pd_cells;      // [P][pd_cap] SUM mode: the cells each pedestrian has added itself to ...
+    int* pd_n;               // [P] ... and their number
+    int pd_cap, ped_box_cells;
     uint8_t* seg_tag;        // STAMP mode: [cells / 64] tag of the last step that stamped a cell of the segment
     // STAMP mode with big views (view_big.h): everything k_crop_big needs of a cell in ONE byte, in 8 x 8-cell blocks so that a
     // rotated 8 x 8 tile of the view touches 4-6 half cache lines instead of a dozen map rows: bit 7 = the obstacle map leaves

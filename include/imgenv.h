@@ -164,6 +164,12 @@ typedef struct imgenv_cfg {
  * their step, nothing per cell, best for big or many maps with few agents each.  The result is the same either way. */
 #define IMGENV_FLAG_COMPOSE_DENSE 2
 #define IMGENV_FLAG_COMPOSE_SPARSE 4
+/* (round 5) Where DENSE used to be the library's pick it now keeps COUNTS on the class layer instead: every robot and pedestrian adds
+ * itself to the cells it covers and takes itself off the ones it leaves (fire-and-forget atomics, none at all while it covers
+ * the same cells), so no pass over every cell merges anything per step.  IMGENV_FLAG_COMPOSE_DENSE still asks for the owner
+ * layers + the per-step merge; IMGENV_FLAG_LAYER_SUM asks for the counting layer wherever it can run (the handle owns every
+ * robot, views through k_view), also where the library would have stamped.  Same results in every mode. */
+#define IMGENV_FLAG_LAYER_SUM 512
 /* imgenv_out.view_maps is not wanted.  It only matters where the view is shrunk into the sensor_map (image_size differs from
  * the view size, every shipped config of the reference: a 400 x 400 view, 160 KB per robot, behind a 48 x 48 sensor_map):
  * the library then evaluates only the 4 x 4 view cells each sensor_map pixel reads and never writes the full-size view;

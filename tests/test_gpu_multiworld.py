@@ -230,10 +230,11 @@ def test_one_world_reset_grows_the_shared_tables(worlds):
             c.close()
 
 
-@pytest.mark.parametrize("flags", [2, 4], ids=["composed_layer", "stamped_layer"])
+@pytest.mark.parametrize("flags", [2, 4, 512], ids=["composed_layer", "stamped_layer", "counting_layer"])
 def test_compose_modes_give_the_same_worlds(worlds, flags):
-    """the class layer composed every step from owner layers, or stamped directly by the rasters (STAMP mode): crowded
-    worlds, legs, per-world resets, a map width that is not a multiple of the tile"""
+    """the class layer composed every step from owner layers, stamped directly by the rasters (STAMP mode), or kept as counts
+    by the agents themselves (SUM mode, world.h): crowded worlds, legs, per-world resets, a map width that is not a multiple of
+    the tile"""
     World, OracleWorld = worlds
     fails, _, _ = _run(World, OracleWorld, 4, 12, 9, 30, {5: [1], 6: [1, 3], 20: [0, 1, 2, 3]}, seed=35, n_obstacles=3, ped_shape="leg",
                        grid_size=100, clearance=0.6, flags=flags)
@@ -264,7 +265,7 @@ def test_fuzzed_world_batches_match_one_oracle_each(worlds, seed):
               beams=int(rng.choice([90, 360])), scene=scene, ped_shape=str(rng.choice(["circle", "leg"])),
               relation_ped_robo=int(rng.integers(0, 2)), time_max=int(rng.integers(5, 14)), dt=float(rng.choice([0.25, 0.4])),
               grid_size=int(np.ceil(extent / res)) | int(rng.integers(0, 2)), n_obstacles=int(rng.integers(0, 4)),
-              clearance=float(rng.choice([0.6, 0.8])), flags=int(rng.choice([0, 2, 4])))
+              clearance=float(rng.choice([0.6, 0.8])), flags=int(rng.choice([0, 2, 4, 512])))
     fails, _, _ = _run(World, OracleWorld, W, Rw, Pw, steps, resets, seed=300 + seed, whole_reset=bool(rng.random() < 0.3), **kw)
     assert not fails, (seed, W, Rw, Pw, kw, fails[:2])
 
@@ -303,6 +304,19 @@ def test_stamped_layer_survives_its_tag_coming_round(worlds):
     World, OracleWorld = worlds
     fails, _, _ = _run(World, OracleWorld, 2, 3, 2, 300, {120: [1], 254: [0], 255: [1]}, seed=38, n_obstacles=2, grid_size=100,
                        clearance=0.6, time_max=1000, flags=4)
+    assert not fails, fails[:3]
+
+
+def test_counting_layer_over_long_episodes_with_standing_and_frozen_agents(worlds):
+    """SUM mode keeps its counts by differences (an agent takes itself off the cells it leaves and adds itself to the ones it
+    enters): 150 steps of crowded worlds -- robots that collide and freeze, pedestrians with legs that reach their goals and wait,
+    per-world resets that redraw obstacles underneath standing agents -- must not drift off the oracles by a single cell"""
+    World, OracleWorld = worlds
+    fails, _, _ = _run(World, OracleWorld, 3, 14, 9, 150, {40: [1], 41: [1], 90: [0, 2], 120: [0, 1, 2]}, seed=39, n_obstacles=3, ped_shape="leg",
+                       grid_size=96, clearance=0.6, time_max=1000, flags=512)
+    assert not fails, fails[:3]
+    fails, _, _ = _run(World, OracleWorld, 1, 60, 20, 120, {50: [0]}, seed=40, n_obstacles=3, grid_size=100, res=0.25, clearance=0.55,
+                       time_max=1000, flags=512)
     assert not fails, fails[:3]
 
 

@@ -65,14 +65,22 @@ def worlds():
     return World, OracleWorld
 
 
-@pytest.mark.parametrize("case", list(CASES))
+# the same scenarios on the counting class layer (SUM mode, world.h), which small handles do not pick by themselves
+SUM_CASES = ["8robots_6peds_rvo", "64robots_20peds_rvo", "legs_ervo", "dense_collisions", "res025", "res010_not_pow2", "pedscene_sfm_16m_legs",
+             "view_50_not_a4", "time_limit", "orca_many_obstacle_segments", "1robot_nopeds"]
+
+
+@pytest.mark.parametrize("case", list(CASES) + [c + "+counting_layer" for c in SUM_CASES])
 def test_hip_matches_oracle(worlds, case):
     World, OracleWorld = worlds
+    from img_env_amd import _cabi
+    case, _, layer = case.partition("+")
     kw = dict(CASES[case])
     n = kw["n_robots"]
     grid, params, layout = small_world(**kw)
+    if layer:
+        params = dict(params, flags=int(params.get("flags", 0)) | _cabi.FLAG_LAYER_SUM)
     if case.endswith("_tiled"):
-        from img_env_amd import _cabi
         params = dict(params, flags=int(params.get("flags", 0)) | _cabi.FLAG_VIEW_TILED)
     gpu, cpu = World(params, grid), OracleWorld(params, grid)
     try:
@@ -572,7 +580,7 @@ def test_cfg5_world_matches_oracle(worlds):
         cpu.close()
 
 
-@pytest.mark.parametrize("layer", ["default", "composed"])
+@pytest.mark.parametrize("layer", ["default", "composed", "counting"])
 def test_cfg2_world_matches_oracle(worlds, layer):
     """BASELINE cfg-2 at full size: 1024 robots, no pedestrians, 400 x 400 map at 0.125 m -- with the class layer the library
     picks for it (stamped: a launch-bound handle, csrc/imgenv_hip.hip) and with the composed one (`k_compose`)"""
@@ -582,7 +590,7 @@ def test_cfg2_world_matches_oracle(worlds, layer):
     grid = worldgen.make_grid(400, 0)
     params = worldgen.make_params(n, 0, res=0.125, view_cells=48, beams=360, scene="", time_max=100)
     layout = worldgen.make_layout(grid, 0.125, n, 0, seed=100, clearance=1.0)
-    gpu = World(dict(params, flags=_cabi.FLAG_COMPOSE_DENSE if layer == "composed" else 0), grid)
+    gpu = World(dict(params, flags={"composed": _cabi.FLAG_COMPOSE_DENSE, "counting": _cabi.FLAG_LAYER_SUM}.get(layer, 0)), grid)
     cpu = OracleWorld(params, grid)
     try:
         rng = np.random.default_rng(12)
