@@ -89,6 +89,12 @@ struct imgenv {
     size_t lds_view_big = 0;
     bool big_bits_in_lds = true;  // the crop bitmap of one robot fits the LDS next to the hit words
     int big_max_crop = 1, big_full_chunks = 1;
+    // early-observation steps (world.h): k_obs is launched with the step, beside the move (k_move_raster), from snapshots
+    bool early = false;             // the handle can run them (imgenv_step only; IMGENV_EARLY_OBS=0 in the environment switches them off)
+    float4* ped_snap[2] = {nullptr, nullptr};
+    unsigned orca_seq = 0;          // k_orca launches so far: launch q writes ped_snap[q & 1]
+    hipEvent_t ev_done = nullptr;   // behind the views of the last chain, on the caller's stream
+    bool ev_done_valid = false, early_step = false;
     bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
@@ -456,6 +462,7 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamSynchronize(h->side3);
         (void)hipStreamDestroy(h->side3);
     }
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
     if (h->ev_consumed) (void)hipEventDestroy(h->ev_consumed);
     if (h->sd_storage && h->sd_delete) h->sd_delete(h->sd_storage);
@@ -799,6 +806,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.rx, k.right.x));
             TRY(dev_upload(h, &o.ry, k.right.y));
             memcpy(o.sizes, k.sizes, sizeof(o.sizes));
+            o.box_rad = k.box_rad;
             static const bool no_rows = getenv("IMGENV_FP_ROWS") && getenv("IMGENV_FP_ROWS")[0] == '0';
             o.n_brows = no_rows ? 0 : (int)k.bbox_rows.size(); o.n_lrows = no_rows ? 0 : (int)k.left_rows.size(); o.n_rrows = no_rows ? 0 : (int)k.right_rows.size();
             o.bbox_cy = k.bbox_cy;
@@ -1246,6 +1254,19 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (h->lds_obs > 64 * 1024)
         HIPCHK_H(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     h->serial = getenv("IMGENV_SERIAL") && getenv("IMGENV_SERIAL")[0] == '1';
+    {   // early-observation steps: one world owned whole, an ORCA crowd that nothing but the solve moves (no beep lottery), no
+        // limiter history to carry, views through k_view -- the headline shape and cfg-5; everything else keeps k_obs behind the move
+        const bool limiters = cfg->limiter_v.has_velocity_limits || cfg->limiter_v.has_acceleration_limits || cfg->limiter_v.has_jerk_limits ||
+                              cfg->limiter_w.has_velocity_limits || cfg->limiter_w.has_acceleration_limits || cfg->limiter_w.has_jerk_limits;
+        h->early = !h->serial && W == 1 && RL == R && P > 0 && h->NA > 0 && !d.beep_on && !limiters && !h->big_view &&
+                   h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS;
+        if (h->early) {
+            TRY(dev_alloc(h, &d.rec_snap, (size_t)RL * IMGENV_RECORD_DOUBLES));
+            TRY(dev_alloc(h, &h->ped_snap[0], (size_t)P));
+            TRY(dev_alloc(h, &h->ped_snap[1], (size_t)P));
+            HIPCHK_H(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming | hipEventDisableSystemFence));
+        }
+    }
     HIPCHK_H(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     HIPCHK_H(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     HIPCHK_H(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1392,6 +1413,27 @@ static int outputs_verify(imgenv* h, hipStream_t st) {
     return 0;
 }
 
+static int launch_obs_kernel(imgenv* h, hipStream_t s_obs) {
+    DevWorld& d = h->d;
+    const dim3 go(d.act_nl), bo(WAVE);
+    // An early k_obs (world.h) must not take every wavefront slot of the chip before the rasters arrive: extra LDS per workgroup caps
+    // how many of its one-wavefront workgroups a compute unit holds (IMGENV_OBS_PAD bytes; measurement switch)
+    static const size_t pad_env = getenv("IMGENV_OBS_PAD") ? (size_t)atoi(getenv("IMGENV_OBS_PAD")) : 0;
+    const size_t lds_obs = d.obs_early ? std::max(h->lds_obs, pad_env) : h->lds_obs;
+#define lds_obs_ lds_obs
+    switch (h->obs_E) {
+        case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
+        case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
+        case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
+        case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
+        case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
+        default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
+    }
+#undef lds_obs_
+    h->launches += 1;
+    return 0;
+}
+
 static int launch_obs(imgenv* h, hipStream_t st) {
     if (int rc = chain_begin(h, st)) return rc;
     DevWorld& d = h->d;
@@ -1401,16 +1443,7 @@ static int launch_obs(imgenv* h, hipStream_t st) {
         HIPCHK(hipEventRecord(h->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(s_obs, h->ev_fork, 0));
     }
-    const dim3 go(d.act_nl), bo(WAVE);
-    switch (h->obs_E) {
-        case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-        case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-        case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-        case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-        case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-        default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, h->lds_obs, s_obs>>>(d, h->PP))); break;
-    }
-    h->launches += 1;
+    if (int rc = launch_obs_kernel(h, s_obs)) return rc;
     h->obs_forked = true;
     return 0;
 }
@@ -1450,8 +1483,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = h->elapsed - 1;
 #define RASTER_CASE(N, P2, LM)                                                                                    \
         case N:                                                                                                       \
-            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
-            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds, 0))); \
+            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds, n_g + n_p > 8192 ? 1 : 0))); \
             else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
             else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
             break;
@@ -1486,6 +1519,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             if (int rc = launch_obs(h, st)) return rc;
         h->obs_forked = false;
         hipStream_t s_obs = overlap ? h->side2 : st;
+        if (h->early_step && one_side) HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));  // (k_obs went out with the step, in front of the move: the solve waits for it)
         if (overlap && !one_side) {
             if (d.sharded) {  // the solve needs every rank's robots: a second fork behind the exchange
                 HIPCHK(hipEventRecord(h->ev_fork2, st));
@@ -1513,7 +1547,9 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             L.zero_vel = is_reset;
             L.stage_obst = std::min(cap, 256);  // (a world with more segments than that is solved out of HBM: the kernel checks its count)
             const unsigned blocks = (unsigned)((n_p / per_world) * L.groups);
+            d.ped_snap_out = h->early ? h->ped_snap[h->orca_seq & 1] : nullptr;  // (world.h: what the next step's early k_obs reads)
             TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(blocks), dim3(WAVE), orca_lds_bytes(L), s_orca>>>(d, L)));
+            h->orca_seq += 1;
             h->launches += 1;
         }
         if (overlap) {
@@ -1614,6 +1650,11 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     }
     // no launch for the per-robot scalars: the k_view / k_obs wavefront that completes a group of 64 robots runs them
     // (tail_group).  The caller's stream ends the step behind both side streams
+    if (h->early) {  // the next early k_obs starts behind these views (and, on its own stream, behind this chain's k_obs and solve)
+        HIPCHK(hipEventRecord(h->ev_done, st));
+        h->ev_done_valid = true;
+    }
+    h->early_step = false;
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     h->launches += 3;
     HIPCHK(hipGetLastError());
@@ -2375,6 +2416,10 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     static const int force_fuse = getenv("IMGENV_FUSE_MOVE") ? atoi(getenv("IMGENV_FUSE_MOVE")) : -1;  // (measurement switch)
     const bool fuse_move = h->in_step && !d.sharded && !h->comm && h->RL == h->R && h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS &&
                            (force_fuse >= 0 ? force_fuse != 0 : (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024));
+    // early-observation step (world.h): the move goes into the raster launch whatever the size, and k_obs goes out NOW, on its side
+    // stream, beside it -- behind the last chain's views (ev_done) and, on that stream itself, behind the last solve
+    static const int force_early = getenv("IMGENV_EARLY_OBS") ? atoi(getenv("IMGENV_EARLY_OBS")) : -1;  // (measurement switch)
+    const bool early_step = h->early && h->in_step && !fuse_move && !h->chain_open && h->orca_seq > 0 && h->ev_done_valid && force_early != 0;
     if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
         h->move_pending = true;
         h->move_actions = actions;
@@ -2392,8 +2437,25 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     }
     h->launches += 1;
     set_tail_fields(h, 0, h->elapsed + 1);  // imgenv_step_end counts the step; k_obs goes out before that
-    if (h->P > 0)
+    if (early_step) {
+        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions, so its side stream only
+        // waits for the last chain's views (ev_done; on that stream itself it sits behind the last chain's k_obs and solve).  Queued
+        // BEHIND k_integrate, whose few workgroups are then dispatched first; what the caller's stream forks here is the solve alone.
+        h->chain_open = true;
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
+        d.obs_early = 1;
+        d.obs_actions = actions;
+        d.obs_n_sub = h->n_sub;
+        d.ped_snap_in = h->ped_snap[(h->orca_seq - 1) & 1];
+        const int rc = launch_obs_kernel(h, h->side2);
+        d.obs_early = 0;
+        if (rc) return rc;
+        h->obs_forked = true;
+        h->early_step = true;
+    } else if (h->P > 0) {
         if (int rc = launch_obs(h, st)) return rc;
+    }
     HIPCHK(hipGetLastError());
     return IMGENV_OK;
 }

@@ -596,6 +596,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
             const f2 nv = compute_new_velocity(w, ob, s, j, pref);
             w.anvx[j] = nv.x;
             w.anvy[j] = nv.y;
+            if (w.ped_snap_out) w.ped_snap_out[j] = make_float4(pos.x, pos.y, nv.x, nv.y);
         }
         return;
     }
@@ -730,6 +731,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
         // beep sources -- exist; through the reference's Python API there never are any (yaml_env.py:183-200).
         w.anvx[j] = nv.x;
         w.anvy[j] = nv.y;
+        if (w.ped_snap_out) w.ped_snap_out[j] = make_float4(pos.x, pos.y, nv.x, nv.y);  // what the next step's early k_obs moves this pedestrian by
     }
     ORCA_MARK(15);  // linear programs
 }
@@ -1097,6 +1099,29 @@ __device__ __forceinline__ double2 integrate_heading(double theta, double wv, do
     sincos(a, &sn, &cs);  // (one argument reduction for both)
     return make_double2(cs, sn);
 }
+// the exact pose update of Agent::cmd (agent.cpp:221-236 diff, 238-274 omni) from the sines / cosines of the old and the new heading
+// (one function for k_integrate and for the early k_obs, which advances its robot by itself: the same operations in the same order)
+__device__ __forceinline__ void pose_arc(bool omni, double v, double wv, double v_y, double dt, double c0, double s0, double c1, double s1,
+                                         double& x, double& y) {
+    if (wv == 0) {
+        if (!omni) {
+            x += v * dt * c0;
+            y += v * dt * s0;
+        } else {
+            x += v * dt * c0 - v_y * dt * s0;
+            y += v * dt * s0 + v_y * dt * c0;
+        }
+    } else {
+        const double vw = v / wv;
+        x += -vw * s0 + vw * s1;
+        y += vw * c0 - vw * c1;
+        if (omni) {
+            const double v_yw = v_y / wv;
+            x += -v_yw * c0 + v_yw * c1;
+            y += -v_yw * s0 + v_yw * s1;
+        }
+    }
+}
 // ... and the position recurrence with the arrive tests plus the exact arc, over that table (one lane)
 __device__ __forceinline__ void integrate_finish(const DevWorld& w, int l, double* r, double v, double wv, double v_y, double theta,
                                                  const double2* trig, int n_sub) {
@@ -1131,24 +1156,7 @@ __device__ __forceinline__ void integrate_finish(const DevWorld& w, int l, doubl
     const double c0 = trig[0].x, s0 = trig[0].y;          // cos / sin(theta): sub-step 0's heading is theta
     const double c1 = trig[n_sub].x, s1 = trig[n_sub].y;  // cos / sin(theta + w dt)
     double x = r[0], y = r[1];
-    if (wv == 0) {
-        if (!omni) {
-            x += v * dt * c0;
-            y += v * dt * s0;
-        } else {
-            x += v * dt * c0 - v_y * dt * s0;
-            y += v * dt * s0 + v_y * dt * c0;
-        }
-    } else {
-        const double vw = v / wv;
-        x += -vw * s0 + vw * s1;
-        y += vw * c0 - vw * c1;
-        if (omni) {
-            const double v_yw = v_y / wv;
-            x += -v_yw * c0 + v_yw * c1;
-            y += -v_yw * s0 + v_yw * s1;
-        }
-    }
+    pose_arc(omni, v, wv, v_y, dt, c0, s0, c1, s1, x, y);
     const double th = theta + wv * dt;
     const double cur_dist = sqrt((x - gx) * (x - gx) + (y - gy) * (y - gy));
     if (cur_dist <= 0.3) is_arrive = true;
@@ -1763,7 +1771,7 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
 // NW: wavefronts per workgroup.  1 when a launch fills the machine; 4 in small launches (a reset of a few worlds), where the
 // 15 rounds of footprint samples of one wavefront are pure latency.
 template <bool POW2, int LM, int NW>
-__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM == 1 || !POW2) ? 6 : 8, 8))) void k_raster(DevWorld w, int zero_vel, int split) {
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM == 1 || !POW2) ? 6 : LM == 2 ? 7 : 8, 8))) void k_raster(DevWorld w, int zero_vel, int split) {
     constexpr bool STAMP = LM == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // max(R, P) blocks: block b draws robot b and pedestrian b.  (P + R single-purpose blocks would be 200 more
@@ -1801,11 +1809,14 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM =
 // k_obs and k_view are both bound by vector issue, DESIGN.md section 4 -- so the big launches keep the two kernels.)
 // Blocks [0, R): robots, [R, R + P): pedestrians.
 template <bool POW2, int LM, int NW>
-__global__ __launch_bounds__(WAVE * NW) void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int step, int move_peds) {
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM == 1 || !POW2) ? 6 : LM == 2 ? 7 : 8, 8)))
+void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int step, int move_peds, int peds_first) {
     constexpr bool STAMP = LM == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double2 trig[INT_ITEMS];  // (cos, sin)
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // (peds_first: launches of more blocks than the chip holds wavefronts -- 8192 robots + 200 pedestrians -- start the pedestrians'
+    // blocks, the longer ones, with the first generation instead of behind it)
+    const int b = peds_first ? ((int)blockIdx.x < w.P ? w.R + (int)blockIdx.x : (int)blockIdx.x - w.P) : (int)blockIdx.x, tid = threadIdx.x;
     if (LM != 0 && b == 0 && tid == 0) w.counters[1] = 0;  // (as k_raster)
     const Region g = grid_region(w);
     if (b < w.R) {
@@ -2045,6 +2056,8 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     if ((int)blockIdx.x >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, blockIdx.x);
     const int lane = lane_id();
+    // the robot's record as this chain leaves it, where the next step's early k_obs finds it while the move rewrites the original (world.h)
+    if (w.rec_snap && tid < IMGENV_RECORD_DOUBLES) w.rec_snap[(size_t)l * IMGENV_RECORD_DOUBLES + tid] = w.rec[(size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES + tid];
     if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value (counted in tail_group)
         if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, w.is_coll[l]);
         return;
@@ -2714,8 +2727,60 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     float* stage = (float*)(inbox + PP);
     uint16_t* touched = (uint16_t*)stage;  // the staging buffer is dead by the time discs are stamped
 
-    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-    const Tf2 bw = tf_from_pose_sc(r[0], r[1], r[5], r[6]);
+    // The robot's pose of THIS step.  Behind the move: its record.  An early launch (world.h) runs beside the move and advances the
+    // robot itself from the snapshot of its record: the command as Agent::cmd takes it (no limiters on such handles), the
+    // sines / cosines of the old heading, the new one and its half on three lanes (integrate_heading: k_integrate's own table
+    // entries), the exact arc (pose_arc) -- bit for bit what the move writes.  A dead robot keeps its pose (img_env.cpp:392).
+    const bool early = w.obs_early != 0;  // (uniform)
+    double rx, ry, rsh, rch;
+    if (early) {
+        const double* sn = w.rec_snap + (size_t)l * IMGENV_RECORD_DOUBLES;
+        rx = sn[0];
+        ry = sn[1];
+        rsh = sn[5];
+        rch = sn[6];
+        if (!w.py_done[l]) {
+            const double theta = sn[2];
+            const double v = (double)w.obs_actions[3 * l], wv = (double)w.obs_actions[3 * l + 1], v_y = (double)w.obs_actions[3 * l + 2];
+            const int n_sub = w.obs_n_sub;
+            const double2 tr = integrate_heading(theta, wv, w.step_hz, lane == 0 ? 0 : lane == 1 ? n_sub : n_sub + 1, n_sub);
+            const double c0 = __shfl(tr.x, 0), s0 = __shfl(tr.y, 0), c1 = __shfl(tr.x, 1), s1 = __shfl(tr.y, 1);
+            rch = __shfl(tr.x, 2);
+            rsh = __shfl(tr.y, 2);
+            pose_arc(w.ktype == IMGENV_KTYPE_OMNI, v, wv, v_y, w.step_hz, c0, s0, c1, s1, rx, ry);
+        }
+    } else {
+        const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+        rx = r[0];
+        ry = r[1];
+        rsh = r[5];
+        rch = r[6];
+    }
+    const Tf2 bw = tf_from_pose_sc(rx, ry, rsh, rch);
+    // ... and the pedestrians' state of this step: their arrays behind the move; early, Agent::update (Agent.cpp:840-843) +
+    // getNewPosAndVel (rvoscene.h:72-82) applied to the solve's snapshot -- float32 position + velocity * dt, promoted (ped_update_one)
+    const float4* g_snap = w.ped_snap_in + p_lo;
+    const float ts32 = (float)w.step_hz;
+    auto ped_pos = [&](int j, double& x, double& y) {
+        if (early) {
+            const float4 q = g_snap[j];
+            x = (double)(q.x + q.z * ts32);
+            y = (double)(q.y + q.w * ts32);
+        } else {
+            x = g_ppx[j];
+            y = g_ppy[j];
+        }
+    };
+    auto ped_vel = [&](int j, double& vx, double& vy) {
+        if (early) {
+            const float4 q = g_snap[j];
+            vx = (double)q.z;
+            vy = (double)q.w;
+        } else {
+            vx = g_pvx[j];
+            vy = g_pvy[j];
+        }
+    };
     PHASE_BEGIN();
     double min_dist = w.ped_min_dists[l];
     if (P > 0) {
@@ -2736,7 +2801,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
                 kv[q] = ((unsigned long long)0x7F800000u << 32) | 0xFFFFull;  // padding: +inf, sorts behind everyone
                 if (j < P) {
                     double px, py;
-                    tf_apply(wb, g_ppx[j], g_ppy[j], px, py);
+                    double gx_, gy_;
+                    ped_pos(j, gx_, gy_);
+                    tf_apply(wb, gx_, gy_, px, py);
                     const float fx = (float)px, fy = (float)py;
                     info[j] = make_float2(fx, fy);
                     const double key = (double)fx * (double)fx + (double)fy * (double)fy;
@@ -2788,7 +2855,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             for (int j = lane; j < PP; j += WAVE) {
                 if (j < P) {
                     double px, py;
-                    tf_apply(wb, g_ppx[j], g_ppy[j], px, py);
+                    double gx_, gy_;
+                    ped_pos(j, gx_, gy_);
+                    tf_apply(wb, gx_, gy_, px, py);
                     const float fx = (float)px, fy = (float)py;
                     info[j] = make_float2(fx, fy);
                     key[j] = (double)fx * (double)fx + (double)fy * (double)fy;
@@ -2834,7 +2903,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             if (q < P) {
                 const int j = ord[q];
                 const float2 f = info[j];
-                const double pvx = g_pvx[j], pvy = g_pvy[j];  // PedInfo velocity in the robot frame (img_env.cpp:576-580)
+                double pvx, pvy;  // PedInfo velocity in the robot frame (img_env.cpp:576-580)
+                ped_vel(j, pvx, pvy);
                 const float fvx = (float)((wb.m00 * pvx + wb.m01 * pvy) + 0.0), fvy = (float)((wb.m10 * pvx + wb.m11 * pvy) + 0.0);
                 const double dpx = f.x, dpy = f.y;
                 const double ped_r = g_ped_r_round[j];
@@ -2888,7 +2958,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
             __syncthreads();  // drains this wave's earlier stores: later discs overwrite earlier ones
             const int je = ord[inbox[e]];
             const float2 f = info[je];
-            const double evx = g_pvx[je], evy = g_pvy[je];
+            double evx, evy;
+            ped_vel(je, evx, evy);
             const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
             const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
             int ax, bx, ay, by;

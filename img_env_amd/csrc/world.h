@@ -176,6 +176,16 @@ struct DevWorld {
     uint32_t* own_hi;        // max (robot index + 1) covering the cell, 0 = none
     uint32_t* cell;          // composed layer: class byte | (owning robot or OWNER_MULTI) << 8, one gather per lookup
                              // (STAMP mode: base class | this step's stamp, and the three layers above do not exist)
+    // "early observation" steps (imgenv_step on eligible handles, csrc/imgenv_hip.hip): k_obs starts with the step, beside the
+    // move, instead of behind it.  It then works out its robot's new pose and the pedestrians' new positions ITSELF, from
+    // snapshots nobody writes while it runs: rec_snap = every robot's record as the last k_view found it, ped_snap = every ORCA
+    // pedestrian's position and freshly solved velocity as the last k_orca left them (two buffers, taken in turns: the next
+    // k_orca writes while this step's k_obs may still read)
+    double* rec_snap;            // [RL][IMGENV_RECORD_DOUBLES]
+    float4* ped_snap_out;        // [P] (x, y, new vx, new vy): where this chain's k_orca writes; null: no snapshots
+    const float4* ped_snap_in;   // [P] what an early k_obs reads
+    int obs_early, obs_n_sub;    // this k_obs launch is an early one; sub-steps of Agent::cmd (the heading table's layout)
+    const float* obs_actions;    // the step's actions
     int layer_sum;           // SUM mode (above): ped_layer / own_lo / own_hi do not exist, k_compose never runs
     uint32_t sum_rc_shift, sum_id_shift, sum_pc_mask;
     unsigned long long sum_wg_magic;  // ceil(2^40 / Wg): row of a cell index below 2^24
