@@ -93,7 +93,7 @@ def test_timed_workload_matches_oracle_across_an_episode_and_its_reset(worlds, p
         if policy == "active":
             assert frozen < 0.05  # v = 0: no robot drives into anything; the few frozen ones were walked into by a pedestrian (bench.py's `frozen_fraction`)
         else:
-            assert frozen > 0.5   # the reference's random policy freezes most robots of a shared world within an episode
+            assert frozen > 0.2   # the reference's random policy: a third of the robots are frozen five steps into an episode (89 % on average over one, bench.py)
         print("cfg-3 %s policy: %d comparisons over 106 steps and one reset, %.1f %% of the robots frozen at the end" % (policy, compared, 100 * frozen))
     finally:
         gpu.close()
