@@ -1254,11 +1254,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     if (h->lds_obs > 64 * 1024)
         HIPCHK_H(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
     h->serial = getenv("IMGENV_SERIAL") && getenv("IMGENV_SERIAL")[0] == '1';
-    {   // early-observation steps: one world owned whole, an ORCA crowd that nothing but the solve moves (no beep lottery), no
+    {   // early-observation steps: worlds owned whole, an ORCA crowd that nothing but the solve moves (no beep lottery), no
         // limiter history to carry, views through k_view -- the headline shape and cfg-5; everything else keeps k_obs behind the move
         const bool limiters = cfg->limiter_v.has_velocity_limits || cfg->limiter_v.has_acceleration_limits || cfg->limiter_v.has_jerk_limits ||
                               cfg->limiter_w.has_velocity_limits || cfg->limiter_w.has_acceleration_limits || cfg->limiter_w.has_jerk_limits;
-        h->early = !h->serial && W == 1 && RL == R && P > 0 && h->NA > 0 && !d.beep_on && !limiters && !h->big_view &&
+        h->early = !h->serial && RL == R && P > 0 && h->NA > 0 && !d.beep_on && !limiters && !h->big_view &&
                    h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS;
         if (h->early) {
             TRY(dev_alloc(h, &d.rec_snap, (size_t)RL * IMGENV_RECORD_DOUBLES));
@@ -1547,9 +1547,13 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             L.zero_vel = is_reset;
             L.stage_obst = std::min(cap, 256);  // (a world with more segments than that is solved out of HBM: the kernel checks its count)
             const unsigned blocks = (unsigned)((n_p / per_world) * L.groups);
-            d.ped_snap_out = h->early ? h->ped_snap[h->orca_seq & 1] : nullptr;  // (world.h: what the next step's early k_obs reads)
+            // (world.h: what the next step's early k_obs reads.  A launch over every world writes one buffer and the next one the
+            // other; a launch over some worlds -- a reset chain, nothing else is in flight -- writes both and does not take a turn)
+            const bool partial = d.act_list != nullptr;
+            d.ped_snap_out = h->early ? h->ped_snap[h->orca_seq & 1] : nullptr;
+            d.ped_snap_out2 = h->early && partial ? h->ped_snap[(h->orca_seq + 1) & 1] : nullptr;
             TIMED(h, IMGENV_K_ORCA, s_orca, (k_orca<<<dim3(blocks), dim3(WAVE), orca_lds_bytes(L), s_orca>>>(d, L)));
-            h->orca_seq += 1;
+            if (!partial) h->orca_seq += 1;
             h->launches += 1;
         }
         if (overlap) {

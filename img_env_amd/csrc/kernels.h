@@ -597,6 +597,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
             w.anvx[j] = nv.x;
             w.anvy[j] = nv.y;
             if (w.ped_snap_out) w.ped_snap_out[j] = make_float4(pos.x, pos.y, nv.x, nv.y);
+            if (w.ped_snap_out2) w.ped_snap_out2[j] = make_float4(pos.x, pos.y, nv.x, nv.y);
         }
         return;
     }
@@ -732,6 +733,7 @@ __global__ __launch_bounds__(WAVE) void k_orca(DevWorld w, OrcaLaunch L) {
         w.anvx[j] = nv.x;
         w.anvy[j] = nv.y;
         if (w.ped_snap_out) w.ped_snap_out[j] = make_float4(pos.x, pos.y, nv.x, nv.y);  // what the next step's early k_obs moves this pedestrian by
+        if (w.ped_snap_out2) w.ped_snap_out2[j] = make_float4(pos.x, pos.y, nv.x, nv.y);
     }
     ORCA_MARK(15);  // linear programs
 }

@@ -183,6 +183,7 @@ struct DevWorld {
     // k_orca writes while this step's k_obs may still read)
     double* rec_snap;            // [RL][IMGENV_RECORD_DOUBLES]
     float4* ped_snap_out;        // [P] (x, y, new vx, new vy): where this chain's k_orca writes; null: no snapshots
+    float4* ped_snap_out2;       // a chain over SOME worlds (a reset) writes both buffers: the other worlds' entries stay where the next step reads
     const float4* ped_snap_in;   // [P] what an early k_obs reads
     int obs_early, obs_n_sub;    // this k_obs launch is an early one; sub-steps of Agent::cmd (the heading table's layout)
     const float* obs_actions;    // the step's actions

@@ -18,7 +18,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_write -o p --output-for
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH"; do
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH" \
+           "SQ_WAVES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -d $out/${tag}_sq_$i -o p --output-format csv -- $S > $out/${tag}_sq_$i.log 2>&1
 done
@@ -36,7 +37,7 @@ for cfg in cfg2 cfg4 cfg5 mw; do
 done
 python3 tools/pmc_to_json.py $out/${tag}_fetch $out/${tag}_write $out/${tag}_pmc.json $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 > /dev/null
 python3 tools/pmc_summary.py $out/${tag}_fetch $out/${tag}_write > $out/${tag}_pmc_hbm.txt
-python3 tools/pmc_summary.py $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 > $out/${tag}_pmc_sq.txt
+python3 tools/pmc_summary.py $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 $out/${tag}_sq_4 > $out/${tag}_pmc_sq.txt
 python3 bench.py 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
 # the reference's shipped geometry (test.yaml: 400 x 400 views shrunk to 48 x 48, 1000 beams): timeline + kernel stats at 256 envs,
 # kernel stats + counters at 2048
@@ -48,7 +49,7 @@ PMC_CMD="python3 /root/repo/tools/cfg5_probe.py 8192 0 short" bash tools/profile
 # (profile_pmc.sh averages a kernel over ALL its launches, the reset chain's few-robot ones included; the step's own launches alone:)
 bash tools/pmc_mem.sh ${tag}_shipped2048
 # keep the returned directory small: the raw traces stay on the box
-rm -rf $out/${tag}_trace $out/${tag}_mw $out/${tag}_cfg2 $out/${tag}_cfg4 $out/${tag}_cfg5 $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 $out/${tag}_fetch $out/${tag}_write
+rm -rf $out/${tag}_trace $out/${tag}_mw $out/${tag}_cfg2 $out/${tag}_cfg4 $out/${tag}_cfg5 $out/${tag}_sq_1 $out/${tag}_sq_2 $out/${tag}_sq_3 $out/${tag}_sq_4 $out/${tag}_fetch $out/${tag}_write
 du -sh $out
 # which library the set describes (imgenv_build_id = hash of the sources + flags; bench.py compares it with the library it runs)
 python3 -c "import ctypes;l=ctypes.CDLL('/root/repo/img_env_amd/csrc/libimgenv_hip.so');l.imgenv_build_id.restype=ctypes.c_char_p;print(l.imgenv_build_id().decode())" > $out/${tag}_build_id.txt
