@@ -1416,11 +1416,7 @@ static int outputs_verify(imgenv* h, hipStream_t st) {
 static int launch_obs_kernel(imgenv* h, hipStream_t s_obs) {
     DevWorld& d = h->d;
     const dim3 go(d.act_nl), bo(WAVE);
-    // An early k_obs (world.h) must not take every wavefront slot of the chip before the rasters arrive: extra LDS per workgroup caps
-    // how many of its one-wavefront workgroups a compute unit holds (IMGENV_OBS_PAD bytes; measurement switch)
-    static const size_t pad_env = getenv("IMGENV_OBS_PAD") ? (size_t)atoi(getenv("IMGENV_OBS_PAD")) : 0;
-    const size_t lds_obs = d.obs_early ? std::max(h->lds_obs, pad_env) : h->lds_obs;
-#define lds_obs_ lds_obs
+    const size_t lds_obs = h->lds_obs;
     switch (h->obs_E) {
         case 1: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<1><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
@@ -1429,7 +1425,6 @@ static int launch_obs_kernel(imgenv* h, hipStream_t s_obs) {
         case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
     }
-#undef lds_obs_
     h->launches += 1;
     return 0;
 }
@@ -1483,8 +1478,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
             const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = h->elapsed - 1;
 #define RASTER_CASE(N, P2, LM)                                                                                    \
         case N:                                                                                                       \
-            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds, 0))); \
-            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds, n_g + n_p > 8192 ? 1 : 0))); \
+            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
             else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
             else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
             break;

@@ -1185,6 +1185,9 @@ __device__ __forceinline__ void integrate_finish(const DevWorld& w, int l, doubl
 // lane 0 then runs the (cheap) position recurrence and the arrive tests over the table in LDS.
 __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot, int n_sub, int step) {
     __shared__ double2 trig[INT_ROBOTS][INT_ITEMS];  // (cos, sin)
+    // the step's critical chain (move -> rasters -> views) runs beside the observation's 8192 wavefronts, which are bound by vector
+    // issue: its kernels' wavefronts ask the SIMD's arbiter for the issue slot first (s_setprio; k_obs keeps the default 0)
+    __builtin_amdgcn_s_setprio(3);
     if ((int)blockIdx.x >= nb_robot) {
         const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
         if (j < w.P) {
@@ -1780,6 +1783,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM =
     // than the 8192 wavefronts one MI355X holds at once in the headline configuration: a second, nearly empty round.)
     const int b = blockIdx.x;
     WAVE_T0();
+    __builtin_amdgcn_s_setprio(3);  // (critical chain: see k_integrate)
     if (LM != 0 && b == 0 && threadIdx.x == 0) w.counters[1] = 0;  // tail_group tallies this step's dones (k_compose does this otherwise)
     const Region g = grid_region(w);
     // split > 0 (small launches): the first `split` blocks draw robots, the ones behind them pedestrians -- a robot and a
@@ -1812,13 +1816,11 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM =
 // Blocks [0, R): robots, [R, R + P): pedestrians.
 template <bool POW2, int LM, int NW>
 __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM == 1 || !POW2) ? 6 : LM == 2 ? 7 : 8, 8)))
-void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int step, int move_peds, int peds_first) {
+void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int step, int move_peds) {
     constexpr bool STAMP = LM == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double2 trig[INT_ITEMS];  // (cos, sin)
-    // (peds_first: launches of more blocks than the chip holds wavefronts -- 8192 robots + 200 pedestrians -- start the pedestrians'
-    // blocks, the longer ones, with the first generation instead of behind it)
-    const int b = peds_first ? ((int)blockIdx.x < w.P ? w.R + (int)blockIdx.x : (int)blockIdx.x - w.P) : (int)blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     if (LM != 0 && b == 0 && tid == 0) w.counters[1] = 0;  // (as k_raster)
     const Region g = grid_region(w);
     if (b < w.R) {
