@@ -2815,7 +2815,59 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
                 }
             }
             PHASE_MARK(8);
-            sort_packed_in_registers<EE>(kv, lane);
+            // Distances change little from one step to the next, so last step's ORDER is nearly this step's: the slots are filled in
+            // that order and a few odd-even transposition passes finish the job -- the result is the one order by (packed key), however
+            // it is reached; an order that is still not sorted after w.obs_passes passes (the first step of an episode) goes through the
+            // full network.  (E >= 2: the cross-lane pairs of a pass are then disjoint.)
+            bool presorted = false;
+            if (EE >= 2 && w.obs_ord) {
+                const int OBS_PASSES = w.obs_passes;
+                __syncthreads();  // every pedestrian's info[] is in LDS
+                const uint16_t* prev = w.obs_ord + (size_t)l * (WAVE * EE) + lane * EE;
+#pragma unroll
+                for (int q = 0; q < EE; q++) {
+                    const uint32_t j = prev[q];
+                    kv[q] = ((unsigned long long)0x7F800000u << 32) | 0xFFFFull;
+                    if (j < (uint32_t)P) {
+                        const float2 f = info[j];
+                        const double key = (double)f.x * (double)f.x + (double)f.y * (double)f.y;
+                        kv[q] = ((unsigned long long)__float_as_uint((float)key) << 32) | (unsigned long long)j;
+                    }
+                }
+                for (int pass = 0; pass <= OBS_PASSES; pass++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q + 1 < EE; q++) ok &= kv[q] <= kv[q + 1];
+                    {
+                        const unsigned long long nxt = __shfl_down(kv[0], 1);
+                        ok &= lane == WAVE - 1 || kv[EE - 1] <= nxt;
+                    }
+                    if (__all(ok)) {
+                        presorted = true;
+                        break;
+                    }
+                    if (pass == OBS_PASSES) break;
+#pragma unroll
+                    for (int a = 0; a + 1 < EE; a += 2) {  // even pairs
+                        const unsigned long long x = kv[a], y = kv[a + 1];
+                        kv[a] = x <= y ? x : y;
+                        kv[a + 1] = x <= y ? y : x;
+                    }
+#pragma unroll
+                    for (int a = 1; a + 1 < EE; a += 2) {  // odd pairs inside the lane ...
+                        const unsigned long long x = kv[a], y = kv[a + 1];
+                        kv[a] = x <= y ? x : y;
+                        kv[a + 1] = x <= y ? y : x;
+                    }
+                    {   // ... and the one across the lane boundary: (last slot of lane L, first slot of lane L + 1)
+                        const unsigned long long nxt = __shfl_down(kv[0], 1), prv = __shfl_up(kv[EE - 1], 1);
+                        const unsigned long long last = kv[EE - 1], first = kv[0];
+                        if (lane < WAVE - 1 && last > nxt) kv[EE - 1] = nxt;
+                        if (lane > 0 && prv > first) kv[0] = prv;
+                    }
+                }
+            }
+            if (!presorted) sort_packed_in_registers<EE>(kv, lane);
             // two neighbouring slots with one surrogate (and a pedestrian in the later one): their float64 keys may differ
             uint32_t clash = 0;  // bit q: slots lane * E + q and its successor
 #pragma unroll
@@ -2854,6 +2906,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
                     }
                     again = __any(swapped);
                 }
+            }
+            if (EE >= 2 && w.obs_ord) {  // next step starts from this order
+                uint16_t* keep = w.obs_ord + (size_t)l * (WAVE * EE) + lane * EE;
+#pragma unroll
+                for (int q = 0; q < EE; q++) keep[q] = ord[lane * EE + q];
             }
         } else {
             for (int j = lane; j < PP; j += WAVE) {

@@ -232,6 +232,8 @@ struct DevWorld {
     int* is_coll;                             // [RL]
     uint8_t *is_arr, *py_done, *clean_state;  // [RL]
     double* tmp_dist;                         // [RL]
+    int obs_passes;                           // odd-even passes k_obs tries on last step's order before it sorts in full
+    uint16_t* obs_ord;                        // [RL][64 E] last step's pedestrian order of each robot (k_obs starts from it: a few odd-even passes instead of a full sort); null: always sort
     uint16_t* pm_cells;                       // [RL][PM_CAP] ped_map cells written by the last step
     int* pm_n;                                // [RL] their count, -1 = unknown (dense clear needed)
     uint2* fp_cells;                          // [RL][fp_cap] grid cells under the footprint (cell, last sample index + 1), from k_raster
