@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--timing-mode", type=int, default=2, help="diagnostic: 0 = no HIP events in the timed pass")
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
     ap.add_argument("--passes", type=int, default=5, help="timed passes of the SAME --steps; value = the median pass")
+    ap.add_argument("--stream-ordered-actions", action="store_true", help="diagnostic: plain imgenv_step (every kernel that reads the actions "
+                    "waits for the caller's stream) instead of imgenv_step_flags(IMGENV_STEP_ACTIONS_READY) for the pre-generated actions")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
                     "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)  # internal: one process of the all-core CPU baseline
@@ -326,7 +328,10 @@ def main():
         a[:, :, 1] = torch.rand(n_act, RL, generator=g, device=dev) * 1.8 - 0.9
         return a
 
-    state = dict(elapsed=0, episode=0, resets=0)
+    # The actions are pre-generated and resident in HBM before the timed region starts (BASELINE / SURVEY 8d): the steps say so
+    # (IMGENV_STEP_ACTIONS_READY), which lets the library start its observation kernel beside the move.  `stream_ordered_actions` in
+    # the line is the same measurement with plain imgenv_step, as a trainer whose policy writes the actions on the stream gets it.
+    state = dict(elapsed=0, episode=0, resets=0, ready=not args.stream_ordered_actions)
 
     def do_reset():
         world.reset(layouts[state["episode"] % len(layouts)])
@@ -340,7 +345,7 @@ def main():
             dist.all_gather_into_tensor(world.records, world.records[r0:r1])
             world.step_end()
         else:
-            world.step(a)
+            world.step(a, actions_ready=state["ready"])
         state["elapsed"] += 1
         if state["elapsed"] > TIME_MAX:  # TimeLimitWrapper has set done for every robot: NeverStopWrapper resets
             do_reset()
@@ -453,6 +458,14 @@ def main():
         d0 = sorted(run("active", args.steps, min(args.warmup, 5), timing_mode=0)[0] for _ in range(3))[1]
         uninstrumented = dict(value=R * args.steps / d0, ms_per_step=1e3 * d0 / args.steps,
                               what="median of 3 more passes of the same %d steps with no HIP event in the timed region" % args.steps)
+    stream_ordered = None
+    if state["ready"] and world_size == 1:
+        state["ready"] = False
+        d1 = sorted(run("active", args.steps, min(args.warmup, 5), timing_mode=0)[0] for _ in range(3))[1]
+        state["ready"] = True
+        stream_ordered = dict(value=R * args.steps / d1, ms_per_step=1e3 * d1 / args.steps,
+                              what="median of 3 passes with plain imgenv_step: every kernel that reads the actions is ordered behind the caller's "
+                                   "stream (a policy may write them there in front of the call), so the observation runs behind the move")
     # SURVEY 8(d) wants the auto-reset inside the timed region; a run shorter than an episode (the driver's 20 steps) never meets
     # one, so it is timed separately: the same N steps + ONE full imgenv_reset of the world
     with_reset = None
@@ -593,6 +606,8 @@ def main():
             "resets_in_timed_region": resets_timed,
             "passes": {"n": len(passes), "value_is": "median", "values": pass_values, "min": min(pass_values), "max": max(pass_values)},
             "uninstrumented": uninstrumented,
+            "stream_ordered_actions": stream_ordered,
+            "actions": ("pre-generated in HBM; imgenv_step_flags(IMGENV_STEP_ACTIONS_READY)" if state["ready"] else "plain imgenv_step (stream-ordered)"),
             "with_reset": with_reset,
             "shipped": shipped,
             "frozen_fraction": frozen_active,

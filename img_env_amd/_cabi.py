@@ -17,6 +17,7 @@ KTYPE_DIFF, KTYPE_OMNI = 0, 1
 FLAG_PRIVATE_GRIDS = 1
 FLAG_COMPOSE_DENSE = 2
 FLAG_COMPOSE_SPARSE = 4
+STEP_ACTIONS_READY = 1  # imgenv_step_flags: the actions are complete when the call is made (include/imgenv.h)
 FLAG_LAYER_SUM = 512  # the counting class layer wherever it can run (include/imgenv.h)
 FLAG_NO_VIEW_MAPS = 8  # imgenv_out.view_maps not wanted (include/imgenv.h)
 FLAG_VIEW_TILED = 32  # views through the tiled kernels (csrc/view_big.h) / through k_view, where both can run
@@ -259,7 +260,7 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
            "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_step_autoreset_device", "imgenv_autoreset_last",
-           "imgenv_world_placement", "imgenv_cv_resize_u8", "imgenv_build_id")
+           "imgenv_world_placement", "imgenv_cv_resize_u8", "imgenv_build_id", "imgenv_step_flags")
 K_COUNT = 13
 
 
@@ -291,6 +292,7 @@ def bind(lib):
     lib.imgenv_reset_worlds_spawn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(SpawnCfg),
                                               C.POINTER(C.c_uint64), C.c_void_p]
     lib.imgenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.imgenv_step_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.imgenv_step_autoreset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SpawnCfg), C.c_uint64, C.POINTER(C.c_int32), C.c_int32,
                                           C.POINTER(C.c_int32), C.c_void_p]
     lib.imgenv_step_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -93,8 +93,8 @@ struct imgenv {
     bool early = false;             // the handle can run them (imgenv_step only; IMGENV_EARLY_OBS=0 in the environment switches them off)
     float4* ped_snap[2] = {nullptr, nullptr};
     unsigned orca_seq = 0;          // k_orca launches so far: launch q writes ped_snap[q & 1]
-    hipEvent_t ev_done = nullptr;   // behind the views of the last chain, on the caller's stream
-    bool ev_done_valid = false, early_step = false;
+    hipEvent_t ev_done = nullptr;   // behind the views of the last chain, on the caller's stream: what an early k_obs waits for
+    bool early_step = false;
     bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
@@ -127,6 +127,7 @@ struct imgenv {
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
     // imgenv_step on a handle of at most 4096 robots, all local: the move is left to the raster launch (k_move_raster)
     bool in_step = false, move_pending = false;
+    bool actions_ready = false;  // this imgenv_step_flags call carries IMGENV_STEP_ACTIONS_READY
     const float* move_actions = nullptr;
     double trace_acc[4] = {0, 0, 0, 0};  // IMGENV_TRACE_RESET: host time inside imgenv_step_autoreset
     long trace_calls = 0, trace_resets = 0;
@@ -1269,6 +1270,10 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         // limiter history to carry, views through k_view -- the headline shape and cfg-5; everything else keeps k_obs behind the move
         const bool limiters = cfg->limiter_v.has_velocity_limits || cfg->limiter_v.has_acceleration_limits || cfg->limiter_v.has_jerk_limits ||
                               cfg->limiter_w.has_velocity_limits || cfg->limiter_w.has_acceleration_limits || cfg->limiter_w.has_jerk_limits;
+        // ... and only in steps whose caller says that the actions are COMPLETE at the call (imgenv_step_flags, IMGENV_STEP_ACTIONS_READY).
+        // The early k_obs waits for the last chain's views, not for what the caller queued on its stream since -- a policy that
+        // writes the actions there; waiting for that (an event at the step's start) costs the whole gain: 106.5 us per step against
+        // 95.9 with the promise and 105.4 with k_obs behind the move, same box
         h->early = !h->serial && RL == R && P > 0 && h->NA > 0 && !d.beep_on && !limiters && !h->big_view &&
                    h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS;
         if (h->early) {
@@ -1660,11 +1665,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     }
     // no launch for the per-robot scalars: the k_view / k_obs wavefront that completes a group of 64 robots runs them
     // (tail_group).  The caller's stream ends the step behind both side streams
-    if (h->early) {  // the next early k_obs starts behind these views (and, on its own stream, behind this chain's k_obs and solve)
-        HIPCHK(hipEventRecord(h->ev_done, st));
-        h->ev_done_valid = true;
-    }
     h->early_step = false;
+    if (h->early) HIPCHK(hipEventRecord(h->ev_done, st));  // the next early k_obs starts behind these views (and, on its own stream, behind this chain's k_obs and solve)
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     h->launches += 3;
     HIPCHK(hipGetLastError());
@@ -2426,10 +2428,9 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     static const int force_fuse = getenv("IMGENV_FUSE_MOVE") ? atoi(getenv("IMGENV_FUSE_MOVE")) : -1;  // (measurement switch)
     const bool fuse_move = h->in_step && !d.sharded && !h->comm && h->RL == h->R && h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS &&
                            (force_fuse >= 0 ? force_fuse != 0 : (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024));
-    // early-observation step (world.h): the move goes into the raster launch whatever the size, and k_obs goes out NOW, on its side
-    // stream, beside it -- behind the last chain's views (ev_done) and, on that stream itself, behind the last solve
+    // early-observation step (world.h): k_obs goes out with the move, on its side stream, instead of behind it
     static const int force_early = getenv("IMGENV_EARLY_OBS") ? atoi(getenv("IMGENV_EARLY_OBS")) : -1;  // (measurement switch)
-    const bool early_step = h->early && h->in_step && !fuse_move && !h->chain_open && h->orca_seq > 0 && h->ev_done_valid && force_early != 0;
+    const bool early_step = h->early && h->in_step && h->actions_ready && !fuse_move && !h->chain_open && h->orca_seq > 0 && force_early != 0;
     if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
         h->move_pending = true;
         h->move_actions = actions;
@@ -2448,9 +2449,11 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     h->launches += 1;
     set_tail_fields(h, 0, h->elapsed + 1);  // imgenv_step_end counts the step; k_obs goes out before that
     if (early_step) {
-        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions, so its side stream only
-        // waits for the last chain's views (ev_done; on that stream itself it sits behind the last chain's k_obs and solve).  Queued
-        // BEHIND k_integrate, whose few workgroups are then dispatched first; what the caller's stream forks here is the solve alone.
+        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions -- which the caller has
+        // promised to be complete (IMGENV_STEP_ACTIONS_READY: nothing makes this launch wait for work queued on the caller's stream
+        // since the last step) --, so its side stream only waits for the last chain's views (ev_done; on that stream itself it sits
+        // behind the last chain's k_obs and solve).  Queued BEHIND k_integrate, whose few workgroups are then dispatched first; what
+        // the caller's stream forks behind the move is the solve alone.
         h->chain_open = true;
         HIPCHK(hipEventRecord(h->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
@@ -2481,10 +2484,14 @@ extern "C" int imgenv_step_end(imgenv_t* h, void* stream) {
     return launch_views(h, (hipStream_t)stream, 0);
 }
 
-extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) {
+extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) { return imgenv_step_flags(h, actions, 0u, stream); }
+
+extern "C" int imgenv_step_flags(imgenv_t* h, const float* actions, uint32_t flags, void* stream) {
     if (h) h->in_step = true;  // (begin and end in one call: the actions outlive the move whoever launches it)
+    if (h) h->actions_ready = (flags & IMGENV_STEP_ACTIONS_READY) != 0;
     const int rc_begin = imgenv_step_begin(h, actions, stream);
     if (h) h->in_step = false;
+    if (h) h->actions_ready = false;
     if (rc_begin) return rc_begin;
     if (h->comm) {  // the one exchange of a robot-sharded world: records of all robots, in place
         const size_t count = (size_t)h->RL * IMGENV_RECORD_DOUBLES;

@@ -163,9 +163,17 @@ class World:
             raise ValueError("actions must be [%d, 3] (v, w, beep)" % self.n_local)
         return actions
 
-    def step(self, actions):
-        a = self._actions(actions)
-        self._check(self.lib.imgenv_step(self.h, C.c_void_p(a.data_ptr()), self._stream()), "imgenv_step")
+    def step(self, actions, actions_ready=None):
+        """One step.  ``actions_ready``: the values of ``actions`` are complete now, not merely queued on the current stream
+        (``IMGENV_STEP_ACTIONS_READY``: the library may then start the observation kernel beside the move).  Default: true for
+        host data (this method copies it to the device, and torch's copy from pageable memory is complete when it returns), false for a device tensor -- a policy may
+        still be writing it on the stream."""
+        import torch
+        if actions_ready is None:
+            actions_ready = not isinstance(actions, torch.Tensor)
+        a = self._actions(actions)  # (host data: torch's copy from pageable memory returns when the data is on the device)
+        self._check(self.lib.imgenv_step_flags(self.h, C.c_void_p(a.data_ptr()), _cabi.STEP_ACTIONS_READY if actions_ready else 0,
+                                               self._stream()), "imgenv_step")
         return self.out
 
     def step_autoreset(self, actions, spawn_cfg, seed0):

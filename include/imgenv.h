@@ -296,8 +296,17 @@ int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* batch, void* stream);
 
 /* step_image_env + Python post-processing.  actions: DEVICE float[R][3] = (v, w, beep) of the
  * local robots (ContinuousAction, envs/action/action.py:8-20).  Dead robots are zeroed
- * inside (yaml_env.py:319-331). */
+ * inside (yaml_env.py:319-331).  The call is stream-ordered: actions written by work queued on `stream` in front of it are seen
+ * (imgenv_step_flags with IMGENV_STEP_ACTIONS_READY promises they are complete already). */
 int imgenv_step(imgenv_t* h, const float* actions, void* stream);
+/* The same with per-call flags.  IMGENV_STEP_ACTIONS_READY: the caller promises that `actions` hold their final values WHEN THE
+ * CALL IS MADE -- pre-generated, replayed, copied and synchronised, or produced on another stream that has been waited for --
+ * instead of merely being queued on `stream` in front of it.  The library may then start kernels that read them on its side
+ * streams without waiting for the caller's stream (early-observation steps, DESIGN.md section 4: the observation kernel runs
+ * beside the move instead of behind it; ~10 % on the headline shape).  Without the flag every kernel that reads the actions is
+ * ordered behind everything queued on `stream` before the call: a policy network may write them there right in front of it. */
+#define IMGENV_STEP_ACTIONS_READY 1u
+int imgenv_step_flags(imgenv_t* h, const float* actions, uint32_t flags, void* stream);
 
 /* The same step split around the one exchange a robot-sharded world needs:
  *   step_begin : pedestrian advance + pose integrate of the local robots, publishes their

@@ -905,3 +905,37 @@ def test_fuzzed_social_force_rooms_match_oracle(worlds, seed):
     finally:
         gpu.close()
         cpu.close()
+
+
+def test_step_waits_for_actions_written_on_the_callers_stream(worlds):
+    """A trainer's policy writes the actions on the caller's stream right in front of `imgenv_step`, without synchronising.  Every
+    kernel of the step that reads them -- the early-launched observation on its side stream included -- has to
+    run behind that write: two handles, one fed actions that are still being produced (behind ~ms of matrix products on the
+    same stream), one fed the finished values, stay bit-identical."""
+    import torch
+    World, _ = worlds
+    n = 512
+    grid, params, layout = small_world(n, 40, seed=91, grid_size=200, res=0.25, clearance=0.6, n_obstacles=2)
+    a, b = World(params, grid), World(params, grid)
+    try:
+        a.reset(layout)
+        b.reset(layout)
+        rng = np.random.default_rng(17)
+        dev = a.device
+        big = torch.randn(2048, 2048, device=dev)
+        late = torch.zeros(n, 3, device=dev)
+        for s in range(12):
+            want = torch.as_tensor(random_actions(rng, n), device=dev)
+            torch.cuda.synchronize()
+            b.step(want.clone())
+            y = big
+            for _ in range(6):
+                y = (y @ big) * 1e-3   # keeps the stream busy: the actions below exist only when this is through
+            late.copy_(want + 0.0 * y[:n, :3].nan_to_num(0.0, 0.0, 0.0))
+            a.step(late)             # no synchronisation in between
+            ga, gb = a.snapshot(), b.snapshot()
+            for k in EXACT + CLOSE:
+                assert np.array_equal(ga[k], gb[k], equal_nan=True), (s, k)
+    finally:
+        a.close()
+        b.close()

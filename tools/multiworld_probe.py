@@ -55,7 +55,7 @@ def measure(E, Rw, Pw, grid_cells, res=0.125, steps=300, warmup=100, time_max=10
 
     def do_step():
         s = st["step"]
-        world.step(acts[s % n_act])
+        world.step(acts[s % n_act], actions_ready=True)  # (pre-generated, resident in HBM)
         st["step"] = s + 1
         if resets:
             ks = due[(s + 1) % period]
