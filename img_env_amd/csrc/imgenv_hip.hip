@@ -1368,7 +1368,8 @@ static int check_device_flags(imgenv* h) {
                              "outgrew its scratch)", e[2]);
     if (e[6]) FAIL(IMGENV_EDEVICE, "class layer (counts): a pedestrian's footprint left its raster box or its cell list (code %d)", e[6]);
     if (e[4])
-        FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth) -- more than "
+        FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth, 5 a leaf lock never came free, "
+                             "6 an agent a split re-homed is on the other side of its new leaf's edge than its own move assumed) -- more than "
                              "8 agents piled up outside the tree's 10 m x 10 m root square, where the reference recurses forever "
                              "(ped_tree.cpp:65-96)", e[4]);
     return 0;
@@ -3096,6 +3097,47 @@ extern "C" int imgenv_debug_marks(imgenv_t* h, unsigned long long* out32) {
     if (!h || !out32) FAIL(IMGENV_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out32, h->d.dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return IMGENV_OK;
+}
+// debug / tests: the quadtree of world `world`'s social-force crowd as a digest that does not depend on how the nodes are numbered --
+// node count, member entries, a sum of per-leaf hashes (rectangle + sorted members), a sum of per-agent hashes (the rectangle the
+// agent's treehash entry points at).  tests/test_gpu_parity.py holds it to the oracle's tree (oracle_sfm.c: sfm_tree_digest) step by step.
+extern "C" int imgenv_debug_sfm_tree(imgenv_t* h, int32_t world, uint64_t* out4 /* [8] */) {
+    if (!h || !out4) FAIL(IMGENV_EINVAL, "null argument");
+    const SfmDev& f = h->d.sfm;
+    if (h->cfg.ped_scene_type != IMGENV_SCENE_PEDSIM || f.n <= 0 || world < 0 || world >= f.W) FAIL(IMGENV_EINVAL, "no social-force crowd %d", world);
+    HIPCHK(hipDeviceSynchronize());
+    int n_nodes = 0;
+    HIPCHK(hipMemcpy(&n_nodes, f.n_nodes + world, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_nodes < 1 || n_nodes > f.cap_nodes) FAIL(IMGENV_EDEVICE, "quadtree node count %d", n_nodes);
+    std::vector<SfmNode> nodes((size_t)n_nodes);
+    std::vector<int> hash((size_t)f.n);
+    HIPCHK(hipMemcpy(nodes.data(), f.nodes + (size_t)world * f.cap_nodes, sizeof(SfmNode) * (size_t)n_nodes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hash.data(), f.treehash + (size_t)world * f.n, sizeof(int) * (size_t)f.n, hipMemcpyDeviceToHost));
+    auto mix = [](uint64_t a, uint64_t v) { return (a ^ v) * 0x100000001b3ull; };
+    auto bits = [](double v) {
+        uint64_t b;
+        memcpy(&b, &v, sizeof(b));
+        return b;
+    };
+    auto rect = [&](uint64_t a, const SfmNode& q) { return mix(mix(mix(mix(a, bits(q.x)), bits(q.y)), bits(q.w)), bits(q.h)); };
+    uint64_t members = 0, leaves = 0, agents = 0;
+    out4[4] = out4[5] = out4[6] = out4[7] = 0;  // one bit per agent that is a member of some leaf
+    for (const SfmNode& q : nodes) {
+        if (!q.isleaf || q.n_agents == 0) continue;
+        uint64_t a = mix(rect(0xcbf29ce484222325ull, q), (uint64_t)q.n_agents);
+        for (int e = 0; e < q.n_agents; e++) {
+            a = mix(a, (uint64_t)q.agents[e]);
+            if (q.agents[e] >= 0 && q.agents[e] < 256) out4[4 + (q.agents[e] >> 6)] |= 1ull << (q.agents[e] & 63);
+        }
+        leaves += a;
+        members += (uint64_t)q.n_agents;
+    }
+    for (int a = 0; a < f.n; a++) {
+        if (hash[a] < 0 || hash[a] >= n_nodes) FAIL(IMGENV_EDEVICE, "treehash[%d] = %d", a, hash[a]);
+        agents += rect(mix(0xcbf29ce484222325ull, (uint64_t)a), nodes[(size_t)hash[a]]);
+    }
+    out4[0] = (uint64_t)n_nodes; out4[1] = members; out4[2] = leaves; out4[3] = agents;
     return IMGENV_OK;
 }
 // debug: per-wave (start, end, hw id, 0) records of the last k_view [0, 4 RL) and k_obs [4 RL, 8 RL) launches

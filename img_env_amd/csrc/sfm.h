@@ -122,8 +122,13 @@ SFM_HD inline void sfm_set_erase(SfmNode& q, int a) {
 // never change once they exist, so a descent that was walked on an earlier state of the tree is still a prefix of today's)
 // `rehomed`: one flag per agent; a split sets it to 3 for every member it re-homes (unless it is 2), so that a caller that
 // decides ahead of time who has left its leaf can re-test exactly the agents whose leaf changed
+// `p_old`, `turn`: Tagent::move (ped_agent.cpp:519-571) moves ONE agent and has the scene update the tree (scene->moveAgent(this),
+// line 570) before the next agent moves -- so a split during agent `turn`'s update re-homes the leaf's members by where they are
+// at that moment: agents up to `turn` at their new positions (p), the ones behind it still at their old ones (p_old, `old_stride`
+// doubles per agent).  p_old = nullptr: every position from p (building the initial tree).
 SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err,
-                                 int* work = nullptr, int start = 0, unsigned short* rehomed = nullptr) {
+                                 int* work = nullptr, int start = 0, unsigned short* rehomed = nullptr, const double* p_old = nullptr,
+                                 int old_stride = 3, int turn = 0x7FFFFFFF) {
     int local_stack[2 * SFM_MAX_DEPTH * 8];
     int* st_node = work ? work : local_stack;
     int* st_agent = st_node + SFM_MAX_DEPTH * 8;
@@ -162,7 +167,8 @@ SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* tre
                 q.n_agents = 0;
             }
         } else {
-            const double px = p[3 * a], py = p[3 * a + 1];
+            const bool moved = !p_old || a <= turn;
+            const double px = moved ? p[3 * a] : p_old[old_stride * a], py = moved ? p[3 * a + 1] : p_old[old_stride * a + 1];
             const double cx = q.x + q.w / 2, cy = q.y + q.h / 2;
             // order of the four non-exclusive tests: tree3, tree1, tree2, tree4 (LIFO: push reversed)
             int tgt[4], nt = 0;
@@ -182,7 +188,7 @@ SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* tre
     }
 }
 
-// Tscene::moveAgent -> Ttree::moveAgent (ped_tree.cpp:131-137)
+// Tscene::moveAgent -> Ttree::moveAgent (ped_tree.cpp:131-137); p: the crowd as it stands at this agent's turn
 SFM_HD inline void sfm_move_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int a, int* err,
                                   int* work = nullptr, int start = 0, unsigned short* rehomed = nullptr) {
     const int leaf = treehash[a];
@@ -194,6 +200,195 @@ SFM_HD inline void sfm_move_agent(SfmNode* nodes, int* n_nodes, int cap, int* tr
     }
 }
 
+
+// ---- Tscene::moveAgent for the whole crowd (ped_tree.cpp:131-137), in stages that k_sfm runs with thread i = agent i and a
+// barrier in between, and tests/host/sfm_tree_check.cpp agent by agent against the literal loop (sfm_surgery_literal) ----
+//
+// Most of the moves commute.  What the reference fixes is the ORDER of the inserts and erases of one leaf (agent order; an
+// agent's insert comes before its own erase): a leaf splits the moment an insert makes it 9 agents.  Every agent's two
+// operations are known up front -- the leaf T its descent ends at, the node `old` its treehash points at, and whether each
+// really changes a set (std::set: an insert of a member and an erase of a non-member do nothing) -- and stay what they are as
+// long as neither leaf splits.  So the count of every leaf along the reference's order can be worked out ahead: a leaf whose
+// count never passes 8 is QUIET, it cannot split whatever happens elsewhere (induction over the first split of the step), and
+// what the step leaves in it does not depend on the order: its erases, then its inserts, are done by all agents at once, a
+// lock per leaf (erases first: the count then never passes what the reference's order reaches either; an agent whose two
+// operations hit the same leaf ends up outside it -- that is how libpedsim loses agents -- so it only erases).  Only the
+// operations on the other leaves -- those an insert really takes to 9 -- are replayed by one thread, in agent order, with the
+// splits and the re-tests of the agents a split re-homes as the reference does them.
+// (round 3 counted `members + everybody who wants in` instead: in a crowd outside the tree's rectangle -- cfg-4: the tree covers
+// y in [10, 20], the crowd lives below it -- EVERY agent has left its leaf every step and inserts + erases itself in the same
+// edge leaf, so any stretch of the edge that holds nine agents looked unsafe and half the crowd was replayed serially: ~100 us.)
+// What the assumption does not cover sends the whole step to the serial replay, which is the definition: a descent that is
+// not unique (a position exactly on a centre line: the reference inserts into several children), a tree that lives in HBM, and
+// a leaf about to split that holds an agent whose treehash points elsewhere (left behind by such a multiple insert: the split
+// would re-home it and change what its own move does).
+struct SfmSurgery {
+    SfmNode* nodes;
+    int* n_nodes;
+    int cap_nodes;
+    int* treehash;
+    const double* p;      // [n][3] the new positions
+    const double* p_old;  // [n][old_stride] the positions the step started from (sfm_add_agent: what a split sees of the agents behind the one that moves)
+    int old_stride;
+    int n;
+    unsigned short* flag;         // [agent] 0 stays, 1 has left its leaf, 2 done ahead of the replay, 3 re-homed by a split (test again)
+    unsigned short* leaf;         // [agent] the leaf its descent from the root ends at (0: not unique -- the replay starts at the root)
+    unsigned short* need_serial;  // [1] the whole step is replayed literally
+    unsigned short* ins_leaf;     // [agent] the leaf its insert really grows, 0xFFFF = none
+    unsigned short* ers_leaf;     // [agent] the node its erase really shrinks
+    unsigned short* ends;         // [agent] bit 0: its insert is done (or nothing to do), bit 1: its erase, bit 2: it had left its leaf
+    unsigned short* loud;         // [node] leaves that are not quiet
+    int* arrivals;                // [node] real inserts
+    unsigned long long* todo;     // [(n + 63) / 64] the agents the replay has to visit
+    int* work;                    // sfm_add_agent's stack
+};
+struct SfmMove {  // what an agent keeps between the stages (registers on the device)
+    int T, old;
+    bool mover, in_T, t_quiet, o_quiet, do_erase, do_insert;
+    unsigned short il, el;
+};
+
+// Whether agent i left its leaf, and where the descent of its new position from the root ends: all agents at once, BEFORE anything moves (internal
+// nodes never change once they exist, so a descent walked on an earlier state of the tree is a prefix of the real one; a
+// dependent access per level, ~20 levels once the tree has grown: most of the serial section's time when it was walked there)
+SFM_HD inline void sfm_surgery_descent(const SfmSurgery& c, int i) {
+    const SfmNode* nodes = c.nodes;
+    const SfmNode& q = nodes[c.treehash[i]];
+    const double px = c.p[3 * i], py = c.p[3 * i + 1];
+    const bool left = (px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h));
+    int node = 0;
+    {   // (also for an agent that stays: a split may re-home it by its OLD position into a child its new one is outside of)
+        for (int depth = 0; depth < SFM_MAX_DEPTH && !nodes[node].isleaf; depth++) {
+            const SfmNode& t = nodes[node];
+            const double cx = t.x + t.w / 2, cy = t.y + t.h / 2;
+            int cnt = 0, nxt = 0;
+            if ((px >= cx) && (py >= cy)) { cnt++; nxt = t.child[2]; }
+            if ((px <= cx) && (py <= cy)) { cnt++; nxt = t.child[0]; }
+            if ((px >= cx) && (py <= cy)) { cnt++; nxt = t.child[1]; }
+            if ((px <= cx) && (py >= cy)) { cnt++; nxt = t.child[3]; }
+            if (cnt != 1) {
+                node = 0;
+                break;
+            }
+            node = nxt;
+        }
+    }
+    c.flag[i] = left ? 1 : 0;
+    c.leaf[i] = (unsigned short)(node < 65536 ? node : 0);
+}
+SFM_HD inline bool sfm_is_member(const SfmNode& t, int a) {
+    bool in = false;
+    for (int k = 0; k < t.n_agents; k++) in |= t.agents[k] == a;
+    return in;
+}
+// stage 1: agent i's two operations
+SFM_HD inline SfmMove sfm_surgery_classify(const SfmSurgery& c, int i) {
+    SfmMove m;
+    m.mover = i < c.n && c.flag[i] != 0;
+    m.T = m.mover ? (int)c.leaf[i] : 0;
+    m.old = m.mover ? c.treehash[i] : 0;
+    m.in_T = false;
+    m.t_quiet = m.o_quiet = m.do_erase = m.do_insert = false;
+    m.il = m.el = 0xFFFF;
+    if (i < c.n && (c.leaf[i] == 0 || !c.nodes[c.leaf[i]].isleaf)) *c.need_serial = 1;  // (a descent that is not unique -- of an agent that stays, too)
+    if (m.mover) {
+        if (m.T == 0 || !c.nodes[m.T].isleaf) {
+            *c.need_serial = 1;
+        } else {
+            m.in_T = sfm_is_member(c.nodes[m.T], i);
+            const bool in_old = m.old == m.T ? m.in_T : sfm_is_member(c.nodes[m.old], i);
+            if (!m.in_T) {
+                m.il = (unsigned short)m.T;
+#if defined(__HIP_DEVICE_COMPILE__)
+                atomicAdd(&c.arrivals[m.T], 1);
+#else
+                c.arrivals[m.T] += 1;
+#endif
+            }
+            if (m.old == m.T || in_old) m.el = (unsigned short)m.old;  // (behind its insert it is a member of T)
+        }
+    }
+    c.ins_leaf[i] = m.il;
+    c.ers_leaf[i] = m.el;
+    return m;
+}
+// stage 2: the leaf's count at this agent's insert, along the reference's order (cheap bound first: every insert in front of every erase)
+SFM_HD inline void sfm_surgery_count(const SfmSurgery& c, int i, const SfmMove& m) {
+    if (m.il != 0xFFFF && c.nodes[m.T].n_agents + c.arrivals[m.T] > 8) {
+        int cnt = c.nodes[m.T].n_agents + 1;
+        for (int b = 0; b < i; b++) cnt += (c.ins_leaf[b] == m.il ? 1 : 0) - (c.ers_leaf[b] == m.il ? 1 : 0);
+        if (cnt > 8) c.loud[m.T] = 1;
+    }
+}
+// stage 3, per node: a leaf about to split must hold nobody whose treehash points elsewhere
+SFM_HD inline void sfm_surgery_census(const SfmSurgery& c, int q) {
+    if (!c.loud[q]) return;
+    const SfmNode& t = c.nodes[q];
+    for (int k = 0; k < t.n_agents; k++)
+        if (c.treehash[t.agents[k]] != q) *c.need_serial = 1;
+}
+// stage 4: which of its operations agent i does itself, ahead of the replay (the caller: erases, a barrier, inserts -- under the leaf's lock)
+SFM_HD inline void sfm_surgery_verdict(const SfmSurgery& c, int i, SfmMove& m) {
+    const bool ok = m.mover && *c.need_serial == 0;
+    m.t_quiet = ok && !c.loud[m.T];
+    m.o_quiet = ok && !c.loud[m.old];
+    // (same leaf at both ends: a member leaves, a non-member comes and goes -- either way only the erase counts)
+    m.do_erase = m.o_quiet && m.el != 0xFFFF && (m.old != m.T || m.in_T);
+    m.do_insert = m.t_quiet && m.il != 0xFFFF && m.old != m.T;
+}
+// stage 5: behind its own operations
+SFM_HD inline void sfm_surgery_settle(const SfmSurgery& c, int i, const SfmMove& m) {
+    if (m.t_quiet && m.o_quiet) {
+        c.treehash[i] = m.T;
+        c.flag[i] = 2;  // done: the replay passes it by (also after a split, when it re-tests the split leaf's members)
+    }
+    c.ends[i] = (unsigned short)((m.t_quiet ? 1 : 0) | (m.o_quiet ? 2 : 0) | (m.mover ? 4 : 0));
+}
+// stage 6, one thread: what is left, in agent order.  c.todo: one bit per agent whose flag is 1.
+SFM_HD inline void sfm_surgery_replay(const SfmSurgery& c, int* lerr) {
+    SfmNode* nodes = c.nodes;
+    for (int wd = 0; wd < (c.n + 63) / 64 && *lerr == 0; wd++) {
+        unsigned long long m = c.todo[wd];
+        while (m && *lerr == 0) {
+            int bit = 0;
+            while (!((m >> bit) & 1ull)) bit++;
+            const int a = 64 * wd + bit;
+            m &= m - 1;
+            const int flag = c.flag[a], e = c.ends[a], start = c.leaf[a], nn_before = *c.n_nodes;
+            const int cur = c.treehash[a];
+            bool moves = flag == 1;  // left its leaf, and the leaf is still the one that verdict was about: no second test
+            if (flag == 3) {         // a split re-homed it: Ttree::moveAgent's test on the leaf it is in now
+                const SfmNode& q = nodes[cur];
+                const double px = c.p[3 * a], py = c.p[3 * a + 1];
+                moves = (px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h));
+                // (the split put it into a child by where it stood BEFORE this step, sfm_add_agent: an agent that stays inside the
+                // split leaf may well have left that child.  One that had left the split leaf has left every child of it: the
+                // rectangles' corners are exact sums down to depth 48.  Should that ever fail while its operations have been done
+                // ahead of its turn, the step is reported instead of replayed wrongly.)
+                if (!moves && (e & 4) && *c.need_serial == 0) *lerr = 6;
+            }
+            if (moves && *lerr == 0) {
+                if (e & 1) {  // a quiet leaf: the insert is done
+                    c.treehash[a] = start;
+                } else {
+                    SfmNode& t = nodes[start];
+                    if (start != 0 && t.isleaf && t.n_agents < 8) {  // room in the leaf its descent ended at: no stack, no split
+                        sfm_set_insert(t, a, lerr);
+                        c.treehash[a] = start;
+                    } else {
+                        sfm_add_agent(nodes, c.n_nodes, c.cap_nodes, c.treehash, c.p, a, lerr, c.work, start, c.flag, c.p_old, c.old_stride, a);
+                    }
+                }
+                if (flag == 3 || !(e & 2)) sfm_set_erase(nodes[cur], a);  // erased from the OLD leaf, even if it is the new one (ped_tree.cpp:131-137)
+            }
+            if (*c.n_nodes != nn_before) {  // a split: its members behind this agent get their turn
+                for (int b = a + 1; b < c.n; b++)
+                    if (c.flag[b] == 3) c.todo[b >> 6] |= 1ull << (b & 63);
+                m = c.todo[wd] & ~((2ull << bit) - 1ull);
+            }
+        }
+    }
+}
 #if defined(__HIPCC__)
 struct d3 {
     double x, y, z;
@@ -428,22 +623,31 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
             int count = 0;
             const d3 e = D3(sh[i], sh[n_cap + i], 0);
             // the terms are added in neighbour order (the sums round as the reference's loop does), but their loads do not
-            // depend on each other: eight neighbours' codes and terms are fetched at once, then added one by one
+            // depend on each other: eight neighbours' codes and terms are fetched at once, then added one by one.  Only the
+            // agent's neighbours are visited (everybody else's code says "no vote, no term"): in ascending order out of its bit
+            // set, a word at a time -- a crowd outside the tree's rectangle has a fifth of its agents in the tree at any time
+            // (cfg-4: 25 rounds of loads per agent -> 7; 29 -> 9 us)
             const unsigned char* codes = s.pair_code + i;   // [o][agent]
             const double* terms = s.pair_f + 3 * (size_t)i;
-            for (int o0 = 0; o0 < n; o0 += 8) {
-                unsigned char cd[8];
-                d3 tm[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const size_t o = (size_t)min(o0 + u, n - 1) * n;
-                    cd[u] = o0 + u < n ? codes[o] : (unsigned char)1;  // 1: no vote, no term
-                    tm[u] = D3(terms[3 * o], terms[3 * o + 1], terms[3 * o + 2]);  // (garbage where the code has no term: unused)
-                }
+            for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) {
+                uint32_t wb = mine[k] & ~(k == (i >> 5) ? 1u << (i & 31) : 0u);  // (its own entry carries neither a vote nor a term: the pair loop above)
+                while (wb) {
+                    unsigned char cd[8];
+                    d3 tm[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    count += (int)(cd[u] & 3) - 1;
-                    if (cd[u] & 4) socialforce = socialforce + tm[u];
+                    for (int u = 0; u < 8; u++) {
+                        const bool has = wb != 0;
+                        const size_t o = (size_t)(has ? 32 * k + __ffs((int)wb) - 1 : 0) * n;
+                        wb &= wb - 1;  // (0 stays 0)
+                        cd[u] = has ? codes[o] : (unsigned char)1;  // 1: no vote, no term
+                        tm[u] = D3(terms[3 * o], terms[3 * o + 1], terms[3 * o + 2]);  // (garbage where the code has no term: unused)
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        count += (int)(cd[u] & 3) - 1;
+                        if (cd[u] & 4) socialforce = socialforce + tm[u];
+                    }
                 }
             }
             if (count < 0) {
@@ -505,125 +709,100 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         d3 v = scaled(me_v, 0.5) + scaled(a, h);
         if (len3(v) > s.vmax[i]) v = scaled(normalized(v), s.vmax[i]);
         s.p[3 * i] = p_desired.x; s.p[3 * i + 1] = p_desired.y; s.p[3 * i + 2] = p_desired.z;
-        lp[3 * i] = p_desired.x;  // the serial tree surgery below reads positions from LDS
+        lp[3 * i] = p_desired.x;  // the tree surgery below reads positions from LDS
         lp[3 * i + 1] = p_desired.y;
+        double* lp_old = (double*)(stk + 11 * blockDim.x);  // [n][2]: rows 11-18 of the walk stacks' LDS (dead since the neighbour walk)
+        lp_old[2 * i] = me_p.x;
+        lp_old[2 * i + 1] = me_p.y;
         s.v[3 * i] = v.x; s.v[3 * i + 1] = v.y; s.v[3 * i + 2] = v.z;
     }
     __syncthreads();
     SFM_STAMP(5);
-    // scene->moveAgent(this) in agent order (ped_tree.cpp:131-137).  Whether an agent left its leaf is tested by all agents
-    // at once: the verdict stands as long as the agent's leaf is the same; a split re-homes the leaf's members, and those are
-    // flagged (sfm_add_agent) and tested again when their turn comes.
-    // An agent that did leave also walks its descent from the root NOW, all of them at once (a dependent LDS access per level,
-    // ~20 levels once the tree has grown: most of the serial section's time when it was walked there): stk[blockDim.x + a] is
-    // the leaf it reaches -- unless its position sits exactly on a centre line (the reference then descends into several
-    // children): 0, the serial code starts from the root.
-    if (i < n) {
-        const SfmNode& q = nodes[treehash[i]];
-        const double px = lp[3 * i], py = lp[3 * i + 1];
-        const bool left = (px < q.x) || (px > (q.x + q.w)) || (py < q.y) || (py > (q.y + q.h));
-        int node = 0;
-        if (left) {
-            for (int depth = 0; depth < SFM_MAX_DEPTH && !nodes[node].isleaf; depth++) {
-                const SfmNode& t = nodes[node];
-                const double cx = t.x + t.w / 2, cy = t.y + t.h / 2;
-                int cnt = 0, nxt = 0;
-                if ((px >= cx) && (py >= cy)) { cnt++; nxt = t.child[2]; }
-                if ((px <= cx) && (py <= cy)) { cnt++; nxt = t.child[0]; }
-                if ((px >= cx) && (py <= cy)) { cnt++; nxt = t.child[1]; }
-                if ((px <= cx) && (py >= cy)) { cnt++; nxt = t.child[3]; }
-                if (cnt != 1) {
-                    node = 0;
-                    break;
-                }
-                node = nxt;
-            }
-        }
-        stk[i] = left ? 1 : 0;
-        stk[blockDim.x + i] = (unsigned short)(node < 65536 ? node : 0);
-    }
+    // scene->moveAgent(this) in agent order (ped_tree.cpp:131-137): sfm_surgery_* above (shared with tests/host/sfm_tree_check.cpp,
+    // which runs the same functions agent by agent against the literal loop).  Here: thread i = agent i, a barrier between the stages.
+    SfmSurgery sg;
+    sg.nodes = nodes; sg.n_nodes = n_nodes; sg.cap_nodes = cap_nodes; sg.treehash = treehash; sg.p = lp; sg.n = n;
+    sg.p_old = (const double*)(stk + 11 * blockDim.x); sg.old_stride = 2;
+    sg.flag = stk;                          // rows of the walk stacks' LDS, [blockDim.x] each
+    sg.leaf = stk + blockDim.x;
+    sg.need_serial = stk + 2 * blockDim.x;
+    sg.ins_leaf = stk + 3 * blockDim.x;
+    sg.ers_leaf = stk + 4 * blockDim.x;
+    sg.ends = stk + 5 * blockDim.x;
+    sg.loud = stk + 6 * blockDim.x;         // [SFM_LDS_NODES]: rows 6-9
+    sg.todo = (unsigned long long*)(stk + 10 * blockDim.x);
+    sg.arrivals = (int*)sh_lds;             // [SFM_LDS_NODES] (the LDS angle table, 8 KB, is free by now)
+    sg.work = (int*)sh_lds;                 // (sfm_add_agent's stack, in the serial replay: the counters are dead by then)
+    int* leaf_lock = sg.arrivals + SFM_LDS_NODES;  // [SFM_LDS_NODES]
+    static_assert(SFM_WALK_CAP >= 19 && SFM_LDS_NODES <= 4 * SFM_MAX_AGENTS && SFM_LDS_NODES < 0xFFFF, "rows of the walk stacks reused by the tree surgery");
+    if (i < n) sfm_surgery_descent(sg, i);
+    else if (i < (int)blockDim.x) sg.flag[i] = 0;
     __syncthreads();
     SFM_STAMP(7);
-    // Most of the moves commute.  A leaf is SAFE if its members plus everybody who wants in are at most 8, counted before
-    // anything moves: whatever the order, it cannot split, and without a split a leaf's set simply ends as old members +
-    // arrivals - departures (an agent's own insert-then-erase keeps its order: that is what removes it altogether when its old
-    // and new leaf are the same, ped_tree.cpp:131-137).  Agents whose old AND new leaf are safe do their insert and erase all at
-    // once, a lock per leaf; the others -- a leaf they touch may split, which re-homes its members and changes what "old leaf"
-    // means for them -- are replayed serially afterwards, in agent order, as the reference does.  (A descent that was not
-    // unique, or a tree that lives in HBM: everything serially.)  A finer test -- the leaf's count along the replay order,
-    // departures included -- was tried and is wrong as it stands: moves done out of order can push a leaf past 8 for a while,
-    // and a serial arrival that meets it then splits it.
-    int* arrivals = (int*)sh_lds;              // [SFM_LDS_NODES] (the LDS angle table, 8 KB, is free by now)
-    int* leaf_lock = arrivals + SFM_LDS_NODES;  // [SFM_LDS_NODES]
-    unsigned short* need_serial = stk + 2 * blockDim.x;
     if (in_lds) {
-        for (int q = threadIdx.x; q < 2 * SFM_LDS_NODES; q += blockDim.x) arrivals[q] = 0;
-        if (i == 0) *need_serial = 0;
+        for (int q = threadIdx.x; q < 2 * SFM_LDS_NODES; q += blockDim.x) sg.arrivals[q] = 0;
+        for (int q = threadIdx.x; q < SFM_LDS_NODES; q += blockDim.x) sg.loud[q] = 0;
+        if (i == 0) *sg.need_serial = 0;
         __syncthreads();
-        const bool mover = i < n && stk[i];
-        const int T = mover ? (int)stk[blockDim.x + i] : 0, old = mover ? treehash[i] : 0;
-        if (mover) {
-            if (T == 0 || !nodes[T].isleaf) *need_serial = 1;
-            else atomicAdd(&arrivals[T], 1);
+        SfmMove mv = sfm_surgery_classify(sg, i);
+        __syncthreads();
+        sfm_surgery_count(sg, i, mv);
+        __syncthreads();
+        {
+            const int nn_now = *n_nodes;
+            for (int q = threadIdx.x; q < nn_now; q += blockDim.x) sfm_surgery_census(sg, q);
         }
         __syncthreads();
-        const bool par = mover && *need_serial == 0 && nodes[T].n_agents + arrivals[T] <= 8 && nodes[old].n_agents + arrivals[old] <= 8;
-        __syncthreads();  // every verdict stands before anything moves
+        sfm_surgery_verdict(sg, i, mv);
         int lerr = 0;
         // (the loops run until the whole wavefront is through: with a per-lane exit the compiler may sink the critical section
         // behind the loop, where a lane that holds the lock waits for the lanes that spin on it)
-        bool done = !par;
+        bool done = !mv.do_erase;
         for (int spin = 0; !__all(done) && spin < (1 << 20); spin++) {
             if (!done) {
                 int expected = 0;
-                if (__hip_atomic_compare_exchange_strong(&leaf_lock[T], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    sfm_set_insert(nodes[T], i, &lerr);
-                    __hip_atomic_store(&leaf_lock[T], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__hip_atomic_compare_exchange_strong(&leaf_lock[mv.old], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    sfm_set_erase(nodes[mv.old], i);
+                    __hip_atomic_store(&leaf_lock[mv.old], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     done = true;
                 }
             }
         }
-        if (par && !done) lerr = 5;
-        if (par) treehash[i] = T;
-        done = !par;
+        if (mv.do_erase && !done) lerr = 5;
+        __syncthreads();  // every erase in front of every insert: no leaf ever holds more than it does in the reference's order
+        done = !mv.do_insert;
         for (int spin = 0; !__all(done) && spin < (1 << 20); spin++) {
             if (!done) {
                 int expected = 0;
-                if (__hip_atomic_compare_exchange_strong(&leaf_lock[old], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    sfm_set_erase(nodes[old], i);
-                    __hip_atomic_store(&leaf_lock[old], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__hip_atomic_compare_exchange_strong(&leaf_lock[mv.T], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    sfm_set_insert(nodes[mv.T], i, &lerr);
+                    __hip_atomic_store(&leaf_lock[mv.T], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     done = true;
                 }
             }
         }
-        if (par && !done) lerr = 5;
-        if (par) stk[i] = 2;  // done: the serial replay below passes it by (also after a split, when it re-tests everybody else)
+        if (mv.do_insert && !done) lerr = 5;
+        sfm_surgery_settle(sg, i, mv);
         if (lerr) *s.err = lerr;
+        const unsigned long long m = __ballot(i < n && sg.flag[i] == 1);
+        if ((threadIdx.x & 63) == 0) sg.todo[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (stamp && threadIdx.x == 0) {  // (profile builds: how many agents are left to the serial replay, and why)
+            stamp[10] = (unsigned long long)(__popcll(sg.todo[0]) + __popcll(sg.todo[1]) + __popcll(sg.todo[2]) + __popcll(sg.todo[3]));
+            stamp[11] = *sg.need_serial;
+        }
+    }
+    else {  // the tree in HBM: every agent that left its leaf is replayed, as in a step with a tie
+        if (i == 0) *sg.need_serial = 1;
+        sg.ends[i] = (unsigned short)(i < n && sg.flag[i] ? 4 : 0);
+        const unsigned long long m = __ballot(i < n && sg.flag[i] == 1);
+        if ((threadIdx.x & 63) == 0) sg.todo[threadIdx.x >> 6] = m;
         __syncthreads();
     }
     SFM_STAMP(8);
     if (i == 0) {
         int lerr = 0;  // s.err is page-locked host memory: touched only to report
-        // Who left its leaf was decided for all agents at once; that verdict stands for an agent as long as its leaf is the
-        // same.  A split re-homes the leaf's members: those (and only those) are flagged and tested again at their turn.
-        for (int a = 0; a < n && lerr == 0; a++) {
-            const int flag = stk[a];
-            if (flag != 1 && flag != 3) continue;
-            const int start = stk[blockDim.x + a];
-            if (flag == 1) {  // left its leaf, and the leaf is still the one that verdict was about: no second test
-                const int old = treehash[a];
-                SfmNode& t = nodes[start];
-                if (start != 0 && t.isleaf && t.n_agents < 8) {  // room in the leaf its descent ended at: no stack, no split
-                    sfm_set_insert(t, a, &lerr);
-                    treehash[a] = start;
-                } else {
-                    sfm_add_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds /* (the counters above are dead) */, start, stk);
-                }
-                sfm_set_erase(nodes[old], a);  // erased from the OLD leaf, even if it is the new one (ped_tree.cpp:131-137)
-            } else {  // a split re-homed it: Ttree::moveAgent as it stands, its descent (if it has one) still a valid prefix
-                sfm_move_agent(nodes, n_nodes, cap_nodes, treehash, lp, a, &lerr, (int*)sh_lds, start, stk);
-            }
-        }
+        sfm_surgery_replay(sg, &lerr);
         if (lerr) *s.err = lerr;
     }
     __syncthreads();

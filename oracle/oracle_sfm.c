@@ -544,6 +544,42 @@ void sfm_get_agent(const sfm_scene* s, int idx, double* out6) {
 
 double sfm_get_vmax(const sfm_scene* s, int idx) { return s->ag[idx].vmax; }
 
+/* test aid: a digest of the quadtree that does not depend on how its nodes are numbered -- node count, member entries, a sum of
+ * per-leaf hashes (rectangle + sorted members) and a sum of per-agent hashes (the rectangle its treehash entry points at) */
+static uint64_t digest_mix(uint64_t h, uint64_t v) { return (h ^ v) * 0x100000001b3ull; }
+static uint64_t digest_f64(double v) {
+    uint64_t b;
+    memcpy(&b, &v, sizeof(b));
+    return b;
+}
+void sfm_tree_digest(const sfm_scene* s, uint64_t* out4) { /* out4[4 .. 7]: one bit per agent that is a member of some leaf */
+    uint64_t members = 0, leaves = 0, agents = 0;
+    out4[4] = out4[5] = out4[6] = out4[7] = 0;
+    for (int k = 0; k < s->n_nodes; k++) {
+        const qnode* q = &s->nodes[k];
+        if (!q->isleaf || q->n_agents == 0) continue;
+        uint64_t h = 0xcbf29ce484222325ull;
+        h = digest_mix(h, digest_f64(q->x)); h = digest_mix(h, digest_f64(q->y));
+        h = digest_mix(h, digest_f64(q->w)); h = digest_mix(h, digest_f64(q->h));
+        h = digest_mix(h, (uint64_t)q->n_agents);
+        for (int e = 0; e < q->n_agents; e++) {
+            h = digest_mix(h, (uint64_t)q->agents[e]);
+            if (q->agents[e] < 256) out4[4 + (q->agents[e] >> 6)] |= 1ull << (q->agents[e] & 63);
+        }
+        leaves += h;
+        members += (uint64_t)q->n_agents;
+    }
+    for (int a = 0; a < s->n; a++) {
+        const qnode* q = &s->nodes[s->treehash[a]];
+        uint64_t h = 0xcbf29ce484222325ull;
+        h = digest_mix(h, (uint64_t)a);
+        h = digest_mix(h, digest_f64(q->x)); h = digest_mix(h, digest_f64(q->y));
+        h = digest_mix(h, digest_f64(q->w)); h = digest_mix(h, digest_f64(q->h));
+        agents += h;
+    }
+    out4[0] = (uint64_t)s->n_nodes; out4[1] = members; out4[2] = leaves; out4[3] = agents;
+}
+
 
 #include <stdio.h>
 void sfm_debug_dump(const sfm_scene* s) { /* test aid: tree leaves and treehash */

@@ -33,6 +33,7 @@ def load_oracle():
     lib.oracle_pedinfo.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.oracle_private_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.oracle_grids.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.oracle_sfm_tree.argtypes = [C.c_void_p, C.c_void_p]
     lib.sfm_set_cr_atan2.argtypes = [C.c_int]
     lib.sfm_set_cr_atan2.restype = None
     return lib
@@ -112,6 +113,12 @@ class OracleWorld:
         g = np.zeros(self.grid_shape, np.uint8)
         self._check(self.lib.oracle_private_grid(self.h, robot, g.ctypes.data), "oracle_private_grid")
         return g
+
+    def sfm_tree(self):
+        """(nodes, member entries, leaf hash, treehash hash) of the social-force crowd's quadtree (oracle_sfm.c: sfm_tree_digest)"""
+        out = np.zeros(8, np.uint64)  # (the last four: one bit per agent that is in the tree)
+        self._check(self.lib.oracle_sfm_tree(self.h, out.ctypes.data), "oracle_sfm_tree")
+        return tuple(int(v) for v in out)
 
     def grids(self):
         a, b = C.c_void_p(), C.c_void_p()

@@ -720,6 +720,98 @@ def test_cfg4_full_size_and_shard_match_oracle(worlds, cr_atan2_oracle):
         cpu.close()
 
 
+def _sfm_tree(gpu, world=0):
+    """the library's quadtree of one social-force crowd, digested as the oracle's sfm_tree() digests its own"""
+    import ctypes as C
+    out = np.zeros(8, np.uint64)  # (the last four: one bit per agent that is in the tree)
+    gpu.lib.imgenv_debug_sfm_tree.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    gpu._check(gpu.lib.imgenv_debug_sfm_tree(gpu.h, world, out.ctypes.data), "imgenv_debug_sfm_tree")
+    return tuple(int(v) for v in out)
+
+
+def _quadtree_world(where, n=8):
+    """crowds for the quadtree test: 200 m world at 0.5 m cells, the robots anywhere, the crowd (which ignores them) placed by `where`"""
+    from img_env_amd import worldgen
+    band = int(where[4:]) if where.startswith("band") else -1
+    rng = np.random.default_rng(50 + band if band >= 0 else {"below_root": 6, "round_numbers": 7}[where])
+    P = int(rng.integers(100, 200)) if band >= 0 else {"below_root": 200, "round_numbers": 49}[where]
+    grid = worldgen.make_grid(400, 0)
+    params = worldgen.make_params(n, P, res=0.5, view_cells=48, beams=360, scene="pedscene", time_max=1000, relation_ped_robo=0)
+    layout = worldgen.make_layout(grid, 0.5, n, P, seed=31, clearance=0.5)
+    shape = layout.ped_traj[:, :, :2].shape
+    if band >= 0:                 # a dense band inside the tree's square (x in [0, 10], y in [10, 20]) marching to the far side: it keeps entering leaves that are still coarse
+        c = rng.uniform(1.5, 8.5, 2)
+        g = 10.0 - c
+        layout.ped_pose[:, 0] = np.clip(c[0] + rng.uniform(-1.5, 1.5, P), 0.2, 9.8)
+        layout.ped_pose[:, 1] = 10 + np.clip(c[1] + rng.uniform(-1.5, 1.5, P), 0.2, 9.8)
+        layout.ped_traj[:, :, 0] = np.clip(g[0] + rng.uniform(-1.0, 1.0, shape[:2]), 0.2, 9.8)
+        layout.ped_traj[:, :, 1] = 10 + np.clip(g[1] + rng.uniform(-1.0, 1.0, shape[:2]), 0.2, 9.8)
+        layout.ped_goal[:] = layout.ped_traj[:, -1, :2]
+    elif where == "below_root":   # cfg-4's crowd: y < 10, outside the tree's rectangle -- every agent has left its leaf on every step
+        layout.ped_pose[:, :2] = rng.uniform(0.5, 9.5, (P, 2))
+        layout.ped_traj[:, :, :2] = rng.uniform(3.0, 7.0, shape)
+        layout.ped_goal[:] = rng.uniform(3.0, 7.0, (P, 2))
+    else:                         # on the tree's own centre lines (5, 2.5, 1.25 ...): the reference inserts such an agent into SEVERAL children
+        lat = np.arange(1, 8) * 1.25
+        gx, gy = np.meshgrid(lat, 10.0 + lat)
+        layout.ped_pose[:, 0], layout.ped_pose[:, 1] = gx.ravel(), gy.ravel()
+        pick = rng.permutation(P)
+        layout.ped_goal[:, 0], layout.ped_goal[:, 1] = gx.ravel()[pick], gy.ravel()[pick]
+        layout.ped_traj[:, :, 0] = layout.ped_goal[:, None, 0]
+        layout.ped_traj[:, :, 1] = layout.ped_goal[:, None, 1]
+    return grid, params, layout, rng
+
+
+@pytest.mark.parametrize("where", ["band0", "band1", "band2", "band3", "below_root", "round_numbers"])
+def test_social_force_quadtree_matches_oracle_step_by_step(worlds, cr_atan2_oracle, where):
+    """libpedsim's quadtree is behaviour, not an accelerator (sfm.h): who is in it decides who exerts forces, and Ttree::moveAgent's
+    insert-from-the-root-then-erase (ped_tree.cpp:131-137) loses agents.  k_sfm does the moves that cannot split a leaf all at
+    once and replays the rest in agent order; here the TREE ITSELF -- node count, every leaf's rectangle and members, every agent's
+    treehash entry -- is held to the oracle's after every step (a digest that does not depend on node numbering), next to the
+    outputs: dense bands of 100-200 agents marching through the tree's square (leaves split on every other step: the oracle alone,
+    when the test was written, split on 8-13 of the first 25 steps and grew from ~120 to 160-290 nodes), cfg-4's crowd below the
+    square, and pedestrians that start exactly on the tree's centre lines (inserted into several children: the literal replay).
+    The bands' outputs are compared over the first ten steps only: a packed crowd amplifies the last-bit differences between the
+    device's and the host's exp / sqrt by a digit every few steps (1e-3 m after 40), which says nothing about the tree."""
+    World, OracleWorld = worlds
+    n = 8
+    grid, params, layout, rng = _quadtree_world(where, n)
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    dense = where.startswith("band")
+    try:
+        gpu.reset(layout)
+        cpu.reset(layout)
+        first = cpu.sfm_tree()
+        assert _sfm_tree(gpu) == first
+        steps, split_steps, worst = (25 if dense else 80), 0, 0.0
+        nodes = first[0]
+        for s in range(steps):
+            a = random_actions(rng, n)
+            gpu.step(a)
+            cpu.step(a)
+            want, got = cpu.sfm_tree(), _sfm_tree(gpu)
+            if got != want:
+                bits = lambda t: {64 * k + b for k in range(4) for b in range(64) if (t[4 + k] >> b) & 1}
+                dp = np.abs(gpu.snapshot()["ped_state"] - cpu.snapshot()["ped_state"]).max()
+                raise AssertionError((where, s, got[:4], want[:4], "only in the library's tree", sorted(bits(got) - bits(want)),
+                                      "only in the oracle's", sorted(bits(want) - bits(got)), "pedestrian states differ by", float(dp)))
+            split_steps += want[0] != nodes
+            nodes = want[0]
+            g, c = gpu.snapshot(), cpu.snapshot()
+            worst = max(worst, float(np.abs(g["ped_state"] - c["ped_state"]).max()))
+            if (s % 10 == 9 and not dense) or s < 3 or (dense and s in (5, 9)):
+                bad = compare(g, c)
+                assert not bad, (where, s, bad)
+        last = cpu.sfm_tree()
+        print("%s: quadtree %d -> %d nodes (splits on %d of %d steps), %d -> %d member entries; pedestrian states within %.2g of the oracle's throughout"
+              % (where, first[0], last[0], split_steps, steps, first[1], last[1], worst))
+        if dense:
+            assert split_steps >= 6
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def test_quadtree_overflow_is_reported(worlds):
     """more than 8 social-force agents outside the 10 m x 10 m root square of libpedsim's quadtree: the reference recurses
     forever (ped_tree.cpp:65-96); the library raises the device flag and the next call fails loudly"""
