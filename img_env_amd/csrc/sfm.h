@@ -33,6 +33,7 @@
 #define SFM_LEAF_CAP 12
 #define SFM_MAX_DEPTH 64
 #define SFM_WALK_CAP 24  // LDS stack entries per agent of the neighbour walk
+#define SFM_FULL_CAP 160   // leaves with members that the partial neighbour scan lists (more: the literal walk)
 #define SFM_LDS_NODES 1024  // quadtree nodes mirrored in (dynamic) LDS for a step: 104 KB (larger trees are walked in HBM)
 
 struct SfmNode {  // Ped::Ttree
@@ -129,8 +130,14 @@ SFM_HD inline void sfm_set_erase(SfmNode& q, int a) {
 SFM_HD inline void sfm_add_agent(SfmNode* nodes, int* n_nodes, int cap, int* treehash, const double* p, int agent, int* err,
                                  int* work = nullptr, int start = 0, unsigned short* rehomed = nullptr, const double* p_old = nullptr,
                                  int old_stride = 3, int turn = 0x7FFFFFFF) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the device always passes LDS: a 4 KB array per lane here, used or not, is 4 KB of scratch memory per lane for the whole
+    // kernel -- 2 GB for a full chip of wavefronts, which the runtime hands out per dispatch through an interrupt to the host)
+    int* st_node = work;
+#else
     int local_stack[2 * SFM_MAX_DEPTH * 8];
     int* st_node = work ? work : local_stack;
+#endif
     int* st_agent = st_node + SFM_MAX_DEPTH * 8;
     int sp = 0;
     st_node[sp] = start;
@@ -440,6 +447,7 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
                          unsigned long long* stamp = nullptr /* debug: wall-clock marks of thread 0 */) {
 #define SFM_STAMP(q) do { if (stamp && threadIdx.x == 0) stamp[q] = wall_clock64(); } while (0)
     SFM_STAMP(0);
+    if (phase == 1) SFM_STAMP(12);
     const int i = threadIdx.x;
     const int n = s.n;
     const int n_cap = SFM_MAX_AGENTS;
@@ -461,22 +469,44 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         if (i == 0) *ln_nodes = n_nodes0;
         __syncthreads();
     }
+    if (phase == 1) SFM_STAMP(13);
     // Tscene::getNeighbors asks for the agents of every leaf a 40 m square touches, in a scene of 10 m x 10 m: for an agent
     // anywhere near the scene that is EVERY leaf, and the walk (a visit of every node, per agent: most of this phase's time once
     // the tree has grown) returns the same set for all of them -- the agents that are in the tree at all.  That set is gathered
     // once, every thread a few nodes; only an agent whose square does not contain the root's rectangle walks.
     uint32_t* in_tree = (uint32_t*)(stk + (size_t)(SFM_WALK_CAP - 1) * blockDim.x);  // [8]: the last row of the walk stacks' LDS
+    // ... and the leaves that hold anybody are listed (in any order) for the agents whose square covers only part of the tree
+    // (in the LDS angle table, 8 KB, which is written behind the walk)
+    uint32_t* full_mask = (uint32_t*)sh_lds;                                                 // [SFM_FULL_CAP][SFM_MAX_AGENTS / 32] its members, one bit per agent
+    unsigned short* full_leaf = (unsigned short*)(full_mask + SFM_FULL_CAP * (SFM_MAX_AGENTS / 32));  // [SFM_FULL_CAP] the leaf's node
+    int* n_full = (int*)(full_leaf + SFM_FULL_CAP);  // [0] entries, [1] a leaf thinner than 1e-12 m exists, [2] more leaves than the list holds
+    static_assert(SFM_FULL_CAP % 2 == 0 && SFM_FULL_CAP * (4 * (SFM_MAX_AGENTS / 32) + 2) + 12 <= 8 * 4 * SFM_MAX_AGENTS, "the list of occupied leaves lives in the LDS angle table");
     if (phase <= 1) {
         if (i < SFM_MAX_AGENTS / 32) in_tree[i] = 0;
+        if (i < 3) n_full[i] = 0;
         __syncthreads();
         const int nn_now = *n_nodes;
         for (int q = threadIdx.x; q < nn_now; q += blockDim.x) {
             const SfmNode& t = nodes[q];
-            if (t.isleaf)
+            if (t.isleaf) {
                 for (int k = 0; k < t.n_agents; k++) atomicOr(&in_tree[t.agents[k] >> 5], 1u << (t.agents[k] & 31));
+                if (t.w < 1e-12 || t.h < 1e-12) n_full[1] = 1;
+                if (t.n_agents > 0 && q > 0) {
+                    const int slot = atomicAdd(&n_full[0], 1);
+                    if (slot < SFM_FULL_CAP && q < 65536) {
+                        full_leaf[slot] = (unsigned short)q;
+                        uint32_t* m = full_mask + slot * (SFM_MAX_AGENTS / 32);
+                        for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) m[k] = 0u;
+                        for (int k = 0; k < t.n_agents; k++) m[t.agents[k] >> 5] |= 1u << (t.agents[k] & 31);
+                    } else {
+                        n_full[2] = 1;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
+    if (phase == 1) SFM_STAMP(14);
     d3 desiredforce = D3(0, 0, 0), socialforce = D3(0, 0, 0), obstacleforce = D3(0, 0, 0), lookaheadforce = D3(0, 0, 0);
     d3 me_p = D3(0, 0, 0), me_v = D3(0, 0, 0);
     uint32_t* mine = nb_bits + (size_t)i * (SFM_MAX_AGENTS / 32);
@@ -493,10 +523,43 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         const bool whole_tree = ((me_p.x + 20.0) > (root.x + root.w)) && ((me_p.x - 20.0) < root.x) && ((me_p.y + 20.0) > (root.y + root.h)) &&
                                 ((me_p.y - 20.0) < root.y);  // the square contains the root's rectangle: every child test below passes
         for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) mine[k] = whole_tree ? in_tree[k] : 0u;
+        // An agent whose square does not cover the whole tree -- 20 m beyond an edge of it, or merely below y = 0 with the tree's
+        // top row out of reach -- gets the agents of the leaves its square touches.  The reference walks down from the root and
+        // tests every child's rectangle; a leaf's ancestors contain it, so (the rectangles' corners being exact sums of halves
+        // down to depth ~48) it reaches exactly the leaves whose OWN rectangle passes the test: every thread scans the node array
+        // thread scans the list of the leaves that hold anybody, in step with the others (the same leaf for the whole wavefront:
+        // broadcast reads, no stack, no pointer chase -- the walk itself was ~0.4 us per node for the slowest agent of the crowd:
+        // 80 of the first launch's 90 us in cfg-4, where a few pedestrians always stand below y = 0).  Leaves thinner than
+        // 1e-12 m: the literal walk below.
+        bool walk = false;
+        if (!whole_tree) {
+            if (root.isleaf) {  // (the walk pops the root without a test)
+                for (int k = 0; k < root.n_agents; k++) mine[root.agents[k] >> 5] |= 1u << (root.agents[k] & 31);
+            } else if (n_full[1] || n_full[2]) {
+                walk = true;
+            } else {
+                uint32_t acc[SFM_MAX_AGENTS / 32];
+#pragma unroll
+                for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) acc[k] = 0u;
+                const int n_list = n_full[0];
+                for (int e = 0; e < n_list; e++) {
+                    const SfmNode& t = nodes[full_leaf[e]];
+                    const double tx = t.x, ty = t.y, tw = t.w, th = t.h;  // (fetched together with the members' bits, in front of the test)
+                    const uint32_t* m = full_mask + e * (SFM_MAX_AGENTS / 32);
+                    const bool touched = ((me_p.x + 20.0) > tx) && ((me_p.x - 20.0) < (tx + tw)) && ((me_p.y + 20.0) > ty) && ((me_p.y - 20.0) < (ty + th));
+#pragma unroll
+                    for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) acc[k] |= touched ? m[k] : 0u;
+                }
+                if (!walk) {
+#pragma unroll
+                    for (int k = 0; k < SFM_MAX_AGENTS / 32; k++) mine[k] = acc[k];
+                }
+            }
+        }
         // depth-first walk with the stack in LDS (a dynamically indexed private array would live in scratch memory):
         // entry k of thread i sits at stk[k * blockDim.x + i]  (SFM_WALK_CAP - 1 entries: the last row holds in_tree)
         int sp = 0;
-        if (!whole_tree) stk[(sp++) * blockDim.x + i] = 0;
+        if (walk) stk[(sp++) * blockDim.x + i] = 0;
         while (sp > 0) {
             const SfmNode& t = nodes[stk[(--sp) * blockDim.x + i]];
             if (t.isleaf) {
@@ -544,6 +607,7 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         sh[2 * n_cap + i] = cr_atan2(-desired_direction.x, -desired_direction.y);
         sh[3 * n_cap + i] = cr_atan2(-me_v.x, -me_v.y);
     }
+    if (phase == 1) SFM_STAMP(15);
     if (phase == 1) return;
     __syncthreads();
     // Pair terms of lookaheadForce and socialForce (ped_agent.cpp:316-404, 439-480), one (agent, neighbour) pair per

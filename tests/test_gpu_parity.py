@@ -733,8 +733,8 @@ def _quadtree_world(where, n=8):
     """crowds for the quadtree test: 200 m world at 0.5 m cells, the robots anywhere, the crowd (which ignores them) placed by `where`"""
     from img_env_amd import worldgen
     band = int(where[4:]) if where.startswith("band") else -1
-    rng = np.random.default_rng(50 + band if band >= 0 else {"below_root": 6, "round_numbers": 7}[where])
-    P = int(rng.integers(100, 200)) if band >= 0 else {"below_root": 200, "round_numbers": 49}[where]
+    rng = np.random.default_rng(50 + band if band >= 0 else {"below_root": 6, "round_numbers": 7, "far_corner": 8}[where])
+    P = int(rng.integers(100, 200)) if band >= 0 else {"below_root": 200, "round_numbers": 49, "far_corner": 66}[where]
     grid = worldgen.make_grid(400, 0)
     params = worldgen.make_params(n, P, res=0.5, view_cells=48, beams=360, scene="pedscene", time_max=1000, relation_ped_robo=0)
     layout = worldgen.make_layout(grid, 0.5, n, P, seed=31, clearance=0.5)
@@ -751,6 +751,13 @@ def _quadtree_world(where, n=8):
         layout.ped_pose[:, :2] = rng.uniform(0.5, 9.5, (P, 2))
         layout.ped_traj[:, :, :2] = rng.uniform(3.0, 7.0, shape)
         layout.ped_goal[:] = rng.uniform(3.0, 7.0, (P, 2))
+    elif where == "far_corner":   # 60 inside the square, 6 strolling 15-20 m beyond its far corner: their 40 m squares reach PART of the tree (the partial neighbour walk)
+        far = np.arange(P) >= 60
+        layout.ped_pose[:, 0] = np.where(far, rng.uniform(24.0, 29.5, P), rng.uniform(0.5, 9.5, P))
+        layout.ped_pose[:, 1] = np.where(far, rng.uniform(33.0, 39.5, P), rng.uniform(10.5, 19.5, P))
+        layout.ped_traj[:, :, 0] = np.where(far[:, None], rng.uniform(24.0, 29.5, shape[:2]), rng.uniform(0.5, 9.5, shape[:2]))
+        layout.ped_traj[:, :, 1] = np.where(far[:, None], rng.uniform(33.0, 39.5, shape[:2]), rng.uniform(10.5, 19.5, shape[:2]))
+        layout.ped_goal[:] = layout.ped_traj[:, -1, :2]
     else:                         # on the tree's own centre lines (5, 2.5, 1.25 ...): the reference inserts such an agent into SEVERAL children
         lat = np.arange(1, 8) * 1.25
         gx, gy = np.meshgrid(lat, 10.0 + lat)
@@ -762,7 +769,7 @@ def _quadtree_world(where, n=8):
     return grid, params, layout, rng
 
 
-@pytest.mark.parametrize("where", ["band0", "band1", "band2", "band3", "below_root", "round_numbers"])
+@pytest.mark.parametrize("where", ["band0", "band1", "band2", "band3", "below_root", "round_numbers", "far_corner"])
 def test_social_force_quadtree_matches_oracle_step_by_step(worlds, cr_atan2_oracle, where):
     """libpedsim's quadtree is behaviour, not an accelerator (sfm.h): who is in it decides who exerts forces, and Ttree::moveAgent's
     insert-from-the-root-then-erase (ped_tree.cpp:131-137) loses agents.  k_sfm does the moves that cannot split a leaf all at
@@ -770,7 +777,8 @@ def test_social_force_quadtree_matches_oracle_step_by_step(worlds, cr_atan2_orac
     treehash entry -- is held to the oracle's after every step (a digest that does not depend on node numbering), next to the
     outputs: dense bands of 100-200 agents marching through the tree's square (leaves split on every other step: the oracle alone,
     when the test was written, split on 8-13 of the first 25 steps and grew from ~120 to 160-290 nodes), cfg-4's crowd below the
-    square, and pedestrians that start exactly on the tree's centre lines (inserted into several children: the literal replay).
+    square, pedestrians that start exactly on the tree's centre lines (inserted into several children: the literal replay), and a
+    crowd with a few members 15-20 m beyond the tree's corner, whose neighbour squares reach only part of it.
     The bands' outputs are compared over the first ten steps only: a packed crowd amplifies the last-bit differences between the
     device's and the host's exp / sqrt by a digit every few steps (1e-3 m after 40), which says nothing about the tree."""
     World, OracleWorld = worlds

@@ -26,7 +26,8 @@ buf = (C.c_ulonglong * 32)()
 for rep in range(3):
     w.step(a)
     w.lib.imgenv_debug_marks(w.h, buf)
-    v = list(buf)[:12]
-    print([round((v[q + 1] - v[q]) / 100.0, 1) for q in range(5)], "us: walk, desired+angles, pairs, sums+obstacle, move;  tree surgery:",
+    v = list(buf)[:16]
+    print("first launch:", [round((v[b] - v[a]) / 100.0, 1) for a, b in ((12, 13), (13, 14), (14, 1), (1, 2), (2, 15))], "us: tree into LDS, who is in the tree, neighbour walk, desired force, angles")
+    print([round((v[q + 1] - v[q]) / 100.0, 1) for q in range(2, 5)], "us: pairs (third launch's wait), sums+obstacle, move;  tree surgery:",
           [round((v[b] - v[a]) / 100.0, 1) for a, b in ((5, 7), (7, 8), (8, 9), (9, 6))], "us: who left + descents, counts + moves on quiet leaves, serial replay, tree back to HBM;",
           "agents replayed serially: %d%s" % (v[10], " (whole step: a tie or a stray entry)" if v[11] else ""))
