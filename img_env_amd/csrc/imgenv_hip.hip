@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off (see __graft_entry__.py)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
 
@@ -95,6 +96,10 @@ struct imgenv {
     unsigned orca_seq = 0;          // k_orca launches so far: launch q writes ped_snap[q & 1]
     hipEvent_t ev_done = nullptr;   // behind the views of the last chain, on the caller's stream: what an early k_obs waits for
     bool early_step = false;
+    // an event that only has to say "this kernel is done" rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL's stop
+    // event): a hipEventRecord behind the kernel is a packet of its own, and the caller's stream pays ~6 us for each
+    bool fork_on_move = false;   // ev_fork went out with this step's k_integrate
+    bool done_on_view = false;   // ev_done with this chain's k_view
     bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
@@ -1452,7 +1457,8 @@ static int launch_obs(imgenv* h, hipStream_t st) {
     const bool overlap = !h->serial;
     hipStream_t s_obs = overlap ? h->side2 : st;
     if (overlap) {
-        HIPCHK(hipEventRecord(h->ev_fork, st));
+        if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
+        h->fork_on_move = false;
         HIPCHK(hipStreamWaitEvent(s_obs, h->ev_fork, 0));
     }
     if (int rc = launch_obs_kernel(h, s_obs)) return rc;
@@ -1543,7 +1549,10 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // handles of several worlds with RVO crowds: k_orca does k_side_robots' part for its world itself (one launch less per phase)
         const bool fold_side = h->W > 1 && h->NA > 0;
         if (!fold_side) {
-            k_side_robots<<<dim3((n_g + 255) / 256), dim3(256), 0, s_orca>>>(d, is_reset, h->NA > 0 && d.relation == 1);
+            // (slices of >= 48 pedestrians, four at most: 8192 robots x 200 pedestrians = 128 x 4 wavefronts.  More of them -- cfg-5's
+            // 1000 pedestrians in 16 slices -- only take issue slots from the rasters and the views: 281-286 us per step against 276-278)
+            const int rvo_agents = h->NA > 0 && d.relation == 1, slices = rvo_agents && h->W == 1 ? std::min(4, std::max(1, (h->P + 47) / 48)) : 1;
+            k_side_robots<<<dim3((unsigned)((n_g + WAVE - 1) / WAVE) * (unsigned)slices), dim3(WAVE), 0, s_orca>>>(d, is_reset, rvo_agents, slices);
             h->launches += 1;
         }
         if (h->NA > 0) {
@@ -1645,12 +1654,15 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         const bool eight = force_nw ? force_nw == 8 : (small && !lds_bound);
         const dim3 gv(n_l), bv(eight ? 8 * WAVE : small ? 4 * WAVE : two ? 2 * WAVE : WAVE);
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
+        static const int ext_ev = getenv("IMGENV_EXT_EVENTS") ? atoi(getenv("IMGENV_EXT_EVENTS")) : 1;  // (measurement switch)
+        h->done_on_view = ext_ev != 0 && h->early;  // (ev_done: "these views are complete", what the next early k_obs waits for)
+        const hipEvent_t ev_v = h->done_on_view ? h->ev_done : nullptr;
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
     case N:                                                                                                                     \
-        if (eight) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 8><<<gv, bv, h->lds_view, st>>>(d)));                        \
-        else if (small) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 4><<<gv, bv, h->lds_view, st>>>(d)));                   \
-        else if (two) TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 2><<<gv, bv, h->lds_view, st>>>(d)));                     \
-        else TIMED(h, IMGENV_K_VIEW, st, (k_view<P2, A4_, ST, 1><<<gv, bv, h->lds_view, st>>>(d)));                              \
+        if (eight) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 8>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d)));      \
+        else if (small) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 4>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d))); \
+        else if (two) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 2>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d)));   \
+        else TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 1>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d)));            \
         break;
         switch (variant) {
             VIEW_CASE(7, true, true, true)
@@ -1667,7 +1679,9 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     // no launch for the per-robot scalars: the k_view / k_obs wavefront that completes a group of 64 robots runs them
     // (tail_group).  The caller's stream ends the step behind both side streams
     h->early_step = false;
-    if (h->early) HIPCHK(hipEventRecord(h->ev_done, st));  // the next early k_obs starts behind these views (and, on its own stream, behind this chain's k_obs and solve)
+    // the next early k_obs starts behind these views (and, on its own stream, behind this chain's k_obs and solve)
+    if (h->early && !h->done_on_view) HIPCHK(hipEventRecord(h->ev_done, st));
+    h->done_on_view = false;
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     h->launches += 3;
     HIPCHK(hipGetLastError());
@@ -2441,7 +2455,11 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         const bool peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET);
         if (h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS) {
             const int nb_robot = (h->RL + INT_ROBOTS - 1) / INT_ROBOTS, nb_ped = peds ? (h->P + INT_G * INT_ROBOTS - 1) / (INT_G * INT_ROBOTS) : 0;
-            TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate<<<dim3(nb_robot + nb_ped), dim3(INT_G * INT_ROBOTS), 0, st>>>(d, actions, nb_robot, h->n_sub, h->elapsed)));
+            static const int ext_ev = getenv("IMGENV_EXT_EVENTS") ? atoi(getenv("IMGENV_EXT_EVENTS")) : 1;  // (measurement switch)
+            // (the fork of the side streams follows right behind the move: early steps record it below, the others in launch_obs)
+            h->fork_on_move = ext_ev != 0 && h->P > 0 && !h->serial && !h->chain_open;
+            TIMED(h, IMGENV_K_INTEGRATE, st, (hipExtLaunchKernelGGL(k_integrate, dim3(nb_robot + nb_ped), dim3(INT_G * INT_ROBOTS), 0, st, nullptr,
+                                                                   h->fork_on_move ? h->ev_fork : nullptr, 0, d, actions, nb_robot, h->n_sub, h->elapsed)));
         } else {
             const int nb_robot = (h->RL + 127) / 128, nb_ped = peds ? (h->P + 127) / 128 : 0;
             TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate_serial<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot, h->elapsed)));
@@ -2456,7 +2474,8 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         // behind the last chain's k_obs and solve).  Queued BEHIND k_integrate, whose few workgroups are then dispatched first; what
         // the caller's stream forks behind the move is the solve alone.
         h->chain_open = true;
-        HIPCHK(hipEventRecord(h->ev_fork, st));
+        if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
+        h->fork_on_move = false;
         HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
         d.obs_early = 1;
         d.obs_actions = actions;

@@ -3086,17 +3086,24 @@ __global__ void k_state(DevWorld w) {
 //    from the gathered robot records, so that the solve does not have to wait for the raster;
 //  * Agent::get_state of the local robots (its correctly rounded atan2 is a long serial chain that the tails, on the
 //    critical path, would otherwise run).
+//
+// One wavefront per 64 robots and SLICE of the pedestrians (`slices` workgroups per robot block; slice 0 also writes the agent
+// arrays and runs get_state): the solve waits for this kernel and the step's join for the solve -- with the two event hops of the
+// join that chain ends later than the views' -- so it is spread over the chip instead of 4 wavefronts on each of 32 compute units
+// walking every pedestrian one after the other (8192 robots x 200 pedestrians: 24-32 us beside k_obs; x 1000: 109 us).
 #define SIDE_PED_TILE 1024
-__global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, int rvo_agents) {
+__global__ __launch_bounds__(WAVE) void k_side_robots(DevWorld w, int zero_vel, int rvo_agents, int slices) {
     __shared__ float2 ped_xy[SIDE_PED_TILE];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __builtin_amdgcn_s_setprio(2);  // (on the solve's chain: ahead of the observation's wavefronts, behind the move and the rasters)
+    const int rb = (int)blockIdx.x / slices, slice = (int)blockIdx.x - rb * slices;
+    const int t = rb * WAVE + threadIdx.x;
     const bool valid = t < act_count_g(w);
     const int i = act_member(w, w.Rw, valid ? t : 0);
     if (rvo_agents) {
         const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
         const int a = w.P + i;
         const f2 me = F2((float)r[0], (float)r[1]);
-        if (valid) {
+        if (valid && slice == 0) {
             w.apx[a] = me.x;
             w.apy[a] = me.y;
             w.avx[a] = zero_vel ? 0.0f : (float)r[3];
@@ -3105,16 +3112,17 @@ __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, i
         // neighborDist is 0.5 m (rvoscene.h:57): tell the few pedestrians this robot can matter to, so that the solve does
         // not scan every robot of the world for every pedestrian.  The test is the solve's own float expression with a
         // slightly larger bound; the solve re-tests exactly.
-        if (w.W > 1) {  // several small worlds: every robot walks its own world's pedestrians
+        if (w.W > 1) {  // several small worlds: every robot walks its own world's pedestrians (one slice)
             const int p_lo = world_of_robot(w, i) * w.Pw;
-            for (int j = p_lo; valid && j < p_lo + w.Pw; j++)
+            for (int j = p_lo; valid && slice == 0 && j < p_lo + w.Pw; j++)
                 if (abs_sq(F2(w.apx[j], w.apy[j]) - me) < 0.2500001f) {
                     const int pos = atomicAdd(&w.near_n[j], 1);
                     if (pos < ORCA_NEAR_CAP) w.near_list[(size_t)j * ORCA_NEAR_CAP + pos] = a;
                 }
-        } else {  // one big world: pedestrian positions go through LDS, a tile at a time
-            for (int j0 = 0; j0 < w.P; j0 += SIDE_PED_TILE) {
-                const int nt = min(SIDE_PED_TILE, w.P - j0);
+        } else {  // one big world: this slice's pedestrian positions go through LDS, a tile at a time
+            const int per = (w.P + slices - 1) / slices, j_lo = slice * per, j_hi = min(w.P, j_lo + per);
+            for (int j0 = j_lo; j0 < j_hi; j0 += SIDE_PED_TILE) {
+                const int nt = min(SIDE_PED_TILE, j_hi - j0);
                 __syncthreads();
                 for (int q = threadIdx.x; q < nt; q += blockDim.x) ped_xy[q] = make_float2(w.apx[j0 + q], w.apy[j0 + q]);
                 __syncthreads();
@@ -3131,7 +3139,7 @@ __global__ __launch_bounds__(256) void k_side_robots(DevWorld w, int zero_vel, i
         }
     }
     const int l = i - w.r0;
-    if (valid && l >= 0 && l < w.RL) state_robot(w, l);
+    if (valid && slice == 0 && l >= 0 && l < w.RL) state_robot(w, l);
 }
 
 // NeverStopWrapper's question (base.py:198-211): are all robots of a world done?  One workgroup walks the worlds, a thread
