@@ -98,6 +98,7 @@ struct imgenv {
     bool early_step = false;
     // an event that only has to say "this kernel is done" rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL's stop
     // event): a hipEventRecord behind the kernel is a packet of its own, and the caller's stream pays ~6 us for each
+    uint32_t gate_seq = 0;       // early steps whose k_obs waits behind a gate (world.h: sync) so far
     bool fork_on_move = false;   // ev_fork went out with this step's k_integrate
     bool done_on_view = false;   // ev_done with this chain's k_view
     bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
@@ -1282,6 +1283,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         h->early = !h->serial && RL == R && P > 0 && h->NA > 0 && !d.beep_on && !limiters && !h->big_view &&
                    h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS;
         if (h->early) {
+            TRY(dev_alloc(h, &d.sync, 8));
             TRY(dev_alloc(h, &d.rec_snap, (size_t)RL * IMGENV_RECORD_DOUBLES));
             TRY(dev_alloc(h, &h->ped_snap[0], (size_t)P));
             TRY(dev_alloc(h, &h->ped_snap[1], (size_t)P));
@@ -1371,6 +1373,7 @@ static int check_device_flags(imgenv* h) {
         FAIL(IMGENV_EDEVICE, "device-side auto-reset: a finished world could not be given its placement (code %d: 100 the pool did not hold it; "
                              "1 a fixed start with a random target; 2-4 no admissible placement within 200000 draws; 10-16 the RVO obstacle tree "
                              "outgrew its scratch)", e[2]);
+    if (e[7]) FAIL(IMGENV_EDEVICE, "the observation's gate gave up after 2 s: the caller's stream never reached the step's move (a launch failed, or the stream is stuck)");
     if (e[6]) FAIL(IMGENV_EDEVICE, "class layer (counts): a pedestrian's footprint left its raster box or its cell list (code %d)", e[6]);
     if (e[4])
         FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth, 5 a leaf lock never came free, "
@@ -2445,7 +2448,12 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
                            (force_fuse >= 0 ? force_fuse != 0 : (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024));
     // early-observation step (world.h): k_obs goes out with the move, on its side stream, instead of behind it
     static const int force_early = getenv("IMGENV_EARLY_OBS") ? atoi(getenv("IMGENV_EARLY_OBS")) : -1;  // (measurement switch)
-    const bool early_step = h->early && h->in_step && h->actions_ready && !fuse_move && !h->chain_open && h->orca_seq > 0 && force_early != 0;
+    // ... with the caller's promise that the actions are complete (IMGENV_STEP_ACTIONS_READY), or behind a gate that opens when the
+    // caller's stream reaches this step's move (world.h: sync)
+    static const int gate_sw = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;  // (measurement switch)
+    const bool early_step = h->early && h->in_step && (h->actions_ready || gate_sw != 0) && !fuse_move && !h->chain_open && h->orca_seq > 0 && force_early != 0;
+    const bool early_gated = early_step && !h->actions_ready;
+    if (early_gated) h->gate_seq += 1;
     if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
         h->move_pending = true;
         h->move_actions = actions;
@@ -2459,7 +2467,8 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
             // (the fork of the side streams follows right behind the move: early steps record it below, the others in launch_obs)
             h->fork_on_move = ext_ev != 0 && h->P > 0 && !h->serial && !h->chain_open;
             TIMED(h, IMGENV_K_INTEGRATE, st, (hipExtLaunchKernelGGL(k_integrate, dim3(nb_robot + nb_ped), dim3(INT_G * INT_ROBOTS), 0, st, nullptr,
-                                                                   h->fork_on_move ? h->ev_fork : nullptr, 0, d, actions, nb_robot, h->n_sub, h->elapsed)));
+                                                                   h->fork_on_move ? h->ev_fork : nullptr, 0, d, actions, nb_robot, h->n_sub, h->elapsed,
+                                                                   early_gated ? h->gate_seq : 0u)));
         } else {
             const int nb_robot = (h->RL + 127) / 128, nb_ped = peds ? (h->P + 127) / 128 : 0;
             TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate_serial<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot, h->elapsed)));
@@ -2477,6 +2486,10 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
         h->fork_on_move = false;
         HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
+        if (early_gated) {  // (queued behind the move: see k_gate)
+            k_gate<<<dim3(1), dim3(WAVE), 0, h->side2>>>(d.sync, h->gate_seq, d.err);
+            h->launches += 1;
+        }
         d.obs_early = 1;
         d.obs_actions = actions;
         d.obs_n_sub = h->n_sub;

@@ -1183,11 +1183,31 @@ __device__ __forceinline__ void integrate_finish(const DevWorld& w, int l, doubl
 // 221-236, then the exact arc).  The headings do not depend on the positions, so 8 lanes per robot evaluate them side by
 // side -- each lane re-accumulates `oz += w * 0.05` up to its own sub-step, which keeps the reference's rounding -- and
 // lane 0 then runs the (cheap) position recurrence and the arrive tests over the table in LDS.
-__global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot, int n_sub, int step) {
+// One wavefront in front of a side stream's work polls a word of world.h's `sync` until it has reached `want` (sequence numbers
+// wrap: signed difference).  Relaxed loads -- an acquire per poll would invalidate this XCD's L2 underneath whatever else runs on
+// it, millions of times a second -- and one acquire at the end.  Nothing a gate waits for is queued behind it (the move is launched
+// first), so it cannot starve its own signal; a word that never arrives (the launch failed) raises the device flag after 2 s
+// instead of hanging the queue: the caller's stream may well spend many milliseconds in a policy's kernels before it reaches the step.
+__global__ void k_gate(const uint32_t* word, uint32_t want, int* err) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 200000000ull) {  // (100 MHz)
+            err[7] = 1;
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, const float* __restrict__ actions, int nb_robot, int n_sub, int step, uint32_t seq) {
     __shared__ double2 trig[INT_ROBOTS][INT_ITEMS];  // (cos, sin)
     // the step's critical chain (move -> rasters -> views) runs beside the observation's 8192 wavefronts, which are bound by vector
     // issue: its kernels' wavefronts ask the SIMD's arbiter for the issue slot first (s_setprio; k_obs keeps the default 0)
     __builtin_amdgcn_s_setprio(3);
+    // (world.h: sync) the caller's stream has reached this step
+    if (seq && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&w.sync[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int)blockIdx.x >= nb_robot) {
         const int j = ((int)blockIdx.x - nb_robot) * blockDim.x + threadIdx.x;
         if (j < w.P) {

@@ -303,8 +303,9 @@ int imgenv_step(imgenv_t* h, const float* actions, void* stream);
  * CALL IS MADE -- pre-generated, replayed, copied and synchronised, or produced on another stream that has been waited for --
  * instead of merely being queued on `stream` in front of it.  The library may then start kernels that read them on its side
  * streams without waiting for the caller's stream (early-observation steps, DESIGN.md section 4: the observation kernel runs
- * beside the move instead of behind it; ~10 % on the headline shape).  Without the flag every kernel that reads the actions is
- * ordered behind everything queued on `stream` before the call: a policy network may write them there right in front of it. */
+ * beside the move; ~5 % on the headline shape).  Without the flag every kernel that reads the actions is ordered behind everything
+ * queued on `stream` before the call -- a policy network may write them there right in front of it --: the observation's side
+ * stream then waits behind a one-wavefront gate kernel that polls a word the step's first kernel on `stream` stores. */
 #define IMGENV_STEP_ACTIONS_READY 1u
 int imgenv_step_flags(imgenv_t* h, const float* actions, uint32_t flags, void* stream);
 
