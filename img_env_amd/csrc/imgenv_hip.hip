@@ -99,6 +99,9 @@ struct imgenv {
     // an event that only has to say "this kernel is done" rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL's stop
     // event): a hipEventRecord behind the kernel is a packet of its own, and the caller's stream pays ~6 us for each
     uint32_t gate_seq = 0;       // early steps whose k_obs waits behind a gate (world.h: sync) so far
+    bool no_done = false;        // this chain leaves no ev_done behind its views
+    bool done_valid = false;     // the last chain did
+    bool ready_mode = true;      // the last early step came with IMGENV_STEP_ACTIONS_READY
     bool fork_on_move = false;   // ev_fork went out with this step's k_integrate
     bool done_on_view = false;   // ev_done with this chain's k_view
     bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
@@ -1373,7 +1376,7 @@ static int check_device_flags(imgenv* h) {
         FAIL(IMGENV_EDEVICE, "device-side auto-reset: a finished world could not be given its placement (code %d: 100 the pool did not hold it; "
                              "1 a fixed start with a random target; 2-4 no admissible placement within 200000 draws; 10-16 the RVO obstacle tree "
                              "outgrew its scratch)", e[2]);
-    if (e[7]) FAIL(IMGENV_EDEVICE, "the observation's gate gave up after 2 s: the caller's stream never reached the step's move (a launch failed, or the stream is stuck)");
+    if (e[7]) FAIL(IMGENV_EDEVICE, "the observation's gate gave up after 60 s: the caller's stream never reached the step's move (the stream is stuck behind something)");
     if (e[6]) FAIL(IMGENV_EDEVICE, "class layer (counts): a pedestrian's footprint left its raster box or its cell list (code %d)", e[6]);
     if (e[4])
         FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth, 5 a leaf lock never came free, "
@@ -1658,7 +1661,11 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         const dim3 gv(n_l), bv(eight ? 8 * WAVE : small ? 4 * WAVE : two ? 2 * WAVE : WAVE);
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
         static const int ext_ev = getenv("IMGENV_EXT_EVENTS") ? atoi(getenv("IMGENV_EXT_EVENTS")) : 1;  // (measurement switch)
-        h->done_on_view = ext_ev != 0 && h->early;  // (ev_done: "these views are complete", what the next early k_obs waits for)
+        // (ev_done: "these views are complete", what a promised step's k_obs waits for -- a marker behind k_view costs the caller's
+        // stream a few us, so it is only recorded while the caller makes promises: a gated step needs no event at all)
+        static const int gate_on = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;
+        h->no_done = gate_on != 0 && !h->ready_mode;
+        h->done_on_view = ext_ev != 0 && h->early && !h->no_done;
         const hipEvent_t ev_v = h->done_on_view ? h->ev_done : nullptr;
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
     case N:                                                                                                                     \
@@ -1683,7 +1690,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     // (tail_group).  The caller's stream ends the step behind both side streams
     h->early_step = false;
     // the next early k_obs starts behind these views (and, on its own stream, behind this chain's k_obs and solve)
-    if (h->early && !h->done_on_view) HIPCHK(hipEventRecord(h->ev_done, st));
+    if (h->early && !h->done_on_view && !h->no_done) HIPCHK(hipEventRecord(h->ev_done, st));
+    h->done_valid = h->early && !h->no_done;
     h->done_on_view = false;
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     h->launches += 3;
@@ -2451,8 +2459,12 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     // ... with the caller's promise that the actions are complete (IMGENV_STEP_ACTIONS_READY), or behind a gate that opens when the
     // caller's stream reaches this step's move (world.h: sync)
     static const int gate_sw = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;  // (measurement switch)
-    const bool early_step = h->early && h->in_step && (h->actions_ready || gate_sw != 0) && !fuse_move && !h->chain_open && h->orca_seq > 0 && force_early != 0;
-    const bool early_gated = early_step && !h->actions_ready;
+    const bool early_step = h->early && h->in_step && (gate_sw != 0 || (h->actions_ready && h->done_valid)) && !fuse_move && !h->chain_open &&
+                            h->orca_seq > 0 && force_early != 0;
+    // (a promised step waits for the event behind the last chain's views -- if that chain recorded one: it does when the step before
+    // it was a promised one, see launch_views -- and starts k_obs at once; every other early step takes the gate, which says the same)
+    const bool early_gated = early_step && gate_sw != 0 && (!h->actions_ready || !h->done_valid);
+    if (early_step) h->ready_mode = h->actions_ready;
     if (early_gated) h->gate_seq += 1;
     if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
         h->move_pending = true;
@@ -2485,10 +2497,11 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         h->chain_open = true;
         if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
         h->fork_on_move = false;
-        HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
         if (early_gated) {  // (queued behind the move: see k_gate)
             k_gate<<<dim3(1), dim3(WAVE), 0, h->side2>>>(d.sync, h->gate_seq, d.err);
             h->launches += 1;
+        } else {
+            HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
         }
         d.obs_early = 1;
         d.obs_actions = actions;

@@ -1186,14 +1186,15 @@ __device__ __forceinline__ void integrate_finish(const DevWorld& w, int l, doubl
 // One wavefront in front of a side stream's work polls a word of world.h's `sync` until it has reached `want` (sequence numbers
 // wrap: signed difference).  Relaxed loads -- an acquire per poll would invalidate this XCD's L2 underneath whatever else runs on
 // it, millions of times a second -- and one acquire at the end.  Nothing a gate waits for is queued behind it (the move is launched
-// first), so it cannot starve its own signal; a word that never arrives (the launch failed) raises the device flag after 2 s
-// instead of hanging the queue: the caller's stream may well spend many milliseconds in a policy's kernels before it reaches the step.
+// first), so it cannot starve its own signal; a word that never arrives raises the device flag after 60 s instead
+// of hanging the queue for good (the caller's stream may well spend a long time in a policy's kernels before it reaches the step:
+// the first call of a network that is still being tuned; an event wait would sit there just as long).
 __global__ void k_gate(const uint32_t* word, uint32_t want, int* err) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 200000000ull) {  // (100 MHz)
+        if (wall_clock64() - t0 > 6000000000ull) {  // (100 MHz)
             err[7] = 1;
             break;
         }

@@ -1007,15 +1007,16 @@ def test_fuzzed_social_force_rooms_match_oracle(worlds, seed):
         cpu.close()
 
 
-def test_step_waits_for_actions_written_on_the_callers_stream(worlds):
+@pytest.mark.parametrize("n,grid_size", [(512, 200), (2048, 400), (8192, 400)])
+def test_step_waits_for_actions_written_on_the_callers_stream(worlds, n, grid_size):
     """A trainer's policy writes the actions on the caller's stream right in front of `imgenv_step`, without synchronising.  Every
     kernel of the step that reads them -- the early-launched observation on its side stream included -- has to
     run behind that write: two handles, one fed actions that are still being produced (behind ~ms of matrix products on the
-    same stream), one fed the finished values, stay bit-identical."""
+    same stream), one fed the finished values, stay bit-identical -- also when promised (`IMGENV_STEP_ACTIONS_READY`) and plain steps alternate."""
     import torch
     World, _ = worlds
-    n = 512
-    grid, params, layout = small_world(n, 40, seed=91, grid_size=200, res=0.25, clearance=0.6, n_obstacles=2)
+    # (512 robots: the move inside the raster launch, k_obs behind it; 2048: early-observation steps on one side stream; 8192: on two)
+    grid, params, layout = small_world(n, 40, seed=91, grid_size=grid_size, res=0.25, clearance=0.6, n_obstacles=2)
     a, b = World(params, grid), World(params, grid)
     try:
         a.reset(layout)
@@ -1027,12 +1028,18 @@ def test_step_waits_for_actions_written_on_the_callers_stream(worlds):
         for s in range(12):
             want = torch.as_tensor(random_actions(rng, n), device=dev)
             torch.cuda.synchronize()
-            b.step(want.clone())
-            y = big
-            for _ in range(6):
-                y = (y @ big) * 1e-3   # keeps the stream busy: the actions below exist only when this is through
-            late.copy_(want + 0.0 * y[:n, :3].nan_to_num(0.0, 0.0, 0.0))
-            a.step(late)             # no synchronisation in between
+            b.step(want.clone(), actions_ready=(s % 4 == 1))  # (b: finished values, now and then with the promise -- the two kinds of
+                                                               # early step hand over differently: an event behind the views / the gate)
+            if s % 3 == 2:           # a: every third step with finished values and the promise ...
+                late.copy_(want)
+                torch.cuda.synchronize()
+                a.step(late, actions_ready=True)
+            else:                    # ... the others with actions that are still being produced
+                y = big
+                for _ in range(6):
+                    y = (y @ big) * 1e-3   # keeps the stream busy: the actions below exist only when this is through
+                late.copy_(want + 0.0 * y[:1, :3].nan_to_num(0.0, 0.0, 0.0))  # (depends on the products, changes nothing)
+                a.step(late)             # no synchronisation in between
             ga, gb = a.snapshot(), b.snapshot()
             for k in EXACT + CLOSE:
                 assert np.array_equal(ga[k], gb[k], equal_nan=True), (s, k)
