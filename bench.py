@@ -329,8 +329,9 @@ def main():
         return a
 
     # The actions are pre-generated and resident in HBM before the timed region starts (BASELINE / SURVEY 8d): the steps say so
-    # (IMGENV_STEP_ACTIONS_READY), which lets the library start its observation kernel beside the move.  `stream_ordered_actions` in
-    # the line is the same measurement with plain imgenv_step, as a trainer whose policy writes the actions on the stream gets it.
+    # (IMGENV_STEP_ACTIONS_READY), which lets the library start its observation kernel at once.  `stream_ordered_actions` in the
+    # line is the same measurement with plain imgenv_step, as a trainer whose policy writes the actions on the stream gets it (the
+    # observation then starts behind a gate: include/imgenv.h).
     state = dict(elapsed=0, episode=0, resets=0, ready=not args.stream_ordered_actions)
 
     def do_reset():
@@ -465,7 +466,8 @@ def main():
         state["ready"] = True
         stream_ordered = dict(value=R * args.steps / d1, ms_per_step=1e3 * d1 / args.steps,
                               what="median of 3 passes with plain imgenv_step: every kernel that reads the actions is ordered behind the caller's "
-                                   "stream (a policy may write them there in front of the call), so the observation runs behind the move")
+                                   "stream (a policy may write them there in front of the call): the observation's side stream waits behind a "
+                                   "one-wavefront gate for the step's first kernel on that stream")
     # SURVEY 8(d) wants the auto-reset inside the timed region; a run shorter than an episode (the driver's 20 steps) never meets
     # one, so it is timed separately: the same N steps + ONE full imgenv_reset of the world
     with_reset = None
