@@ -99,6 +99,7 @@ struct imgenv {
     // an event that only has to say "this kernel is done" rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL's stop
     // event): a hipEventRecord behind the kernel is a packet of its own, and the caller's stream pays ~6 us for each
     uint32_t gate_seq = 0;       // early steps whose k_obs waits behind a gate (world.h: sync) so far
+    bool gates_work = false;     // k_gate_probe's verdict: kernels of two streams run side by side in this process
     bool no_done = false;        // this chain leaves no ev_done behind its views
     bool done_valid = false;     // the last chain did
     bool ready_mode = true;      // the last early step came with IMGENV_STEP_ACTIONS_READY
@@ -1295,6 +1296,19 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     }
     HIPCHK_H(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     HIPCHK_H(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    if (h->early) {  // gates (world.h: sync) only where kernels of two streams really run side by side: k_gate_probe
+        static int gates_work = -1;  // (per process)
+        if (gates_work < 0) {
+            k_gate_probe<<<dim3(1), dim3(WAVE), 0, h->side2>>>(d.sync + 2);
+            k_gate_probe_set<<<dim3(1), dim3(1), 0, h->side>>>(d.sync + 2);
+            HIPCHK_H(hipStreamSynchronize(h->side2));
+            HIPCHK_H(hipStreamSynchronize(h->side));
+            uint32_t verdict = 0;
+            HIPCHK_H(hipMemcpy(&verdict, d.sync + 3, sizeof(verdict), hipMemcpyDeviceToHost));
+            gates_work = verdict == 1u ? 1 : 0;
+        }
+        h->gates_work = gates_work == 1;
+    }
     HIPCHK_H(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_H(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_H(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1664,7 +1678,7 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // (ev_done: "these views are complete", what a promised step's k_obs waits for -- a marker behind k_view costs the caller's
         // stream a few us, so it is only recorded while the caller makes promises: a gated step needs no event at all)
         static const int gate_on = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;
-        h->no_done = gate_on != 0 && !h->ready_mode;
+        h->no_done = gate_on != 0 && h->gates_work && !h->ready_mode;
         h->done_on_view = ext_ev != 0 && h->early && !h->no_done;
         const hipEvent_t ev_v = h->done_on_view ? h->ev_done : nullptr;
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
@@ -2458,7 +2472,8 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     static const int force_early = getenv("IMGENV_EARLY_OBS") ? atoi(getenv("IMGENV_EARLY_OBS")) : -1;  // (measurement switch)
     // ... with the caller's promise that the actions are complete (IMGENV_STEP_ACTIONS_READY), or behind a gate that opens when the
     // caller's stream reaches this step's move (world.h: sync)
-    static const int gate_sw = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;  // (measurement switch)
+    static const int gate_env = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;  // (measurement switch)
+    const int gate_sw = gate_env != 0 && h->gates_work ? 1 : 0;
     const bool early_step = h->early && h->in_step && (gate_sw != 0 || (h->actions_ready && h->done_valid)) && !fuse_move && !h->chain_open &&
                             h->orca_seq > 0 && force_early != 0;
     // (a promised step waits for the event behind the last chain's views -- if that chain recorded one: it does when the step before
