@@ -2504,11 +2504,13 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     h->launches += 1;
     set_tail_fields(h, 0, h->elapsed + 1);  // imgenv_step_end counts the step; k_obs goes out before that
     if (early_step) {
-        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions -- which the caller has
-        // promised to be complete (IMGENV_STEP_ACTIONS_READY: nothing makes this launch wait for work queued on the caller's stream
-        // since the last step) --, so its side stream only waits for the last chain's views (ev_done; on that stream itself it sits
-        // behind the last chain's k_obs and solve).  Queued BEHIND k_integrate, whose few workgroups are then dispatched first; what
-        // the caller's stream forks behind the move is the solve alone.
+        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions.  Promised complete
+        // (IMGENV_STEP_ACTIONS_READY), nothing has to make this launch wait for work queued on the caller's stream since the last
+        // step: its side stream only waits for the last chain's views (ev_done; on that stream itself it sits behind the last
+        // chain's k_obs and solve).  Otherwise it waits behind a gate that opens when the caller's stream reaches the move (k_gate):
+        // that also says that the last chain's views are complete.  Queued BEHIND k_integrate either way -- a gate must follow
+        // the kernel that opens it in queue order, and the move's few workgroups are dispatched first; what the caller's stream
+        // forks behind the move is the solve alone.
         h->chain_open = true;
         if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
         h->fork_on_move = false;

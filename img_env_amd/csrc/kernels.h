@@ -1204,12 +1204,13 @@ __global__ void k_gate(const uint32_t* word, uint32_t want, int* err) {
 
 // Can a kernel on one stream wait for a kernel on another that is queued BEHIND it?  Not when something runs the process's
 // kernels strictly one at a time (rocprofv3's counter collection does): a gate would then sit there until its bound.  Asked once per
-// process (imgenv_create): this kernel polls for 2 ms, k_gate_probe_set -- launched behind it on another stream -- stores the word.
+// process (imgenv_create): this kernel polls for up to 20 ms (a busy chip may take its time to start the other one),
+// k_gate_probe_set -- launched behind it on another stream -- stores the word.
 __global__ void k_gate_probe(uint32_t* word) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     uint32_t seen = 0;
-    while ((seen = __hip_atomic_load(&word[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < 200000ull) __builtin_amdgcn_s_sleep(16);
+    while ((seen = __hip_atomic_load(&word[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < 2000000ull) __builtin_amdgcn_s_sleep(16);
     word[1] = seen ? 1u : 2u;
 }
 __global__ void k_gate_probe_set(uint32_t* word) { __hip_atomic_store(&word[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

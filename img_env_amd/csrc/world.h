@@ -189,7 +189,7 @@ struct DevWorld {
     // An early k_obs of a step whose actions may still be in the making on the caller's stream (plain imgenv_step) must not read
     // them before that stream has reached the step: the move's first workgroup stores the step's sequence number here -- the
     // caller's stream runs in order, so that store is the witness -- and a one-wavefront kernel in front of k_obs polls it (k_gate).
-    // An event recorded in front of the move would say the same, and cost the caller's stream ~6 us per step.
+    // An event recorded in front of the move would say the same, and cost the caller's stream ~6 us per step.  [2], [3]: k_gate_probe.
     uint32_t* sync;
     const float* obs_actions;    // the step's actions
     int layer_sum;           // SUM mode (above): ped_layer / own_lo / own_hi do not exist, k_compose never runs
