@@ -99,6 +99,17 @@ struct imgenv {
     // an event that only has to say "this kernel is done" rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL's stop
     // event): a hipEventRecord behind the kernel is a packet of its own, and the caller's stream pays ~6 us for each
     uint32_t gate_seq = 0;       // early steps whose k_obs waits behind a gate (world.h: sync) so far
+    // the social-force crowd a step AHEAD (sfm.h: SfmDev *_out): crowds that ignore the robots (relation_ped_robo = 0) depend on
+    // nothing of a step, so k_sfm for step t + 1 runs on a stream of its own underneath step t's rasters and views, reads the
+    // crowd as it is and leaves the next state in a second set of arrays; step t + 1 swaps the sets and only publishes
+    // (k_sfm_publish).  A reset in between drops what was computed ahead.
+    bool sfm_ahead = false;        // the handle can do that
+    bool sfm_ahead_valid = false;  // the other set holds the state of the next step (computed or being computed on sfm_stream)
+    bool sfm_input_moved = false;  // the caller's stream has written the live set since sfm_stream last looked (a reset, an in-place step)
+    int sfm_steps_since_reset = 0;
+    SfmDev sfm_other;              // the other set of the arrays a step writes (its p / v / dq / dest / last / nodes / n_nodes / treehash)
+    hipStream_t sfm_stream = nullptr;
+    hipEvent_t ev_sfm = nullptr, ev_sfm_in = nullptr;
     bool gates_work = false;     // k_gate_probe's verdict: kernels of two streams run side by side in this process
     bool no_done = false;        // this chain leaves no ev_done behind its views
     bool done_valid = false;     // the last chain did
@@ -474,6 +485,12 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamDestroy(h->side3);
     }
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->sfm_stream) {
+        (void)hipStreamSynchronize(h->sfm_stream);
+        (void)hipStreamDestroy(h->sfm_stream);
+    }
+    if (h->ev_sfm) (void)hipEventDestroy(h->ev_sfm);
+    if (h->ev_sfm_in) (void)hipEventDestroy(h->ev_sfm_in);
     if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
     if (h->ev_consumed) (void)hipEventDestroy(h->ev_consumed);
     if (h->sd_storage && h->sd_delete) h->sd_delete(h->sd_storage);
@@ -1064,6 +1081,23 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             f.n_obs_w = nobs;
             h->sfm_cap_obs = f.cap_obs;
             h->sfm_nobs_w.assign(W, 0);
+        }
+        f.p_out = f.p; f.v_out = f.v; f.dq_out = f.dq; f.dest_out = f.dest; f.last_out = f.last;  // (a step in place)
+        f.nodes_out = f.nodes; f.n_nodes_out = f.n_nodes; f.treehash_out = f.treehash;
+        {
+            static const int ahead_sw = getenv("IMGENV_SFM_AHEAD") ? atoi(getenv("IMGENV_SFM_AHEAD")) : 1;  // (measurement switch)
+            h->sfm_ahead = ahead_sw != 0 && cfg->relation_ped_robo != 1 && n > 0 && !h->serial;
+        }
+        if (h->sfm_ahead) {
+            SfmDev& o = h->sfm_other;
+            o = f;
+            TRY(dev_alloc(h, &o.p, Wn * 3)); TRY(dev_alloc(h, &o.v, Wn * 3));
+            TRY(dev_alloc(h, &o.dq, Wn * SFM_MAX_WP)); TRY(dev_alloc(h, &o.dest, Wn, 0xFF)); TRY(dev_alloc(h, &o.last, Wn, 0xFF));
+            TRY(dev_alloc(h, &o.nodes, (size_t)W * f.cap_nodes)); TRY(dev_alloc(h, &o.n_nodes, W)); TRY(dev_alloc(h, &o.treehash, Wn));
+            HIPCHK_H(hipStreamCreateWithFlags(&h->sfm_stream, hipStreamNonBlocking));
+            HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm, hipEventDisableTiming | hipEventDisableSystemFence));
+            HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm_in, hipEventDisableTiming | hipEventDisableSystemFence));
+            h->sfm_input_moved = true;
         }
         for (int k = 0; k < W; k++) {
             HIPCHK_H(hipMemcpy(f.p + (size_t)k * n1 * 3, p0.data(), sizeof(double) * 3 * n1, hipMemcpyHostToDevice));
@@ -2213,8 +2247,10 @@ static int reset_blocks(imgenv* h, int n, const int* list) {
     return 0;
 }
 
+static int sfm_ahead_drop(imgenv* h, hipStream_t st);
 static int reset_launch(imgenv* h, const int* list, int n, hipStream_t st, int whole) {
     DevWorld& d = h->d;
+    if (int rc = sfm_ahead_drop(h, st)) return rc;  // (a reset writes the live crowd: positions, waypoints)
     if (h->sd_ready) {  // a host-side reset draws obstacles the device-side restore does not know: whole-map restore next time
         static const std::vector<int> zeros(1 << 16, 0);
         SpawnDev& c = *(SpawnDev*)h->sd_storage;
@@ -2428,6 +2464,40 @@ extern "C" int imgenv_reset_world(imgenv_t* h, int32_t world, const imgenv_reset
 }
 
 // ---------------------------------------------------------------------------------------- step
+// k_sfm for one step of every crowd, on stream s: from the live set into `out` (null: in place), with or without the write-back to
+// the pedestrians' arrays
+static int launch_sfm(imgenv* h, hipStream_t s, const SfmDev* out, int publish) {
+    DevWorld d = h->d;
+    if (out) {
+        d.sfm.p_out = out->p; d.sfm.v_out = out->v; d.sfm.dq_out = out->dq; d.sfm.dest_out = out->dest; d.sfm.last_out = out->last;
+        d.sfm.nodes_out = out->nodes; d.sfm.n_nodes_out = out->n_nodes; d.sfm.treehash_out = out->treehash;
+    }
+    const int n_sfm = d.sfm.n, n_pairs = n_sfm * n_sfm;  // (of one world's crowd; a workgroup per world)
+    const unsigned nw = (unsigned)h->W, pb = (unsigned)((n_pairs + SFM_MAX_AGENTS - 1) / SFM_MAX_AGENTS);
+    if (n_pairs <= 4096) {  // small crowd: one launch
+        TIMED(h, IMGENV_K_ORCA, s, (k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, s>>>(d, 0, publish)));
+        h->launches += 1;
+    } else {  // the n^2 pair terms (three correctly rounded atan2 each) spread over the chip between two one-workgroup launches
+        const bool on = timing_on(h, IMGENV_K_ORCA);
+        if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, s, 0)) return rc_; }
+        k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, s>>>(d, 1, publish);
+        k_sfm<<<dim3(nw * pb), dim3(SFM_MAX_AGENTS), 0, s>>>(d, 2, publish);
+        k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, s>>>(d, 3, publish);
+        if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, s, 1)) return rc_; }
+        h->launches += 3;
+    }
+    return 0;
+}
+// Something is about to write the live crowd on stream st (a reset, a step in place, a device-side auto-reset): what was computed
+// ahead is dropped, and the writer waits for the launch that may still be reading the live set
+static int sfm_ahead_drop(imgenv* h, hipStream_t st) {
+    if (h->sfm_ahead_valid) HIPCHK(hipStreamWaitEvent(st, h->ev_sfm, 0));
+    h->sfm_ahead_valid = false;
+    if (h->sfm_ahead) h->sfm_input_moved = true;
+    h->sfm_steps_since_reset = 0;
+    return 0;
+}
+
 extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream) {
     if (!h || !actions) FAIL(IMGENV_EINVAL, "null argument");
     if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
@@ -2444,19 +2514,39 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
     // step's views and was joined at the end of that step; its velocities are applied by k_integrate's pedestrian blocks
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
-        const int n_sfm = h->d.sfm.n, n_pairs = n_sfm * n_sfm;  // (of one world's crowd; a workgroup per world)
-        const unsigned nw = (unsigned)h->W, pb = (unsigned)((n_pairs + SFM_MAX_AGENTS - 1) / SFM_MAX_AGENTS);
-        if (n_pairs <= 4096) {  // small crowd: one launch
-            TIMED(h, IMGENV_K_ORCA, st, (k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 0)));
-            h->launches += 1;
-        } else {  // the n^2 pair terms (three correctly rounded atan2 each) spread over the chip between two one-workgroup launches
-            const bool on = timing_on(h, IMGENV_K_ORCA);
-            if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, st, 0)) return rc_; }
-            k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 1);
-            k_sfm<<<dim3(nw * pb), dim3(SFM_MAX_AGENTS), 0, st>>>(d, 2);
-            k_sfm<<<dim3(nw), dim3(SFM_MAX_AGENTS), sizeof(SfmNode) * SFM_LDS_NODES, st>>>(d, 3);
-            if (on) { if (int rc_ = timing_mark(h, IMGENV_K_ORCA, st, 1)) return rc_; }
-            h->launches += 3;
+        if (h->sfm_ahead && h->in_step && !d.step_vars) {
+            // a crowd that ignores the robots: this step's state was computed during the last step (launch_sfm below) -- swap the
+            // two sets and publish -- or, right behind a reset, is computed now, in place; then the NEXT step's goes out on its stream
+            if (h->sfm_ahead_valid) {
+                SfmDev& a = h->d.sfm;
+                SfmDev& b = h->sfm_other;
+                std::swap(a.p, b.p); std::swap(a.v, b.v); std::swap(a.dq, b.dq); std::swap(a.dest, b.dest); std::swap(a.last, b.last);
+                std::swap(a.nodes, b.nodes); std::swap(a.n_nodes, b.n_nodes); std::swap(a.treehash, b.treehash);
+                a.p_out = a.p; a.v_out = a.v; a.dq_out = a.dq; a.dest_out = a.dest; a.last_out = a.last;
+                a.nodes_out = a.nodes; a.n_nodes_out = a.n_nodes; a.treehash_out = a.treehash;
+                HIPCHK(hipStreamWaitEvent(st, h->ev_sfm, 0));
+                k_sfm_publish<<<dim3((unsigned)h->W), dim3(SFM_MAX_AGENTS), 0, st>>>(d);
+                h->launches += 1;
+            } else {
+                if (int rc = launch_sfm(h, st, nullptr, 1)) return rc;
+                h->sfm_input_moved = true;
+            }
+            // (not in the first step behind a reset: a handle whose worlds are reset every other step -- many small worlds with
+            // their own time limits -- would compute ahead what the next reset drops, and make that reset wait for it)
+            if (h->sfm_steps_since_reset >= 1) {
+                if (h->sfm_input_moved) {  // (the live set was written on the caller's stream: a reset, the step in place)
+                    HIPCHK(hipEventRecord(h->ev_sfm_in, st));
+                    HIPCHK(hipStreamWaitEvent(h->sfm_stream, h->ev_sfm_in, 0));
+                    h->sfm_input_moved = false;
+                }
+                if (int rc = launch_sfm(h, h->sfm_stream, &h->sfm_other, 0)) return rc;
+                HIPCHK(hipEventRecord(h->ev_sfm, h->sfm_stream));
+                h->sfm_ahead_valid = true;
+            }
+            h->sfm_steps_since_reset += 1;
+        } else {
+            if (int rc = sfm_ahead_drop(h, st)) return rc;
+            if (int rc = launch_sfm(h, st, nullptr, 1)) return rc;
         }
     }
     if (d.beep_on) {  // beep lottery + ERVO's evacuation term on top of the velocities the solve left (img_env.cpp:323-343)
@@ -2958,6 +3048,10 @@ extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, c
     if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
     if (h->obs_forked) FAIL(IMGENV_ESTATE, "imgenv_step_autoreset_device between imgenv_step_begin and imgenv_step_end");
     hipStream_t st = (hipStream_t)stream;
+    if (h->sfm_ahead) {  // kernels reset finished worlds here, crowds included, without the host knowing which: the crowd steps in place
+        if (int rc = sfm_ahead_drop(h, st)) return rc;
+        h->sfm_ahead = false;
+    }
     const uint64_t fp = spawn_cfg_fingerprint(*cfg);
     if (!h->sd_ready || fp != h->sd_fp) {  // the first call fixes seed0: the k-th world reset from now on takes placement seed0 + k
         if (int rc = spawn_device_setup(h, cfg, seed0, st)) return rc;

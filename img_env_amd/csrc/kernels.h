@@ -879,7 +879,32 @@ __device__ __forceinline__ void ped_update_one(const DevWorld& w, int j) {
 
 // PedScene::step (pedscene.h:48-50) = Tscene::moveAgents(step_hz) for the whole social-force crowd, then the
 // write-back of img_env.cpp:344-358 (getNewPosAndVel pedscene.h:82-91, set_position, update_bbox)
-__global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w, int phase) {
+// the write-back of img_env.cpp:344-358 for pedestrian jw of crowd `world`: from the crowd's (new) positions and velocities
+__device__ __forceinline__ void sfm_publish_one(const DevWorld& w, int world, int jw, const double* p, const double* v, int n_peds) {
+    const int j = world * n_peds + jw;  // the pedestrian's index in the handle
+    const double ox = w.ppx[j], oy = w.ppy[j];
+    const double x = p[3 * jw], y = p[3 * jw + 1];
+    const double vx = v[3 * jw], vy = v[3 * jw + 1];
+    w.plx[j] = ox;
+    w.ply[j] = oy;
+    w.ppx[j] = x;
+    w.ppy[j] = y;
+    w.pyaw[j] = 0.0;  // uninitialised local `yaw` in the reference (img_env.cpp:346-349)
+    w.pvx[j] = vx;
+    w.pvy[j] = vy;
+    w.ped_state[4 * j] = x;
+    w.ped_state[4 * j + 1] = y;
+    w.ped_state[4 * j + 2] = vx;
+    w.ped_state[4 * j + 3] = vy;
+    ped_leg_gait(w, j, x, y, ox, oy);
+}
+// ... as a launch of its own, for a crowd whose step ran ahead (SfmDev: *_out; the host has swapped the two sets by now)
+__global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm_publish(DevWorld w) {
+    const int world = blockIdx.x, jw = threadIdx.x;
+    const SfmDev f = sfm_of_world(w.sfm, world);
+    if (jw < f.n_peds) sfm_publish_one(w, world, jw, f.p, f.v, f.n_peds);
+}
+__global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w, int phase, int publish) {
     __shared__ uint32_t nb_bits[SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32)];
     __shared__ double sfm_sh[4 * SFM_MAX_AGENTS];
     __shared__ __attribute__((aligned(16))) unsigned short sfm_stk[SFM_WALK_CAP * SFM_MAX_AGENTS];  // (its last row doubles as eight 32-bit words: sfm_step)
@@ -896,25 +921,9 @@ __global__ __launch_bounds__(SFM_MAX_AGENTS) void k_sfm(DevWorld w, int phase) {
 #else
     sfm_step(f, w.step_hz, phase, nb_bits, sfm_sh, sfm_stk, sfm_nodes, sfm_hash, &sfm_nn, pblock, pblocks);
 #endif
-    if (phase == 1 || phase == 2) return;
+    if (phase == 1 || phase == 2 || !publish) return;
     const int jw = threadIdx.x;
-    if (jw >= f.n_peds) return;
-    const int j = world * f.n_peds + jw;  // the pedestrian's index in the handle
-    const double ox = w.ppx[j], oy = w.ppy[j];
-    const double x = f.p[3 * jw], y = f.p[3 * jw + 1];
-    const double vx = f.v[3 * jw], vy = f.v[3 * jw + 1];
-    w.plx[j] = ox;
-    w.ply[j] = oy;
-    w.ppx[j] = x;
-    w.ppy[j] = y;
-    w.pyaw[j] = 0.0;  // uninitialised local `yaw` in the reference (img_env.cpp:346-349)
-    w.pvx[j] = vx;
-    w.pvy[j] = vy;
-    w.ped_state[4 * j] = x;
-    w.ped_state[4 * j + 1] = y;
-    w.ped_state[4 * j + 2] = vx;
-    w.ped_state[4 * j + 3] = vy;
-    ped_leg_gait(w, j, x, y, ox, oy);
+    if (jw < f.n_peds) sfm_publish_one(w, world, jw, f.p_out, f.v_out, f.n_peds);
 }
 
 // ------------------------------------------------------------------------------------------------

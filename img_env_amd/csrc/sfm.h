@@ -61,6 +61,13 @@ struct SfmDev {  // one crowd, or W of them back to back (one per world of a mul
     unsigned char* pair_code;  // [n (neighbour)][n (agent)] lookahead vote + 1 | has-term << 2
     uint32_t* g_nb;            // [SFM_MAX_AGENTS][SFM_MAX_AGENTS / 32] neighbour sets, phase 1 -> 2 of a split step
     double* g_sh;              // [4][SFM_MAX_AGENTS] desired direction x / y and two angles per agent, phase 1 -> 2, 3
+    // Where a step WRITES the state it changes.  The same arrays as above: the step happens in place.  A second set: the step reads
+    // the crowd as it is and leaves the next state beside it (k_sfm run a step AHEAD, on a stream of its own underneath the
+    // previous step's rasters and views -- imgenv_hip.hip: sfm_ahead; a reset in between simply drops what was computed ahead)
+    double *p_out, *v_out;
+    int *dq_out, *dest_out, *last_out;
+    SfmNode* nodes_out;
+    int *n_nodes_out, *treehash_out;
 };
 
 #if defined(__HIPCC__)
@@ -75,6 +82,11 @@ __device__ __forceinline__ SfmDev sfm_of_world(const SfmDev& f, int k) {
     g.nodes += (size_t)k * f.cap_nodes;
     g.n_nodes += k;
     g.treehash += a;
+    g.p_out += a * 3; g.v_out += a * 3;
+    g.dq_out += a * SFM_MAX_WP; g.dest_out += a; g.last_out += a;
+    g.nodes_out += (size_t)k * f.cap_nodes;
+    g.n_nodes_out += k;
+    g.treehash_out += a;
     g.pair_f += (size_t)k * n * n * 3;
     g.pair_code += (size_t)k * n * n;
     g.g_nb += (size_t)k * SFM_MAX_AGENTS * (SFM_MAX_AGENTS / 32);
@@ -458,9 +470,19 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
     double* lp = (double*)nb_lds;  // [n][3] new positions; the LDS neighbour bit sets (8 KB) are dead once the pair terms exist
     const int n_nodes0 = *s.n_nodes;
     const bool in_lds = phase != 2 && n_nodes0 + 32 <= SFM_LDS_NODES;
-    SfmNode* nodes = in_lds ? lnodes : s.nodes;
-    int* treehash = in_lds ? lhash : s.treehash;
-    int* n_nodes = in_lds ? ln_nodes : s.n_nodes;
+    // (a tree too large for LDS is edited in HBM: in the OUTPUT copy, made first, when the step does not happen in place)
+    const bool edits_tree = phase == 0 || phase == 3, hbm_copy = !in_lds && edits_tree && s.nodes_out != s.nodes;
+    if (hbm_copy) {
+        const int words = n_nodes0 * (int)(sizeof(SfmNode) / 4);
+        for (int q = threadIdx.x; q < words; q += blockDim.x) ((uint32_t*)s.nodes_out)[q] = ((const uint32_t*)s.nodes)[q];
+        if (i < n) s.treehash_out[i] = s.treehash[i];
+        if (i == 0) *s.n_nodes_out = n_nodes0;
+        __threadfence_block();
+        __syncthreads();
+    }
+    SfmNode* nodes = in_lds ? lnodes : hbm_copy ? s.nodes_out : s.nodes;
+    int* treehash = in_lds ? lhash : hbm_copy ? s.treehash_out : s.treehash;
+    int* n_nodes = in_lds ? ln_nodes : hbm_copy ? s.n_nodes_out : s.n_nodes;
     const int cap_nodes = in_lds ? SFM_LDS_NODES : s.cap_nodes;
     if (in_lds) {
         const int words = n_nodes0 * (int)(sizeof(SfmNode) / 4);
@@ -579,11 +601,14 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
         // Tagent::desiredForce (ped_agent.cpp:236-306)
         int dest = s.dest[i], last = s.last[i];
         const int dqn = s.dq_n[i];
-        int* dq = s.dq + (size_t)i * SFM_MAX_WP;
+        const int* dq = s.dq + (size_t)i * SFM_MAX_WP;
+        int* dq_o = s.dq_out + (size_t)i * SFM_MAX_WP;
         if ((dest == -1) && (dqn > 0)) {
             dest = dq[0];
-            for (int k = 0; k + 1 < dqn; k++) dq[k] = dq[k + 1];
-            dq[dqn - 1] = dest;
+            for (int k = 0; k + 1 < dqn; k++) dq_o[k] = dq[k + 1];  // (in place as well: entry k + 1 is read before it is overwritten)
+            dq_o[dqn - 1] = dest;
+        } else if (dq_o != dq) {
+            for (int k = 0; k < dqn; k++) dq_o[k] = dq[k];
         }
         d3 desired_direction = D3(0, 0, 0);
         bool reached = false;
@@ -596,8 +621,8 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
             last = dest;
             dest = -1;
         }
-        s.dest[i] = dest;
-        s.last[i] = last;
+        s.dest_out[i] = dest;
+        s.last_out[i] = last;
         desiredforce = scaled(normalized(desired_direction), s.vmax[i]);
         SFM_STAMP(2);
         // loop-invariant angles of Tagent::lookaheadForce (ped_agent.cpp:439-480): of my desired direction and of my
@@ -772,13 +797,13 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
                       scaled(lookaheadforce, 1.0)) + D3(0, 0, 0);
         d3 v = scaled(me_v, 0.5) + scaled(a, h);
         if (len3(v) > s.vmax[i]) v = scaled(normalized(v), s.vmax[i]);
-        s.p[3 * i] = p_desired.x; s.p[3 * i + 1] = p_desired.y; s.p[3 * i + 2] = p_desired.z;
+        s.p_out[3 * i] = p_desired.x; s.p_out[3 * i + 1] = p_desired.y; s.p_out[3 * i + 2] = p_desired.z;
         lp[3 * i] = p_desired.x;  // the tree surgery below reads positions from LDS
         lp[3 * i + 1] = p_desired.y;
         double* lp_old = (double*)(stk + 11 * blockDim.x);  // [n][2]: rows 11-18 of the walk stacks' LDS (dead since the neighbour walk)
         lp_old[2 * i] = me_p.x;
         lp_old[2 * i + 1] = me_p.y;
-        s.v[3 * i] = v.x; s.v[3 * i + 1] = v.y; s.v[3 * i + 2] = v.z;
+        s.v_out[3 * i] = v.x; s.v_out[3 * i + 1] = v.y; s.v_out[3 * i + 2] = v.z;
     }
     __syncthreads();
     SFM_STAMP(5);
@@ -873,9 +898,9 @@ __device__ void sfm_step(const SfmDev& s, double h, int phase, uint32_t* nb_lds 
     SFM_STAMP(9);
     if (in_lds) {  // back to HBM for the next step (a reset only moves positions, as Tagent::setPosition does: the tree catches up in the next step)
         const int words = *ln_nodes * (int)(sizeof(SfmNode) / 4);
-        for (int q = threadIdx.x; q < words; q += blockDim.x) ((uint32_t*)s.nodes)[q] = ((const uint32_t*)lnodes)[q];
-        if (i < n) s.treehash[i] = lhash[i];
-        if (i == 0) *s.n_nodes = *ln_nodes;
+        for (int q = threadIdx.x; q < words; q += blockDim.x) ((uint32_t*)s.nodes_out)[q] = ((const uint32_t*)lnodes)[q];
+        if (i < n) s.treehash_out[i] = lhash[i];
+        if (i == 0) *s.n_nodes_out = *ln_nodes;
     }
     SFM_STAMP(6);
 #undef SFM_STAMP

@@ -320,13 +320,15 @@ def test_counting_layer_over_long_episodes_with_standing_and_frozen_agents(world
     assert not fails, fails[:3]
 
 
-def test_pedscene_worlds_match_one_oracle_each(worlds):
+@pytest.mark.parametrize("relation", [1, 0])
+def test_pedscene_worlds_match_one_oracle_each(worlds, relation):
     """a social-force crowd per world (the reference: one PedScene per env process, pedscene.h:17-91): 3 worlds x (2 robots that
     are crowd members, 7 pedestrians, own obstacle segments), per-world resets in mid-flight -- positions persist in the
-    library's quadtree per world, velocities persist across resets per world"""
+    library's quadtree per world, velocities persist across resets per world.  relation 0: crowds that ignore the robots are
+    stepped a step AHEAD on a stream of their own; a reset in between drops what was computed ahead."""
     World, OracleWorld = worlds
-    fails, snap, _ = _run(World, OracleWorld, W=3, Rw=2, Pw=7, steps=14, resets={4: [1], 9: [0, 2]}, seed=71, scene="pedscene",
-                          grid_size=88, n_obstacles=3)
+    fails, snap, _ = _run(World, OracleWorld, W=3, Rw=2, Pw=7, steps=14, resets={4: [1], 9: [0, 2], 10: [1]}, seed=71, scene="pedscene",
+                          grid_size=88, n_obstacles=3, relation_ped_robo=relation)
     assert not fails, fails[:3]
     assert np.abs(snap["ped_state"][:, 2:]).max() > 0.05  # the crowds really moved
 
