@@ -1318,13 +1318,16 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         // The early k_obs waits for the last chain's views, not for what the caller queued on its stream since -- a policy that
         // writes the actions there; waiting for that (an event at the step's start) costs the whole gain: 106.5 us per step against
         // 95.9 with the promise and 105.4 with k_obs behind the move, same box
-        h->early = !h->serial && RL == R && P > 0 && h->NA > 0 && !d.beep_on && !limiters && !h->big_view &&
+        // ... or a social-force crowd that is stepped a step ahead (sfm_ahead): its arrays are published in front of the move and
+        // stand still during the step, so the early k_obs reads them as they are (obs_early = 2) -- always behind the gate, which
+        // also says that the publishing is done
+        h->early = !h->serial && RL == R && P > 0 && (h->NA > 0 || h->sfm_ahead) && !d.beep_on && !limiters && !h->big_view &&
                    h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS;
         if (h->early) {
             TRY(dev_alloc(h, &d.sync, 8));
             TRY(dev_alloc(h, &d.rec_snap, (size_t)RL * IMGENV_RECORD_DOUBLES));
-            TRY(dev_alloc(h, &h->ped_snap[0], (size_t)P));
-            TRY(dev_alloc(h, &h->ped_snap[1], (size_t)P));
+            TRY(dev_alloc(h, &h->ped_snap[0], (size_t)(h->NA > 0 ? P : 1)));
+            TRY(dev_alloc(h, &h->ped_snap[1], (size_t)(h->NA > 0 ? P : 1)));
             HIPCHK_H(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming | hipEventDisableSystemFence));
         }
     }
@@ -2564,12 +2567,13 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     // caller's stream reaches this step's move (world.h: sync)
     static const int gate_env = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;  // (measurement switch)
     const int gate_sw = gate_env != 0 && h->gates_work ? 1 : 0;
-    const bool early_step = h->early && h->in_step && (gate_sw != 0 || (h->actions_ready && h->done_valid)) && !fuse_move && !h->chain_open &&
-                            h->orca_seq > 0 && force_early != 0;
+    const bool live_peds = h->NA == 0;  // (a social-force crowd a step ahead: see imgenv_create)
+    const bool early_step = h->early && h->in_step && (gate_sw != 0 || (h->actions_ready && h->done_valid && !live_peds)) && !fuse_move &&
+                            !h->chain_open && (live_peds ? h->sfm_ahead : h->orca_seq > 0) && force_early != 0;
     // (a promised step waits for the event behind the last chain's views -- if that chain recorded one: it does when the step before
     // it was a promised one, see launch_views -- and starts k_obs at once; every other early step takes the gate, which says the same)
-    const bool early_gated = early_step && gate_sw != 0 && (!h->actions_ready || !h->done_valid);
-    if (early_step) h->ready_mode = h->actions_ready;
+    const bool early_gated = early_step && gate_sw != 0 && (!h->actions_ready || !h->done_valid || live_peds);
+    if (early_step) h->ready_mode = h->actions_ready && !live_peds;
     if (early_gated) h->gate_seq += 1;
     if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
         h->move_pending = true;
@@ -2610,7 +2614,7 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         } else {
             HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
         }
-        d.obs_early = 1;
+        d.obs_early = live_peds ? 2 : 1;
         d.obs_actions = actions;
         d.obs_n_sub = h->n_sub;
         d.ped_snap_in = h->ped_snap[(h->orca_seq - 1) & 1];

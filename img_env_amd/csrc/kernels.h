@@ -2808,8 +2808,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     // getNewPosAndVel (rvoscene.h:72-82) applied to the solve's snapshot -- float32 position + velocity * dt, promoted (ped_update_one)
     const float4* g_snap = w.ped_snap_in + p_lo;
     const float ts32 = (float)w.step_hz;
+    const bool snap_peds = w.obs_early == 1;  // (2: an early launch beside a crowd whose arrays stand still during the step -- social force, published in front of the move)
     auto ped_pos = [&](int j, double& x, double& y) {
-        if (early) {
+        if (snap_peds) {
             const float4 q = g_snap[j];
             x = (double)(q.x + q.z * ts32);
             y = (double)(q.y + q.w * ts32);
@@ -2819,7 +2820,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
         }
     };
     auto ped_vel = [&](int j, double& vx, double& vy) {
-        if (early) {
+        if (snap_peds) {
             const float4 q = g_snap[j];
             vx = (double)q.z;
             vy = (double)q.w;

@@ -644,6 +644,10 @@ def test_cfg4_share_matches_oracle(worlds, cr_atan2_oracle):
         assert not fails, fails[:3]
         snap = cpu.snapshot()
         assert np.abs(snap["ped_state"][:, 2:]).max() > 0.05  # the crowd moved
+        # ... and on through a reset between two steps: the crowd is stepped a step AHEAD here (it ignores the robots) and the
+        # observation starts beside the move -- the reset drops what was computed ahead, velocities and tree persist (pedscene.h:34-46)
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(5)])
+        assert not fails, ("behind the reset", fails[:3])
     finally:
         gpu.close()
         cpu.close()
