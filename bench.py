@@ -46,15 +46,25 @@ N_PEDS = 200
 GRID = 400
 TIME_MAX = 100
 
-#: the two BASELINE configurations bench.py can time (worldgen.PRESETS holds the same numbers)
+#: the BASELINE configurations bench.py can time (worldgen.PRESETS holds the same numbers); `robots` is the world's robot count for
+#: "strong" scaling (the same world at every GPU count), the robots PER GPU for "weak" and "replicas"
 #: cfg3 res / clearance: SURVEY 8(d) density rule for 8192 robots on 400x400: R*0.25 m^2 <= 0.5*(Hg*res)^2 -> 0.25 m; starts 0.7 m
 #: apart, so that two r=0.17 m footprints never share a 0.25 m cell at reset
 WORKLOADS = {
-    "cfg3": dict(scene="rvoscene", res=0.25, clearance=0.7, relation_ped_robo=1, scaling="strong", ped_box=None,
+    "cfg2": dict(scene="", res=0.125, clearance=1.0, relation_ped_robo=1, scaling="replicas", ped_box=None, robots=1024, peds=0, grid=400,
+                 view=48, beams=360,
+                 name="cfg-2: one world of %(RL)d robots per GPU (x %(N)d GPUs: independent replicas, no exchange), no pedestrians"),
+    "cfg3": dict(scene="rvoscene", res=0.25, clearance=0.7, relation_ped_robo=1, scaling="strong", ped_box=None, robots=8192, peds=200,
+                 grid=400, view=48, beams=360,
                  name="cfg-3: one world, %(R)d robots (%(RL)d per GPU x %(N)d GPUs%(strong)s), %(P)d ORCA peds (rvoscene)"),
-    "cfg4": dict(scene="pedscene", res=0.5, clearance=0.5, relation_ped_robo=0, scaling="weak", ped_box=(0.5, 9.5),
+    "cfg4": dict(scene="pedscene", res=0.5, clearance=0.5, relation_ped_robo=0, scaling="weak", ped_box=(0.5, 9.5), robots=8192, peds=200,
+                 grid=400, view=48, beams=360,
                  name="cfg-4: one world, %(R)d robots (%(RL)d per GPU x %(N)d GPUs, weak scaling: 65536 at 8 GPUs), %(P)d social-force "
                       "peds (pedscene, inside libpedsim's 10 m root square)"),
+    "cfg5": dict(scene="ervoscene", res=0.125, clearance=0.7, relation_ped_robo=1, scaling="strong", ped_box=None, robots=8192, peds=1000,
+                 grid=800, view=96, beams=720,
+                 name="cfg-5: one world, %(R)d robots (%(RL)d per GPU x %(N)d GPUs%(strong)s), %(P)d ERVO peds (ervoscene), the "
+                      "LDS-pressure case"),
 }
 RES, CLEARANCE = WORKLOADS["cfg3"]["res"], WORKLOADS["cfg3"]["clearance"]
 
@@ -68,7 +78,7 @@ def make_workload(cfg_name, R, P, n_layouts, robot_begin=0, robot_end=None, sort
     """grid, params and reset layouts of a BASELINE configuration with R robots in the world"""
     from img_env_amd import worldgen
     wl = WORKLOADS[cfg_name]
-    grid = worldgen.make_grid(GRID, 0)
+    grid = worldgen.make_grid(wl["grid"], 0)
     layouts = [worldgen.make_layout(grid, wl["res"], R, P, seed=seed0 + s, clearance=wl["clearance"]) for s in range(n_layouts)]
     for lay in layouts:
         if wl["ped_box"] is not None:  # libpedsim's quadtree covers x in [0, 10], y in [10, 20] only (pedscene.h:18): the crowd stays in its square
@@ -83,15 +93,16 @@ def make_workload(cfg_name, R, P, n_layouts, robot_begin=0, robot_end=None, sort
             order = np.argsort(lay.robot_pose[:, 0], kind="stable")
             lay.robot_pose = lay.robot_pose[order].copy()
             lay.robot_goal = lay.robot_goal[order].copy()
-    params = worldgen.make_params(R, P, res=wl["res"], view_cells=48, beams=360, scene=wl["scene"], time_max=TIME_MAX,
+    params = worldgen.make_params(R, P, res=wl["res"], view_cells=wl["view"], beams=wl["beams"], scene=wl["scene"], time_max=TIME_MAX,
                                   relation_ped_robo=wl["relation_ped_robo"], robot_begin=robot_begin,
                                   robot_end=R if robot_end is None else robot_end)
     return grid, params, layouts
 
 
-def algorithmic_bytes(P, hv=48, wv=48, beams=360, max_ped=N_PEDS):
+def algorithmic_bytes(P, hv=48, wv=48, beams=360, max_ped=None):
     """SURVEY 8(d) per robot-step (the variant that materialises the f16 copy of the sensor map, as this build
     does), split by the kernel that moves them"""
+    max_ped = P if max_ped is None else max_ped
     view = hv * wv + hv * wv + 2 * hv * wv + 4 * beams   # grid window gather + sensor_map u8 + f16 copy + lasers f32
     obs = (20 * P + 3 * 48 * 48 * 4 + 4 * (1 + 7 * max_ped)) if P > 0 else 0
     state = 128
@@ -155,11 +166,17 @@ def cpu_baseline(cfg_name, params, grid, layout, peds, seconds=6.0, all_core_sec
     p = dict(params)
     p["robot_begin"], p["robot_end"] = 0, p["n_robots"]
     R = p["n_robots"]
-    w = OracleWorld(p, grid)
-    w.reset(layout)
-    steps, dt = _oracle_run(w, R, seconds, 50)
+    # (one thread on the GPU's own world where a step of it takes seconds -- cfg-3 / cfg-4; a 1024-robot world of the same
+    # geometry where it would take minutes: cfg-5's 1000 pedestrians and 96 x 96 views)
+    R1 = R if cfg_name in ("cfg3", "cfg4") else min(R, 1024)
+    if R1 == R:
+        w = OracleWorld(p, grid)
+        w.reset(layout)
+    else:
+        w = _oracle_world(cfg_name, R1, peds, seed=100)
+    steps, dt = _oracle_run(w, R1, seconds, 50)
     w.close()
-    single = R * steps / dt
+    single = R1 * steps / dt
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -186,17 +203,17 @@ def cpu_baseline(cfg_name, params, grid, layout, peds, seconds=6.0, all_core_sec
     # (200 pedestrians, map copy) weigh less -- more robots in total than the GPU stepped, but the better robot-steps/s
     per = max(1, R // cores)
     split, ok1, t1 = all_cores(per)
-    big, ok2, t2 = all_cores(1024)
+    big, ok2, t2 = all_cores(1024) if per != 1024 else (split, ok1, t1)
     best = max(split, big)
     return dict(value=best if (ok1 or ok2) else None, unit="robot-steps/s", cores=max(ok1, ok2), kind="port", cpu_model=_cpu_model(),
                 nproc=cores, single_thread_value=single, all_cores_split_world_value=split, all_cores_1024_robot_worlds_value=big,
                 sample="all cores: %d single-threaded oracle processes side by side (one per hardware thread, the reference's env_num "
-                       "idiom), each its own world + %d %s peds on the 400x400 map @%.2f m, v=0 policy: %d robots per world (the "
+                       "idiom), each its own world + %d %s peds on the configuration's map @%.3f m, v=0 policy: %d robots per world (the "
                        "benchmark's %d split over the cores, %.1f s) and 1024 robots per world (%.1f s); value = the better of the two; "
-                       "single_thread_value: 1 thread, %d steps of the same %d-robot shared world the GPU ran, %.1f s.  kind \"port\": the "
+                       "single_thread_value: 1 thread, %d steps of a %d-robot shared world of the GPU's geometry, %.1f s.  kind \"port\": the "
                        "oracle keeps ONE shared owner layer per world where the reference copies the whole map once per robot and step "
                        "(img_env.cpp:623) -- the reference itself would be slower than this figure, which therefore flatters the CPU"
-                       % (max(ok1, ok2), peds, WORKLOADS[cfg_name]["scene"], WORKLOADS[cfg_name]["res"], per, R, t1, t2, steps, R, dt))
+                       % (max(ok1, ok2), peds, WORKLOADS[cfg_name]["scene"] or "no", WORKLOADS[cfg_name]["res"], per, R, t1, t2, steps, R1, dt))
 
 
 def launch_ranks(args):
@@ -224,24 +241,37 @@ def launch_ranks(args):
         raise SystemExit("bench.py: ranks exited with %s%s" % (rcs, "" if lines else " and rank 0 printed no result line"))
 
 
+def first_step_ped_velocities(cfg_name, peds):
+    """cpu_baseline leg (the oracle, before this process touches a GPU), cfg-4 only: the velocities the CPU oracle -- linked
+    against the host's glibc atan2, as the reference is -- gives the social-force crowd on the FIRST step of a handle's first
+    episode.  The crowd ignores the robots, so a one-robot world holds the same crowd.  bench.py compares the library's own
+    first step with it and prints how many pedestrians differ (`sfm_first_step_sign_flips`): the documented exception to the
+    1e-4 bar (ped_agent.cpp:352-360: sign of a rounding residue while the whole crowd stands still)."""
+    w = _oracle_world(cfg_name, 1, peds, seed=100)
+    w.step(np.zeros((1, 3), np.float32))
+    v = np.array(w.snapshot()["ped_state"][:, 2:4], np.float64)
+    w.close()
+    return v
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg3", help="BASELINE configuration: cfg3 = the metric's 8192-robot "
-                    "world, strong-scaled over the GPUs (default); cfg4 = 8192 robots per GPU beside 200 social-force pedestrians, weak scaling")
+                    "world, strong-scaled over the GPUs (default); cfg4 = 8192 robots per GPU beside 200 social-force pedestrians, weak scaling; "
+                    "cfg2 = 1024 robots without pedestrians (independent replicas on N GPUs); cfg5 = 8192 robots, 1000 ERVO pedestrians, 96x96 "
+                    "views, 720 beams on 800x800, strong-scaled")
     ap.add_argument("--robots-per-gpu", type=int, default=None, help="diagnostic: robots per GPU instead of the configuration's")
-    ap.add_argument("--peds", type=int, default=N_PEDS)
+    ap.add_argument("--peds", type=int, default=None, help="diagnostic: pedestrians instead of the configuration's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-episode", action="store_true")
-    ap.add_argument("--no-multi-world", action="store_true", help="skip the secondary env_num-style measurement")
+    ap.add_argument("--no-episode", action="store_true", help="skip the secondary policies (episode_policy, spec_policy) and full_rewrite")
+    ap.add_argument("--no-multi-world", action="store_true", help="skip the secondary env_num-style measurements")
     ap.add_argument("--spinup", type=int, default=2000, help="untimed steps before the warm-up (clock ramp)")
     ap.add_argument("--timing-mode", type=int, default=2, help="diagnostic: 0 = no HIP events in the timed pass")
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: extra timed passes, printed to stderr")
     ap.add_argument("--passes", type=int, default=5, help="timed passes of the SAME --steps; value = the median pass")
-    ap.add_argument("--stream-ordered-actions", action="store_true", help="diagnostic: plain imgenv_step (every kernel that reads the actions "
-                    "waits for the caller's stream) instead of imgenv_step_flags(IMGENV_STEP_ACTIONS_READY) for the pre-generated actions")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and use the "
                     "step_begin / all_gather / step_end path even with one rank (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)  # internal: one process of the all-core CPU baseline
@@ -249,6 +279,9 @@ def main():
     ap.add_argument("--cpu-worker-seconds", type=float, default=8.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-start", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    wl = WORKLOADS[args.config]
+    if args.peds is None:
+        args.peds = wl["peds"]
     if args.cpu_worker is not None:
         return cpu_worker(args)
     if "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("IMGENV_BENCH_FORCE_LAUNCHER")):
@@ -256,7 +289,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from img_env_amd import worldgen
+    from img_env_amd import _cabi
     from img_env_amd.world import World
 
     rank = int(os.environ.get("RANK", "0"))
@@ -264,47 +297,67 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world_size))
-    wl = WORKLOADS[args.config]
+    replicas = wl["scaling"] == "replicas"  # every rank its own world: no shard, no exchange
     if args.robots_per_gpu:  # diagnostic override: that many robots on every rank, whatever the configuration says
         RL = args.robots_per_gpu
     elif wl["scaling"] == "strong":
-        if ROBOTS % world_size:
-            raise SystemExit("bench.py: %d robots do not split over %d GPUs" % (ROBOTS, world_size))
-        RL = ROBOTS // world_size
+        if wl["robots"] % world_size:
+            raise SystemExit("bench.py: %d robots do not split over %d GPUs" % (wl["robots"], world_size))
+        RL = wl["robots"] // world_size
     else:
-        RL = ROBOTS_PER_GPU
-    R = RL * world_size
+        RL = wl["robots"]
+    R = RL if replicas else RL * world_size   # robots of ONE world
+    R_job = RL * world_size                   # robots the whole job steps
     P = args.peds
-    res, clearance = wl["res"], wl["clearance"]
-    side = GRID
+    res = wl["res"]
+    side = wl["grid"]
     n_layouts = 2 + (args.steps + args.warmup) // (TIME_MAX + 1)
-    grid, params, layouts = make_workload(args.config, R, P, min(n_layouts, 4 if R <= 16384 else 2), robot_begin=rank * RL, robot_end=(rank + 1) * RL,
-                                          sort_x=world_size > 1)
+    shard = not replicas and world_size > 1
+    grid, params, layouts = make_workload(args.config, R, P, min(n_layouts, 4 if R <= 16384 else 2), robot_begin=rank * RL if shard else 0,
+                                          robot_end=(rank + 1) * RL if shard else R, sort_x=shard, seed0=100 + (1000 * rank if replicas else 0))
 
     # The CPU baseline runs FIRST, before this process makes its first GPU call: its all-core leg starts worker processes,
     # and nothing may be started from a process that holds a GPU context on this pool.
-    cpu_base = None
+    cpu_base, oracle_first_v = None, None
     if world_size == 1 and not args.no_cpu_baseline and not args.force_dist:
         try:
             cpu_base = cpu_baseline(args.config, dict(params), grid, layouts[0], P)
         except Exception as e:
             cpu_base = {"value": None, "unit": "robot-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        if args.config == "cfg4" and P > 0:
+            try:
+                oracle_first_v = first_step_ped_velocities(args.config, P)
+            except Exception:
+                oracle_first_v = None
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world_size > 1 or args.force_dist
+    exchange = use_dist and not replicas
     comm_ranks = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
+    sfm_flips = None
+    if oracle_first_v is not None:  # (cfg-4, one GPU) the library's first step of its first episode against the glibc-linked oracle's
+        w0 = World(dict(params), grid, device=local_rank)
+        w0.reset(layouts[0])
+        w0.step(torch.zeros(RL, 3, device=dev))
+        v0 = w0.snapshot()["ped_state"][:, 2:4]
+        w0.close()
+        dv = np.abs(v0 - oracle_first_v).max(axis=1)
+        sfm_flips = dict(count=int((dv > 1e-9).sum()), of=int(P), max_abs_dv=float(dv.max()),
+                         what="pedestrians whose first-step velocity (first episode of a handle: the crowd at rest) differs from the CPU oracle linked "
+                              "against the host's glibc atan2 -- the device's atan2 is correctly rounded, glibc's is not; ped_agent.cpp:352-360, INTEGRATION.md")
+
     world = World(params, grid, device=local_rank)
     if world.lib.imgenv_backend() != b"hip-gfx950":
         raise SystemExit("bench.py: %r is not the product library (experiment / profile build)" % world.lib.imgenv_backend())
-    r0, r1 = rank * RL, (rank + 1) * RL
+    r0, r1 = (rank * RL, (rank + 1) * RL) if shard else (0, RL)
     native = False
-    if use_dist:
+    if exchange:
         try:  # preferred: the library runs ncclAllGather itself, on the step's stream
             world.init_comm(rank, world_size)
             native = True
@@ -323,52 +376,50 @@ def main():
         # generated on the device: a pageable host-to-device copy here leaves a deferred un-pin behind in the HIP runtime
         # that was seen to stall kernel submission for ~30 ms a few dozen steps later
         a = torch.zeros(n_act, RL, 3, device=dev)
-        if policy == "episode":
+        if policy in ("episode", "spec"):  # env_test.py:8-19
             a[:, :, 0] = torch.rand(n_act, RL, generator=g, device=dev) * 0.6
         a[:, :, 1] = torch.rand(n_act, RL, generator=g, device=dev) * 1.8 - 0.9
         return a
 
-    # The actions are pre-generated and resident in HBM before the timed region starts (BASELINE / SURVEY 8d): the steps say so
-    # (IMGENV_STEP_ACTIONS_READY), which lets the library start its observation kernel at once.  `stream_ordered_actions` in the
-    # line is the same measurement with plain imgenv_step, as a trainer whose policy writes the actions on the stream gets it (the
-    # observation then starts behind a gate: include/imgenv.h).
-    state = dict(elapsed=0, episode=0, resets=0, ready=not args.stream_ordered_actions)
+    # The actions are pre-generated and resident in HBM before the timed region starts (BASELINE / SURVEY 8d); the steps are
+    # plain stream-ordered imgenv_step calls -- what a trainer whose policy writes the actions on the stream makes.
+    ctx = dict(world=world, time_max=TIME_MAX)
+    state = dict(elapsed=0, episode=0, resets=0)
 
     def do_reset():
-        world.reset(layouts[state["episode"] % len(layouts)])
+        ctx["world"].reset(layouts[state["episode"] % len(layouts)])
         state["episode"] += 1
         state["elapsed"] = 0
         state["resets"] += 1
 
     def do_step(a):
-        if use_dist and not native:
-            world.step_begin(a)
-            dist.all_gather_into_tensor(world.records, world.records[r0:r1])
-            world.step_end()
+        w = ctx["world"]
+        if exchange and not native:
+            w.step_begin(a)
+            dist.all_gather_into_tensor(w.records, w.records[r0:r1])
+            w.step_end()
         else:
-            world.step(a, actions_ready=state["ready"])
+            w.step(a)
         state["elapsed"] += 1
-        if state["elapsed"] > TIME_MAX:  # TimeLimitWrapper has set done for every robot: NeverStopWrapper resets
+        if state["elapsed"] > ctx["time_max"]:  # TimeLimitWrapper has set done for every robot: NeverStopWrapper resets
             do_reset()
 
     def run(policy, steps, warmup, timing_mode=0, which=-1):
+        w = ctx["world"]
         acts = make_actions(policy)
         state["episode"] = 0
         do_reset()
         for s in range(warmup):
             do_step(acts[s % n_act])
-        frozen0 = int(world.out["counters"][3].item())
+        frozen0 = int(w.out["counters"][3].item())
         resets0 = state["resets"]
-        world.timing(timing_mode, which)
+        w.timing(timing_mode, which)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if os.environ.get("BENCH_TRACE"):  # diagnostic: where inside a pass does the time go (adds a sync every 20 steps)
             tw, marks = t0, []
-            if os.environ.get("BENCH_TRACE") == "2":
-                world.timing(1)
-                prevk = world.timing_read()
             for s in range(steps):
                 e0 = state["episode"]
                 do_step(acts[s % n_act])
@@ -379,12 +430,6 @@ def main():
                     now = time.perf_counter()
                     print("  trace %s steps %d-%d: %.1f us/step%s" % (policy, s - 19, s, 1e6 * (now - tw) / 20,
                                                                   " reset@%s" % marks if marks else ""), file=sys.stderr)
-                    if os.environ.get("BENCH_TRACE") == "2":
-                        curk = world.timing_read()
-                        print("      kernels: " + " ".join("%s %.0f" % (k[2:], 1e3 * (curk[k][0] - prevk[k][0]) / max(curk[k][1] - prevk[k][1], 1))
-                                                         for k in curk), file=sys.stderr)
-                        prevk = curk
-                        now = time.perf_counter()
                     tw, marks = now, []
         else:
             for s in range(steps):
@@ -393,13 +438,13 @@ def main():
         if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
-        tm = world.timing_read()
-        world.timing(0)
+        tm = w.timing_read()
+        w.timing(0)
         if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        frozen = int(world.out["counters"][3].item()) - frozen0
+        frozen = int(w.out["counters"][3].item()) - frozen0
         state["resets_timed"] = state["resets"] - resets0
         return dt, tm, frozen / float(steps * RL)
 
@@ -449,25 +494,16 @@ def main():
     order = sorted(range(len(passes)), key=lambda q: passes[q][0])
     dt, tm, frozen_active, resets_timed = passes[order[len(order) // 2]]
     dom_ms, dom_n = tm[dominant]
-    value = R * args.steps / dt
-    pass_values = [R * args.steps / p[0] for p in passes]
+    value = R_job * args.steps / dt
+    pass_values = [R_job * args.steps / p[0] for p in passes]
     # ... and the same passes once more WITHOUT the HIP events around the dominant kernel (every 8th launch carries a pair, and an
     # event operation is a dependency bubble on its stream: the timed region above pays just under 1 % for carrying the roofline's
     # measurement inside it).  Reported beside `value`, never instead of it.
     uninstrumented = None
     if args.timing_mode != 0 and world_size == 1:
         d0 = sorted(run("active", args.steps, min(args.warmup, 5), timing_mode=0)[0] for _ in range(3))[1]
-        uninstrumented = dict(value=R * args.steps / d0, ms_per_step=1e3 * d0 / args.steps,
+        uninstrumented = dict(value=R_job * args.steps / d0, ms_per_step=1e3 * d0 / args.steps,
                               what="median of 3 more passes of the same %d steps with no HIP event in the timed region" % args.steps)
-    stream_ordered = None
-    if state["ready"] and world_size == 1:
-        state["ready"] = False
-        d1 = sorted(run("active", args.steps, min(args.warmup, 5), timing_mode=0)[0] for _ in range(3))[1]
-        state["ready"] = True
-        stream_ordered = dict(value=R * args.steps / d1, ms_per_step=1e3 * d1 / args.steps,
-                              what="median of 3 passes with plain imgenv_step: every kernel that reads the actions is ordered behind the caller's "
-                                   "stream (a policy may write them there in front of the call): the observation's side stream waits behind a "
-                                   "one-wavefront gate for the step's first kernel on that stream")
     # SURVEY 8(d) wants the auto-reset inside the timed region; a run shorter than an episode (the driver's 20 steps) never meets
     # one, so it is timed separately: the same N steps + ONE full imgenv_reset of the world
     with_reset = None
@@ -492,7 +528,7 @@ def main():
             t = torch.tensor([dtr], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtr = float(t.item())
-        with_reset = dict(value=R * args.steps / dtr, ms_per_step=1e3 * dtr / args.steps,
+        with_reset = dict(value=R_job * args.steps / dtr, ms_per_step=1e3 * dtr / args.steps,
                           what="%d steps + one full imgenv_reset of the world inside the timed region" % args.steps)
     for q in range(args.repeat):
         for mode in (0, 2):
@@ -504,9 +540,65 @@ def main():
     episode = None
     if not args.no_episode:
         dte, _, frozen_ep = run("episode", args.steps, args.warmup)
-        episode = dict(value=R * args.steps / dte, frozen_fraction=frozen_ep)
+        episode = dict(value=R_job * args.steps / dte, frozen_fraction=frozen_ep,
+                       what="v~U(0,0.6), w~U(-0.9,0.9) at the configuration's time_max %d: a shared world freezes most robots within a few steps" % TIME_MAX)
 
     launches_per_step = world.launches()
+    layer_mode = world.layer_mode()
+
+    # SURVEY 8(d)'s own action distribution (env_test.py:8-19: v~U(0,0.6), w~U(-0.9,0.9)) with the frozen fraction held under
+    # 10 % the way the spec says -- by the auto-reset: robots of one shared world run into each other within a few steps and
+    # freeze (agent.cpp:358-360), so the episode's time limit is set to the longest T whose frozen robot-steps stay below 9 %
+    # (measured on an untimed episode), and every episode ends in a full reset INSIDE the timed region.
+    spec_policy = None
+    if not args.no_episode and world_size == 1 and not args.force_dist:
+        try:
+            acts_s = make_actions("spec")
+            ctx["time_max"] = 10 ** 9
+            state["episode"] = 0
+            do_reset()
+            f0, cum = int(world.out["counters"][3].item()), []
+            for t in range(40):
+                do_step(acts_s[t % n_act])
+                cum.append(int(world.out["counters"][3].item()) - f0)
+            T = 1
+            for t in range(1, 41):
+                if cum[t - 1] / float(t * RL) < 0.09:
+                    T = t
+            ctx["time_max"] = TIME_MAX
+            sp = dict(params)
+            sp["time_max"] = T
+            w_spec = World(sp, grid, device=local_rank)
+            ctx["world"], ctx["time_max"] = w_spec, T
+            n_spec = max(args.steps, 3 * (T + 1))
+            res_s = sorted((run("spec", n_spec, T + 1) + (state["resets_timed"],) for _ in range(3)), key=lambda r: r[0])[1]
+            spec_policy = dict(value=R_job * n_spec / res_s[0], ms_per_step=1e3 * res_s[0] / n_spec, frozen_fraction=res_s[2], time_max=T,
+                               steps=n_spec, resets_in_timed_region=res_s[3],
+                               what="SURVEY 8(d) actions v~U(0,0.6), w~U(-0.9,0.9); time_max = the longest episode whose frozen robot-steps stay "
+                                    "below 9 %% (%d steps on this layout); a full imgenv_reset whenever the time limit runs out, inside the timed "
+                                    "region; median of 3 passes" % T)
+            w_spec.close()
+        except Exception as e:  # a secondary number must never cost the headline line
+            spec_policy = {"error": repr(e)}
+        ctx["world"], ctx["time_max"] = world, TIME_MAX
+
+    # The safe boundary: IMGENV_FLAG_FULL_REWRITE hands out copies rewritten in full by every call (the reference's ownership,
+    # img_env.cpp:745-749) -- the same passes under it
+    full_rewrite = None
+    if not args.no_episode and world_size == 1 and not args.force_dist:
+        try:
+            w_fr = World(dict(params, output_guard="copy"), grid, device=local_rank)
+            ctx["world"] = w_fr
+            run("active", 300, 0)
+            d_fr = sorted(run("active", args.steps, min(args.warmup, 5))[0] for _ in range(3))[1]
+            full_rewrite = dict(value=R_job * args.steps / d_fr, ms_per_step=1e3 * d_fr / args.steps, copy_bytes_per_step=int(w_fr.arena.numel()),
+                                what="the same passes on a handle created with IMGENV_FLAG_FULL_REWRITE: imgenv_outputs() hands out a second "
+                                     "arena that receives a complete device-to-device copy at the end of every call; median of 3 passes")
+            w_fr.close()
+        except Exception as e:
+            full_rewrite = {"error": repr(e)}
+        ctx["world"] = world
+
     multi_world = None
     if world_size == 1 and args.config == "cfg3" and not args.no_multi_world and not args.force_dist:
         # secondary: the reference's own env_num idiom -- E independent worlds of R/E robots at
@@ -549,15 +641,19 @@ def main():
             shipped = {"error": repr(e)}
 
     if rank == 0:
-        ab = algorithmic_bytes(P)
+        ab = algorithmic_bytes(P, hv=wl["view"], wv=wl["view"], beams=wl["beams"])
         kernel_bytes = ab.get(dominant, ab["total"]) * RL
         dur_s = (dom_ms / dom_n) * 1e-3 if dom_n else float("nan")
         achieved = kernel_bytes / dur_s / 1e9
         traffic, path_traffic, traffic_source = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        # counters: profiles/pmc_<config>.json (pmc_latest.json = the headline's, its name since round 1), collected by
+        # tools/profile_cfg.sh on a named build
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json" if args.config == "cfg3" else "pmc_%s.json" % args.config)
         build_id = world.lib.imgenv_build_id().decode()
         counters_ok = False  # the committed counters describe THIS library (same sources + flags), or they are not quoted
-        if os.path.exists(pmc) and args.config == "cfg3" and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
+        default_shape = world_size == 1 and RL == wl["robots"] and P == wl["peds"] and not args.force_dist
+        counters = {}
+        if os.path.exists(pmc) and default_shape:
             try:
                 counters = json.load(open(pmc))
                 pmc_id = counters.get("build_id")
@@ -567,12 +663,12 @@ def main():
                     # every kernel of a step once (k_reset_apply is not part of a step)
                     path_traffic = sum(v["hbm_bytes_per_launch"] for k, v in counters.items()
                                        if k.startswith("k_") and not k.startswith("k_reset") and k != "k_cell_base" and isinstance(v, dict))
-                    traffic_source = ("profiles/pmc_latest.json, collected on build %s = the library of this run: rocprofv3 --pmc FETCH_SIZE and "
+                    traffic_source = ("profiles/%s, collected on build %s = the library of this run: rocprofv3 --pmc FETCH_SIZE and "
                                       "--pmc WRITE_SIZE passes (separate runs, gfx950 corrections) over this same bench command -- committed "
-                                      "with the build, NOT collected during this run" % pmc_id)
+                                      "with the build, NOT collected during this run" % (os.path.basename(pmc), pmc_id))
                 else:
-                    traffic_source = ("none: profiles/pmc_latest.json was collected on build %s, this run's library is %s (imgenv_build_id) -- "
-                                      "counters of another build are not quoted" % (pmc_id, build_id))
+                    traffic_source = ("none: profiles/%s was collected on build %s, this run's library is %s (imgenv_build_id) -- "
+                                      "counters of another build are not quoted" % (os.path.basename(pmc), pmc_id, build_id))
             except Exception:
                 traffic = None
         # instruction-issue ceiling of the dominant kernel: wavefronts x vector instructions per wavefront (SQ_INSTS_VALU of the
@@ -580,37 +676,40 @@ def main():
         # but plain add / and, which take 2.4) over 1024 SIMDs
         issue = None
         try:
-            cnt = json.load(open(pmc)).get(dominant, {}) if (os.path.exists(pmc) and counters_ok) else {}
-            if cnt.get("valu_per_wave") and args.config == "cfg3" and world_size == 1 and RL == ROBOTS_PER_GPU and P == N_PEDS:
+            cnt = counters.get(dominant, {}) if counters_ok else {}
+            if cnt.get("valu_per_wave"):
                 waves, vpw = cnt["waves_per_launch"], cnt["valu_per_wave"]
                 lo, hi = (waves * vpw * c / (1024 * 2.4e9) * 1e6 for c in (2.4, 4.2))
                 issue = {"valu_per_wave": vpw, "waves_per_launch": waves, "cycles_model": "4.2 cycles per wave64 VALU instruction per SIMD "
                          "(2.4 for v_add_u32 / v_and_b32), 1024 SIMDs at 2.4 GHz: profiles/r3_valu_issue.txt", "ceiling_us": hi,
-                         "ceiling_us_if_all_were_adds": lo, "frac": hi / (dur_s * 1e6), "source": "profiles/pmc_latest.json (SQ passes)"}
+                         "ceiling_us_if_all_were_adds": lo, "frac": hi / (dur_s * 1e6), "source": "profiles/%s (SQ passes)" % os.path.basename(pmc)}
         except Exception:
             issue = None
         out = {
             "metric": "robot-steps/sec (whole node) at 8192 robots, 48x48 maps, 360 lasers",
             "value": value, "unit": "robot-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": wl["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak" if replicas else wl["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (wl["name"] % dict(R=R, RL=RL, N=world_size, P=P, strong="" if world_size == 1 else
                                                       ": strong scaling, the same world at every GPU count")) +
-                                   ", %dx%d grid @%.3f m, 48x48 sensor_map + 3ch ped_map, 360-beam laser, time_max %d, full reset whenever the "
-                                   "time limit runs out (%d inside the %d timed steps)" % (side, side, res, TIME_MAX, resets_timed, args.steps),
+                                   ", %dx%d grid @%.3f m, %dx%d sensor_map + 3ch ped_map, %d-beam laser, time_max %d, full reset whenever the "
+                                   "time limit runs out (%d inside the %d timed steps)" % (side, side, res, wl["view"], wl["view"], wl["beams"],
+                                                                                           TIME_MAX, resets_timed, args.steps),
                        "baseline_config": args.config,
-                       "robots": R, "peds": P, "grid": side, "resolution": res, "view": 48, "beams": 360,
-                       "policy": "active: v=0, w~U(-0.9,0.9): every robot-step runs the full view path",
-                       "parallelism": ("robot-sharded x%d, RCCL all-gather of robot records (%s)" % (
-                           world_size, ("ncclAllGather inside imgenv_step, communicator of %d ranks as reported by RCCL" % comm_ranks)
-                           if native else "torch.distributed between step_begin/step_end"))
+                       "robots": R_job, "peds": P, "grid": side, "resolution": res, "view": wl["view"], "beams": wl["beams"],
+                       "policy": "active: v=0, w~U(-0.9,0.9): every robot-step runs the full view path (spec_policy: SURVEY 8(d)'s own actions)",
+                       "parallelism": (("%d independent replicas, no exchange" % world_size) if replicas else
+                                       "robot-sharded x%d, RCCL all-gather of robot records (%s)" % (
+                                           world_size, ("ncclAllGather inside imgenv_step, communicator of %d ranks as reported by RCCL" % comm_ranks)
+                                           if native else "torch.distributed between step_begin/step_end"))
                        if use_dist else "single GPU"},
             "resets_in_timed_region": resets_timed,
             "passes": {"n": len(passes), "value_is": "median", "values": pass_values, "min": min(pass_values), "max": max(pass_values)},
             "uninstrumented": uninstrumented,
-            "stream_ordered_actions": stream_ordered,
-            "actions": ("pre-generated in HBM; imgenv_step_flags(IMGENV_STEP_ACTIONS_READY)" if state["ready"] else "plain imgenv_step (stream-ordered)"),
+            "actions": "pre-generated in HBM; plain stream-ordered imgenv_step (IMGENV_STEP_ACTIONS_READY is without effect since round 6)",
             "with_reset": with_reset,
+            "spec_policy": spec_policy,
+            "full_rewrite": full_rewrite,
             "shipped": shipped,
             "frozen_fraction": frozen_active,
             "multi_world": multi_world,
@@ -620,8 +719,12 @@ def main():
             "per_rank_kernel_us": per_rank_kernel_us,  # N > 1: every rank's kernels and `rccl_all_gather`, the in-library exchange
             "build_id": build_id,
             "launches_per_step": launches_per_step,
+            "layer_mode": layer_mode,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                         # the same fraction from the COUNTERS' bytes of the dominant kernel: what it really moved (a kernel that
+                         # updates its output sparsely -- k_obs and the ped_map -- moves far less than the algorithmic figure)
+                         "frac_by_counters": (traffic / dur_s / 1e9 / 8000.0) if traffic else None,
                          # HBM bytes of ALL kernels of one step (same counters) and what that is per second at the measured rate
                          "path_traffic_bytes_per_step": path_traffic,
                          "path_traffic_frac": (path_traffic / (dt / args.steps) / 1e9 / 8000.0) if path_traffic else None,
@@ -633,6 +736,8 @@ def main():
                          "path_algorithmic_gbps": ab["total"] * value / world_size / 1e9,
                          "issue": issue},
         }
+        if sfm_flips is not None:
+            out["sfm_first_step_sign_flips"] = sfm_flips
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
     world.close()

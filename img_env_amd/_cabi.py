@@ -260,8 +260,8 @@ SYMBOLS = ("imgenv_backend", "imgenv_abi_version", "imgenv_last_error", "imgenv_
            "imgenv_records", "imgenv_outputs", "imgenv_step_launches", "imgenv_timing", "imgenv_timing_read",
            "imgenv_kernel_name", "imgenv_comm_unique_id", "imgenv_comm_init", "imgenv_comm_info", "imgenv_reset_world", "imgenv_reset_worlds", "imgenv_spawn",
            "imgenv_reset_worlds_spawn", "imgenv_step_autoreset", "imgenv_step_autoreset_device", "imgenv_autoreset_last",
-           "imgenv_world_placement", "imgenv_cv_resize_u8", "imgenv_build_id", "imgenv_step_flags")
-K_COUNT = 13
+           "imgenv_world_placement", "imgenv_cv_resize_u8", "imgenv_build_id", "imgenv_step_flags", "imgenv_layer_mode")
+K_COUNT = 14
 
 
 def library_path():
@@ -300,6 +300,7 @@ def bind(lib):
     lib.imgenv_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.imgenv_outputs.argtypes = [C.c_void_p, C.POINTER(Out)]
     lib.imgenv_step_launches.argtypes = [C.c_void_p]
+    lib.imgenv_layer_mode.argtypes = [C.c_void_p]
     lib.imgenv_timing.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.imgenv_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.imgenv_comm_unique_id.argtypes = [C.c_void_p]

@@ -91,31 +91,27 @@ struct imgenv {
     bool big_bits_in_lds = true;  // the crop bitmap of one robot fits the LDS next to the hit words
     int big_max_crop = 1, big_full_chunks = 1;
     // early-observation steps (world.h): k_obs is launched with the step, beside the move (k_move_raster), from snapshots
-    bool early = false;             // the handle can run them (imgenv_step only; IMGENV_EARLY_OBS=0 in the environment switches them off)
+    bool early = false;             // the handle can run them (IMGENV_EARLY_OBS=0 in the environment switches them off)
     float4* ped_snap[2] = {nullptr, nullptr};
     unsigned orca_seq = 0;          // k_orca launches so far: launch q writes ped_snap[q & 1]
-    hipEvent_t ev_done = nullptr;   // behind the views of the last chain, on the caller's stream: what an early k_obs waits for
+    double* rec_snap[2] = {nullptr, nullptr};
+    unsigned view_seq = 0;          // k_view launches over every world so far: launch q writes rec_snap[q & 1]
     bool early_step = false;
     // an event that only has to say "this kernel is done" rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL's stop
     // event): a hipEventRecord behind the kernel is a packet of its own, and the caller's stream pays ~6 us for each
-    uint32_t gate_seq = 0;       // early steps whose k_obs waits behind a gate (world.h: sync) so far
+    uint32_t gate_seq = 0;       // early steps so far: each one's k_obs waits behind a gate (world.h: sync) for its number
     // the social-force crowd a step AHEAD (sfm.h: SfmDev *_out): crowds that ignore the robots (relation_ped_robo = 0) depend on
     // nothing of a step, so k_sfm for step t + 1 runs on a stream of its own underneath step t's rasters and views, reads the
     // crowd as it is and leaves the next state in a second set of arrays; step t + 1 swaps the sets and only publishes
     // (k_sfm_publish).  A reset in between drops what was computed ahead.
     bool sfm_ahead = false;        // the handle can do that
     bool sfm_ahead_valid = false;  // the other set holds the state of the next step (computed or being computed on sfm_stream)
-    bool sfm_input_moved = false;  // the caller's stream has written the live set since sfm_stream last looked (a reset, an in-place step)
     int sfm_steps_since_reset = 0;
     SfmDev sfm_other;              // the other set of the arrays a step writes (its p / v / dq / dest / last / nodes / n_nodes / treehash)
     hipStream_t sfm_stream = nullptr;
     hipEvent_t ev_sfm = nullptr, ev_sfm_in = nullptr;
     bool gates_work = false;     // k_gate_probe's verdict: kernels of two streams run side by side in this process
-    bool no_done = false;        // this chain leaves no ev_done behind its views
-    bool done_valid = false;     // the last chain did
-    bool ready_mode = true;      // the last early step came with IMGENV_STEP_ACTIONS_READY
     bool fork_on_move = false;   // ev_fork went out with this step's k_integrate
-    bool done_on_view = false;   // ev_done with this chain's k_view
     bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
     bool stamp = false;      // STAMP mode of the class layer (world.h) instead of two owner layers + k_compose
     uint32_t stamp_seq = 0;  // steps so far: the stamps of a step carry tag stamp_seq % STAMP_TAGS + 1
@@ -148,7 +144,6 @@ struct imgenv {
     bool obs_forked = false;  // k_obs of the current step is already in flight (launched by step_begin)
     // imgenv_step on a handle of at most 4096 robots, all local: the move is left to the raster launch (k_move_raster)
     bool in_step = false, move_pending = false;
-    bool actions_ready = false;  // this imgenv_step_flags call carries IMGENV_STEP_ACTIONS_READY
     const float* move_actions = nullptr;
     double trace_acc[4] = {0, 0, 0, 0};  // IMGENV_TRACE_RESET: host time inside imgenv_step_autoreset
     long trace_calls = 0, trace_resets = 0;
@@ -157,16 +152,8 @@ struct imgenv {
     int fill_due = 0;  // calls until the placement pool is refilled again (SPAWN_FILL_PERIOD)
     bool fill_pending = false;  // ev_fill has been recorded behind a k_spawn_fill that nothing has waited for yet
     bool wobst_all = false;  // the per-world RVO table has to be uploaded as a whole (its slices moved)
-    // ... and, on request (IMGENV_GRAPH=1), the whole step + reset chain as one hipGraph: per-step values then live in device
-    // memory (DevWorld::step_vars), the actions are copied into a buffer of the handle, and a step costs the host one copy and
-    // one graph launch.  Off by default -- measured (1024 envs x 4 robots, tools/host_issue_probe.py): this runtime issues a
-    // replayed graph node by node, 222 us of host time per step against 195 us for the same ~25 plain launches
-    int* d_step_vars = nullptr;
-    float* act_buf = nullptr;
-    hipStream_t gstream = nullptr;  // capture stream
-    hipGraphExec_t gexec = nullptr;
-    int dev_calls = 0;              // un-graphed calls since the set-up (the first ones warm the path up)
-    bool no_graph = true;           // unless IMGENV_GRAPH=1
+    // (The chain as a replayed hipGraph was measured in round 4 and dropped in round 6: this runtime issues a replayed graph node
+    // by node, 222 us of host time per step against 195 us for the same ~25 plain launches -- docs/HISTORY.md.)
     int act_hint = 0;  // device-side auto-reset: robots the reset chain is expected to cover (picks the small-launch kernel variants)
     uint64_t sd_fp = 0;
     hipStream_t side3 = nullptr;
@@ -232,7 +219,8 @@ static RcclApi* rccl_api() {
 }
 
 static const char* const KERNEL_NAMES[IMGENV_K_COUNT] = {"k_orca", "k_ped_update", "k_integrate", "k_raster", "k_compose",
-                                                         "k_view", "k_obs", "k_tail", "k_crop_big", "k_fullview_big", "k_taps_big", "k_move_raster", "rccl_all_gather"};
+                                                         "k_view", "k_obs", "k_tail", "k_crop_big", "k_fullview_big", "k_taps_big", "k_move_raster", "rccl_all_gather",
+                                                         "k_remote"};
 extern "C" const char* imgenv_kernel_name(int id) { return (id >= 0 && id < IMGENV_K_COUNT) ? KERNEL_NAMES[id] : ""; }
 
 static int timing_flush(imgenv* h) {
@@ -328,7 +316,10 @@ extern "C" const char* imgenv_backend(void) { return "hip-gfx950"; }
 #ifndef IMGENV_BUILD_ID
 #define IMGENV_BUILD_ID "unstamped"
 #endif
-extern "C" const char* imgenv_build_id(void) { return IMGENV_BUILD_ID; }
+// (the id sits behind a marker so that a build script can read it out of the file's bytes without loading the library into its
+// own process: a dlopen'ed image is never replaced by a rebuild of the same path -- __graft_entry__._built_id)
+extern "C" const char imgenv_build_marker[] = "IMGENV_BUILD_ID=" IMGENV_BUILD_ID;
+extern "C" const char* imgenv_build_id(void) { return imgenv_build_marker + 16; }
 extern "C" int32_t imgenv_abi_version(void) { return IMGENV_ABI_VERSION; }
 extern "C" const char* imgenv_last_error(void) { return g_err; }
 
@@ -478,13 +469,10 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         for (auto& c : h->stage_gen[g]) (void)hipHostFree(c.p);
         if (h->ev_gen[g]) (void)hipEventDestroy(h->ev_gen[g]);
     }
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    if (h->gstream) (void)hipStreamDestroy(h->gstream);
     if (h->side3) {
         (void)hipStreamSynchronize(h->side3);
         (void)hipStreamDestroy(h->side3);
     }
-    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->sfm_stream) {
         (void)hipStreamSynchronize(h->sfm_stream);
         (void)hipStreamDestroy(h->sfm_stream);
@@ -566,6 +554,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
 
     imgenv* h = new imgenv();
     h->cfg = *cfg;
+    h->serial = getenv("IMGENV_SERIAL") && getenv("IMGENV_SERIAL")[0] == '1';  // (profiling aid: no side streams, clean per-kernel timings)
     h->geom = g;
     h->R = cfg->n_robots;
     h->P = cfg->n_peds;
@@ -718,19 +707,24 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         if (h->stamp && R >= STAMP_MAX_ROBOTS) h->stamp = false;
         // ... and where the owner layers + k_compose used to be the answer, the counting layer is (round 5: no pass over every cell
         // of every world per step, a robot that covers the same cells as a step ago issues no atomic at all) -- wherever it can
-        // run: the handle owns every robot (another rank's robots have no list to take themselves off again), every footprint
-        // fits the rasters' LDS box, views through k_view, and the word has room for the counts: 3 bits of base class, as many
-        // pedestrian bits as a world has pedestrians, the robot's index within its world, and at least 6 bits of robot count
+        // run: every footprint fits the rasters' LDS box, views through k_view, and the word has room for the counts: 3 bits of
+        // base class, as many pedestrian bits as a world has pedestrians, the robot's index within its world, and at least 6 bits
+        // of robot count.  A robot SHARD (round 6; world.h: sum_shard) numbers its own robots 1 .. RL in the index field and needs
+        // every footprint's box to fit a 64-bit bitmap, which is how the other ranks' robots arrive.
         auto bits = [](int v) { int b = 0; while ((1 << b) <= v) b++; return b; };  // bits to count up to v
-        const int id_bits = std::max(1, bits(h->Rw - 1)), pc_bits = bits(h->Pw);
+        const bool shard = RL != R;
+        const int id_bits = shard ? bits(RL) : std::max(1, bits(h->Rw - 1)), pc_bits = bits(h->Pw);
         bool fits = G < ((size_t)1 << 24) && 3 + pc_bits + 6 + id_bits <= 32;
-        for (const RobotClassHost& k : h->rcls) fits = fits && !k.big && (2 * k.box_rad + 1) * (2 * k.box_rad + 1) <= RASTER_BOX_CELLS;
+        for (const RobotClassHost& k : h->rcls)
+            fits = fits && !k.big && (2 * k.box_rad + 1) * (2 * k.box_rad + 1) <= RASTER_BOX_CELLS &&
+                   (!shard || (2 * k.box_rad - 3) * (2 * k.box_rad - 3) <= WAVE);  // (the bitmap: the box without its margin of two cells)
         for (const PedClassHost& k : h->pcls) fits = fits && (2 * k.box_rad + 1) * (2 * k.box_rad + 1) <= RASTER_BOX_CELLS;
         const bool want_sum = (cfg->flags & IMGENV_FLAG_LAYER_SUM) != 0 || (!h->stamp && !(cfg->flags & IMGENV_FLAG_COMPOSE_DENSE));
-        h->sum = want_sum && fits && RL == R;
+        h->sum = want_sum && fits;
         if (h->sum) {
             h->stamp = false;
             d.layer_sum = 1;
+            d.sum_shard = shard ? 1 : 0;
             d.sum_pc_mask = (1u << pc_bits) - 1u;
             d.sum_rc_shift = 3u + (uint32_t)pc_bits;
             d.sum_id_shift = 32u - (uint32_t)id_bits;
@@ -738,6 +732,13 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         }
     }
     d.stamp_tag = 1;
+    if (d.sum_shard) {
+        d.rm_rad = h->rcls[0].box_rad - 2;
+        for (const RobotClassHost& k : h->rcls)
+            if (k.box_rad - 2 != d.rm_rad) d.rm_rad = -1;
+        TRY(dev_alloc(h, &d.rm_bits, (size_t)R));
+        TRY(dev_alloc(h, &d.rm_center, (size_t)R));
+    }
     if (!h->stamp && !h->sum) {
         TRY(dev_alloc(h, &d.ped_layer, Gp));
         TRY(dev_alloc(h, &d.own_lo, Gp, 0xFF));
@@ -805,8 +806,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             o.big = k.big ? 1 : 0;
             h->big_view = h->big_view || k.big;
             o.box_rad = k.box_rad;
-            static const bool no_rows = getenv("IMGENV_FP_ROWS") && getenv("IMGENV_FP_ROWS")[0] == '0';  // (measurement switch: the literal sample walk)
-            o.n_rows = no_rows ? 0 : (int)k.fp_rows.size();
+            o.n_rows = (int)k.fp_rows.size();
             o.rows = nullptr;
             o.fp_cy = k.fp_cy;
             if (o.n_rows) TRY(dev_upload(h, &o.rows, k.fp_rows));
@@ -835,8 +835,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_upload(h, &o.ry, k.right.y));
             memcpy(o.sizes, k.sizes, sizeof(o.sizes));
             o.box_rad = k.box_rad;
-            static const bool no_rows = getenv("IMGENV_FP_ROWS") && getenv("IMGENV_FP_ROWS")[0] == '0';
-            o.n_brows = no_rows ? 0 : (int)k.bbox_rows.size(); o.n_lrows = no_rows ? 0 : (int)k.left_rows.size(); o.n_rrows = no_rows ? 0 : (int)k.right_rows.size();
+            o.n_brows = (int)k.bbox_rows.size(); o.n_lrows = (int)k.left_rows.size(); o.n_rrows = (int)k.right_rows.size();
             o.bbox_cy = k.bbox_cy;
             if (o.n_brows) TRY(dev_upload(h, &o.brows, k.bbox_rows));
             if (o.n_lrows) TRY(dev_upload(h, &o.lrows, k.left_rows));
@@ -1084,10 +1083,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         }
         f.p_out = f.p; f.v_out = f.v; f.dq_out = f.dq; f.dest_out = f.dest; f.last_out = f.last;  // (a step in place)
         f.nodes_out = f.nodes; f.n_nodes_out = f.n_nodes; f.treehash_out = f.treehash;
-        {
-            static const int ahead_sw = getenv("IMGENV_SFM_AHEAD") ? atoi(getenv("IMGENV_SFM_AHEAD")) : 1;  // (measurement switch)
-            h->sfm_ahead = ahead_sw != 0 && cfg->relation_ped_robo != 1 && n > 0 && !h->serial;
-        }
+        h->sfm_ahead = cfg->relation_ped_robo != 1 && n > 0 && !h->serial;
         if (h->sfm_ahead) {
             SfmDev& o = h->sfm_other;
             o = f;
@@ -1097,7 +1093,6 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             HIPCHK_H(hipStreamCreateWithFlags(&h->sfm_stream, hipStreamNonBlocking));
             HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm, hipEventDisableTiming | hipEventDisableSystemFence));
             HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm_in, hipEventDisableTiming | hipEventDisableSystemFence));
-            h->sfm_input_moved = true;
         }
         for (int k = 0; k < W; k++) {
             HIPCHK_H(hipMemcpy(f.p + (size_t)k * n1 * 3, p0.data(), sizeof(double) * 3 * n1, hipMemcpyHostToDevice));
@@ -1254,7 +1249,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->PP = WAVE;  // sort slots of k_obs: a power of two, 64 * E of them in registers up to 1024 pedestrians
     while (h->PP < h->Pw) h->PP <<= 1;
     h->obs_E = h->PP <= 1024 ? h->PP / WAVE : 0;
-    if (h->obs_E >= 2 && !(getenv("IMGENV_OBS_PRESORT") && getenv("IMGENV_OBS_PRESORT")[0] == '0')) {  // (measurement switch: always the full sort)
+    if (h->obs_E >= 2) {
         // last step's pedestrian order per robot (k_obs): any permutation of the slots will do to start from
         std::vector<uint16_t> ident((size_t)h->PP);
         for (int q = 0; q < h->PP; q++) ident[q] = q < h->Pw ? (uint16_t)q : (uint16_t)0xFFFF;
@@ -1263,7 +1258,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         for (int r = 0; r < RL; r++) memcpy(&all[(size_t)r * h->PP], ident.data(), sizeof(uint16_t) * (size_t)h->PP);
         HIPCHK_H(hipMemcpy(d.obs_ord, all.data(), sizeof(uint16_t) * all.size(), hipMemcpyHostToDevice));
         // (measured: 200 pedestrians 1 pass 101.8, 2-5 passes 94-96 us per headline step; 1000 pedestrians 1 / 3 / 6 / 12 passes 316 / 303 / 282 / 282 us per cfg-5 step, 294 with the full sort every step)
-        d.obs_passes = getenv("IMGENV_OBS_PASSES") ? atoi(getenv("IMGENV_OBS_PASSES")) : (h->obs_E >= 8 ? 6 : 3);  // (measurement switch)
+        d.obs_passes = h->obs_E >= 8 ? 6 : 3;
     }
     const size_t NC = (size_t)g.Hv * g.Wv;
     max_stride += 4;  // + the dummy beam of view cells that no beam crosses (kept a multiple of 16 bytes)
@@ -1272,6 +1267,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16 + 4 * (2 * (max_stride / 8 + 1) + 4);
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
     h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
+    if (h->obs_E == 16) h->lds_obs += (size_t)h->PP * 8 + 4 * 4 * 8 + (size_t)(h->PP / WAVE) * 4;  // k_obs_wg<4, 4>: packed keys, edge words, per-chunk counts
     if (h->big_view) {  // k_beams_big: the occupied plane of the crop bitmap; k_taps_big: the hit words
         const size_t lds_bits = 4 * (size_t)d.big_words;
         h->big_bits_in_lds = lds_bits <= 150 * 1024;  // beyond that (views above ~1000 x 1000 cells) the beams read the bitmap from HBM
@@ -1309,30 +1305,41 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         HIPCHK_H(hipFuncSetAttribute((const void*)k_sfm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(SfmNode) * SFM_LDS_NODES)));
     if (h->lds_obs > 64 * 1024)
         HIPCHK_H(hipFuncSetAttribute((const void*)k_obs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
-    h->serial = getenv("IMGENV_SERIAL") && getenv("IMGENV_SERIAL")[0] == '1';
     {   // early-observation steps: worlds owned whole, an ORCA crowd that nothing but the solve moves (no beep lottery), no
         // limiter history to carry, views through k_view -- the headline shape and cfg-5; everything else keeps k_obs behind the move
         const bool limiters = cfg->limiter_v.has_velocity_limits || cfg->limiter_v.has_acceleration_limits || cfg->limiter_v.has_jerk_limits ||
                               cfg->limiter_w.has_velocity_limits || cfg->limiter_w.has_acceleration_limits || cfg->limiter_w.has_jerk_limits;
-        // ... and only in steps whose caller says that the actions are COMPLETE at the call (imgenv_step_flags, IMGENV_STEP_ACTIONS_READY).
-        // The early k_obs waits for the last chain's views, not for what the caller queued on its stream since -- a policy that
-        // writes the actions there; waiting for that (an event at the step's start) costs the whole gain: 106.5 us per step against
-        // 95.9 with the promise and 105.4 with k_obs behind the move, same box
+        // The early k_obs always waits behind the GATE (world.h: sync): it reads the step's actions and REWRITES output arrays, so it
+        // must run behind everything the caller queued on its stream in front of the step -- a policy that writes the actions, a
+        // copy of the last observation into a replay buffer, FULL_REWRITE's own copy.  (Rounds 4-5 also had an ungated variant for
+        // callers that promised complete actions, IMGENV_STEP_ACTIONS_READY; it only waited for the last chain's views, which does
+        // not cover readers of the outputs -- and measured the same as the gate, 92.0 against 92.3 us per step.  Dropped in round 6.)
         // ... or a social-force crowd that is stepped a step ahead (sfm_ahead): its arrays are published in front of the move and
-        // stand still during the step, so the early k_obs reads them as they are (obs_early = 2) -- always behind the gate, which
-        // also says that the publishing is done
-        h->early = !h->serial && RL == R && P > 0 && (h->NA > 0 || h->sfm_ahead) && !d.beep_on && !limiters && !h->big_view &&
+        // stand still during the step, so the early k_obs reads them as they are (obs_early = 2); the gate also says that the
+        // publishing is done
+        // (robot shards too, since round 6: k_obs reads the rank's own robots' snapshots and the replicated pedestrians')
+        h->early = !h->serial && P > 0 && (h->NA > 0 || h->sfm_ahead) && !d.beep_on && !limiters && !h->big_view &&
                    h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS;
         if (h->early) {
             TRY(dev_alloc(h, &d.sync, 8));
-            TRY(dev_alloc(h, &d.rec_snap, (size_t)RL * IMGENV_RECORD_DOUBLES));
+            TRY(dev_alloc(h, &h->rec_snap[0], (size_t)RL * IMGENV_RECORD_DOUBLES));
+            TRY(dev_alloc(h, &h->rec_snap[1], (size_t)RL * IMGENV_RECORD_DOUBLES));
             TRY(dev_alloc(h, &h->ped_snap[0], (size_t)(h->NA > 0 ? P : 1)));
             TRY(dev_alloc(h, &h->ped_snap[1], (size_t)(h->NA > 0 ? P : 1)));
-            HIPCHK_H(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming | hipEventDisableSystemFence));
         }
     }
     HIPCHK_H(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    HIPCHK_H(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    {   // (round-6 experiment, IMGENV_OBS_CUS=n: the observation's stream on n of the chip's compute units only -- mask bits are dealt
+        // round-robin over the XCDs -- so that the move's successors find free units at once; see docs/HISTORY.md for the verdict)
+        static const int obs_cus = getenv("IMGENV_OBS_CUS") ? atoi(getenv("IMGENV_OBS_CUS")) : 0;
+        if (obs_cus > 0 && obs_cus < 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int q = 0; q < obs_cus; q++) mask[q >> 5] |= 1u << (q & 31);
+            HIPCHK_H(hipExtStreamCreateWithCUMask(&h->side2, 8, mask));
+        } else {
+            HIPCHK_H(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+        }
+    }
     if (h->early) {  // gates (world.h: sync) only where kernels of two streams really run side by side: k_gate_probe
         static int gates_work = -1;  // (per process)
         if (gates_work < 0) {
@@ -1428,6 +1435,10 @@ static int check_device_flags(imgenv* h) {
                              "1 a fixed start with a random target; 2-4 no admissible placement within 200000 draws; 10-16 the RVO obstacle tree "
                              "outgrew its scratch)", e[2]);
     if (e[7]) FAIL(IMGENV_EDEVICE, "the observation's gate gave up after 60 s: the caller's stream never reached the step's move (the stream is stuck behind something)");
+    if (e[6] == 10) FAIL(IMGENV_EDEVICE, "class layer (counts) in a robot shard: a footprint cell fell outside the record's bitmap (internal)");
+    if (e[6] == 9)
+        FAIL(IMGENV_EDEVICE, "class layer (counts): more robot footprints on one cell than the layer's count field holds (at least 63; robots "
+                             "were placed on top of each other) -- create the handle with IMGENV_FLAG_COMPOSE_DENSE, whose owner layers have no such limit");
     if (e[6]) FAIL(IMGENV_EDEVICE, "class layer (counts): a pedestrian's footprint left its raster box or its cell list (code %d)", e[6]);
     if (e[4])
         FAIL(IMGENV_EDEVICE, "pedscene: the social-force quadtree overflowed (code %d: 1 leaf capacity, 2 node pool, 3 / 4 depth, 5 a leaf lock never came free, "
@@ -1501,7 +1512,8 @@ static int launch_obs_kernel(imgenv* h, hipStream_t s_obs) {
         case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
-        case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
+        // (513 .. 1024 pedestrians: four wavefronts share one robot's LDS -- k_obs_wg)
+        case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs_wg<4, 4><<<go, dim3(4 * WAVE), lds_obs, s_obs>>>(d, h->PP))); break;
         default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
     }
     h->launches += 1;
@@ -1523,6 +1535,59 @@ static int launch_obs(imgenv* h, hipStream_t st) {
     return 0;
 }
 
+// The rasters of a chain of launches (in front of them, in STAMP mode, every STAMP_TAGS steps the sweep): every robot of the launch
+// and every pedestrian -- or, local_only (a step of a robot shard in SUM mode, world.h: sum_shard), this rank's robots and the
+// pedestrians: the other ranks' robots follow behind the exchange (k_remote)
+static int launch_rasters(imgenv* h, hipStream_t st, int is_reset, bool moved, bool local_only) {
+    DevWorld& d = h->d;
+    const int keep_ng = d.act_ng;
+    if (local_only) {
+        d.act_ng = h->RL;
+        d.act_g0 = h->r0;
+    }
+    const int n_g = d.act_ng, n_p = d.act_np;
+    // k_compose / k_cell_base: 4 cells per thread over everything, or a fixed number of 256-thread blocks per listed world
+    const unsigned compose_blocks = d.act_list ? (unsigned)(((h->Gs / 4 + 255) / 256) * d.act_nw) : (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
+    // STAMP mode: no compose.  A reset has given the worlds it covers their base classes together with their obstacle maps
+    // (k_reset_apply, k_reset_obstacles); every STAMP_TAGS steps one sweep drops all stamps before their tags come round again.
+    if (h->stamp && !is_reset && h->stamp_seq % STAMP_TAGS == 0)
+        TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
+    const int n_blocks = n_p > n_g ? n_p : n_g;
+    // four wavefronts per robot / pedestrian when the launch cannot fill the machine (device-side auto-reset: by the expected
+    // number of robots, the grid itself is sized for every world)
+    const bool small = (d.act_n_dev ? std::min(n_blocks, h->act_hint) : n_blocks) <= 1024;
+    // robots and pedestrians in blocks of their own while all of them fit the chip at once (8192 wavefronts): a robot and a
+    // pedestrian one behind the other in one block is twice a block's chain of memory round trips
+    // (1024 envs x (4 + 3): k_raster 34 -> 22 us; the headline's 8192 + 200 stay as they are: a second, nearly empty round)
+    const bool roomy = !small && n_g + n_p <= 8192;
+    const int split = (small || roomy) && n_g > 0 && n_p > 0 ? n_g : 0;
+    const dim3 gr(split || moved ? n_g + n_p : n_blocks), br(small ? 4 * WAVE : WAVE);
+    const size_t lds = 4 * (size_t)d.box_cells + 16;
+    const int variant = (h->pow2 ? 3 : 0) + (h->stamp ? 1 : h->sum ? 2 : 0);
+    // (k_move_raster: the step's move in the same launch -- the RVO / recorded pedestrians' too; a social-force crowd has moved in k_sfm)
+    // (imgenv_step_end has counted the step when it launches this; a shard's imgenv_step_begin has not yet)
+    const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = local_only ? h->elapsed : h->elapsed - 1;
+#define RASTER_CASE(N, P2, LM)                                                                                        \
+    case N:                                                                                                           \
+        if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+        else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
+        else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, is_reset, split)));     \
+        else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, is_reset, split)));               \
+        break;
+    switch (variant) {
+        RASTER_CASE(5, true, 2)
+        RASTER_CASE(4, true, 1)
+        RASTER_CASE(3, true, 0)
+        RASTER_CASE(2, false, 2)
+        RASTER_CASE(1, false, 1)
+        RASTER_CASE(0, false, 0)
+    }
+#undef RASTER_CASE
+    d.act_ng = keep_ng;
+    d.act_g0 = 0;
+    return 0;
+}
+
 static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     DevWorld& d = h->d;
     const int n_g = d.act_ng, n_p = d.act_np, n_l = d.act_nl;
@@ -1531,48 +1596,17 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     if (h->P == 0)
         if (int rc = chain_begin(h, st)) return rc;
     const unsigned compose_blocks = d.act_list ? (unsigned)(((h->Gs / 4 + 255) / 256) * d.act_nw) : (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
-    // the rasters (in front of them, in STAMP mode, every STAMP_TAGS steps the sweep): in a step whose move was left to them
-    // (imgenv_step_begin: k_move_raster) they come first and the side stream forks behind them, otherwise behind the side launches
+    // the rasters: in a step whose move was left to them (imgenv_step_begin: k_move_raster) they come first and the side stream forks
+    // behind them, otherwise behind the side launches; a robot shard in SUM mode has drawn its own robots in imgenv_step_begin, in
+    // front of the exchange, and takes the other ranks' from their records now (k_remote)
     const bool moved = h->move_pending;
     h->move_pending = false;
+    const bool remote_only = h->d.sum_shard && !is_reset;
     auto rasters = [&]() -> int {
-        // STAMP mode: no compose.  A reset has given the worlds it covers their base classes together with their obstacle maps
-        // (k_reset_apply, k_reset_obstacles); every STAMP_TAGS steps one sweep drops all stamps before their tags come round again.
-        if (h->stamp && !is_reset && h->stamp_seq % STAMP_TAGS == 0)
-            TIMED(h, IMGENV_K_COMPOSE, st, (k_cell_base<<<dim3(compose_blocks), dim3(256), 0, st>>>(d)));
-        {
-            const int n_blocks = n_p > n_g ? n_p : n_g;
-            // four wavefronts per robot / pedestrian when the launch cannot fill the machine (device-side auto-reset: by the expected
-            // number of robots, the grid itself is sized for every world)
-            const bool small = (d.act_n_dev ? std::min(n_blocks, h->act_hint) : n_blocks) <= 1024;
-            static const int force_split = getenv("IMGENV_RASTER_SPLIT") ? atoi(getenv("IMGENV_RASTER_SPLIT")) : 0;  // (measurement switch)
-            // robots and pedestrians in blocks of their own while all of them fit the chip at once (8192 wavefronts): a robot and a
-            // pedestrian one behind the other in one block is twice a block's chain of memory round trips
-            // (1024 envs x (4 + 3): k_raster 34 -> 22 us; the headline's 8192 + 200 stay as they are: a second, nearly empty round)
-            const bool roomy = !small && n_g + n_p <= 8192 && force_split >= 0;
-            const int split = (small || roomy || force_split > 0) && n_g > 0 && n_p > 0 ? n_g : 0;
-            const dim3 gr(split || moved ? n_g + n_p : n_blocks), br(small ? 4 * WAVE : WAVE);
-            const size_t lds = 4 * (size_t)d.box_cells + 16;
-            const int variant = (h->pow2 ? 3 : 0) + (h->stamp ? 1 : h->sum ? 2 : 0);
-            // (k_move_raster: the step's move in the same launch -- the RVO / recorded pedestrians' too; a social-force crowd has moved in k_sfm)
-            const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = h->elapsed - 1;
-#define RASTER_CASE(N, P2, LM)                                                                                    \
-        case N:                                                                                                       \
-            if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
-            else if (moved) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
-            else if (small) TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, is_reset, split)));         \
-            else TIMED(h, IMGENV_K_RASTER, st, (k_raster<P2, LM, 1><<<gr, br, lds, st>>>(d, is_reset, split)));           \
-            break;
-            switch (variant) {
-                RASTER_CASE(5, true, 2)
-                RASTER_CASE(4, true, 1)
-                RASTER_CASE(3, true, 0)
-                RASTER_CASE(2, false, 2)
-                RASTER_CASE(1, false, 1)
-                RASTER_CASE(0, false, 0)
-            }
-#undef RASTER_CASE
-        }
+        if (!remote_only) return launch_rasters(h, st, is_reset, moved, false);
+        const unsigned nb = (unsigned)((h->R - h->RL + 255) / 256);
+        if (h->pow2) TIMED(h, IMGENV_K_REMOTE, st, (k_remote<true><<<dim3(nb), dim3(256), 0, st>>>(d)));
+        else TIMED(h, IMGENV_K_REMOTE, st, (k_remote<false><<<dim3(nb), dim3(256), 0, st>>>(d)));
         return 0;
     };
     if (moved)
@@ -1661,10 +1695,9 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // 155 us at 2048 robots, i.e. worse -- the prologue's cost is its loads, not its arithmetic.)
         const int n_eff = d.act_n_dev ? std::min(n_l, h->act_hint) : n_l;
         const int tpw = n_eff >= 1024 ? 64 : n_eff >= 48 ? 32 : 8, crop_chunks = (h->big_max_crop + (VBC_T / WAVE) * tpw - 1) / ((VBC_T / WAVE) * tpw);
-        static const int force_qpw = getenv("IMGENV_BEAMS_QPW") ? atoi(getenv("IMGENV_BEAMS_QPW")) : 0;  // (measurement switch)
         // (2048 robots x 1000 beams: one block of 256 beams per workgroup 98 us, two 87, four 87 -- but end to end two win: 3.85 M robot-steps/s
         // against 3.79 / 3.78: the first workgroup of a robot also hands the collision code to the step's tail)
-        const int qpw = force_qpw ? std::min(force_qpw, quarters) : (n_eff >= 1024 ? std::min(2, quarters) : 1);
+        const int qpw = n_eff >= 1024 ? std::min(2, quarters) : 1;
         const dim3 gc((unsigned)((n_l + 7) / 8 * 8) * (unsigned)crop_chunks), gb((unsigned)n_l * (unsigned)((quarters + qpw - 1) / qpw));
         const dim3 gf((unsigned)n_l * (unsigned)h->big_full_chunks);
         static_assert(VBT_T == TAP_CHUNK_PIXELS, "host_tables.h lists k_taps_big's chunks");
@@ -1700,30 +1733,28 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         // compute unit with 16 or fewer one-wavefront workgroups -- four or fewer wavefronts per SIMD where the registers allow
         // eight: four wavefronts then share one view's LDS (cfg-5, 8192 robots: k_view 252 -> 179 us alone, the step 472 -> 377 us;
         // at 48 x 48 cells, 5 KB and 32 workgroups per unit, it loses: 63 -> 87 us)
-        static const int force_nw = getenv("IMGENV_VIEW_NW") ? atoi(getenv("IMGENV_VIEW_NW")) : 0;  // (measurement switch)
         const bool lds_bound = (160 * 1024) / ((h->lds_view + 1279) / 1280 * 1280) <= 16;
-        const bool small = force_nw ? force_nw == 4 : (lds_bound || (d.act_n_dev ? std::min(n_l, h->act_hint) : n_l) <= 1024);
+        const bool small = lds_bound || (d.act_n_dev ? std::min(n_l, h->act_hint) : n_l) <= 1024;
         // two wavefronts per robot in between (1025-4096 robots: every wavefront still resident at once; 1024 envs x 4: 39 -> 28 us)
         const int n_view = d.act_n_dev ? std::min(n_l, h->act_hint) : n_l;
-        const bool two = force_nw ? force_nw == 2 : (!small && n_view <= 4096);
+        const bool two = !small && n_view <= 4096;
         // ... and eight where a launch is at most 1024 robots and the view small (48 x 48 cells and 360 beams are then ONE round of groups
         // and ONE round of beams per wavefront: cfg-2 k_view 21.6 -> 20.4 us)
-        const bool eight = force_nw ? force_nw == 8 : (small && !lds_bound);
+        const bool eight = small && !lds_bound;
         const dim3 gv(n_l), bv(eight ? 8 * WAVE : small ? 4 * WAVE : two ? 2 * WAVE : WAVE);
+        {   // (world.h: what the next step's early k_obs reads; turns as for ped_snap)
+            const bool partial = d.act_list != nullptr;
+            d.rec_snap_out = h->early ? h->rec_snap[h->view_seq & 1] : nullptr;
+            d.rec_snap_out2 = h->early && partial ? h->rec_snap[(h->view_seq + 1) & 1] : nullptr;
+            if (!partial) h->view_seq += 1;
+        }
         const int variant = (h->pow2 ? 4 : 0) | (h->geom.Wv % 4 == 0 ? 2 : 0) | (h->stamp ? 1 : 0);
-        static const int ext_ev = getenv("IMGENV_EXT_EVENTS") ? atoi(getenv("IMGENV_EXT_EVENTS")) : 1;  // (measurement switch)
-        // (ev_done: "these views are complete", what a promised step's k_obs waits for -- a marker behind k_view costs the caller's
-        // stream a few us, so it is only recorded while the caller makes promises: a gated step needs no event at all)
-        static const int gate_on = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;
-        h->no_done = gate_on != 0 && h->gates_work && !h->ready_mode;
-        h->done_on_view = ext_ev != 0 && h->early && !h->no_done;
-        const hipEvent_t ev_v = h->done_on_view ? h->ev_done : nullptr;
 #define VIEW_CASE(N, P2, A4_, ST)                                                                                               \
     case N:                                                                                                                     \
-        if (eight) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 8>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d)));      \
-        else if (small) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 4>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d))); \
-        else if (two) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 2>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d)));   \
-        else TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 1>), gv, bv, (uint32_t)h->lds_view, st, nullptr, ev_v, 0, d)));            \
+        if (eight) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 8>), gv, bv, (uint32_t)h->lds_view, st, nullptr, nullptr, 0, d)));      \
+        else if (small) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 4>), gv, bv, (uint32_t)h->lds_view, st, nullptr, nullptr, 0, d))); \
+        else if (two) TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 2>), gv, bv, (uint32_t)h->lds_view, st, nullptr, nullptr, 0, d)));   \
+        else TIMED(h, IMGENV_K_VIEW, st, (hipExtLaunchKernelGGL((k_view<P2, A4_, ST, 1>), gv, bv, (uint32_t)h->lds_view, st, nullptr, nullptr, 0, d)));            \
         break;
         switch (variant) {
             VIEW_CASE(7, true, true, true)
@@ -1740,10 +1771,6 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     // no launch for the per-robot scalars: the k_view / k_obs wavefront that completes a group of 64 robots runs them
     // (tail_group).  The caller's stream ends the step behind both side streams
     h->early_step = false;
-    // the next early k_obs starts behind these views (and, on its own stream, behind this chain's k_obs and solve)
-    if (h->early && !h->done_on_view && !h->no_done) HIPCHK(hipEventRecord(h->ev_done, st));
-    h->done_valid = h->early && !h->no_done;
-    h->done_on_view = false;
     if (h->P > 0 && !h->serial) HIPCHK(hipStreamWaitEvent(st, h->ev_join2, 0));
     h->launches += 3;
     HIPCHK(hipGetLastError());
@@ -2351,10 +2378,6 @@ extern "C" int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* b, void* stre
         RTRY(stage_put(h, h->d.bbox, init, sizeof(init)));
     }
     h->elapsed = 0;  // TimeLimitWrapper.reset (base.py:229-231)
-    if (h->d_step_vars) {
-        static const int zero = 0;
-        RTRY(stage_put(h, h->d_step_vars, &zero, sizeof(int)));
-    }
     h->dev_reset_used = false;  // every world's host copy is current again
     RTRY(reset_launch(h, nullptr, 0, st, 1));  // no host wait: the copies read the handle's pinned chunks
     h->has_reset = true;
@@ -2496,7 +2519,6 @@ static int launch_sfm(imgenv* h, hipStream_t s, const SfmDev* out, int publish) 
 static int sfm_ahead_drop(imgenv* h, hipStream_t st) {
     if (h->sfm_ahead_valid) HIPCHK(hipStreamWaitEvent(st, h->ev_sfm, 0));
     h->sfm_ahead_valid = false;
-    if (h->sfm_ahead) h->sfm_input_moved = true;
     h->sfm_steps_since_reset = 0;
     return 0;
 }
@@ -2510,16 +2532,13 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     if (int rc = outputs_verify(h, st)) return rc;
     DevWorld& d = h->d;
     h->launches = 0;
-    if (d.step_vars) {  // the device-side twins of h->elapsed / h->stamp_seq (advanced here; the host's in imgenv_step_end)
-        k_tick<<<dim3(1), dim3(1), 0, st>>>(h->d_step_vars, h->stamp ? 1 : 0);
-        h->launches += 1;
-    }
     // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
     // step's views and was joined at the end of that step; its velocities are applied by k_integrate's pedestrian blocks
     if (h->cfg.ped_scene_type == IMGENV_SCENE_PEDSIM && h->d.sfm.n > 0) {  // PedScene::step + write-back (img_env.cpp:343-358)
-        if (h->sfm_ahead && h->in_step && !d.step_vars) {
+        if (h->sfm_ahead) {
             // a crowd that ignores the robots: this step's state was computed during the last step (launch_sfm below) -- swap the
             // two sets and publish -- or, right behind a reset, is computed now, in place; then the NEXT step's goes out on its stream
+            bool in_recorded = false;  // ev_sfm_in has been recorded behind this step's last access to the crowd's sets on the caller's stream
             if (h->sfm_ahead_valid) {
                 SfmDev& a = h->d.sfm;
                 SfmDev& b = h->sfm_other;
@@ -2528,20 +2547,23 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
                 a.p_out = a.p; a.v_out = a.v; a.dq_out = a.dq; a.dest_out = a.dest; a.last_out = a.last;
                 a.nodes_out = a.nodes; a.n_nodes_out = a.n_nodes; a.treehash_out = a.treehash;
                 HIPCHK(hipStreamWaitEvent(st, h->ev_sfm, 0));
-                k_sfm_publish<<<dim3((unsigned)h->W), dim3(SFM_MAX_AGENTS), 0, st>>>(d);
+                // (the "published" event rides on the kernel's dispatch packet: see launch_sfm's caller below)
+                hipExtLaunchKernelGGL(k_sfm_publish, dim3((unsigned)h->W), dim3(SFM_MAX_AGENTS), 0, st, nullptr, h->sfm_steps_since_reset >= 1 ? h->ev_sfm_in : nullptr, 0, d);
+                in_recorded = h->sfm_steps_since_reset >= 1;
                 h->launches += 1;
             } else {
                 if (int rc = launch_sfm(h, st, nullptr, 1)) return rc;
-                h->sfm_input_moved = true;
             }
             // (not in the first step behind a reset: a handle whose worlds are reset every other step -- many small worlds with
             // their own time limits -- would compute ahead what the next reset drops, and make that reset wait for it)
             if (h->sfm_steps_since_reset >= 1) {
-                if (h->sfm_input_moved) {  // (the live set was written on the caller's stream: a reset, the step in place)
-                    HIPCHK(hipEventRecord(h->ev_sfm_in, st));
-                    HIPCHK(hipStreamWaitEvent(h->sfm_stream, h->ev_sfm_in, 0));
-                    h->sfm_input_moved = false;
-                }
+                // The launch below reads the live set and WRITES the other one -- the set that was live a step ago, which that step's
+                // k_sfm_publish read on the caller's stream.  Nothing else orders the crowd's stream behind the caller's: a host that
+                // queues steps faster than the device drains them (an asynchronous trainer, bench.py's timed loop) would let the crowd
+                // run several steps ahead and overwrite a set before it has been published.  So EVERY launch ahead waits for this step's
+                // last access to the sets on the caller's stream: the publish (which sits behind last step's), a reset, a step in place.
+                if (!in_recorded) HIPCHK(hipEventRecord(h->ev_sfm_in, st));
+                HIPCHK(hipStreamWaitEvent(h->sfm_stream, h->ev_sfm_in, 0));
                 if (int rc = launch_sfm(h, h->sfm_stream, &h->sfm_other, 0)) return rc;
                 HIPCHK(hipEventRecord(h->ev_sfm, h->sfm_stream));
                 h->sfm_ahead_valid = true;
@@ -2558,23 +2580,26 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         h->launches += 2;
     }
     // _step_robot (img_env.cpp:388-410)
-    static const int force_fuse = getenv("IMGENV_FUSE_MOVE") ? atoi(getenv("IMGENV_FUSE_MOVE")) : -1;  // (measurement switch)
-    const bool fuse_move = h->in_step && !d.sharded && !h->comm && h->RL == h->R && h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS &&
-                           (force_fuse >= 0 ? force_fuse != 0 : (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024));
-    // early-observation step (world.h): k_obs goes out with the move, on its side stream, instead of behind it
+    // (a robot shard in SUM mode draws its own robots in this call anyway: the move goes into that launch, whoever runs the exchange)
+    const bool fuse_move = ((h->in_step && !d.sharded && !h->comm && h->RL == h->R) || d.sum_shard) && h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS &&
+                           (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024);
+    // early-observation step (world.h): k_obs goes out with the move, on its side stream, instead of behind it -- behind a gate that
+    // opens when the caller's stream reaches this step's move (world.h: sync; only where gates work: k_gate_probe)
     static const int force_early = getenv("IMGENV_EARLY_OBS") ? atoi(getenv("IMGENV_EARLY_OBS")) : -1;  // (measurement switch)
-    // ... with the caller's promise that the actions are complete (IMGENV_STEP_ACTIONS_READY), or behind a gate that opens when the
-    // caller's stream reaches this step's move (world.h: sync)
-    static const int gate_env = getenv("IMGENV_EARLY_GATE") ? atoi(getenv("IMGENV_EARLY_GATE")) : 1;  // (measurement switch)
-    const int gate_sw = gate_env != 0 && h->gates_work ? 1 : 0;
     const bool live_peds = h->NA == 0;  // (a social-force crowd a step ahead: see imgenv_create)
-    const bool early_step = h->early && h->in_step && (gate_sw != 0 || (h->actions_ready && h->done_valid && !live_peds)) && !fuse_move &&
-                            !h->chain_open && (live_peds ? h->sfm_ahead : h->orca_seq > 0) && force_early != 0;
-    // (a promised step waits for the event behind the last chain's views -- if that chain recorded one: it does when the step before
-    // it was a promised one, see launch_views -- and starts k_obs at once; every other early step takes the gate, which says the same)
-    const bool early_gated = early_step && gate_sw != 0 && (!h->actions_ready || !h->done_valid || live_peds);
-    if (early_step) h->ready_mode = h->actions_ready && !live_peds;
-    if (early_gated) h->gate_seq += 1;
+    const bool early_step = h->early && h->gates_work && !fuse_move && !h->chain_open && (live_peds ? h->sfm_ahead : h->orca_seq > 0) && h->view_seq > 0 &&
+                            force_early != 0;
+    if (early_step) h->gate_seq += 1;
+    if (fuse_move && d.sum_shard) {  // k_move_raster over the shard's own robots and the pedestrians, now; the observation behind it
+        h->move_actions = actions;
+        if (int rc = launch_rasters(h, st, 0, true, true)) return rc;
+        h->launches += 1;
+        set_tail_fields(h, 0, h->elapsed + 1);
+        if (h->P > 0)
+            if (int rc = launch_obs(h, st)) return rc;
+        HIPCHK(hipGetLastError());
+        return IMGENV_OK;
+    }
     if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
         h->move_pending = true;
         h->move_actions = actions;
@@ -2584,12 +2609,11 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         const bool peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET);
         if (h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS) {
             const int nb_robot = (h->RL + INT_ROBOTS - 1) / INT_ROBOTS, nb_ped = peds ? (h->P + INT_G * INT_ROBOTS - 1) / (INT_G * INT_ROBOTS) : 0;
-            static const int ext_ev = getenv("IMGENV_EXT_EVENTS") ? atoi(getenv("IMGENV_EXT_EVENTS")) : 1;  // (measurement switch)
-            // (the fork of the side streams follows right behind the move: early steps record it below, the others in launch_obs)
-            h->fork_on_move = ext_ev != 0 && h->P > 0 && !h->serial && !h->chain_open;
+            // (the fork of the side streams follows right behind the move, on its dispatch packet)
+            h->fork_on_move = h->P > 0 && !h->serial && !h->chain_open;
             TIMED(h, IMGENV_K_INTEGRATE, st, (hipExtLaunchKernelGGL(k_integrate, dim3(nb_robot + nb_ped), dim3(INT_G * INT_ROBOTS), 0, st, nullptr,
                                                                    h->fork_on_move ? h->ev_fork : nullptr, 0, d, actions, nb_robot, h->n_sub, h->elapsed,
-                                                                   early_gated ? h->gate_seq : 0u)));
+                                                                   early_step ? h->gate_seq : 0u)));
         } else {
             const int nb_robot = (h->RL + 127) / 128, nb_ped = peds ? (h->P + 127) / 128 : 0;
             TIMED(h, IMGENV_K_INTEGRATE, st, (k_integrate_serial<<<dim3(nb_robot + nb_ped), dim3(128), 0, st>>>(d, actions, nb_robot, h->elapsed)));
@@ -2598,26 +2622,21 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     h->launches += 1;
     set_tail_fields(h, 0, h->elapsed + 1);  // imgenv_step_end counts the step; k_obs goes out before that
     if (early_step) {
-        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions.  Promised complete
-        // (IMGENV_STEP_ACTIONS_READY), nothing has to make this launch wait for work queued on the caller's stream since the last
-        // step: its side stream only waits for the last chain's views (ev_done; on that stream itself it sits behind the last
-        // chain's k_obs and solve).  Otherwise it waits behind a gate that opens when the caller's stream reaches the move (k_gate):
-        // that also says that the last chain's views are complete.  Queued BEHIND k_integrate either way -- a gate must follow
-        // the kernel that opens it in queue order, and the move's few workgroups are dispatched first; what the caller's stream
-        // forks behind the move is the solve alone.
+        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions.  It waits behind a
+        // gate that opens when the caller's stream reaches the move (k_gate): everything queued there in front of the step is then
+        // complete -- whoever writes the actions, whoever still reads the last step's outputs, the last chain's views.  Queued BEHIND
+        // k_integrate -- a gate must follow the kernel that opens it in queue order, and the move's few workgroups are dispatched
+        // first; what the caller's stream forks behind the move is the solve alone.
         h->chain_open = true;
         if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
         h->fork_on_move = false;
-        if (early_gated) {  // (queued behind the move: see k_gate)
-            k_gate<<<dim3(1), dim3(WAVE), 0, h->side2>>>(d.sync, h->gate_seq, d.err);
-            h->launches += 1;
-        } else {
-            HIPCHK(hipStreamWaitEvent(h->side2, h->ev_done, 0));
-        }
+        k_gate<<<dim3(1), dim3(WAVE), 0, h->side2>>>(d.sync, h->gate_seq, d.err);
+        h->launches += 1;
         d.obs_early = live_peds ? 2 : 1;
         d.obs_actions = actions;
         d.obs_n_sub = h->n_sub;
         d.ped_snap_in = h->ped_snap[(h->orca_seq - 1) & 1];
+        d.rec_snap_in = h->rec_snap[(h->view_seq - 1) & 1];
         const int rc = launch_obs_kernel(h, h->side2);
         d.obs_early = 0;
         if (rc) return rc;
@@ -2626,6 +2645,10 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     } else if (h->P > 0) {
         if (int rc = launch_obs(h, st)) return rc;
     }
+    // a robot shard in SUM mode (world.h: sum_shard) draws its own robots -- and the pedestrians -- NOW, in front of the exchange:
+    // their records then carry the cells they cover to the other ranks
+    if (d.sum_shard)
+        if (int rc = launch_rasters(h, st, 0, false, true)) return rc;
     HIPCHK(hipGetLastError());
     return IMGENV_OK;
 }
@@ -2644,11 +2667,10 @@ extern "C" int imgenv_step_end(imgenv_t* h, void* stream) {
 extern "C" int imgenv_step(imgenv_t* h, const float* actions, void* stream) { return imgenv_step_flags(h, actions, 0u, stream); }
 
 extern "C" int imgenv_step_flags(imgenv_t* h, const float* actions, uint32_t flags, void* stream) {
+    (void)flags;  // (IMGENV_STEP_ACTIONS_READY: accepted, and since round 6 without effect -- include/imgenv.h)
     if (h) h->in_step = true;  // (begin and end in one call: the actions outlive the move whoever launches it)
-    if (h) h->actions_ready = (flags & IMGENV_STEP_ACTIONS_READY) != 0;
     const int rc_begin = imgenv_step_begin(h, actions, stream);
     if (h) h->in_step = false;
-    if (h) h->actions_ready = false;
     if (rc_begin) return rc_begin;
     if (h->comm) {  // the one exchange of a robot-sharded world: records of all robots, in place
         const size_t count = (size_t)h->RL * IMGENV_RECORD_DOUBLES;
@@ -2914,23 +2936,6 @@ static int spawn_device_setup(imgenv* h, const imgenv_spawn_cfg* cfg, uint64_t s
     c.traj = h->d_traj;
     c.traj_len = h->d_traj_len;
     c.traj_cap = h->traj_cap;
-    if (!h->d_step_vars && getenv("IMGENV_GRAPH") && getenv("IMGENV_GRAPH")[0] == '1') {
-        RTRY(dev_alloc(h, &h->d_step_vars, 2));
-        RTRY(dev_alloc(h, &h->act_buf, (size_t)h->RL * 3));
-        HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
-        h->no_graph = false;
-    }
-    if (h->d_step_vars) {
-        HIPCHK(hipStreamSynchronize(st));
-        const int vars[2] = {h->elapsed, (int)h->stamp_seq};
-        HIPCHK(hipMemcpy(h->d_step_vars, vars, sizeof(vars), hipMemcpyHostToDevice));
-        h->d.step_vars = h->d_step_vars;
-    }
-    if (h->gexec) {  // a chain captured for another spawn cfg
-        (void)hipGraphExecDestroy(h->gexec);
-        h->gexec = nullptr;
-    }
-    h->dev_calls = 0;
     if (!h->side3) {
         HIPCHK(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -2975,11 +2980,6 @@ static int spawn_dev_refresh(imgenv* h, hipStream_t st) {
     c.traj = h->d_traj;
     c.traj_len = h->d_traj_len;
     c.traj_cap = h->traj_cap;
-    if (h->gexec) {  // the captured chain carries the old copies
-        (void)hipGraphExecDestroy(h->gexec);
-        h->gexec = nullptr;
-        h->dev_calls = 0;
-    }
     return 0;
 }
 
@@ -2990,7 +2990,7 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
     const int W = h->W, nob = c.n_obstacles;
     // the pool, underneath the step: the slots whose placements earlier steps handed out -- on every SPAWN_FILL_PERIOD-th call
     // (two event operations and a launch less on the others: each costs the caller's stream a dependency bubble and the host a call)
-    const bool fill = h->fill_due <= 0 || !h->no_graph;  // (a captured chain is replayed as it was captured: with the refill)
+    const bool fill = h->fill_due <= 0;
     if (fill) {
         HIPCHK(hipEventRecord(h->ev_consumed, st));
         HIPCHK(hipStreamWaitEvent(h->side3, h->ev_consumed, 0));
@@ -3003,7 +3003,7 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
     if (int rc = imgenv_step(h, actions, st)) return rc;
     k_finished_dev<<<dim3(1), dim3(1024), 0, st>>>(d, c);
     // (also the set-up's fill, which runs on the side stream whatever this call's fill_due was: k_respawn must not meet half-drawn slots)
-    if (h->fill_pending || !h->no_graph) HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
+    if (h->fill_pending) HIPCHK(hipStreamWaitEvent(st, h->ev_fill, 0));
     h->fill_pending = false;
     k_respawn<<<dim3(W), dim3(WAVE), 0, st>>>(d, c, h->elapsed);
     // grids for a guess of the finished worlds (four times the last count; the kernels stride over the rest if there are more)
@@ -3024,7 +3024,6 @@ static int autoreset_device_chain(imgenv* h, const float* actions, hipStream_t s
         // own, under which those stamps have expired like any older ones (two tags per step; the sweep comes round accordingly)
         h->stamp_seq += 1;
         d.stamp_tag = h->stamp_seq % STAMP_TAGS + 1;
-        if (d.step_vars) k_tick_seq<<<dim3(1), dim3(1), 0, st>>>(h->d_step_vars);
         if (h->stamp_seq % STAMP_TAGS == 0) {
             const unsigned blocks = (unsigned)((d.act_cells / 4 + 255) / 256 + 1);
             k_cell_base<<<dim3(blocks), dim3(256), 0, st>>>(d);
@@ -3067,51 +3066,7 @@ extern "C" int imgenv_step_autoreset_device(imgenv_t* h, const float* actions, c
         const int last = h->finished_host[0];
         h->act_hint = std::max(8, 2 * std::max(last, 0)) * std::max(std::max(h->Rw, h->Pw), 1);  // (twice the last count: with four times, 64 worlds of 4 pedestrians sat ON the 1024 threshold and flipped between the kernel variants)
     }
-    // The chain as a graph: captured on the third call (the first ones have loaded every kernel), replayed from then on --
-    // except while per-kernel timing is on and on the steps that sweep the stamped class layer (every STAMP_TAGS-th)
-    const bool sweep = h->stamp && ((h->stamp_seq + 1) % STAMP_TAGS == 0 || (h->stamp_seq + 2) % STAMP_TAGS == 0);
-    const bool graphable = !h->no_graph && h->t_mode == 0 && !sweep && !h->comm && !h->serial && !h->guard_check;  // (the guard's verification synchronises)
-    if (graphable && !h->gexec && h->dev_calls >= 2) {
-        if (int rc = check_device_flags(h)) return rc;
-        // (the capture runs nothing: the host's counters, which the chain advances as it is issued, are put back)
-        const int elapsed0 = h->elapsed, launches0 = h->launches;
-        const uint32_t seq0 = h->stamp_seq, tag0 = h->d.stamp_tag;
-        hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed));
-        const int rc = autoreset_device_chain(h, h->act_buf, h->gstream);
-        const hipError_t e = hipStreamEndCapture(h->gstream, &graph);
-        h->elapsed = elapsed0;
-        h->launches = launches0;
-        h->stamp_seq = seq0;
-        h->d.stamp_tag = tag0;
-        if (rc || e != hipSuccess || !graph) {
-            if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            h->no_graph = true;  // this runtime cannot capture the chain: plain launches from now on
-        } else {
-            const hipError_t e2 = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e2 != hipSuccess) {
-                h->gexec = nullptr;
-                (void)hipGetLastError();
-                h->no_graph = true;
-            }
-        }
-    }
-    int rc = IMGENV_OK;
-    if (graphable && h->gexec) {
-        if (int rc2 = check_device_flags(h)) return rc2;
-        HIPCHK(hipMemcpyAsync(h->act_buf, actions, sizeof(float) * 3 * (size_t)h->RL, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipGraphLaunch(h->gexec, st));
-        h->elapsed += 1;  // the host's twins of the device-side counters (imgenv_step_end, and the reset chain's own tag)
-        if (h->stamp) {
-            h->stamp_seq += 2;
-            h->d.stamp_tag = h->stamp_seq % STAMP_TAGS + 1;
-        }
-    } else {
-        rc = autoreset_device_chain(h, actions, st);
-        h->dev_calls += 1;
-    }
+    const int rc = autoreset_device_chain(h, actions, st);
     if (rc == IMGENV_OK) h->dev_reset_used = true;
     return rc;
 }
@@ -3243,6 +3198,10 @@ extern "C" int imgenv_cv_resize_u8(int kind, const uint8_t* src, int32_t sh, int
 }
 
 extern "C" int imgenv_step_launches(imgenv_t* h) { return h ? h->launches : 0; }
+extern "C" int imgenv_layer_mode(imgenv_t* h) {
+    if (!h) return -1;
+    return (h->stamp ? 1 : h->sum ? 2 : 0) | (h->d.sum_shard ? 4 : 0) | (h->early && h->gates_work ? 8 : 0) | (h->sfm_ahead ? 16 : 0);
+}
 
 // debug: read (and clear) the per-phase cycle counters of IMGENV_PHASE_PROFILE builds
 extern "C" int imgenv_debug_phases(imgenv_t* h, unsigned long long* out16) {

@@ -211,9 +211,41 @@ __device__ __forceinline__ uint32_t cell_seen_class_sum(const DevWorld& w, uint3
     return base;
 }
 __device__ __forceinline__ uint32_t sum_robot_word(const DevWorld& w, uint32_t self_w) { return (1u << w.sum_rc_shift) + (self_w << w.sum_id_shift); }
-// per-step values: kernel arguments, or (replayed chains) the device-side counters k_tick advances
-__device__ __forceinline__ int tail_elapsed_of(const DevWorld& w) { return w.step_vars ? w.step_vars[0] : w.tail_elapsed; }
-__device__ __forceinline__ uint32_t stamp_tag_of(const DevWorld& w) { return w.step_vars ? (uint32_t)w.step_vars[1] % STAMP_TAGS + 1u : w.stamp_tag; }
+// what robot i (world-wide index) puts into the word's index field: its index within its world -- in a robot shard its local
+// index + 1, robots of other ranks count with 0 (world.h: sum_shard)
+__device__ __forceinline__ uint32_t sum_self_id(const DevWorld& w, int i) {
+    return w.sum_shard ? (uint32_t)(i - w.r0 + 1) : (uint32_t)(i - world_of_robot(w, i) * (w.W > 1 ? w.Rw : 0));
+}
+// SUM mode in a robot shard: robot i of ANOTHER rank now covers the cells `nb` (a bitmap over the box of side x side cells around
+// (cm, cn)); take it off the cells it has left since the bitmap this rank holds for it, add it to the ones it has entered.  One lane.
+__device__ __forceinline__ void sum_apply_bits(const DevWorld& w, int i, unsigned long long nb, int cm, int cn, int rad, int side, uint32_t cell0) {
+    const unsigned long long ob = w.rm_bits[i];
+    const int2 oc = w.rm_center[i];
+    if (ob == nb && oc.x == cm && oc.y == cn) return;  // (the common case: a robot moves a few centimetres per step, a cell is 25)
+    const uint32_t word = 1u << w.sum_rc_shift, rc_mask = (1u << (w.sum_id_shift - w.sum_rc_shift)) - 1u;
+    for (unsigned long long t = ob; t != 0ull; t &= t - 1ull) {
+        const int b = __ffsll((long long)t) - 1, bm = b / side;
+        const int m = oc.x - rad + bm, n = oc.y - rad + (b - bm * side);
+        const int dm = m - cm + rad, dn = n - cn + rad;
+        const bool still = dm >= 0 && dm < side && dn >= 0 && dn < side && ((nb >> (dm * side + dn)) & 1ull) != 0ull;
+        if (!still && m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) atomicAdd(&w.cell[cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n], 0u - word);
+    }
+    for (unsigned long long t = nb; t != 0ull; t &= t - 1ull) {
+        const int b = __ffsll((long long)t) - 1, bm = b / side;
+        const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
+        const int dm = m - oc.x + rad, dn = n - oc.y + rad;
+        const bool was = dm >= 0 && dm < side && dn >= 0 && dn < side && ((ob >> (dm * side + dn)) & 1ull) != 0ull;
+        if (!was && m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
+            const uint32_t before = atomicAdd(&w.cell[cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n], word);
+            if (((before >> w.sum_rc_shift) & rc_mask) == rc_mask) w.err[6] = 9;  // (as in raster_robot)
+        }
+    }
+    w.rm_bits[i] = nb;
+    w.rm_center[i] = make_int2(cm, cn);
+}
+// per-step values travel as kernel arguments
+__device__ __forceinline__ int tail_elapsed_of(const DevWorld& w) { return w.tail_elapsed; }
+__device__ __forceinline__ uint32_t stamp_tag_of(const DevWorld& w) { return w.stamp_tag; }
 // ---- output guard (IMGENV_FLAG_CHECK_OUTPUTS): a position-weighted 64-bit sum per output array
 #define OUT_SUM_CHUNK 65536  // bytes one workgroup sums
 struct OutSpan {
@@ -245,11 +277,6 @@ __global__ void k_out_verify(const unsigned long long* sealed, const unsigned lo
     if (f < n && sealed[f] != found[f]) err[5] = f + 1;  // (page-locked host memory: a plain store; any of the changed arrays names the problem)
 }
 
-__global__ void k_tick(int* vars, int stamp) {
-    vars[0] += 1;  // TimeLimitWrapper._elapsed_steps (base.py:224)
-    if (stamp) vars[1] += 1;  // this step's stamps get a new tag
-}
-__global__ void k_tick_seq(int* vars) { vars[1] += 1; }  // the reset chain of a device-side auto-reset stamps under its own tag
 // robots / pedestrians of a launch: the host's count, or (device-side auto-reset) what k_finished_dev counted
 __device__ __forceinline__ int act_count_l(const DevWorld& w) { return w.act_n_dev ? *w.act_n_dev * w.Rw : w.act_nl; }
 __device__ __forceinline__ int act_count_g(const DevWorld& w) { return w.act_n_dev ? *w.act_n_dev * w.Rw : w.act_ng; }
@@ -1592,8 +1619,10 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
     }
     // another rank's robot only matters where this rank's robots can see it (a local robot's footprint is inside the
     // region by construction, so the clip never changes its own cells)
-    const int lo_m = local ? 0 : g.m0, hi_m = local ? w.Hg : g.m1, lo_n = local ? 0 : g.n0, hi_n = local ? w.Wg : g.n1;
-    if (!local && (cm + rad < lo_m || cm - rad >= hi_m || cn + rad < lo_n || cn - rad >= hi_n)) return;
+    // (SUM mode in a shard keeps every robot's counts everywhere: they persist, and the shard's box moves)
+    const bool whole = local || (SUM && w.sum_shard != 0);
+    const int lo_m = whole ? 0 : g.m0, hi_m = whole ? w.Hg : g.m1, lo_n = whole ? 0 : g.n0, hi_n = whole ? w.Wg : g.n1;
+    if (!whole && (cm + rad < lo_m || cm - rad >= hi_m || cn + rad < lo_n || cn - rad >= hi_n)) return;
     // A robot that has not moved since its cell list was made (frozen after a collision or an arrival, dead, or simply
     // standing still) covers the same cells: re-stamp them from the list instead of walking the 901 samples again.
     if (local) {
@@ -1742,7 +1771,23 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         // of all four are read together and their compare-and-swaps go out together: stamp_robot_batch)
         uint2* list = w.fp_cells + (size_t)(local ? l : 0) * w.fp_cap;
         int n_out = 0;
-        const uint32_t sum_word = SUM ? sum_robot_word(w, (uint32_t)(i - world * w.Rw)) : 0u;
+        const uint32_t sum_word = SUM ? sum_robot_word(w, sum_self_id(w, i)) : 0u;
+        // The covered cells as a BITMAP: what a robot shard's other ranks need of this robot (world.h: sum_shard), carried by the
+        // record's eighth double -- written in every layer mode, so that any handle's records can feed a shard.  It spans the
+        // box without its margin of two cells: a sample lies within `ext` of the robot's origin and round(a + b) - round(a) is
+        // within +-ceil(|b|), so the covered cells are within box_rad - 2 = ceil(ext / res) of the centre cell (checked below).
+        const int brad = rad - 2, bside = 2 * brad + 1;
+        unsigned long long fp_bits = 0ull;
+        if (bside * bside <= WAVE && tid < WAVE) {
+            const int bm = tid / bside, bn = tid - bm * bside;
+            fp_bits = __ballot(tid < bside * bside && box[(bm + 2) * side + bn + 2] != 0u);
+            if (SUM && !local) {  // another rank's robot, rasterised here (a reset: every rank knows every pose from the batch)
+                if (lane == 0) sum_apply_bits(w, i, fp_bits, cm, cn, brad, bside, cell0);
+            } else if (local && lane == 0) {
+                ((unsigned long long*)w.rec)[(size_t)i * IMGENV_RECORD_DOUBLES + 7] = fp_bits;
+            }
+        }
+        if (SUM && !local) return;  // (uniform)
         if (SUM && !alone) {
             // the cells this robot counted itself on so far: still under its footprint -> marked in the box (top bit: nothing to add),
             // left behind -> its word comes off again.  (Handles in SUM mode own every robot: `local` always holds.)
@@ -1775,7 +1820,13 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
                 const int bm = b / side;
                 const int m = cm - rad + bm, n = cn - rad + (b - bm * side);
                 c[u] = go[u] ? cell0 + (uint32_t)m * (uint32_t)w.Wg + (uint32_t)n : 0u;
-                if (SUM && go[u] && !counted && !alone) atomicAdd(&w.cell[c[u]], sum_word);  // a cell the robot has just entered
+                if (SUM && go[u] && !counted && !alone) {  // a cell the robot has just entered
+                    // (the one returning atomic of the layer: the count field is at least 6 bits wide and reset poses are the caller's --
+                    // the robot that would carry it into the index sum says so instead of corrupting the word silently)
+                    const uint32_t before = atomicAdd(&w.cell[c[u]], sum_word);
+                    const uint32_t rc_mask = (1u << (w.sum_id_shift - w.sum_rc_shift)) - 1u;
+                    if (((before >> w.sum_rc_shift) & rc_mask) == rc_mask) w.err[6] = 9;
+                }
             }
             if (alone || SUM) {
             } else if (STAMP) {
@@ -1811,6 +1862,8 @@ __device__ __forceinline__ void raster_robot(const DevWorld& w, int i, const Rob
         RASTER_MARK(7);  // box -> stamps + cell list
         const bool any_stray = NW > 1 ? *stray_flag != 0 : __any(stray);
         if (local && tid == 0) w.fp_n[l] = (n_out <= w.fp_cap && !any_stray) ? n_out : -1;
+        // (a covered cell in the box's margin would be missing from the bitmap: never, by the bound above -- said aloud if it happens)
+        if (w.sum_shard && local && tid == 0 && __popcll(fp_bits) != n_out) w.err[6] = 10;
     } else if (local && tid == 0) {
         w.fp_n[l] = -1;
     }
@@ -1832,7 +1885,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu((LM =
     // split > 0 (small launches): the first `split` blocks draw robots, the ones behind them pedestrians -- a robot and a
     // pedestrian one after the other in the same block is twice one block's chain of memory round trips
     if (b < act_count_g(w) && (split == 0 || b < split)) {
-        const int i = act_member(w, w.Rw, b);
+        const int i = act_member(w, w.Rw, b) + w.act_g0;
         raster_robot<POW2, LM, NW>(w, i, robot_class(w, w.robot_cls[i]), (uint32_t*)smem, g);
     }
     const int bp = split > 0 ? b - split : b;
@@ -1866,12 +1919,13 @@ void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int
     const int b = blockIdx.x, tid = threadIdx.x;
     if (LM != 0 && b == 0 && tid == 0) w.counters[1] = 0;  // (as k_raster)
     const Region g = grid_region(w);
-    if (b < w.R) {
-        const int l = b;  // (every robot is local: r0 = 0)
+    const int n_rob = w.act_ng;  // the handle's robots: every robot of the world (r0 = 0), or a shard's own (world.h: sum_shard)
+    if (b < n_rob) {
+        const int l = b, gi = w.act_g0 + b;
         // (the class index in a scalar register: behind the stores below the compiler would fetch it per lane, and a per-lane index
         // into the class records of the kernel argument sends the whole argument through scratch memory)
-        const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[l]);
-        double* r = w.rec + (size_t)l * IMGENV_RECORD_DOUBLES;
+        const int cls = __builtin_amdgcn_readfirstlane(w.robot_cls[gi]);
+        double* r = w.rec + (size_t)gi * IMGENV_RECORD_DOUBLES;
         if (!w.py_done[l]) {  // alive = (dones == 0); dead robots keep their pose (img_env.cpp:392)
             double v, wv, v_y;
             integrate_command(w, actions, l, v, wv, v_y);
@@ -1882,9 +1936,9 @@ void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int
         }
         if (w.state_in_integrate && tid == 0) state_robot(w, l);  // no pedestrians, no side stream: get_state right behind the move
         __syncthreads();  // the new record, for every lane
-        raster_robot<POW2, LM, NW>(w, l, robot_class(w, cls), (uint32_t*)smem, g);
-    } else if (b - w.R < w.P) {
-        const int j = b - w.R;
+        raster_robot<POW2, LM, NW>(w, gi, robot_class(w, cls), (uint32_t*)smem, g);
+    } else if (b - n_rob < w.P) {
+        const int j = b - n_rob;
         const int cls = __builtin_amdgcn_readfirstlane(w.ped_cls[j]);
         if (move_peds) {
             if (tid == 0) {
@@ -1896,6 +1950,19 @@ void k_move_raster(DevWorld w, const float* __restrict__ actions, int n_sub, int
         if (LM == 2) raster_ped_sum<POW2, NW>(w, j, w.pc[cls], (uint32_t*)smem);
         else raster_ped<POW2, STAMP, NW>(w, j, w.pc[cls], g);
     }
+}
+
+// SUM mode in a robot shard (world.h: sum_shard): the robots of the OTHER ranks, as the exchange has just delivered them -- a thread each
+template <bool POW2>
+__global__ __launch_bounds__(256) void k_remote(DevWorld w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= w.R - w.RL) return;
+    const int i = t < w.r0 ? t : t + w.RL;
+    const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+    // (the bitmap's radius: one for the whole world when every class has the same, which spares two dependent loads)
+    const int rad = (w.rm_rad >= 0 ? w.rm_rad : w.rc_mem[w.robot_cls[i]].box_rad - 2), side = 2 * rad + 1;
+    const int cm = w2m_t<POW2>(r[0], w.res, w.inv_res), cn = w2m_t<POW2>(r[1], w.res, w.inv_res);
+    sum_apply_bits(w, i, (unsigned long long)__double_as_longlong(r[7]), cm, cn, rad, side, 0u);
 }
 
 // `cell` of the cells [c0, min(c0 + 4, G)) from the map and the raster layers; re-arms the raster layers
@@ -2028,7 +2095,7 @@ __device__ __forceinline__ uint32_t collision_from_samples(const DevWorld& w, co
         w2m_pair<POW2>(wx, wy, res, inv, m, n);
         if (m >= 0 && m < w.Hg && n >= 0 && n < w.Wg) {
             const uint32_t v = w.cell[(size_t)world_of_robot(w, (int)self) * w.Gs + (size_t)m * w.Wg + n];
-            const uint32_t cc = (!STAMP && w.layer_sum) ? cell_seen_class_sum(w, v, self - (uint32_t)(world_of_robot(w, (int)self) * w.Rw))
+            const uint32_t cc = (!STAMP && w.layer_sum) ? cell_seen_class_sum(w, v, sum_self_id(w, (int)self))
                                                         : cell_seen_class<STAMP>(v, self, stamp_tag_of(w));
             if (cc <= 2) best = max(best, ((uint32_t)(q + 1) << 2) | (cc + 1));
         }
@@ -2104,7 +2171,11 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     const int l = act_member(w, w.Rw, blockIdx.x);
     const int lane = lane_id();
     // the robot's record as this chain leaves it, where the next step's early k_obs finds it while the move rewrites the original (world.h)
-    if (w.rec_snap && tid < IMGENV_RECORD_DOUBLES) w.rec_snap[(size_t)l * IMGENV_RECORD_DOUBLES + tid] = w.rec[(size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES + tid];
+    if (w.rec_snap_out && tid < IMGENV_RECORD_DOUBLES) {
+        const double v = w.rec[(size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES + tid];
+        w.rec_snap_out[(size_t)l * IMGENV_RECORD_DOUBLES + tid] = v;
+        if (w.rec_snap_out2) w.rec_snap_out2[(size_t)l * IMGENV_RECORD_DOUBLES + tid] = v;
+    }
     if (w.is_coll[l] || w.is_arr[l]) {  // frozen: every per-robot output keeps its last value (counted in tail_group)
         if (tid < WAVE) tail_arrive_view(w, blockIdx.x, l, w.is_coll[l]);
         return;
@@ -2125,7 +2196,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     const uint32_t tag = STAMP ? stamp_tag_of(w) : 0u;
     const uint32_t free_plain = CLS_HIGH;
     const bool layer_sum = !STAMP && w.layer_sum != 0;  // (uniform) counts instead of owners: the same two compares per crop cell
-    const uint32_t self_w = self - (uint32_t)(world_of_robot(w, i) * (w.W > 1 ? w.Rw : 0));
+    const uint32_t self_w = sum_self_id(w, i);
     const uint32_t free_own = STAMP ? (CLS_HIGH | (STAMP_ONE << STAMP_KIND_SHIFT) | (tag << STAMP_TAG_SHIFT) | (self << STAMP_OWNER_SHIFT))
                               : layer_sum ? (CLS_HIGH + sum_robot_word(w, self_w))
                                           : (CLS_HIGH | CLS_ROBOT | (self << 8));
@@ -2781,7 +2852,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     const bool early = w.obs_early != 0;  // (uniform)
     double rx, ry, rsh, rch;
     if (early) {
-        const double* sn = w.rec_snap + (size_t)l * IMGENV_RECORD_DOUBLES;
+        const double* sn = w.rec_snap_in + (size_t)l * IMGENV_RECORD_DOUBLES;
         rx = sn[0];
         ry = sn[1];
         rsh = sn[5];
@@ -3113,6 +3184,349 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     }
     PHASE_MARK(11);
     WAVE_DONE(1);
+    if (lane == 0) w.ped_min_dists[l] = min_dist;
+    tail_arrive_obs(w, blockIdx.x, l, min_dist);
+}
+
+// k_obs for crowds of 513 .. 1024 pedestrians (BASELINE cfg-5), NW wavefronts per robot (round 6).  One wavefront per robot
+// needs ~14 KB of LDS for such a crowd -- 11 workgroups, i.e. under 3 wavefronts per SIMD, on a compute unit, and the kernel spent
+// 71 % of its wave-cycles waiting (profiles/r5_90_cfg5_pmc.json).  Here NW wavefronts share ONE robot's LDS: E = PP / (64 NW)
+// sort slots per lane, the odd-even passes over last step's order cross the wavefront boundaries through two LDS words per
+// wavefront, the full sort (first step of an episode) is a bitonic network over the packed keys in LDS, the pedestrian vector is
+// stored by all NW wavefronts, the ped_map's discs (a handful of pedestrians within +-3 m) stay with wavefront 0.  Same results
+// bit for bit: the order by (float64 key, index) is unique however it is reached.
+// LDS: keys[PP] u64 | info[P] float2 | ord[PP] u16 | inbox[PP] u16 | stage / touched | edges[2][2][NW] u64 | cnt[PP / 64] | flags
+template <int E, int NW>
+__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_obs_wg(DevWorld w, int PP) {
+    constexpr int NT = WAVE * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= act_count_l(w)) return;
+    const int l = act_member(w, w.Rw, blockIdx.x), lane = lane_id(), tid = threadIdx.x, wid = tid >> 6;
+    const int i = w.r0 + l;
+    const int P = w.W > 1 ? w.Pw : w.P, p_lo = w.W > 1 ? world_of_robot(w, i) * w.Pw : 0;
+    const double *g_ppx = w.ppx + p_lo, *g_ppy = w.ppy + p_lo, *g_pvx = w.pvx + p_lo, *g_pvy = w.pvy + p_lo;
+    const double* g_ped_r_round = w.ped_r_round + p_lo;
+    const int Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
+    const int Pa = P > 0 ? P : 1;
+    unsigned long long* keys = (unsigned long long*)smem;
+    float2* info = (float2*)(smem + (size_t)PP * 8);
+    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)Pa * 8);
+    uint16_t* inbox = ord + PP;
+    float* stage = (float*)(inbox + PP);
+    uint16_t* touched = (uint16_t*)stage;
+    unsigned long long* edges = (unsigned long long*)(stage + WAVE * 7);  // [2][2][NW]: exchange (check / boundary pair) x (first, last) x wavefront
+    int* cnt = (int*)(edges + 4 * NW);                                     // [PP / 64] pedestrians inside the box per chunk of 64 ranks
+
+    // the robot's pose of this step (see k_obs): every wavefront works it out for itself
+    const bool early = w.obs_early != 0;
+    double rx, ry, rsh, rch;
+    if (early) {
+        const double* sn = w.rec_snap_in + (size_t)l * IMGENV_RECORD_DOUBLES;
+        rx = sn[0];
+        ry = sn[1];
+        rsh = sn[5];
+        rch = sn[6];
+        if (!w.py_done[l]) {
+            const double theta = sn[2];
+            const double v = (double)w.obs_actions[3 * l], wv = (double)w.obs_actions[3 * l + 1], v_y = (double)w.obs_actions[3 * l + 2];
+            const int n_sub = w.obs_n_sub;
+            const double2 tr = integrate_heading(theta, wv, w.step_hz, lane == 0 ? 0 : lane == 1 ? n_sub : n_sub + 1, n_sub);
+            const double c0 = __shfl(tr.x, 0), s0 = __shfl(tr.y, 0), c1 = __shfl(tr.x, 1), s1 = __shfl(tr.y, 1);
+            rch = __shfl(tr.x, 2);
+            rsh = __shfl(tr.y, 2);
+            pose_arc(w.ktype == IMGENV_KTYPE_OMNI, v, wv, v_y, w.step_hz, c0, s0, c1, s1, rx, ry);
+        }
+    } else {
+        const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
+        rx = r[0];
+        ry = r[1];
+        rsh = r[5];
+        rch = r[6];
+    }
+    const Tf2 bw = tf_from_pose_sc(rx, ry, rsh, rch);
+    const float4* g_snap = w.ped_snap_in + p_lo;
+    const float ts32 = (float)w.step_hz;
+    const bool snap_peds = w.obs_early == 1;
+    auto ped_pos = [&](int j, double& x, double& y) {
+        if (snap_peds) {
+            const float4 q = g_snap[j];
+            x = (double)(q.x + q.z * ts32);
+            y = (double)(q.y + q.w * ts32);
+        } else {
+            x = g_ppx[j];
+            y = g_ppy[j];
+        }
+    };
+    auto ped_vel = [&](int j, double& vx, double& vy) {
+        if (snap_peds) {
+            const float4 q = g_snap[j];
+            vx = (double)q.z;
+            vy = (double)q.w;
+        } else {
+            vx = g_pvx[j];
+            vy = g_pvy[j];
+        }
+    };
+    // the packed key of slot-holder j (see sort_packed_in_registers): padding sorts behind everyone
+    auto packed = [&](uint32_t j) -> unsigned long long {
+        if (j >= (uint32_t)P) return ((unsigned long long)0x7F800000u << 32) | 0xFFFFull;
+        const float2 f = info[j];
+        const double key = (double)f.x * (double)f.x + (double)f.y * (double)f.y;
+        return ((unsigned long long)__float_as_uint((float)key) << 32) | (unsigned long long)j;
+    };
+    // this lane's neighbours' edge slots: the last slot of the thread in front, the first slot of the thread behind (across the
+    // wavefront boundaries through LDS; `which` picks one of two buffers so that a buffer is never rewritten before it has been read)
+    auto neighbours = [&](unsigned long long first, unsigned long long last, int which, unsigned long long& prv, unsigned long long& nxt) {
+        unsigned long long* e = edges + which * 2 * NW;
+        if (lane == 0) e[wid] = first;
+        if (lane == WAVE - 1) e[NW + wid] = last;
+        __syncthreads();
+        nxt = __shfl_down(first, 1);
+        prv = __shfl_up(last, 1);
+        if (lane == WAVE - 1 && wid + 1 < NW) nxt = e[wid + 1];
+        if (lane == 0 && wid > 0) prv = e[NW + wid - 1];
+    };
+    const bool last_thread = tid == NT - 1, first_thread = tid == 0;
+    double min_dist = w.ped_min_dists[l];
+    Tf2 wb = tf_inverse(bw);
+    wb.m00 = uniform_f64(wb.m00);
+    wb.m01 = uniform_f64(wb.m01);
+    wb.m10 = uniform_f64(wb.m10);
+    wb.m11 = uniform_f64(wb.m11);
+    wb.ox = uniform_f64(wb.ox);
+    wb.oy = uniform_f64(wb.oy);
+    // PedInfo in the robot base frame, float32 on the wire (img_env.cpp:568-584)
+    for (int j = tid; j < P; j += NT) {
+        double gx_, gy_, px, py;
+        ped_pos(j, gx_, gy_);
+        tf_apply(wb, gx_, gy_, px, py);
+        info[j] = make_float2((float)px, (float)py);
+    }
+    __syncthreads();
+    unsigned long long kv[E];
+    bool presorted = false;
+    if (w.obs_ord) {  // last step's order, a few odd-even transposition passes (see k_obs)
+        const uint16_t* prev = w.obs_ord + (size_t)l * PP + tid * E;
+#pragma unroll
+        for (int q = 0; q < E; q++) kv[q] = packed(prev[q]);
+        const int OBS_PASSES = w.obs_passes;
+        for (int pass = 0; pass <= OBS_PASSES; pass++) {
+            unsigned long long prv, nxt;
+            neighbours(kv[0], kv[E - 1], 0, prv, nxt);
+            bool ok = last_thread || kv[E - 1] <= nxt;
+#pragma unroll
+            for (int q = 0; q + 1 < E; q++) ok &= kv[q] <= kv[q + 1];
+            if (__syncthreads_and(ok ? 1 : 0)) {
+                presorted = true;
+                break;
+            }
+            if (pass == OBS_PASSES) break;
+#pragma unroll
+            for (int a = 0; a + 1 < E; a += 2) {  // even pairs
+                const unsigned long long x = kv[a], y = kv[a + 1];
+                kv[a] = x <= y ? x : y;
+                kv[a + 1] = x <= y ? y : x;
+            }
+#pragma unroll
+            for (int a = 1; a + 1 < E; a += 2) {  // odd pairs inside the thread ...
+                const unsigned long long x = kv[a], y = kv[a + 1];
+                kv[a] = x <= y ? x : y;
+                kv[a + 1] = x <= y ? y : x;
+            }
+            {   // ... and the one across the thread boundary
+                neighbours(kv[0], kv[E - 1], 1, prv, nxt);
+                const unsigned long long last = kv[E - 1], first = kv[0];
+                if (!last_thread && last > nxt) kv[E - 1] = nxt;
+                if (!first_thread && prv > first) kv[0] = prv;
+            }
+        }
+    }
+    if (!presorted) {  // the full sort: a bitonic network over the packed keys in LDS (the first step of an episode)
+        for (int e = tid; e < PP; e += NT) keys[e] = packed((uint32_t)e);
+        __syncthreads();
+        for (int kk = 2; kk <= PP; kk <<= 1) {
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int t2 = tid; t2 < PP / 2; t2 += NT) {
+                    const int a = ((t2 / jj) * 2 * jj) + (t2 % jj), b = a + jj;
+                    const bool up = (a & kk) == 0;
+                    const unsigned long long ka = keys[a], kb = keys[b];
+                    if ((ka > kb) == up) {
+                        keys[a] = kb;
+                        keys[b] = ka;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < E; q++) kv[q] = keys[tid * E + q];
+    }
+    // two neighbouring slots with one float32 surrogate (and a pedestrian in the later one): their float64 keys may differ
+    uint32_t clash = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < E; q++) clash |= ((uint32_t)(kv[q] >> 32) == (uint32_t)(kv[q + 1] >> 32) && (uint32_t)kv[q + 1] != 0xFFFFu) ? (1u << q) : 0u;
+    {
+        unsigned long long prv, nxt;
+        neighbours(kv[0], kv[E - 1], 0, prv, nxt);
+        clash |= (!last_thread && (uint32_t)(kv[E - 1] >> 32) == (uint32_t)(nxt >> 32) && (uint32_t)nxt != 0xFFFFu) ? (1u << (E - 1)) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < E; q++) ord[tid * E + q] = (uint16_t)(uint32_t)kv[q];
+    if (__builtin_expect(__syncthreads_or(clash != 0u ? 1 : 0), 0)) {  // rare: see k_obs
+        int again = 1;
+        while (again) {
+            int swapped = 0;
+            for (int parity = 0; parity < 2; parity++) {
+                for (int q = 0; q < E; q++) {
+                    const int e = tid * E + q;
+                    if (((clash >> q) & 1u) != 0u && (e & 1) == parity) {
+                        const uint32_t ja = ord[e], jb = ord[e + 1];
+                        const float2 fa = info[ja], fb = info[jb];
+                        const double ka = (double)fa.x * (double)fa.x + (double)fa.y * (double)fa.y;
+                        const double kb = (double)fb.x * (double)fb.x + (double)fb.y * (double)fb.y;
+                        if (ka > kb || (ka == kb && ja > jb)) {
+                            ord[e] = (uint16_t)jb;
+                            ord[e + 1] = (uint16_t)ja;
+                            swapped = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            again = __syncthreads_or(swapped);
+        }
+    }
+    if (w.obs_ord) {  // next step starts from this order
+        uint16_t* keep = w.obs_ord + (size_t)l * PP + tid * E;
+#pragma unroll
+        for (int q = 0; q < E; q++) keep[q] = ord[tid * E + q];
+    }
+    // ped_tmp vector (yaml_env.py:397-408) in rank order, by all wavefronts; the pedestrians inside the +-3 m box are counted per
+    // chunk of 64 ranks first and collected in rank order behind the barrier
+    float* pt = w.ped_vector_states + (size_t)l * w.PV;
+    if (tid == 0) pt[0] = (float)P;
+    const double rsl = w.robot_size_last[i];
+    unsigned long long in_mask[E];
+#pragma unroll
+    for (int it = 0; it < E; it++) {
+        const int q = it * NT + tid;
+        bool in_box = false;
+        if (q < P) {
+            const int j = ord[q];
+            const float2 f = info[j];
+            double pvx, pvy;
+            ped_vel(j, pvx, pvy);
+            const float fvx = (float)((wb.m00 * pvx + wb.m01 * pvy) + 0.0), fvy = (float)((wb.m10 * pvx + wb.m11 * pvy) + 0.0);
+            const double dpx = f.x, dpy = f.y;
+            const double ped_r = g_ped_r_round[j];
+            const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
+            float* o = pt + 1 + 7 * (size_t)q;
+            o[0] = f.x;
+            o[1] = f.y;
+            o[2] = fvx;
+            o[3] = fvy;
+            o[4] = (float)ped_r;
+            o[5] = (float)(ped_r + rsl);
+            o[6] = dist;
+            if (q == 0) min_dist = (double)(float)(dist - (float)(ped_r + rsl));  // yaml_env.py:455-456
+            in_box = !(dpx > 3 || dpx < -3 || dpy > 3 || dpy < -3);          // yaml_env.py:409-410
+        }
+        in_mask[it] = __ballot(in_box);
+        if (lane == 0) cnt[it * NW + wid] = __popcll(in_mask[it]);
+    }
+    __syncthreads();
+    int n_in = 0;
+    {
+        int before = 0;  // pedestrians inside the box in the chunks in front of this wavefront's next one
+        int c = 0;
+#pragma unroll
+        for (int it = 0; it < E; it++) {
+            const int mine = it * NW + wid;
+            for (; c < mine; c++) before += cnt[c];
+            const int q = it * NT + tid;
+            if ((in_mask[it] >> lane) & 1ull) inbox[before + __popcll(in_mask[it] & ((1ull << lane) - 1ull))] = (uint16_t)q;
+        }
+        for (int c2 = 0; c2 < E * NW; c2++) n_in += cnt[c2];
+    }
+    // ped_map (yaml_env.py:409-427), sparse update (see k_obs): last step's cells cleared by everyone, the discs stamped by wavefront 0
+    float* pm = w.ped_maps + (size_t)l * 3 * NP;
+    uint16_t* prev = w.pm_cells + (size_t)l * PM_CAP;
+    const int n_prev = w.pm_n[l];
+    if (n_prev >= 0) {
+        for (int e = tid; e < n_prev; e += NT) {
+            const int c = prev[e];
+            pm[c] = 0.0f;
+            pm[NP + c] = 0.0f;
+            pm[2 * NP + c] = 0.0f;
+        }
+    } else {
+        for (int c4 = tid * 4; c4 < 3 * NP; c4 += NT * 4) {
+            if (c4 + 4 <= 3 * NP) {
+                *(float4*)(pm + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int q = c4; q < 3 * NP; q++) pm[q] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();  // the clears are out, the box list is complete
+    if (wid != 0) return;
+    min_dist = __shfl(min_dist, 0);
+    int n_new = 0;
+    const double pres = w.ped_res, pinv = w.ped_inv_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
+    for (int e = 0; e < n_in; e++) {
+        // (this wavefront's earlier stores are out before the next disc goes over them: later discs overwrite earlier ones)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int je = ord[inbox[e]];
+        const float2 f = info[je];
+        double evx, evy;
+        ped_vel(je, evx, evy);
+        const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
+        const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
+        int ax, bx, ay, by;
+        if (pinv != 0.0) {
+            ax = (int)floor((tmx - pr) * pinv);
+            bx = (int)floor((tmx + pr) * pinv);
+            ay = (int)floor((tmy - pr) * pinv);
+            by = (int)floor((tmy + pr) * pinv);
+        } else {
+            ax = (int)py_floordiv(tmx - pr, pres);
+            bx = (int)py_floordiv(tmx + pr, pres);
+            ay = (int)py_floordiv(tmy - pr, pres);
+            by = (int)py_floordiv(tmy + pr, pres);
+        }
+        const int wy = by - ay, n_c = (bx - ax) * wy;
+        for (int t0 = 0; t0 < n_c; t0 += WAVE) {
+            const int tt = t0 + lane;
+            bool hitc = false;
+            int c = 0;
+            if (tt < n_c) {
+                const int jj = ax + tt / wy, kq = ay + tt % wy;
+                if (jj >= 0 && jj < Hp && kq >= 0 && kq < Wp) {
+                    const double ddx = (jj + 0.5) * pres - tmx, ddy = (kq + 0.5) * pres - tmy;
+                    hitc = ddx * ddx + ddy * ddy < pr2;
+                    c = jj * Wp + kq;
+                }
+            }
+            if (hitc) {
+                pm[c] = 1.0f;
+                pm[NP + c] = fvx;
+                pm[2 * NP + c] = fvy;
+            }
+            const unsigned long long mask = __ballot(hitc);
+            const int pos = n_new + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hitc && pos < PM_CAP) touched[pos] = (uint16_t)c;
+            n_new += __popcll(mask);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (n_new <= PM_CAP) {
+        for (int e = lane; e < n_new; e += WAVE) prev[e] = touched[e];
+        if (lane == 0) w.pm_n[l] = n_new;
+    } else if (lane == 0) {
+        w.pm_n[l] = -1;
+    }
     if (lane == 0) w.ped_min_dists[l] = min_dist;
     tail_arrive_obs(w, blockIdx.x, l, min_dist);
 }

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(WAVE) void k_respawn(DevWorld w, SpawnDev c, int el
     if (tid == 0) {
         c.n_obst_w[world] = n_ob;
         c.oroot_w[world] = c.s_rvo_n[4 * s + 2];
-        c.world_epoch[world] = w.step_vars ? w.step_vars[0] : elapsed;  // its TimeLimitWrapper starts over
+        c.world_epoch[world] = elapsed;  // its TimeLimitWrapper starts over
     }
 }
 

@@ -143,10 +143,6 @@ struct DevWorld {
     // device-side auto-reset (spawn_device.h): the list's length lives in device memory, the launches are sized for every world
     // of the handle and blocks beyond the count leave at once (act_nw ... act_np then hold the launch's capacity)
     const int* act_n_dev;
-    // Replayed launch chains (imgenv_step_autoreset_device as a hipGraph) cannot take per-step values as kernel arguments: when
-    // set, the step counter (TimeLimitWrapper._elapsed_steps) and the stamp sequence live here, advanced by k_tick at the
-    // start of every step: [0] steps so far, [1] stamp sequence
-    const int* step_vars;
     // the step's per-robot scalars (tail_group in kernels.h) are run by k_view / k_obs wavefronts themselves
     unsigned long long* tail_sig;  // [RL] exchange word: k_obs' min_dist (float bits) << 32 | k_view's collision code << 8 | who has been here (2 view, 1 obs)
     int* tail_cnt;                 // [ceil(RL / 64)][32] (one per 128-byte line) robots of the group whose two wavefronts have both been here
@@ -179,9 +175,13 @@ struct DevWorld {
     // "early observation" steps (imgenv_step on eligible handles, csrc/imgenv_hip.hip): k_obs starts with the step, beside the
     // move, instead of behind it.  It then works out its robot's new pose and the pedestrians' new positions ITSELF, from
     // snapshots nobody writes while it runs: rec_snap = every robot's record as the last k_view found it, ped_snap = every ORCA
-    // pedestrian's position and freshly solved velocity as the last k_orca left them (two buffers, taken in turns: the next
-    // k_orca writes while this step's k_obs may still read)
-    double* rec_snap;            // [RL][IMGENV_RECORD_DOUBLES]
+    // pedestrian's position and freshly solved velocity as the last k_orca left them -- two buffers each, taken in turns: this
+    // step's k_view / k_orca write while this step's k_obs may still read.  (Round 5 kept ONE rec_snap: an early k_obs that was
+    // late -- another stream of the process keeping the chip busy -- then read the record its own step's k_view had already
+    // replaced and advanced the robot twice; tests/test_gpu_stream_order.py.)
+    double* rec_snap_out;        // [RL][IMGENV_RECORD_DOUBLES] where this chain's k_view writes; null: no snapshots
+    double* rec_snap_out2;       // a chain over SOME worlds (a reset) writes both buffers
+    const double* rec_snap_in;   // what an early k_obs reads
     float4* ped_snap_out;        // [P] (x, y, new vx, new vy): where this chain's k_orca writes; null: no snapshots
     float4* ped_snap_out2;       // a chain over SOME worlds (a reset) writes both buffers: the other worlds' entries stay where the next step reads
     const float4* ped_snap_in;   // [P] what an early k_obs reads
@@ -193,6 +193,17 @@ struct DevWorld {
     uint32_t* sync;
     const float* obs_actions;    // the step's actions
     int layer_sum;           // SUM mode (above): ped_layer / own_lo / own_hi do not exist, k_compose never runs
+    // SUM mode in a ROBOT SHARD (round 6).  The rank's own robots keep their cell lists as everywhere; another rank's robot arrives
+    // as its record, whose eighth double carries the cells under its footprint as a BITMAP over the (2 (box_rad - 2) + 1)^2 <= 64
+    // cells around its centre cell -- made by its owner's raster, which runs in FRONT of the exchange -- and k_remote adds / takes
+    // off the difference to the bitmap the robot left a step ago (rm_bits / rm_center): a thread per remote robot and no atomic at
+    // all while its cells stay.  Local robots count with index l + 1 in the word's index field, remote ones with 0: "the only
+    // robot on the cell is me" stays one compare.  No owner layers, no k_compose, no bounding box of the shard.
+    int sum_shard;
+    int act_g0;              // first robot (world-wide index) of a raster launch over the robots [act_g0, act_g0 + act_ng)
+    int rm_rad;                   // the bitmaps' radius box_rad - 2 when every robot class has the same one, else -1
+    unsigned long long* rm_bits;  // [R] the bitmap each robot of ANOTHER rank currently counts itself on ...
+    int2* rm_center;              // [R] ... and the centre cell it is relative to
     uint32_t sum_rc_shift, sum_id_shift, sum_pc_mask;
     unsigned long long sum_wg_magic;  // ceil(2^40 / Wg): row of a cell index below 2^24
     uint32_t* pd_cells;      // [P][pd_cap] SUM mode: the cells each pedestrian has added itself to ...

@@ -256,6 +256,12 @@ class World:
     def launches(self):
         return self.lib.imgenv_step_launches(self.h)
 
+    def layer_mode(self):
+        """what ``imgenv_create`` decided: {"layer": composed | stamped | counting, "shard_bitmaps", "early_observation", "crowd_ahead"}"""
+        m = self.lib.imgenv_layer_mode(self.h)
+        return dict(layer=("composed", "stamped", "counting")[m & 3], shard_bitmaps=bool(m & 4), early_observation=bool(m & 8),
+                    crowd_ahead=bool(m & 16))
+
     def timing(self, mode, which=-1):
         """0 off, 1 every kernel, 2 only kernel id ``which`` (HIP events on the launch stream)"""
         self._check(self.lib.imgenv_timing(self.h, mode, which), "imgenv_timing")

@@ -296,16 +296,15 @@ int imgenv_reset(imgenv_t* h, const imgenv_reset_batch* batch, void* stream);
 
 /* step_image_env + Python post-processing.  actions: DEVICE float[R][3] = (v, w, beep) of the
  * local robots (ContinuousAction, envs/action/action.py:8-20).  Dead robots are zeroed
- * inside (yaml_env.py:319-331).  The call is stream-ordered: actions written by work queued on `stream` in front of it are seen
- * (imgenv_step_flags with IMGENV_STEP_ACTIONS_READY promises they are complete already). */
+ * inside (yaml_env.py:319-331).  The call is stream-ordered: actions written by work queued on `stream` in front of it are
+ * seen, and outputs of the previous call are not rewritten before work queued on `stream` in front of it has read them. */
 int imgenv_step(imgenv_t* h, const float* actions, void* stream);
-/* The same with per-call flags.  IMGENV_STEP_ACTIONS_READY: the caller promises that `actions` hold their final values WHEN THE
- * CALL IS MADE -- pre-generated, replayed, copied and synchronised, or produced on another stream that has been waited for --
- * instead of merely being queued on `stream` in front of it.  The library may then start kernels that read them on its side
- * streams without waiting for the caller's stream (early-observation steps, DESIGN.md section 4: the observation kernel runs
- * beside the move; ~5 % on the headline shape).  Without the flag every kernel that reads the actions is ordered behind everything
- * queued on `stream` before the call -- a policy network may write them there right in front of it --: the observation's side
- * stream then waits behind a one-wavefront gate kernel that polls a word the step's first kernel on `stream` stores. */
+/* The same with per-call flags.  IMGENV_STEP_ACTIONS_READY: "the actions hold their final values when the call is made".
+ * Accepted, and WITHOUT EFFECT since round 6: rounds 4-5 let such a step start its observation kernel on a side stream behind the
+ * previous step's views alone, which was not ordered behind the caller's readers of the previous outputs (a replay-buffer copy
+ * queued on `stream`, IMGENV_FLAG_FULL_REWRITE's own copy).  Every step now starts that kernel behind a one-wavefront gate that
+ * opens when `stream` reaches the step's first kernel -- ordered behind everything queued in front of the call, at the same rate
+ * (92.3 against 92.0 us per headline step). */
 #define IMGENV_STEP_ACTIONS_READY 1u
 int imgenv_step_flags(imgenv_t* h, const float* actions, uint32_t flags, void* stream);
 
@@ -315,6 +314,9 @@ int imgenv_step_flags(imgenv_t* h, const float* actions, uint32_t flags, void* s
  *   (caller all-gathers `records` in place across ranks, e.g. RCCL ncclAllGather)
  *   step_end   : rasters + per-robot view/observation/reward kernels
  * imgenv_step == step_begin; step_end when the handle owns the whole world. */
+/* `actions` must stay as they are until imgenv_step_end has been called: kernels of the step read them on the library's side
+ * streams, which are joined into `stream` again at the end of imgenv_step_end (work queued on `stream` BEHIND step_end may
+ * overwrite them; work queued between the two calls may not). */
 int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream);
 int imgenv_step_end(imgenv_t* h, void* stream);
 /* records: DEVICE double[n_robots][IMGENV_RECORD_DOUBLES] = x, y, theta, vx, vy, sin(theta/2), cos(theta/2), pad
@@ -435,6 +437,10 @@ int imgenv_cv_resize_u8(int kind, const uint8_t* src, int32_t sh, int32_t sw, ui
 
 /* number of kernels launched by the last step (bench / profiling aid) */
 int imgenv_step_launches(imgenv_t* h);
+/* how the handle keeps its class layer and schedules its steps (what imgenv_create decided; tests and probes assert on it):
+ * bits 0-1: 0 composed owner layers + k_compose, 1 stamps, 2 counts (SUM); bit 2: robot shard in SUM mode (bitmaps in the
+ * records, k_remote); bit 3: early-observation steps; bit 4: the social-force crowd a step ahead */
+int imgenv_layer_mode(imgenv_t* h);
 
 /* Live per-kernel timing with HIP events recorded on the stream the kernels are launched on.
  * mode 0: off; 1: every launch of every kernel; 2: every 8th launch of kernel `which` only (sampling keeps the
@@ -452,7 +458,8 @@ int imgenv_step_launches(imgenv_t* h);
 #define IMGENV_K_TAPS 10     /* k_taps_big */
 #define IMGENV_K_MOVE_RASTER 11 /* k_move_raster: K_INTEGRATE + K_RASTER as one launch (small / pedestrian-free handles) */
 #define IMGENV_K_EXCHANGE 12    /* the in-library ncclAllGather of the robot records (imgenv_comm_init), between K_INTEGRATE and K_RASTER */
-#define IMGENV_K_COUNT 13
+#define IMGENV_K_REMOTE 13      /* k_remote: a robot shard takes the other ranks' robots from their records, behind the exchange */
+#define IMGENV_K_COUNT 14
 int imgenv_timing(imgenv_t* h, int mode, int which);
 /* synchronises the recorded events and returns accumulated milliseconds / launch counts per kernel
  * id since the last imgenv_timing() call; arrays of IMGENV_K_COUNT entries */

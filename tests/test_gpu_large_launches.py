@@ -406,63 +406,3 @@ def test_device_side_reset_of_pedscene_worlds():
         _device_reset_against_oracles(cfg, 5, 16, DEVICE_RESET_FIELDS)
     finally:
         set_cr_atan2(False)
-
-
-def test_device_side_reset_replayed_as_a_graph(monkeypatch):
-    """IMGENV_GRAPH=1: from its third call on the step + reset chain is replayed as a captured hipGraph (the step counter and the
-    stamp tag then live in device memory); the same oracles, a host reset with longer waypoint lists in between (the captured chain
-    carries the table's old address: it is captured again)"""
-    import torch
-    from img_env_amd import spawn, worldgen
-    from img_env_amd.vec_env import VecImageEnv
-    from oracle_binding import OracleWorld, build_oracle
-    build_oracle()
-    monkeypatch.setenv("IMGENV_GRAPH", "1")
-    E, R, P, n_obs = 7, 2, 3, 2
-    grid = worldgen.make_grid(200, 3)
-    cfg = worldgen.make_yaml_cfg(R, P, grid, time_max=4, n_obstacles=n_obs, seed=11)
-    vec = VecImageEnv(copy.deepcopy(cfg), env_num=E, seed=11, device_reset=True)
-    cpus = [OracleWorld(vec.params, vec.grid) for _ in range(E)]
-    fields = ("is_collisions", "is_arrives", "view_maps", "vector_states", "lasers", "ped_maps", "ped_vector_states", "rewards", "dones",
-              "dones_info", "robot_pose", "ped_state")
-
-    def check(where):
-        snap = vec.world.snapshot()
-        for k, c in enumerate(cpus):
-            mine = {f: (snap[f][k * P:(k + 1) * P] if f == "ped_state" else snap[f][k * R:(k + 1) * R]) for f in fields}
-            bad = compare(mine, c.snapshot(), fields)
-            assert not bad, (where, k, bad)
-
-    try:
-        vec.reset()
-        for k in range(E):
-            cpus[k].reset(spawn.native_spawn(cfg, vec._spawn_seed + k))
-        rng = np.random.default_rng(6)
-        n_reset = 0
-        for s in range(24):
-            a = np.zeros((E * R, 3), np.float32)
-            a[:, 0], a[:, 1] = rng.uniform(0, 0.6, E * R), rng.uniform(-0.9, 0.9, E * R)
-            vec.step(torch.as_tensor(a, device="cuda"))
-            worlds, _ = vec.world.autoreset_last()
-            for k, c in enumerate(cpus):
-                c.step(a[k * R:(k + 1) * R])
-            for k in worlds:
-                lay, _ = vec.world.world_placement(k, n_obs)
-                cpus[k].reset(lay)
-            n_reset += len(worlds)
-            check(s)
-            if s == 10:
-                lay = worldgen.make_layout(grid, 0.125, R, P, seed=78, n_obstacles=n_obs)
-                traj = np.zeros((P, 4, 3))
-                for j in range(P):
-                    for q in range(4):
-                        traj[j, q, :2] = lay.ped_pose[j, :2] + rng.uniform(-1.5, 1.5, 2)
-                lay.ped_traj, lay.ped_traj_len = traj, np.full(P, 4, np.int32)
-                vec.reset_envs([3], layouts=[lay])
-                cpus[3].reset(lay)
-                check("host reset")
-        assert n_reset >= 3 * E
-    finally:
-        vec.close()
-        for c in cpus:
-            c.close()

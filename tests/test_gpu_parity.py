@@ -308,15 +308,33 @@ def test_step_before_reset_is_an_error(worlds):
         gpu.close()
 
 
-@pytest.mark.parametrize("by_x", [False, True], ids=["interleaved", "spatial_shards"])
-def test_two_sharded_handles_match_single_world(worlds, by_x):
-    """Two handles on one GPU play ranks 0 / 1 of a robot-sharded world (caller-owned exchange between step_begin and
-    step_end).  Every shard must equal the same robots of the unsharded world bit for bit -- in particular with
-    spatially separated shards, where each rank rasterises only what its own robots can see."""
+def _exchange_by_hand(ranks, bounds):
+    """what the all-gather of a robot-sharded world delivers: every rank's own slice of the records, to every other rank"""
     import torch
+    torch.cuda.synchronize()
+    for r, w in enumerate(ranks):
+        for q, o in enumerate(ranks):
+            if q != r:
+                w.records[bounds[q]:bounds[q + 1]].copy_(o.records[bounds[q]:bounds[q + 1]])
+
+
+SHARD_FIELDS = ("vector_states", "view_maps", "sensor_maps", "lasers", "ped_vector_states", "ped_maps", "is_collisions", "is_arrives", "rewards",
+                "dones", "dones_info", "step_ds", "ped_min_dists")
+
+
+@pytest.mark.parametrize("layer", ["counting", "composed"])
+@pytest.mark.parametrize("by_x", [False, True], ids=["interleaved", "spatial_shards"])
+def test_two_sharded_handles_match_single_world(worlds, by_x, layer):
+    """Two handles on one GPU play ranks 0 / 1 of a robot-sharded world (caller-owned exchange between step_begin and
+    step_end).  Every shard must equal the same robots of the unsharded world bit for bit -- with the counting layer (the
+    other rank's robots arrive as bitmaps in their records, k_remote) and with the composed owner layers (each rank rasterises
+    the other's robots itself, clipped to what its own robots can see: spatially separated shards)."""
+    from img_env_amd import _cabi
     World, _ = worlds
     n, n_peds, steps = 24, 10, 30
     grid, params, layout = small_world(n, n_peds, seed=31, grid_size=320, clearance=0.8)
+    if layer == "composed":
+        params = dict(params, flags=int(params.get("flags", 0)) | _cabi.FLAG_COMPOSE_DENSE)
     if by_x:  # contiguous index ranges = vertical strips of the map
         order = np.argsort(layout.robot_pose[:, 0], kind="stable")
         layout.robot_pose = layout.robot_pose[order].copy()
@@ -324,6 +342,9 @@ def test_two_sharded_handles_match_single_world(worlds, by_x):
     full = World(params, grid)
     ranks = [World(dict(params, robot_begin=r * n // 2, robot_end=(r + 1) * n // 2), grid) for r in range(2)]
     try:
+        for w in ranks:
+            mode = w.layer_mode()
+            assert mode["layer"] == layer and mode["shard_bitmaps"] == (layer == "counting") and mode["early_observation"], mode
         full.reset(layout)
         for w in ranks:
             w.reset(layout)
@@ -333,20 +354,66 @@ def test_two_sharded_handles_match_single_world(worlds, by_x):
             full.step(a)
             for r, w in enumerate(ranks):
                 w.step_begin(a[r * n // 2:(r + 1) * n // 2])
-            torch.cuda.synchronize()
-            for r, w in enumerate(ranks):  # the all-gather, by hand
-                for q, o in enumerate(ranks):
-                    if q != r:
-                        w.records[q * n // 2:(q + 1) * n // 2].copy_(o.records[q * n // 2:(q + 1) * n // 2])
+            _exchange_by_hand(ranks, [0, n // 2, n])
             for w in ranks:
                 w.step_end()
             want = full.snapshot()
             for r, w in enumerate(ranks):
                 got = w.snapshot()
                 sl = slice(r * n // 2, (r + 1) * n // 2)
-                for k in ("vector_states", "view_maps", "sensor_maps", "lasers", "ped_vector_states", "ped_maps", "is_collisions",
-                          "is_arrives", "rewards", "dones", "dones_info", "step_ds", "ped_min_dists"):
+                for k in SHARD_FIELDS:
                     assert np.array_equal(got[k], want[k][sl]), (s, r, k)
+    finally:
+        full.close()
+        for w in ranks:
+            w.close()
+
+
+@pytest.mark.parametrize("case", ["dense_circles", "rectangles", "fine_grid_falls_back"])
+def test_four_shards_through_a_reset_match_single_world(worlds, case):
+    """ranks 0..3 of a crowded world -- robots brush past each other and collide, so footprints of different ranks share cells
+    and leave them again -- over 25 steps, a reset onto another layout, and 15 more steps.  `rectangles`: a 7 x 7-cell footprint
+    box; `fine_grid_falls_back`: 0.05 m cells, where a footprint's box no longer fits the record's 64-bit bitmap and the shards
+    keep the composed owner layers."""
+    from img_env_amd import worldgen
+    World, _ = worlds
+    n, n_peds, nr = 256, 12, 4
+    res = 0.05 if case == "fine_grid_falls_back" else 0.125
+    size = 400 if case == "fine_grid_falls_back" else 168
+    grid = worldgen.make_grid(size, 2)
+    params = worldgen.make_params(n, n_peds, res=res, view_cells=48 if res > 0.1 else 60)
+    if case == "rectangles":
+        _rect(params, n)
+    layouts = [worldgen.make_layout(grid, res, n, n_peds, seed=41 + q, n_obstacles=2, clearance=0.45) for q in range(2)]
+    full = World(params, grid)
+    bounds = [q * n // nr for q in range(nr + 1)]
+    ranks = [World(dict(params, robot_begin=bounds[r], robot_end=bounds[r + 1]), grid) for r in range(nr)]
+    try:
+        want_bitmaps = case != "fine_grid_falls_back"
+        for w in ranks:
+            assert w.layer_mode()["shard_bitmaps"] == want_bitmaps, w.layer_mode()
+        rng = np.random.default_rng(7)
+        collided = 0
+        for episode, steps in enumerate((25, 15)):
+            full.reset(layouts[episode])
+            for w in ranks:
+                w.reset(layouts[episode])
+            for s in range(-1, steps):
+                if s >= 0:
+                    a = random_actions(rng, n)
+                    full.step(a)
+                    for r, w in enumerate(ranks):
+                        w.step_begin(a[bounds[r]:bounds[r + 1]])
+                    _exchange_by_hand(ranks, bounds)
+                    for w in ranks:
+                        w.step_end()
+                want = full.snapshot()
+                for r, w in enumerate(ranks):
+                    got = w.snapshot()
+                    for k in SHARD_FIELDS:
+                        assert np.array_equal(got[k], want[k][bounds[r]:bounds[r + 1]]), (case, episode, s, r, k)
+            collided += int((want["is_collisions"] == 3).sum())
+        assert collided > 0, "no robot ever ran into another one: the case does not exercise the inter-robot layer"
     finally:
         full.close()
         for w in ranks:
