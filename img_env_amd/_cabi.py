@@ -25,6 +25,7 @@ FLAG_VIEW_WAVE = 64
 FLAG_AGENT_STATE_EXTRAS = 16  # AgentState.hits_x / hits_y / angular_map as well
 FLAG_CHECK_OUTPUTS = 128  # debug: checksum every output array between calls, EINVAL "the caller wrote into imgenv_out.<field>"
 FLAG_FULL_REWRITE = 256   # the outputs are copies rewritten in full by every call (the reference's value-copy ownership)
+FLAG_CHECK_OUTPUTS_FIRST = 1024  # FLAG_CHECK_OUTPUTS for the handle's first 64 calls only (World's default)
 ANGULAR_BINS = 72
 
 SHAPES = {"circle": SHAPE_CIRCLE, "rectangle": SHAPE_RECTANGLE, "leg": SHAPE_LEG}

@@ -570,6 +570,7 @@ struct RvoNodeHost {
     int obstacle, left, right;
 };
 
+// (restates RVO2's KdTree::buildObstacleTree -- Copyright 2008 University of North Carolina at Chapel Hill, Apache License 2.0; see NOTICE)
 struct RvoObstacles {
     std::vector<RvoObstHost> ob;
     std::vector<RvoNodeHost> nodes;

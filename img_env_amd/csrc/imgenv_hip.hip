@@ -109,7 +109,10 @@ struct imgenv {
     int sfm_steps_since_reset = 0;
     SfmDev sfm_other;              // the other set of the arrays a step writes (its p / v / dq / dest / last / nodes / n_nodes / treehash)
     hipStream_t sfm_stream = nullptr;
-    hipEvent_t ev_sfm = nullptr, ev_sfm_in = nullptr;
+    hipEvent_t ev_sfm = nullptr;
+    hipEvent_t ev_sfm_in[2] = {nullptr, nullptr};  // behind a step's last access to the crowd's sets on the caller's stream, by step parity
+    int sfm_par = 0;
+    int sfm_ahead_wait = -1;  // >= 0: this imgenv_step_begin still owes the crowd's launch ahead, behind ev_sfm_in[that]
     bool gates_work = false;     // k_gate_probe's verdict: kernels of two streams run side by side in this process
     bool fork_on_move = false;   // ev_fork went out with this step's k_integrate
     bool sum = false;        // SUM mode of the class layer (world.h): base class + counts kept by the agents themselves, no k_compose
@@ -166,6 +169,7 @@ struct imgenv {
     size_t arena_bytes = 0;
     imgenv_out pub_out;
     bool guard_check = false, guard_sealed = false;
+    int guard_left = -1;  // IMGENV_FLAG_CHECK_OUTPUTS_FIRST: verifications until the guard switches itself off (-1: never)
     OutSpan* d_spans = nullptr;          // CHECK_OUTPUTS: the output arrays as (pointer, bytes, first block) ...
     int n_spans = 0, span_blocks = 0;
     unsigned long long* d_sums = nullptr;  // ... and their checksums: [2][n_spans], sealed | found at the next call
@@ -478,7 +482,8 @@ extern "C" void imgenv_destroy(imgenv_t* h) {
         (void)hipStreamDestroy(h->sfm_stream);
     }
     if (h->ev_sfm) (void)hipEventDestroy(h->ev_sfm);
-    if (h->ev_sfm_in) (void)hipEventDestroy(h->ev_sfm_in);
+    for (hipEvent_t e : h->ev_sfm_in)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
     if (h->ev_consumed) (void)hipEventDestroy(h->ev_consumed);
     if (h->sd_storage && h->sd_delete) h->sd_delete(h->sd_storage);
@@ -1092,7 +1097,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
             TRY(dev_alloc(h, &o.nodes, (size_t)W * f.cap_nodes)); TRY(dev_alloc(h, &o.n_nodes, W)); TRY(dev_alloc(h, &o.treehash, Wn));
             HIPCHK_H(hipStreamCreateWithFlags(&h->sfm_stream, hipStreamNonBlocking));
             HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm, hipEventDisableTiming | hipEventDisableSystemFence));
-            HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm_in, hipEventDisableTiming | hipEventDisableSystemFence));
+            HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm_in[0], hipEventDisableTiming | hipEventDisableSystemFence));
+            HIPCHK_H(hipEventCreateWithFlags(&h->ev_sfm_in[1], hipEventDisableTiming | hipEventDisableSystemFence));
         }
         for (int k = 0; k < W; k++) {
             HIPCHK_H(hipMemcpy(f.p + (size_t)k * n1 * 3, p0.data(), sizeof(double) * 3 * n1, hipMemcpyHostToDevice));
@@ -1219,7 +1225,8 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
                          (void**)&h->pub_out.step_all_down, (void**)&h->pub_out.hits_x, (void**)&h->pub_out.hits_y, (void**)&h->pub_out.angular_map})
             if (*f) *f = (unsigned char*)*f + shift;
     }
-    if (cfg->flags & IMGENV_FLAG_CHECK_OUTPUTS) {  // every array of imgenv_out (not the records: the caller's exchange writes those)
+    if (cfg->flags & (IMGENV_FLAG_CHECK_OUTPUTS | IMGENV_FLAG_CHECK_OUTPUTS_FIRST)) {  // every array of imgenv_out (not the records: the caller's exchange writes those)
+        if (!(cfg->flags & IMGENV_FLAG_CHECK_OUTPUTS)) h->guard_left = IMGENV_CHECK_FIRST_CALLS;
         static const char* const names[32] = {"vector_states", "view_maps", "sensor_maps", "lasers_raw", "lasers", "ped_vector_states", "ped_maps",
                                               "is_collisions", "is_arrives", "step_ds", "ped_min_dists", "base_rewards", "base_dones", "rewards", "dones",
                                               "dones_info", "is_clean", "robot_pose", "ped_state", "counters", "records", "paper_rewards", "step_rewards",
@@ -1267,7 +1274,6 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
     h->lds_view = ((NC + 16) & ~(size_t)15) + 4 * max_stride + 16 * (size_t)g.Wv + 16 + 4 * (2 * (max_stride / 8 + 1) + 4);
     static_assert(PM_CAP * 2 <= WAVE * 7 * 4, "the touched-cell list reuses the staging buffer");
     h->lds_obs = (h->obs_E == 0 ? (size_t)h->PP * 8 : 0) + (size_t)(h->Pw > 0 ? h->Pw : 1) * 8 + (size_t)h->PP * 4 + WAVE * 7 * 4 + 16;
-    if (h->obs_E == 16) h->lds_obs += (size_t)h->PP * 8 + 4 * 4 * 8 + (size_t)(h->PP / WAVE) * 4;  // k_obs_wg<4, 4>: packed keys, edge words, per-chunk counts
     if (h->big_view) {  // k_beams_big: the occupied plane of the crop bitmap; k_taps_big: the hit words
         const size_t lds_bits = 4 * (size_t)d.big_words;
         h->big_bits_in_lds = lds_bits <= 150 * 1024;  // beyond that (views above ~1000 x 1000 cells) the beams read the bitmap from HBM
@@ -1493,6 +1499,10 @@ static int outputs_verify(imgenv* h, hipStream_t st) {
     k_out_verify<<<dim3(1), dim3(64), 0, st>>>(h->d_sums, found, h->n_spans, h->d.err);
     HIPCHK(hipStreamSynchronize(st));
     const int f = h->err_host ? h->err_host[5] : 0;
+    if (h->guard_left > 0 && --h->guard_left == 0) {  // (IMGENV_FLAG_CHECK_OUTPUTS_FIRST: this was the last look)
+        h->guard_check = false;
+        h->guard_sealed = false;
+    }
     if (f) {
         h->err_host[5] = 0;
         h->guard_sealed = false;  // (the next chain seals what it finds; the caller has been told)
@@ -1513,7 +1523,10 @@ static int launch_obs_kernel(imgenv* h, hipStream_t s_obs) {
         case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         // (513 .. 1024 pedestrians: four wavefronts share one robot's LDS -- k_obs_wg)
-        case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs_wg<4, 4><<<go, dim3(4 * WAVE), lds_obs, s_obs>>>(d, h->PP))); break;
+        // (four wavefronts per robot for 513 .. 1024 pedestrians -- three times the occupancy, a third of the LDS per wavefront --
+        // were measured in round 6 and LOSE: cfg-5 277 -> 325 us per step, 321 with two, 406 with eight: the step is bound by the
+        // instructions it issues, k_obs beside k_view, not by this kernel's occupancy.  docs/HISTORY.md)
+        case 16: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<16><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         default: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<0><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
     }
     h->launches += 1;
@@ -1602,13 +1615,22 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
     const bool moved = h->move_pending;
     h->move_pending = false;
     const bool remote_only = h->d.sum_shard && !is_reset;
+    // what the side streams read of the OTHER ranks' robots: their RVO agents (k_side_robots, k_orca) -- nothing when the crowd
+    // ignores the robots or is no RVO crowd
+    const bool side_reads_all = h->P > 0 && h->NA > 0 && d.relation == 1;
     auto rasters = [&]() -> int {
         if (!remote_only) return launch_rasters(h, st, is_reset, moved, false);
-        const unsigned nb = (unsigned)((h->R - h->RL + 255) / 256);
-        if (h->pow2) TIMED(h, IMGENV_K_REMOTE, st, (k_remote<true><<<dim3(nb), dim3(256), 0, st>>>(d)));
-        else TIMED(h, IMGENV_K_REMOTE, st, (k_remote<false><<<dim3(nb), dim3(256), 0, st>>>(d)));
-        return 0;
+        return 0;  // (k_remote went out in front of the side launches: below)
     };
+    if (remote_only) {
+        // the other ranks' robots, right behind the exchange; "the records are complete" for the side streams rides on this kernel's
+        // dispatch packet (a hipEventRecord behind the exchange is a packet of its own on the caller's stream: ~6 us)
+        const unsigned nb = (unsigned)((h->R - h->RL + 255) / 256);
+        const hipEvent_t ev = side_reads_all && !h->serial ? h->ev_fork2 : nullptr;
+        if (h->pow2) TIMED(h, IMGENV_K_REMOTE, st, (hipExtLaunchKernelGGL(k_remote<true>, dim3(nb), dim3(256), 0, st, nullptr, ev, 0, d)));
+        else TIMED(h, IMGENV_K_REMOTE, st, (hipExtLaunchKernelGGL(k_remote<false>, dim3(nb), dim3(256), 0, st, nullptr, ev, 0, d)));
+        h->launches += 1;
+    }
     if (moved)
         if (int rc = rasters()) return rc;
     if (h->P > 0) {
@@ -1630,8 +1652,8 @@ static int launch_views(imgenv* h, hipStream_t st, int is_reset) {
         hipStream_t s_obs = overlap ? h->side2 : st;
         if (h->early_step && one_side) HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));  // (k_obs went out with the step, in front of the move: the solve waits for it)
         if (overlap && !one_side) {
-            if (d.sharded) {  // the solve needs every rank's robots: a second fork behind the exchange
-                HIPCHK(hipEventRecord(h->ev_fork2, st));
+            if (d.sharded && side_reads_all) {  // the solve needs every rank's robots: a second fork behind the exchange
+                if (!remote_only) HIPCHK(hipEventRecord(h->ev_fork2, st));  // (k_remote carries it otherwise)
                 HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork2, 0));
             } else {
                 HIPCHK(hipStreamWaitEvent(s_orca, h->ev_fork, 0));
@@ -2523,6 +2545,17 @@ static int sfm_ahead_drop(imgenv* h, hipStream_t st) {
     return 0;
 }
 
+// the social-force crowd's step AHEAD, on its own stream (see imgenv_step_begin): queued once the step's own first kernels are out
+static int sfm_launch_ahead(imgenv* h) {
+    if (h->sfm_ahead_wait < 0) return 0;
+    HIPCHK(hipStreamWaitEvent(h->sfm_stream, h->ev_sfm_in[h->sfm_ahead_wait], 0));
+    h->sfm_ahead_wait = -1;
+    if (int rc = launch_sfm(h, h->sfm_stream, &h->sfm_other, 0)) return rc;
+    HIPCHK(hipEventRecord(h->ev_sfm, h->sfm_stream));
+    h->sfm_ahead_valid = true;
+    return 0;
+}
+
 extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream) {
     if (!h || !actions) FAIL(IMGENV_EINVAL, "null argument");
     if (!h->has_reset) FAIL(IMGENV_ESTATE, "step before reset");
@@ -2538,7 +2571,17 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         if (h->sfm_ahead) {
             // a crowd that ignores the robots: this step's state was computed during the last step (launch_sfm below) -- swap the
             // two sets and publish -- or, right behind a reset, is computed now, in place; then the NEXT step's goes out on its stream
-            bool in_recorded = false;  // ev_sfm_in has been recorded behind this step's last access to the crowd's sets on the caller's stream
+            // Ordering against the caller's stream.  The launch ahead (below) reads the live set and WRITES the other one -- the set
+            // that was live a step ago, which THAT step's k_sfm_publish (or in-place step) touched on the caller's stream.  Nothing else
+            // orders the crowd's stream behind the caller's: a host that queues steps faster than the device drains them (an
+            // asynchronous trainer, bench.py's timed loop) would let the crowd run several steps ahead and overwrite a set before it has
+            // been published (rounds 3-5 did).  So every step leaves an event behind its access to the sets on the caller's stream,
+            // by step parity, and the launch ahead waits for the LAST step's -- this step's publish only reads the live set, as the
+            // launch ahead does, so the crowd may run up to one step ahead of the caller's stream -- or for this step's own when it
+            // wrote the live set in place.
+            const int cur = h->sfm_par;
+            h->sfm_par ^= 1;
+            bool in_place = false;
             if (h->sfm_ahead_valid) {
                 SfmDev& a = h->d.sfm;
                 SfmDev& b = h->sfm_other;
@@ -2547,27 +2590,19 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
                 a.p_out = a.p; a.v_out = a.v; a.dq_out = a.dq; a.dest_out = a.dest; a.last_out = a.last;
                 a.nodes_out = a.nodes; a.n_nodes_out = a.n_nodes; a.treehash_out = a.treehash;
                 HIPCHK(hipStreamWaitEvent(st, h->ev_sfm, 0));
-                // (the "published" event rides on the kernel's dispatch packet: see launch_sfm's caller below)
-                hipExtLaunchKernelGGL(k_sfm_publish, dim3((unsigned)h->W), dim3(SFM_MAX_AGENTS), 0, st, nullptr, h->sfm_steps_since_reset >= 1 ? h->ev_sfm_in : nullptr, 0, d);
-                in_recorded = h->sfm_steps_since_reset >= 1;
+                // (the event rides on the kernel's dispatch packet: a hipEventRecord behind it is a packet of its own, ~6 us of the caller's stream)
+                hipExtLaunchKernelGGL(k_sfm_publish, dim3((unsigned)h->W), dim3(SFM_MAX_AGENTS), 0, st, nullptr, h->ev_sfm_in[cur], 0, d);
                 h->launches += 1;
             } else {
                 if (int rc = launch_sfm(h, st, nullptr, 1)) return rc;
+                HIPCHK(hipEventRecord(h->ev_sfm_in[cur], st));
+                in_place = true;
             }
             // (not in the first step behind a reset: a handle whose worlds are reset every other step -- many small worlds with
             // their own time limits -- would compute ahead what the next reset drops, and make that reset wait for it)
-            if (h->sfm_steps_since_reset >= 1) {
-                // The launch below reads the live set and WRITES the other one -- the set that was live a step ago, which that step's
-                // k_sfm_publish read on the caller's stream.  Nothing else orders the crowd's stream behind the caller's: a host that
-                // queues steps faster than the device drains them (an asynchronous trainer, bench.py's timed loop) would let the crowd
-                // run several steps ahead and overwrite a set before it has been published.  So EVERY launch ahead waits for this step's
-                // last access to the sets on the caller's stream: the publish (which sits behind last step's), a reset, a step in place.
-                if (!in_recorded) HIPCHK(hipEventRecord(h->ev_sfm_in, st));
-                HIPCHK(hipStreamWaitEvent(h->sfm_stream, h->ev_sfm_in, 0));
-                if (int rc = launch_sfm(h, h->sfm_stream, &h->sfm_other, 0)) return rc;
-                HIPCHK(hipEventRecord(h->ev_sfm, h->sfm_stream));
-                h->sfm_ahead_valid = true;
-            }
+            // (queued at the END of this call, behind the step's own first launches: its five host calls in front of the move were
+            // ~25 us in which the caller's stream sat idle -- sfm_launch_ahead)
+            h->sfm_ahead_wait = h->sfm_steps_since_reset >= 1 ? (in_place ? cur : cur ^ 1) : -1;
             h->sfm_steps_since_reset += 1;
         } else {
             if (int rc = sfm_ahead_drop(h, st)) return rc;
@@ -2598,12 +2633,12 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
         if (h->P > 0)
             if (int rc = launch_obs(h, st)) return rc;
         HIPCHK(hipGetLastError());
-        return IMGENV_OK;
+        return sfm_launch_ahead(h);
     }
     if (fuse_move) {  // k_move_raster, launched by launch_views (the fork of the side stream with it)
         h->move_pending = true;
         h->move_actions = actions;
-        return IMGENV_OK;
+        return sfm_launch_ahead(h);
     }
     {   // ... and the pedestrians' move (img_env.cpp:343-358) in the same launch
         const bool peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET);
@@ -2650,7 +2685,7 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     if (d.sum_shard)
         if (int rc = launch_rasters(h, st, 0, false, true)) return rc;
     HIPCHK(hipGetLastError());
-    return IMGENV_OK;
+    return sfm_launch_ahead(h);
 }
 
 extern "C" int imgenv_step_end(imgenv_t* h, void* stream) {

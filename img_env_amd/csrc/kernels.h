@@ -77,10 +77,12 @@ __device__ __forceinline__ void bbox_accumulate(const DevWorld& w, bool valid, d
         hi_y = max(hi_y, (uint32_t)__shfl_xor((int)hi_y, off));
     }
     if (lane_id() == 0 && lo_x != BBOX_INIT_MIN) {
-        atomicMin(&w.bbox[0], lo_x);
-        atomicMin(&w.bbox[1], lo_y);
-        atomicMax(&w.bbox[2], hi_x);
-        atomicMax(&w.bbox[3], hi_y);
+        // (only a wavefront that widens the box as it reads it -- the box only ever grows during a launch, so a stale read costs an
+        // atomic that changes nothing: four atomics per wavefront on four words were 4096 of them queued up one behind the other)
+        if (lo_x < __hip_atomic_load(&w.bbox[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&w.bbox[0], lo_x);
+        if (lo_y < __hip_atomic_load(&w.bbox[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&w.bbox[1], lo_y);
+        if (hi_x > __hip_atomic_load(&w.bbox[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&w.bbox[2], hi_x);
+        if (hi_y > __hip_atomic_load(&w.bbox[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&w.bbox[3], hi_y);
     }
 }
 
@@ -1280,7 +1282,9 @@ __global__ __launch_bounds__(INT_G * INT_ROBOTS) void k_integrate(DevWorld w, co
     __syncthreads();
     if (alive && g == 0) integrate_finish(w, l, r, v, wv, v_y, theta, trig[rb], n_sub);
     if (w.state_in_integrate && valid && g == 0) state_robot(w, l);  // no pedestrians, no side stream: get_state right behind the move
-    if (w.sharded) bbox_accumulate(w, valid && g == 0, r[0], r[1]);
+    // (the shard's box: only where the other ranks' robots are rasterised and clipped to it -- the composed layers; its four contended
+    // atomics per wavefront made this kernel 50 us instead of 13 at 8192 robots)
+    if (w.sharded && !w.sum_shard) bbox_accumulate(w, valid && g == 0, r[0], r[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3184,349 +3188,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
     }
     PHASE_MARK(11);
     WAVE_DONE(1);
-    if (lane == 0) w.ped_min_dists[l] = min_dist;
-    tail_arrive_obs(w, blockIdx.x, l, min_dist);
-}
-
-// k_obs for crowds of 513 .. 1024 pedestrians (BASELINE cfg-5), NW wavefronts per robot (round 6).  One wavefront per robot
-// needs ~14 KB of LDS for such a crowd -- 11 workgroups, i.e. under 3 wavefronts per SIMD, on a compute unit, and the kernel spent
-// 71 % of its wave-cycles waiting (profiles/r5_90_cfg5_pmc.json).  Here NW wavefronts share ONE robot's LDS: E = PP / (64 NW)
-// sort slots per lane, the odd-even passes over last step's order cross the wavefront boundaries through two LDS words per
-// wavefront, the full sort (first step of an episode) is a bitonic network over the packed keys in LDS, the pedestrian vector is
-// stored by all NW wavefronts, the ped_map's discs (a handful of pedestrians within +-3 m) stay with wavefront 0.  Same results
-// bit for bit: the order by (float64 key, index) is unique however it is reached.
-// LDS: keys[PP] u64 | info[P] float2 | ord[PP] u16 | inbox[PP] u16 | stage / touched | edges[2][2][NW] u64 | cnt[PP / 64] | flags
-template <int E, int NW>
-__global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_obs_wg(DevWorld w, int PP) {
-    constexpr int NT = WAVE * NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if ((int)blockIdx.x >= act_count_l(w)) return;
-    const int l = act_member(w, w.Rw, blockIdx.x), lane = lane_id(), tid = threadIdx.x, wid = tid >> 6;
-    const int i = w.r0 + l;
-    const int P = w.W > 1 ? w.Pw : w.P, p_lo = w.W > 1 ? world_of_robot(w, i) * w.Pw : 0;
-    const double *g_ppx = w.ppx + p_lo, *g_ppy = w.ppy + p_lo, *g_pvx = w.pvx + p_lo, *g_pvy = w.pvy + p_lo;
-    const double* g_ped_r_round = w.ped_r_round + p_lo;
-    const int Hp = w.Hp, Wp = w.Wp, NP = Hp * Wp;
-    const int Pa = P > 0 ? P : 1;
-    unsigned long long* keys = (unsigned long long*)smem;
-    float2* info = (float2*)(smem + (size_t)PP * 8);
-    uint16_t* ord = (uint16_t*)(smem + (size_t)PP * 8 + (size_t)Pa * 8);
-    uint16_t* inbox = ord + PP;
-    float* stage = (float*)(inbox + PP);
-    uint16_t* touched = (uint16_t*)stage;
-    unsigned long long* edges = (unsigned long long*)(stage + WAVE * 7);  // [2][2][NW]: exchange (check / boundary pair) x (first, last) x wavefront
-    int* cnt = (int*)(edges + 4 * NW);                                     // [PP / 64] pedestrians inside the box per chunk of 64 ranks
-
-    // the robot's pose of this step (see k_obs): every wavefront works it out for itself
-    const bool early = w.obs_early != 0;
-    double rx, ry, rsh, rch;
-    if (early) {
-        const double* sn = w.rec_snap_in + (size_t)l * IMGENV_RECORD_DOUBLES;
-        rx = sn[0];
-        ry = sn[1];
-        rsh = sn[5];
-        rch = sn[6];
-        if (!w.py_done[l]) {
-            const double theta = sn[2];
-            const double v = (double)w.obs_actions[3 * l], wv = (double)w.obs_actions[3 * l + 1], v_y = (double)w.obs_actions[3 * l + 2];
-            const int n_sub = w.obs_n_sub;
-            const double2 tr = integrate_heading(theta, wv, w.step_hz, lane == 0 ? 0 : lane == 1 ? n_sub : n_sub + 1, n_sub);
-            const double c0 = __shfl(tr.x, 0), s0 = __shfl(tr.y, 0), c1 = __shfl(tr.x, 1), s1 = __shfl(tr.y, 1);
-            rch = __shfl(tr.x, 2);
-            rsh = __shfl(tr.y, 2);
-            pose_arc(w.ktype == IMGENV_KTYPE_OMNI, v, wv, v_y, w.step_hz, c0, s0, c1, s1, rx, ry);
-        }
-    } else {
-        const double* r = w.rec + (size_t)i * IMGENV_RECORD_DOUBLES;
-        rx = r[0];
-        ry = r[1];
-        rsh = r[5];
-        rch = r[6];
-    }
-    const Tf2 bw = tf_from_pose_sc(rx, ry, rsh, rch);
-    const float4* g_snap = w.ped_snap_in + p_lo;
-    const float ts32 = (float)w.step_hz;
-    const bool snap_peds = w.obs_early == 1;
-    auto ped_pos = [&](int j, double& x, double& y) {
-        if (snap_peds) {
-            const float4 q = g_snap[j];
-            x = (double)(q.x + q.z * ts32);
-            y = (double)(q.y + q.w * ts32);
-        } else {
-            x = g_ppx[j];
-            y = g_ppy[j];
-        }
-    };
-    auto ped_vel = [&](int j, double& vx, double& vy) {
-        if (snap_peds) {
-            const float4 q = g_snap[j];
-            vx = (double)q.z;
-            vy = (double)q.w;
-        } else {
-            vx = g_pvx[j];
-            vy = g_pvy[j];
-        }
-    };
-    // the packed key of slot-holder j (see sort_packed_in_registers): padding sorts behind everyone
-    auto packed = [&](uint32_t j) -> unsigned long long {
-        if (j >= (uint32_t)P) return ((unsigned long long)0x7F800000u << 32) | 0xFFFFull;
-        const float2 f = info[j];
-        const double key = (double)f.x * (double)f.x + (double)f.y * (double)f.y;
-        return ((unsigned long long)__float_as_uint((float)key) << 32) | (unsigned long long)j;
-    };
-    // this lane's neighbours' edge slots: the last slot of the thread in front, the first slot of the thread behind (across the
-    // wavefront boundaries through LDS; `which` picks one of two buffers so that a buffer is never rewritten before it has been read)
-    auto neighbours = [&](unsigned long long first, unsigned long long last, int which, unsigned long long& prv, unsigned long long& nxt) {
-        unsigned long long* e = edges + which * 2 * NW;
-        if (lane == 0) e[wid] = first;
-        if (lane == WAVE - 1) e[NW + wid] = last;
-        __syncthreads();
-        nxt = __shfl_down(first, 1);
-        prv = __shfl_up(last, 1);
-        if (lane == WAVE - 1 && wid + 1 < NW) nxt = e[wid + 1];
-        if (lane == 0 && wid > 0) prv = e[NW + wid - 1];
-    };
-    const bool last_thread = tid == NT - 1, first_thread = tid == 0;
-    double min_dist = w.ped_min_dists[l];
-    Tf2 wb = tf_inverse(bw);
-    wb.m00 = uniform_f64(wb.m00);
-    wb.m01 = uniform_f64(wb.m01);
-    wb.m10 = uniform_f64(wb.m10);
-    wb.m11 = uniform_f64(wb.m11);
-    wb.ox = uniform_f64(wb.ox);
-    wb.oy = uniform_f64(wb.oy);
-    // PedInfo in the robot base frame, float32 on the wire (img_env.cpp:568-584)
-    for (int j = tid; j < P; j += NT) {
-        double gx_, gy_, px, py;
-        ped_pos(j, gx_, gy_);
-        tf_apply(wb, gx_, gy_, px, py);
-        info[j] = make_float2((float)px, (float)py);
-    }
-    __syncthreads();
-    unsigned long long kv[E];
-    bool presorted = false;
-    if (w.obs_ord) {  // last step's order, a few odd-even transposition passes (see k_obs)
-        const uint16_t* prev = w.obs_ord + (size_t)l * PP + tid * E;
-#pragma unroll
-        for (int q = 0; q < E; q++) kv[q] = packed(prev[q]);
-        const int OBS_PASSES = w.obs_passes;
-        for (int pass = 0; pass <= OBS_PASSES; pass++) {
-            unsigned long long prv, nxt;
-            neighbours(kv[0], kv[E - 1], 0, prv, nxt);
-            bool ok = last_thread || kv[E - 1] <= nxt;
-#pragma unroll
-            for (int q = 0; q + 1 < E; q++) ok &= kv[q] <= kv[q + 1];
-            if (__syncthreads_and(ok ? 1 : 0)) {
-                presorted = true;
-                break;
-            }
-            if (pass == OBS_PASSES) break;
-#pragma unroll
-            for (int a = 0; a + 1 < E; a += 2) {  // even pairs
-                const unsigned long long x = kv[a], y = kv[a + 1];
-                kv[a] = x <= y ? x : y;
-                kv[a + 1] = x <= y ? y : x;
-            }
-#pragma unroll
-            for (int a = 1; a + 1 < E; a += 2) {  // odd pairs inside the thread ...
-                const unsigned long long x = kv[a], y = kv[a + 1];
-                kv[a] = x <= y ? x : y;
-                kv[a + 1] = x <= y ? y : x;
-            }
-            {   // ... and the one across the thread boundary
-                neighbours(kv[0], kv[E - 1], 1, prv, nxt);
-                const unsigned long long last = kv[E - 1], first = kv[0];
-                if (!last_thread && last > nxt) kv[E - 1] = nxt;
-                if (!first_thread && prv > first) kv[0] = prv;
-            }
-        }
-    }
-    if (!presorted) {  // the full sort: a bitonic network over the packed keys in LDS (the first step of an episode)
-        for (int e = tid; e < PP; e += NT) keys[e] = packed((uint32_t)e);
-        __syncthreads();
-        for (int kk = 2; kk <= PP; kk <<= 1) {
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                for (int t2 = tid; t2 < PP / 2; t2 += NT) {
-                    const int a = ((t2 / jj) * 2 * jj) + (t2 % jj), b = a + jj;
-                    const bool up = (a & kk) == 0;
-                    const unsigned long long ka = keys[a], kb = keys[b];
-                    if ((ka > kb) == up) {
-                        keys[a] = kb;
-                        keys[b] = ka;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < E; q++) kv[q] = keys[tid * E + q];
-    }
-    // two neighbouring slots with one float32 surrogate (and a pedestrian in the later one): their float64 keys may differ
-    uint32_t clash = 0;
-#pragma unroll
-    for (int q = 0; q + 1 < E; q++) clash |= ((uint32_t)(kv[q] >> 32) == (uint32_t)(kv[q + 1] >> 32) && (uint32_t)kv[q + 1] != 0xFFFFu) ? (1u << q) : 0u;
-    {
-        unsigned long long prv, nxt;
-        neighbours(kv[0], kv[E - 1], 0, prv, nxt);
-        clash |= (!last_thread && (uint32_t)(kv[E - 1] >> 32) == (uint32_t)(nxt >> 32) && (uint32_t)nxt != 0xFFFFu) ? (1u << (E - 1)) : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < E; q++) ord[tid * E + q] = (uint16_t)(uint32_t)kv[q];
-    if (__builtin_expect(__syncthreads_or(clash != 0u ? 1 : 0), 0)) {  // rare: see k_obs
-        int again = 1;
-        while (again) {
-            int swapped = 0;
-            for (int parity = 0; parity < 2; parity++) {
-                for (int q = 0; q < E; q++) {
-                    const int e = tid * E + q;
-                    if (((clash >> q) & 1u) != 0u && (e & 1) == parity) {
-                        const uint32_t ja = ord[e], jb = ord[e + 1];
-                        const float2 fa = info[ja], fb = info[jb];
-                        const double ka = (double)fa.x * (double)fa.x + (double)fa.y * (double)fa.y;
-                        const double kb = (double)fb.x * (double)fb.x + (double)fb.y * (double)fb.y;
-                        if (ka > kb || (ka == kb && ja > jb)) {
-                            ord[e] = (uint16_t)jb;
-                            ord[e + 1] = (uint16_t)ja;
-                            swapped = 1;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            again = __syncthreads_or(swapped);
-        }
-    }
-    if (w.obs_ord) {  // next step starts from this order
-        uint16_t* keep = w.obs_ord + (size_t)l * PP + tid * E;
-#pragma unroll
-        for (int q = 0; q < E; q++) keep[q] = ord[tid * E + q];
-    }
-    // ped_tmp vector (yaml_env.py:397-408) in rank order, by all wavefronts; the pedestrians inside the +-3 m box are counted per
-    // chunk of 64 ranks first and collected in rank order behind the barrier
-    float* pt = w.ped_vector_states + (size_t)l * w.PV;
-    if (tid == 0) pt[0] = (float)P;
-    const double rsl = w.robot_size_last[i];
-    unsigned long long in_mask[E];
-#pragma unroll
-    for (int it = 0; it < E; it++) {
-        const int q = it * NT + tid;
-        bool in_box = false;
-        if (q < P) {
-            const int j = ord[q];
-            const float2 f = info[j];
-            double pvx, pvy;
-            ped_vel(j, pvx, pvy);
-            const float fvx = (float)((wb.m00 * pvx + wb.m01 * pvy) + 0.0), fvy = (float)((wb.m10 * pvx + wb.m11 * pvy) + 0.0);
-            const double dpx = f.x, dpy = f.y;
-            const double ped_r = g_ped_r_round[j];
-            const float dist = (float)sqrt(dpx * dpx + dpy * dpy);
-            float* o = pt + 1 + 7 * (size_t)q;
-            o[0] = f.x;
-            o[1] = f.y;
-            o[2] = fvx;
-            o[3] = fvy;
-            o[4] = (float)ped_r;
-            o[5] = (float)(ped_r + rsl);
-            o[6] = dist;
-            if (q == 0) min_dist = (double)(float)(dist - (float)(ped_r + rsl));  // yaml_env.py:455-456
-            in_box = !(dpx > 3 || dpx < -3 || dpy > 3 || dpy < -3);          // yaml_env.py:409-410
-        }
-        in_mask[it] = __ballot(in_box);
-        if (lane == 0) cnt[it * NW + wid] = __popcll(in_mask[it]);
-    }
-    __syncthreads();
-    int n_in = 0;
-    {
-        int before = 0;  // pedestrians inside the box in the chunks in front of this wavefront's next one
-        int c = 0;
-#pragma unroll
-        for (int it = 0; it < E; it++) {
-            const int mine = it * NW + wid;
-            for (; c < mine; c++) before += cnt[c];
-            const int q = it * NT + tid;
-            if ((in_mask[it] >> lane) & 1ull) inbox[before + __popcll(in_mask[it] & ((1ull << lane) - 1ull))] = (uint16_t)q;
-        }
-        for (int c2 = 0; c2 < E * NW; c2++) n_in += cnt[c2];
-    }
-    // ped_map (yaml_env.py:409-427), sparse update (see k_obs): last step's cells cleared by everyone, the discs stamped by wavefront 0
-    float* pm = w.ped_maps + (size_t)l * 3 * NP;
-    uint16_t* prev = w.pm_cells + (size_t)l * PM_CAP;
-    const int n_prev = w.pm_n[l];
-    if (n_prev >= 0) {
-        for (int e = tid; e < n_prev; e += NT) {
-            const int c = prev[e];
-            pm[c] = 0.0f;
-            pm[NP + c] = 0.0f;
-            pm[2 * NP + c] = 0.0f;
-        }
-    } else {
-        for (int c4 = tid * 4; c4 < 3 * NP; c4 += NT * 4) {
-            if (c4 + 4 <= 3 * NP) {
-                *(float4*)(pm + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                for (int q = c4; q < 3 * NP; q++) pm[q] = 0.0f;
-            }
-        }
-    }
-    __syncthreads();  // the clears are out, the box list is complete
-    if (wid != 0) return;
-    min_dist = __shfl(min_dist, 0);
-    int n_new = 0;
-    const double pres = w.ped_res, pinv = w.ped_inv_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
-    for (int e = 0; e < n_in; e++) {
-        // (this wavefront's earlier stores are out before the next disc goes over them: later discs overwrite earlier ones)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const int je = ord[inbox[e]];
-        const float2 f = info[je];
-        double evx, evy;
-        ped_vel(je, evx, evy);
-        const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
-        const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
-        int ax, bx, ay, by;
-        if (pinv != 0.0) {
-            ax = (int)floor((tmx - pr) * pinv);
-            bx = (int)floor((tmx + pr) * pinv);
-            ay = (int)floor((tmy - pr) * pinv);
-            by = (int)floor((tmy + pr) * pinv);
-        } else {
-            ax = (int)py_floordiv(tmx - pr, pres);
-            bx = (int)py_floordiv(tmx + pr, pres);
-            ay = (int)py_floordiv(tmy - pr, pres);
-            by = (int)py_floordiv(tmy + pr, pres);
-        }
-        const int wy = by - ay, n_c = (bx - ax) * wy;
-        for (int t0 = 0; t0 < n_c; t0 += WAVE) {
-            const int tt = t0 + lane;
-            bool hitc = false;
-            int c = 0;
-            if (tt < n_c) {
-                const int jj = ax + tt / wy, kq = ay + tt % wy;
-                if (jj >= 0 && jj < Hp && kq >= 0 && kq < Wp) {
-                    const double ddx = (jj + 0.5) * pres - tmx, ddy = (kq + 0.5) * pres - tmy;
-                    hitc = ddx * ddx + ddy * ddy < pr2;
-                    c = jj * Wp + kq;
-                }
-            }
-            if (hitc) {
-                pm[c] = 1.0f;
-                pm[NP + c] = fvx;
-                pm[2 * NP + c] = fvy;
-            }
-            const unsigned long long mask = __ballot(hitc);
-            const int pos = n_new + __popcll(mask & ((1ull << lane) - 1ull));
-            if (hitc && pos < PM_CAP) touched[pos] = (uint16_t)c;
-            n_new += __popcll(mask);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (n_new <= PM_CAP) {
-        for (int e = lane; e < n_new; e += WAVE) prev[e] = touched[e];
-        if (lane == 0) w.pm_n[l] = n_new;
-    } else if (lane == 0) {
-        w.pm_n[l] = -1;
-    }
     if (lane == 0) w.ped_min_dists[l] = min_dist;
     tail_arrive_obs(w, blockIdx.x, l, min_dist);
 }

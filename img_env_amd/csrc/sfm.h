@@ -1,3 +1,10 @@
+/*
+ * THIRD-PARTY NOTICE.  The force model, its constants, the waypoint logic and the quadtree's insert / erase / split rules in this
+ * file restate libpedsim ("pedsim - A microscopic pedestrian simulation system.  Copyright (c) by Christian Gloor",
+ * http://pedsim.silmaril.org/, distributed under the GNU General Public License) as vendored by the reference in
+ * src/3rdparty/pedsimros -- formulas and rule order are necessarily its own, since results must match it.
+ * Changes made here: restated for one 256-thread workgroup per crowd on gfx950 -- pair terms spread over the chip, the tree's surgery decided from per-leaf counts and replayed only where order matters, a correctly rounded atan2 (cr_atan2.h).  See NOTICE at the repository root.
+ */
 // sfm.h -- libpedsim social-force pedestrians (PedScene, src/img_env/src/pedscene.h:17-91) for the HIP path.
 //
 // Reference: src/3rdparty/pedsimros  Tagent::desiredForce / socialForce / obstacleForce / lookaheadForce /

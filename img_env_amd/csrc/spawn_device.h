@@ -368,6 +368,7 @@ __device__ bool sp_rvo_add(SpawnScratch& L, const float* xy, int n) {
     return true;
 }
 
+// (restates RVO2's KdTree::buildObstacleTree -- Copyright 2008 University of North Carolina at Chapel Hill, Apache License 2.0; see NOTICE)
 // KdTree::buildObstacleTreeRecursive (KdTree.cpp:131-257) with an explicit stack; returns the root or -1, status on overflow
 __device__ int sp_rvo_build(SpawnScratch& L) {
     const float EPS = 0.00001f;

@@ -37,16 +37,21 @@ class World:
         self.params["device"] = self.device.index
         # Output ownership.  The reference hands out fresh copies with every step (ROS responses); this library hands out its
         # working copies, read-only by contract (include/imgenv.h).  params["output_guard"] (or IMGENV_OUTPUT_GUARD in the
-        # environment, which wins): "check" = IMGENV_FLAG_CHECK_OUTPUTS, a write by the caller fails the next call;
-        # "copy" = IMGENV_FLAG_FULL_REWRITE, `out` is then a second arena rewritten in full by every call.  Default: neither.
-        guard = os.environ.get("IMGENV_OUTPUT_GUARD") or self.params.pop("output_guard", None)
+        # environment, which wins): "first" (THE DEFAULT) = IMGENV_FLAG_CHECK_OUTPUTS_FIRST, a write by the caller during the
+        # handle's first 64 calls fails the next call, loudly, and the guard then switches itself off; "check" = the same for
+        # good (IMGENV_FLAG_CHECK_OUTPUTS); "copy" = IMGENV_FLAG_FULL_REWRITE, `out` is then a second arena rewritten in full by
+        # every call; "none" = the bare C-ABI default.
+        guard = os.environ.get("IMGENV_OUTPUT_GUARD") or self.params.pop("output_guard", None) or "first"
         self.params.pop("output_guard", None)
-        if guard not in (None, "", "none", "check", "copy"):
-            raise ValueError("output_guard: none | check | copy")
+        if guard not in ("none", "first", "check", "copy"):
+            raise ValueError("output_guard: none | first | check | copy")
         if guard == "check":
             self.params["flags"] = int(self.params.get("flags", 0)) | _cabi.FLAG_CHECK_OUTPUTS
         elif guard == "copy":
             self.params["flags"] = int(self.params.get("flags", 0)) | _cabi.FLAG_FULL_REWRITE
+        elif guard == "first" and not int(self.params.get("flags", 0)) & (_cabi.FLAG_CHECK_OUTPUTS | _cabi.FLAG_FULL_REWRITE):
+            self.params["flags"] = int(self.params.get("flags", 0)) | _cabi.FLAG_CHECK_OUTPUTS_FIRST
+        self.output_guard = guard
         self.grid = np.ascontiguousarray(grid, np.uint8)
         cfg, self._keep = _cabi.make_cfg(self.params)
         nbytes = self.lib.imgenv_arena_bytes(C.byref(cfg))

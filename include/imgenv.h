@@ -194,6 +194,13 @@ typedef struct imgenv_cfg {
  * Costs one device-to-device copy of imgenv_arena_bytes() per call. */
 #define IMGENV_FLAG_CHECK_OUTPUTS 128
 #define IMGENV_FLAG_FULL_REWRITE 256
+/* IMGENV_FLAG_CHECK_OUTPUTS for the first IMGENV_CHECK_FIRST_CALLS reset / step calls of the handle only; the guard then switches
+ * itself off and costs nothing.  A trainer that normalises observations in place does so from its first step: it is told at once,
+ * loudly, instead of training on silently corrupted views -- and a correct one pays a synchronisation per call for a fraction of
+ * a second.  The Python mirror (img_env_amd.World, ImageEnv, VecImageEnv) creates every handle with it unless told otherwise
+ * (params["output_guard"] = "none" | "first" | "check" | "copy"). */
+#define IMGENV_FLAG_CHECK_OUTPUTS_FIRST 1024
+#define IMGENV_CHECK_FIRST_CALLS 64
 
 /* ResetEnv.srv:1-6 (img_env.cpp:162-292).  Poses are (x, y, qz, qw): geometry_msgs/Pose with a
  * planar orientation; yaw is recovered with tf::Matrix3x3(q).getRPY as the node does. */

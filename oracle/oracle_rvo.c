@@ -1,4 +1,19 @@
 /*
+ * THIRD-PARTY NOTICE.  The ORCA half-plane construction, the linear programs and the obstacle k-d tree walk in this file follow
+ * the RVO2 Library (as vendored by the reference in src/3rdparty/ervo_ros, with the ERVO additions) statement for statement --
+ * a float32 LP whose result depends on the order of its operations has essentially one spelling if it is to stay bit-exact:
+ *
+ *   RVO2 Library.  Copyright 2008 University of North Carolina at Chapel Hill.
+ *   Licensed under the Apache License, Version 2.0 (the "License"); you may not use this file except in compliance with the
+ *   License.  You may obtain a copy of the License at http://www.apache.org/licenses/LICENSE-2.0
+ *   Unless required by applicable law or agreed to in writing, software distributed under the License is distributed on an
+ *   "AS IS" BASIS, WITHOUT WARRANTIES OR CONDITIONS OF ANY KIND, either express or implied.  See the License for the specific
+ *   language governing permissions and limitations under the License.
+ *   Authors: Jur van den Berg, Stephen J. Guy, Jamie Snape, Ming C. Lin, Dinesh Manocha -- <http://gamma.cs.unc.edu/RVO2/>
+ *
+ * Changes made here: restated in plain C, index links instead of pointers, one translation unit, used as a test oracle only.  See NOTICE at the repository root.
+ */
+/*
  * oracle_rvo.c -- TEST INFRASTRUCTURE (oracle), never linked into the product library.
  *
  * CPU restatement (plain C, float32) of the RVO2 v2.0.x ORCA library + the ERVO add-on the

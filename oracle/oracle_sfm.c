@@ -1,4 +1,11 @@
 /*
+ * THIRD-PARTY NOTICE.  The force model, its constants, the waypoint logic and the quadtree's insert / erase / split rules in this
+ * file restate libpedsim ("pedsim - A microscopic pedestrian simulation system.  Copyright (c) by Christian Gloor",
+ * http://pedsim.silmaril.org/, distributed under the GNU General Public License) as vendored by the reference in
+ * src/3rdparty/pedsimros -- formulas and rule order are necessarily its own, since results must match it.
+ * Changes made here: restated in plain C in one translation unit, agents in arrays instead of heap objects; used as a test oracle only.  See NOTICE at the repository root.
+ */
+/*
  * oracle_sfm.c -- TEST INFRASTRUCTURE (oracle), never linked into the product library.
  *
  * CPU restatement (plain C, float64) of the libpedsim social-force model the reference vendors in

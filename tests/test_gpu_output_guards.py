@@ -113,3 +113,36 @@ def test_full_rewrite_is_refused_in_a_robot_shard(World):
     params = dict(params, output_guard="copy", robot_begin=0, robot_end=12)
     with pytest.raises(ValueError, match="robot shard"):
         World(params, grid)
+
+
+def test_default_handle_is_loud_for_its_first_calls_and_free_afterwards(World):
+    """`World`'s default (output_guard "first" = IMGENV_FLAG_CHECK_OUTPUTS_FIRST): a trainer that normalises an observation in
+    place is told on its next call -- during the handle's first 64 calls; afterwards the guard has switched itself off (no
+    checksum kernels, no synchronisation), and what a caller writes then is its own business, as the header says."""
+    import torch
+    from img_env_amd import _cabi
+    w, layout = _world(World, None)
+    try:
+        assert w.output_guard == "first" and w.params["flags"] & _cabi.FLAG_CHECK_OUTPUTS_FIRST
+        rng = np.random.default_rng(8)
+        n = CASE["n_robots"]
+        w.reset(layout)
+        w.step(random_actions(rng, n))
+        torch.cuda.synchronize()
+        w.out["sensor_maps"].view(-1)[5] += 1  # the in-place write
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match=r"wrote into imgenv_out\.sensor_maps"):
+            w.step(random_actions(rng, n))
+        w.out["sensor_maps"].view(-1)[5] -= 1
+        torch.cuda.synchronize()
+        launches_guarded = None
+        for s in range(70):  # past the 64th call
+            w.step(random_actions(rng, n))
+            if s == 0:
+                launches_guarded = w.launches()
+        torch.cuda.synchronize()
+        w.out["sensor_maps"].view(-1)[5] += 1
+        torch.cuda.synchronize()
+        w.step(random_actions(rng, n))  # no longer looked at
+    finally:
+        w.close()

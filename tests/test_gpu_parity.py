@@ -1094,6 +1094,7 @@ def test_step_waits_for_actions_written_on_the_callers_stream(worlds, n, grid_si
     World, _ = worlds
     # (512 robots: the move inside the raster launch, k_obs behind it; 2048: early-observation steps on one side stream; 8192: on two)
     grid, params, layout = small_world(n, 40, seed=91, grid_size=grid_size, res=0.25, clearance=0.6, n_obstacles=2)
+    params = dict(params, output_guard="none")  # (World's default guard synchronises during a handle's first 64 calls)
     a, b = World(params, grid), World(params, grid)
     try:
         a.reset(layout)

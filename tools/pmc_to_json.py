@@ -46,16 +46,12 @@ for d in sys.argv[4:]:
                 out[k][key] = v / sq_waves[k]
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (8192 robots, 200 peds); "
                 "KiB -> bytes; FETCH doubled per the gfx950 correction; per kernel launch")
-# which library these passes ran on: bench.py quotes the counters only for a library with the same id (imgenv_build_id)
-import ctypes
+# which library these passes ran on: bench.py quotes the counters only for a library with the same id (imgenv_build_id), read
+# from the file's bytes as __graft_entry__ does
 import os
-_so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "img_env_amd", "csrc", "libimgenv_hip.so")
-try:
-    _lib = ctypes.CDLL(_so)
-    _lib.imgenv_build_id.restype = ctypes.c_char_p
-    out["build_id"] = _lib.imgenv_build_id().decode()
-except (OSError, AttributeError):
-    out["build_id"] = None
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as _g  # noqa: E402
+out["build_id"] = _g._built_id(os.path.join(_g.CSRC, "libimgenv_hip.so"))
 path = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_latest.json"
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 so = os.path.join(g.CSRC, "libimgenv_hip_tl.so")
-subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + ["-DIMGENV_WAVE_TIMELINE", os.path.join(g.CSRC, "imgenv_hip.hip"), "-o", so])
+subprocess.check_call(g.hip_command(so, ["-DIMGENV_WAVE_TIMELINE"]))
 from img_env_amd import _cabi, worldgen  # noqa: E402
 _cabi.library_path = lambda: so
 import torch  # noqa: E402
