@@ -665,8 +665,10 @@ def main():
                 if counters_ok:
                     traffic = counters.get(dominant, {}).get("hbm_bytes_per_launch")
                     # every kernel of a step once (k_reset_apply is not part of a step)
+                    # (nor are the output guard's checksum kernels of a handle's first 64 calls, or the once-per-process gate probe)
                     path_traffic = sum(v["hbm_bytes_per_launch"] for k, v in counters.items()
-                                       if k.startswith("k_") and not k.startswith("k_reset") and k != "k_cell_base" and isinstance(v, dict))
+                                       if k.startswith("k_") and not k.startswith(("k_reset", "k_out_", "k_gate_probe", "k_state")) and k != "k_cell_base"
+                                       and isinstance(v, dict))
                     traffic_source = ("profiles/%s, collected on build %s = the library of this run: rocprofv3 --pmc FETCH_SIZE and "
                                       "--pmc WRITE_SIZE passes (separate runs, gfx950 corrections) over this same bench command -- committed "
                                       "with the build, NOT collected during this run" % (os.path.basename(pmc), pmc_id))

@@ -1335,17 +1335,11 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         }
     }
     HIPCHK_H(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    {   // (round-6 experiment, IMGENV_OBS_CUS=n: the observation's stream on n of the chip's compute units only -- mask bits are dealt
-        // round-robin over the XCDs -- so that the move's successors find free units at once; see docs/HISTORY.md for the verdict)
-        static const int obs_cus = getenv("IMGENV_OBS_CUS") ? atoi(getenv("IMGENV_OBS_CUS")) : 0;
-        if (obs_cus > 0 && obs_cus < 256) {
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int q = 0; q < obs_cus; q++) mask[q >> 5] |= 1u << (q & 31);
-            HIPCHK_H(hipExtStreamCreateWithCUMask(&h->side2, 8, mask));
-        } else {
-            HIPCHK_H(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-        }
-    }
+    // (Round 6 tried the observation's stream on a subset of the compute units, hipExtStreamCreateWithCUMask, so that the move's
+    // successors find free units at once: such a stream is a BLOCKING one -- it serialises against a caller on the null stream, 95 ->
+    // 213 us per step whatever the mask -- and beside a caller on a stream of its own 24 / 28 / 16 of an XCD's 32 units cost 99.2 /
+    // 99.5 / 108.3 us against 95.5: the step is bound by the instructions it issues, not by where they run.  docs/HISTORY.md)
+    HIPCHK_H(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     if (h->early) {  // gates (world.h: sync) only where kernels of two streams really run side by side: k_gate_probe
         static int gates_work = -1;  // (per process)
         if (gates_work < 0) {
@@ -1522,7 +1516,6 @@ static int launch_obs_kernel(imgenv* h, hipStream_t s_obs) {
         case 2: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<2><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         case 4: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<4><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
         case 8: TIMED(h, IMGENV_K_OBS, s_obs, (k_obs<8><<<go, bo, lds_obs, s_obs>>>(d, h->PP))); break;
-        // (513 .. 1024 pedestrians: four wavefronts share one robot's LDS -- k_obs_wg)
         // (four wavefronts per robot for 513 .. 1024 pedestrians -- three times the occupancy, a third of the LDS per wavefront --
         // were measured in round 6 and LOSE: cfg-5 277 -> 325 us per step, 321 with two, 406 with eight: the step is bound by the
         // instructions it issues, k_obs beside k_view, not by this kernel's occupancy.  docs/HISTORY.md)
@@ -1551,7 +1544,7 @@ static int launch_obs(imgenv* h, hipStream_t st) {
 // The rasters of a chain of launches (in front of them, in STAMP mode, every STAMP_TAGS steps the sweep): every robot of the launch
 // and every pedestrian -- or, local_only (a step of a robot shard in SUM mode, world.h: sum_shard), this rank's robots and the
 // pedestrians: the other ranks' robots follow behind the exchange (k_remote)
-static int launch_rasters(imgenv* h, hipStream_t st, int is_reset, bool moved, bool local_only) {
+static int launch_rasters(imgenv* h, hipStream_t st, int is_reset, bool moved, bool local_only, bool from_begin = false) {
     DevWorld& d = h->d;
     const int keep_ng = d.act_ng;
     if (local_only) {
@@ -1578,8 +1571,8 @@ static int launch_rasters(imgenv* h, hipStream_t st, int is_reset, bool moved, b
     const size_t lds = 4 * (size_t)d.box_cells + 16;
     const int variant = (h->pow2 ? 3 : 0) + (h->stamp ? 1 : h->sum ? 2 : 0);
     // (k_move_raster: the step's move in the same launch -- the RVO / recorded pedestrians' too; a social-force crowd has moved in k_sfm)
-    // (imgenv_step_end has counted the step when it launches this; a shard's imgenv_step_begin has not yet)
-    const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = local_only ? h->elapsed : h->elapsed - 1;
+    // (imgenv_step_end has counted the step when it launches this; imgenv_step_begin has not yet)
+    const int move_peds = h->P > 0 && (h->NA > 0 || h->cfg.ped_scene_type == IMGENV_SCENE_DATASET) ? 1 : 0, step_now = from_begin ? h->elapsed : h->elapsed - 1;
 #define RASTER_CASE(N, P2, LM)                                                                                        \
     case N:                                                                                                           \
         if (moved && small) TIMED(h, IMGENV_K_MOVE_RASTER, st, (k_move_raster<P2, LM, 4><<<gr, br, lds, st>>>(d, h->move_actions, h->n_sub, step_now, move_peds))); \
@@ -2563,6 +2556,9 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     if (int rc = check_device_flags(h)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (int rc = outputs_verify(h, st)) return rc;
+    // (from here on the step's own kernels write output arrays; the chain's end seals them again.  A step that is begun and never
+    // ended -- the caller's exchange failed -- must not read as "the caller wrote into imgenv_out" at the reset that recovers it)
+    h->guard_sealed = false;
     DevWorld& d = h->d;
     h->launches = 0;
     // _step_ped_normal (img_env.cpp:304-359): the ORCA solve for this step ran on the side stream during the previous
@@ -2616,18 +2612,45 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     }
     // _step_robot (img_env.cpp:388-410)
     // (a robot shard in SUM mode draws its own robots in this call anyway: the move goes into that launch, whoever runs the exchange)
-    const bool fuse_move = ((h->in_step && !d.sharded && !h->comm && h->RL == h->R) || d.sum_shard) && h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS &&
-                           (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024);
+    const bool fuse_ok = h->n_sub >= 1 && h->n_sub + 2 <= INT_ITEMS;
+    const bool whole_call = h->in_step && !d.sharded && !h->comm && h->RL == h->R;  // imgenv_step on a handle that owns its world
+    const bool fuse_small = (whole_call || d.sum_shard) && fuse_ok && (h->P == 0 ? h->RL <= 4096 : h->RL <= 1024);
+    // (the move inside the raster launch of BIG handles, with the early observation gated on that launch, was measured again in round 6:
+    // 95.0 -> 103.1 us per headline step, cfg-4 117-123 -> 126, cfg-5 280 -> 282: the move's serial chain in front of every robot's
+    // raster costs more than the launch it saves)
+    const bool fuse_move = fuse_small;
     // early-observation step (world.h): k_obs goes out with the move, on its side stream, instead of behind it -- behind a gate that
     // opens when the caller's stream reaches this step's move (world.h: sync; only where gates work: k_gate_probe)
     static const int force_early = getenv("IMGENV_EARLY_OBS") ? atoi(getenv("IMGENV_EARLY_OBS")) : -1;  // (measurement switch)
     const bool live_peds = h->NA == 0;  // (a social-force crowd a step ahead: see imgenv_create)
-    const bool early_step = h->early && h->gates_work && !fuse_move && !h->chain_open && (live_peds ? h->sfm_ahead : h->orca_seq > 0) && h->view_seq > 0 &&
-                            force_early != 0;
+    const bool early_step = h->early && h->gates_work && !fuse_move && !h->chain_open && (live_peds ? h->sfm_ahead : h->orca_seq > 0) &&
+                            h->view_seq > 0 && force_early != 0;
     if (early_step) h->gate_seq += 1;
-    if (fuse_move && d.sum_shard) {  // k_move_raster over the shard's own robots and the pedestrians, now; the observation behind it
+    // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions.  It waits behind a gate
+    // that opens when the caller's stream reaches the move (k_gate): everything queued there in front of the step is then complete
+    // -- whoever writes the actions, whoever still reads the last step's outputs, the last chain's views.  Queued BEHIND the move --
+    // a gate must follow the kernel that opens it in queue order; what the caller's stream forks behind the move is the solve alone.
+    auto early_obs = [&]() -> int {
+        h->chain_open = true;
+        if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
+        h->fork_on_move = false;
+        k_gate<<<dim3(1), dim3(WAVE), 0, h->side2>>>(d.sync, h->gate_seq, d.err);
+        h->launches += 1;
+        d.obs_early = live_peds ? 2 : 1;
+        d.obs_actions = actions;
+        d.obs_n_sub = h->n_sub;
+        d.ped_snap_in = h->ped_snap[(h->orca_seq - 1) & 1];
+        d.rec_snap_in = h->rec_snap[(h->view_seq - 1) & 1];
+        const int rc = launch_obs_kernel(h, h->side2);
+        d.obs_early = 0;
+        if (rc) return rc;
+        h->obs_forked = true;
+        h->early_step = true;
+        return 0;
+    };
+    if (fuse_move && d.sum_shard) {  // k_move_raster over the shard's own robots and the pedestrians, now (in front of the exchange); the observation behind it
         h->move_actions = actions;
-        if (int rc = launch_rasters(h, st, 0, true, true)) return rc;
+        if (int rc = launch_rasters(h, st, 0, true, true, true)) return rc;
         h->launches += 1;
         set_tail_fields(h, 0, h->elapsed + 1);
         if (h->P > 0)
@@ -2657,33 +2680,14 @@ extern "C" int imgenv_step_begin(imgenv_t* h, const float* actions, void* stream
     h->launches += 1;
     set_tail_fields(h, 0, h->elapsed + 1);  // imgenv_step_end counts the step; k_obs goes out before that
     if (early_step) {
-        // k_obs beside the move instead of behind it (world.h): it needs nothing of this step but the actions.  It waits behind a
-        // gate that opens when the caller's stream reaches the move (k_gate): everything queued there in front of the step is then
-        // complete -- whoever writes the actions, whoever still reads the last step's outputs, the last chain's views.  Queued BEHIND
-        // k_integrate -- a gate must follow the kernel that opens it in queue order, and the move's few workgroups are dispatched
-        // first; what the caller's stream forks behind the move is the solve alone.
-        h->chain_open = true;
-        if (!h->fork_on_move) HIPCHK(hipEventRecord(h->ev_fork, st));
-        h->fork_on_move = false;
-        k_gate<<<dim3(1), dim3(WAVE), 0, h->side2>>>(d.sync, h->gate_seq, d.err);
-        h->launches += 1;
-        d.obs_early = live_peds ? 2 : 1;
-        d.obs_actions = actions;
-        d.obs_n_sub = h->n_sub;
-        d.ped_snap_in = h->ped_snap[(h->orca_seq - 1) & 1];
-        d.rec_snap_in = h->rec_snap[(h->view_seq - 1) & 1];
-        const int rc = launch_obs_kernel(h, h->side2);
-        d.obs_early = 0;
-        if (rc) return rc;
-        h->obs_forked = true;
-        h->early_step = true;
+        if (int rc = early_obs()) return rc;
     } else if (h->P > 0) {
         if (int rc = launch_obs(h, st)) return rc;
     }
     // a robot shard in SUM mode (world.h: sum_shard) draws its own robots -- and the pedestrians -- NOW, in front of the exchange:
     // their records then carry the cells they cover to the other ranks
     if (d.sum_shard)
-        if (int rc = launch_rasters(h, st, 0, false, true)) return rc;
+        if (int rc = launch_rasters(h, st, 0, false, true, true)) return rc;
     HIPCHK(hipGetLastError());
     return sfm_launch_ahead(h);
 }
@@ -3256,8 +3260,8 @@ extern "C" int imgenv_debug_marks(imgenv_t* h, unsigned long long* out32) {
 // debug / tests: the quadtree of world `world`'s social-force crowd as a digest that does not depend on how the nodes are numbered --
 // node count, member entries, a sum of per-leaf hashes (rectangle + sorted members), a sum of per-agent hashes (the rectangle the
 // agent's treehash entry points at).  tests/test_gpu_parity.py holds it to the oracle's tree (oracle_sfm.c: sfm_tree_digest) step by step.
-extern "C" int imgenv_debug_sfm_tree(imgenv_t* h, int32_t world, uint64_t* out4 /* [8] */) {
-    if (!h || !out4) FAIL(IMGENV_EINVAL, "null argument");
+extern "C" int imgenv_debug_sfm_tree(imgenv_t* h, int32_t world, uint64_t* out8 /* [8]: node count, member entries, leaf-hash sum, agent-hash sum, 256 membership bits */) {
+    if (!h || !out8) FAIL(IMGENV_EINVAL, "null argument");
     const SfmDev& f = h->d.sfm;
     if (h->cfg.ped_scene_type != IMGENV_SCENE_PEDSIM || f.n <= 0 || world < 0 || world >= f.W) FAIL(IMGENV_EINVAL, "no social-force crowd %d", world);
     HIPCHK(hipDeviceSynchronize());
@@ -3276,13 +3280,13 @@ extern "C" int imgenv_debug_sfm_tree(imgenv_t* h, int32_t world, uint64_t* out4 
     };
     auto rect = [&](uint64_t a, const SfmNode& q) { return mix(mix(mix(mix(a, bits(q.x)), bits(q.y)), bits(q.w)), bits(q.h)); };
     uint64_t members = 0, leaves = 0, agents = 0;
-    out4[4] = out4[5] = out4[6] = out4[7] = 0;  // one bit per agent that is a member of some leaf
+    out8[4] = out8[5] = out8[6] = out8[7] = 0;  // one bit per agent that is a member of some leaf
     for (const SfmNode& q : nodes) {
         if (!q.isleaf || q.n_agents == 0) continue;
         uint64_t a = mix(rect(0xcbf29ce484222325ull, q), (uint64_t)q.n_agents);
         for (int e = 0; e < q.n_agents; e++) {
             a = mix(a, (uint64_t)q.agents[e]);
-            if (q.agents[e] >= 0 && q.agents[e] < 256) out4[4 + (q.agents[e] >> 6)] |= 1ull << (q.agents[e] & 63);
+            if (q.agents[e] >= 0 && q.agents[e] < 256) out8[4 + (q.agents[e] >> 6)] |= 1ull << (q.agents[e] & 63);
         }
         leaves += a;
         members += (uint64_t)q.n_agents;
@@ -3291,7 +3295,7 @@ extern "C" int imgenv_debug_sfm_tree(imgenv_t* h, int32_t world, uint64_t* out4 
         if (hash[a] < 0 || hash[a] >= n_nodes) FAIL(IMGENV_EDEVICE, "treehash[%d] = %d", a, hash[a]);
         agents += rect(mix(0xcbf29ce484222325ull, (uint64_t)a), nodes[(size_t)hash[a]]);
     }
-    out4[0] = (uint64_t)n_nodes; out4[1] = members; out4[2] = leaves; out4[3] = agents;
+    out8[0] = (uint64_t)n_nodes; out8[1] = members; out8[2] = leaves; out8[3] = agents;
     return IMGENV_OK;
 }
 // debug: per-wave (start, end, hw id, 0) records of the last k_view [0, 4 RL) and k_obs [4 RL, 8 RL) launches

@@ -169,10 +169,9 @@ class World:
         return actions
 
     def step(self, actions, actions_ready=None):
-        """One step.  ``actions_ready``: the values of ``actions`` are complete now, not merely queued on the current stream
-        (``IMGENV_STEP_ACTIONS_READY``: the library may then start the observation kernel beside the move).  Default: true for
-        host data (this method copies it to the device, and torch's copy from pageable memory is complete when it returns), false for a device tensor -- a policy may
-        still be writing it on the stream."""
+        """One step, ordered on the current stream: behind whatever writes ``actions`` there, and behind whatever still reads the
+        last step's outputs there.  ``actions_ready`` (``IMGENV_STEP_ACTIONS_READY``) is accepted for compatibility and has had no
+        effect since round 6 (include/imgenv.h)."""
         import torch
         if actions_ready is None:
             actions_ready = not isinstance(actions, torch.Tensor)

@@ -40,7 +40,7 @@ void oracle_test_corners(int shape, const double* sizes, double x, double y, dou
 /* the first n values of glibc's rand() after srand(seed), from the oracle's restatement (the beep lottery's stream) */
 void oracle_test_glibc_rand(unsigned int seed, int n, int32_t* out);
 /* the social-force crowd's quadtree as a digest that does not depend on node numbering (oracle_sfm.c: sfm_tree_digest) */
-int oracle_sfm_tree(oracle_world* w, uint64_t* out4);
+int oracle_sfm_tree(oracle_world* w, uint64_t* out8);
 
 #ifdef __cplusplus
 }

@@ -723,9 +723,9 @@ int oracle_grids(oracle_world* w, const uint8_t** obs_map, const uint8_t** peds_
     return IMGENV_OK;
 }
 
-int oracle_sfm_tree(oracle_world* w, uint64_t* out4) {
-    if (!w || !w->sfm || !out4) return IMGENV_EINVAL;
-    sfm_tree_digest(w->sfm, out4);
+int oracle_sfm_tree(oracle_world* w, uint64_t* out8) {
+    if (!w || !w->sfm || !out8) return IMGENV_EINVAL;
+    sfm_tree_digest(w->sfm, out8);
     return IMGENV_OK;
 }
 

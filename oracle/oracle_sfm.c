@@ -559,9 +559,9 @@ static uint64_t digest_f64(double v) {
     memcpy(&b, &v, sizeof(b));
     return b;
 }
-void sfm_tree_digest(const sfm_scene* s, uint64_t* out4) { /* out4[4 .. 7]: one bit per agent that is a member of some leaf */
+void sfm_tree_digest(const sfm_scene* s, uint64_t* out8 /* [8] */) { /* out8[4 .. 7]: one bit per agent that is a member of some leaf */
     uint64_t members = 0, leaves = 0, agents = 0;
-    out4[4] = out4[5] = out4[6] = out4[7] = 0;
+    out8[4] = out8[5] = out8[6] = out8[7] = 0;
     for (int k = 0; k < s->n_nodes; k++) {
         const qnode* q = &s->nodes[k];
         if (!q->isleaf || q->n_agents == 0) continue;
@@ -571,7 +571,7 @@ void sfm_tree_digest(const sfm_scene* s, uint64_t* out4) { /* out4[4 .. 7]: one 
         h = digest_mix(h, (uint64_t)q->n_agents);
         for (int e = 0; e < q->n_agents; e++) {
             h = digest_mix(h, (uint64_t)q->agents[e]);
-            if (q->agents[e] < 256) out4[4 + (q->agents[e] >> 6)] |= 1ull << (q->agents[e] & 63);
+            if (q->agents[e] < 256) out8[4 + (q->agents[e] >> 6)] |= 1ull << (q->agents[e] & 63);
         }
         leaves += h;
         members += (uint64_t)q->n_agents;
@@ -584,7 +584,7 @@ void sfm_tree_digest(const sfm_scene* s, uint64_t* out4) { /* out4[4 .. 7]: one 
         h = digest_mix(h, digest_f64(q->w)); h = digest_mix(h, digest_f64(q->h));
         agents += h;
     }
-    out4[0] = (uint64_t)s->n_nodes; out4[1] = members; out4[2] = leaves; out4[3] = agents;
+    out8[0] = (uint64_t)s->n_nodes; out8[1] = members; out8[2] = leaves; out8[3] = agents;
 }
 
 

@@ -29,7 +29,7 @@ void sfm_get_ped(const sfm_scene* s, int j, double* x, double* y, double* vx, do
 void sfm_get_agent(const sfm_scene* s, int idx, double* out6);
 double sfm_get_vmax(const sfm_scene* s, int idx);
 /* test aid: node count, member entries, numbering-independent hashes of the leaves and of the treehash (oracle_sfm.c) */
-void sfm_tree_digest(const sfm_scene* s, uint64_t* out4);
+void sfm_tree_digest(const sfm_scene* s, uint64_t* out8 /* [8] */);
 /* restart the two process-global random streams (minstd_rand0 for vmax, glibc rand() for the tree positions) */
 void sfm_reseed(void);
 /* test-only: 1 = every atan2 of the model correctly rounded (libquadmath atan2q rounded once), 0 = the host libm's (default) */

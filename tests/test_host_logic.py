@@ -311,3 +311,25 @@ def test_episode_stats_accumulate_what_the_reference_computes_from_lists():
         for k, x in want.items():
             assert abs(float(out[k][r]) - x) < 1e-9, (k, r)
     assert float(st.n.sum()) == 0  # finish() starts the accumulators over
+
+
+def test_bench_workloads_are_the_baseline_configs():
+    """bench.py's --config table against BASELINE.json's configs as worldgen.PRESETS spells them, and the algorithmic bytes per
+    robot-step against SURVEY.md section 8(d)'s own numbers (10 784 B for cfg-2 with the f16 copy, 48 036 for cfg-3, 97 092 +
+    2 x 96^2 for cfg-5 with the f16 copy)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for name, wl in bench.WORKLOADS.items():
+        pre = worldgen.PRESETS[name]
+        assert wl["grid"] == pre["grid"] and wl["res"] == pre["res"] and wl["view"] == pre["view_cells"] and wl["beams"] == pre["beams"], name
+        assert wl["peds"] == pre["n_peds"] and wl["scene"] == pre["scene"], name
+        # robots: the world's for the configs that fit (or are strong-scaled over) one node, the per-GPU share of cfg-4's 65 536
+        assert wl["robots"] == (pre["n_robots"] if name != "cfg4" else pre["n_robots"] // 8), name
+    ab = bench.algorithmic_bytes
+    assert ab(0)["total"] == 10784
+    assert ab(200)["total"] == 48036
+    assert ab(1000, hv=96, wv=96, beams=720)["total"] == 97092 + 2 * 96 * 96
+    # every rank its own world, the same world strong-scaled, or one GPU's share weak-scaled: the three ways bench.py places robots
+    assert {w["scaling"] for w in bench.WORKLOADS.values()} == {"replicas", "strong", "weak"}
