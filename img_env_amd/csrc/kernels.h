@@ -2742,6 +2742,7 @@ __device__ __forceinline__ int tail_robot(const DevWorld& w, int l, int is_reset
 }
 
 #define PM_CAP 512  // cells of a robot's ped_map that may be non-zero before it falls back to dense clears
+#define OBS_DISCS_SERIAL 12  // pedestrians inside a robot's ped_map box up to which k_obs stamps their discs one behind the other
 
 // LDS: (key[PP] f64 sort keys, LDS sort only) | info[P] float2 (px,py) | ord[PP] u16 sorted ped index |
 //      inbox[PP] u16 ranks of the pedestrians inside the +-3 m box | stage[64*7] f32, later touched[PM_CAP] u16
@@ -3134,7 +3135,108 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(E <= 8 ? 8
         }
         int n_new = 0;
         const double pres = w.ped_res, pinv = w.ped_inv_res, pr = w.ped_image_r, pr2 = w.ped_image_r2;
-        for (int e = 0; e < n_in; e++) {
+        // A robot that stands IN a crowd has dozens of pedestrians inside its box (cfg-4: up to 200 around the robots near the crowd's
+        // 10 m square), and discs one behind the other -- each waits for the last one's stores -- made those few wavefronts the
+        // kernel's tail: 93 us where the others take 30.  "Later discs overwrite earlier ones" = every cell ends with its HIGHEST-ranked
+        // disc, so: (A) a lane per disc puts its rank on its cells with atomicMax (plane 0 of the map holds the rank for a moment:
+        // cleared to 0 above, ranks 1 .. n_in, never the bits of 1.0f); (B) the lanes walk their discs again and the one whose rank a
+        // cell holds writes the cell's three values and lists it.  No order between discs is needed any more.  The same map, bit for bit.
+        const bool discs_in_parallel = n_in > OBS_DISCS_SERIAL;
+        if (discs_in_parallel) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the clears above are out before the first atomic lands on them)
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* rank_plane = (uint32_t*)pm;
+            for (int e0 = 0; e0 < n_in; e0 += WAVE) {  // uniform trip counts (ballots inside)
+                const int e = e0 + lane;
+                const bool has = e < n_in;
+                const int je = ord[inbox[has ? e : 0]];
+                const float2 f = info[je];
+                double evx, evy;
+                ped_vel(je, evx, evy);
+                const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
+                const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
+                int ax, bx, ay, by;
+                if (pinv != 0.0) {
+                    ax = (int)floor((tmx - pr) * pinv);
+                    bx = (int)floor((tmx + pr) * pinv);
+                    ay = (int)floor((tmy - pr) * pinv);
+                    by = (int)floor((tmy + pr) * pinv);
+                } else {
+                    ax = (int)py_floordiv(tmx - pr, pres);
+                    bx = (int)py_floordiv(tmx + pr, pres);
+                    ay = (int)py_floordiv(tmy - pr, pres);
+                    by = (int)py_floordiv(tmy + pr, pres);
+                }
+                const int wy = by - ay, cnt = has ? (bx - ax) * wy : 0;
+                int cnt_max = cnt;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cnt_max = max(cnt_max, __shfl_xor(cnt_max, off));
+                auto cell_of = [&](int tt, int& c) -> bool {  // the tt-th cell of this lane's disc's bounding box: inside the map and the disc?
+                    if (tt >= cnt) return false;
+                    const int a = tt / wy, jj = ax + a, kq = ay + (tt - a * wy);
+                    if (!(jj >= 0 && jj < Hp && kq >= 0 && kq < Wp)) return false;
+                    const double ddx = (jj + 0.5) * pres - tmx, ddy = (kq + 0.5) * pres - tmy;
+                    c = jj * Wp + kq;
+                    return ddx * ddx + ddy * ddy < pr2;
+                };
+                for (int tt = 0; tt < cnt_max; tt++) {  // (A)
+                    int c = 0;
+                    if (cell_of(tt, c)) atomicMax(&rank_plane[c], (uint32_t)(e + 1));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every rank has landed: the atomics are performed in L2)
+            __builtin_amdgcn_wave_barrier();
+            for (int e0 = 0; e0 < n_in; e0 += WAVE) {
+                const int e = e0 + lane;
+                const bool has = e < n_in;
+                const int je = ord[inbox[has ? e : 0]];
+                const float2 f = info[je];
+                double evx, evy;
+                ped_vel(je, evx, evy);
+                const float fvx = (float)((wb.m00 * evx + wb.m01 * evy) + 0.0), fvy = (float)((wb.m10 * evx + wb.m11 * evy) + 0.0);
+                const double tmx = -(double)f.x + 3, tmy = -(double)f.y + 3;
+                int ax, bx, ay, by;
+                if (pinv != 0.0) {
+                    ax = (int)floor((tmx - pr) * pinv);
+                    bx = (int)floor((tmx + pr) * pinv);
+                    ay = (int)floor((tmy - pr) * pinv);
+                    by = (int)floor((tmy + pr) * pinv);
+                } else {
+                    ax = (int)py_floordiv(tmx - pr, pres);
+                    bx = (int)py_floordiv(tmx + pr, pres);
+                    ay = (int)py_floordiv(tmy - pr, pres);
+                    by = (int)py_floordiv(tmy + pr, pres);
+                }
+                const int wy = by - ay, cnt = has ? (bx - ax) * wy : 0;
+                int cnt_max = cnt;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cnt_max = max(cnt_max, __shfl_xor(cnt_max, off));
+                for (int tt = 0; tt < cnt_max; tt++) {  // (B)
+                    bool mine = false;
+                    int c = 0;
+                    if (tt < cnt) {
+                        const int a = tt / wy, jj = ax + a, kq = ay + (tt - a * wy);
+                        if (jj >= 0 && jj < Hp && kq >= 0 && kq < Wp) {
+                            const double ddx = (jj + 0.5) * pres - tmx, ddy = (kq + 0.5) * pres - tmy;
+                            c = jj * Wp + kq;
+                            // (a cell another lane has finished already holds the bits of 1.0f: nobody's rank)
+                            mine = ddx * ddx + ddy * ddy < pr2 &&
+                                   __hip_atomic_load(&rank_plane[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(e + 1);
+                        }
+                    }
+                    if (mine) {
+                        pm[c] = 1.0f;
+                        pm[NP + c] = fvx;
+                        pm[2 * NP + c] = fvy;
+                    }
+                    const unsigned long long mask = __ballot(mine);
+                    const int pos = n_new + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (mine && pos < PM_CAP) touched[pos] = (uint16_t)c;
+                    n_new += __popcll(mask);
+                }
+            }
+        }
+        for (int e = 0; e < (discs_in_parallel ? 0 : n_in); e++) {
             __syncthreads();  // drains this wave's earlier stores: later discs overwrite earlier ones
             const int je = ord[inbox[e]];
             const float2 f = info[je];

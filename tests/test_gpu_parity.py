@@ -978,6 +978,37 @@ def test_ragged_trajectories_and_padded_ped_vector(worlds):
         cpu.close()
 
 
+@pytest.mark.parametrize("n_peds", [13, 40, 150])
+def test_robots_inside_a_crowd_get_the_reference_ped_map(worlds, n_peds):
+    """yaml_env.py:409-427 stamps the pedestrians inside the +-3 m box nearest first, so that farther discs overwrite nearer ones.
+    With more than a dozen of them k_obs stamps all discs at once (every cell takes its highest-ranked disc: rank plane +
+    atomicMax); a crowd packed into 3 m x 3 m around the robots -- every pedestrian in every robot's box, discs overlapping by the
+    dozen -- must give the oracle's map bit for bit, every step, also right behind the threshold between the two ways (13) and
+    with several rounds of 64 discs (150)."""
+    from img_env_amd import worldgen
+    World, OracleWorld = worlds
+    n = 6
+    grid = worldgen.make_grid(120, 5)
+    params = worldgen.make_params(n, n_peds, res=0.125)
+    layout = worldgen.make_layout(grid, 0.125, n, n_peds, seed=77, clearance=0.25)
+    rng = np.random.default_rng(9)
+    # everybody inside the same 3 m square: every robot has every pedestrian in its box
+    layout.robot_pose[:, :2] = rng.uniform(6.0, 9.0, (n, 2))
+    layout.ped_pose[:, :2] = rng.uniform(6.0, 9.0, (n_peds, 2))
+    layout.ped_traj[:, 1, :2] = layout.ped_pose[:, :2]
+    gpu, cpu = World(params, grid), OracleWorld(params, grid)
+    try:
+        fails = run_pair(gpu, cpu, layout, [random_actions(rng, n) for _ in range(10)])
+        assert not fails, fails[:2]
+        snap = cpu.snapshot()
+        inside = (np.abs(snap["ped_vector_states"][:, 1:].reshape(n, -1, 7)[:, :n_peds, :2]) <= 3).all(axis=2).sum(axis=1)
+        assert inside.max() > 12, inside  # the all-at-once path ran
+        assert (snap["ped_maps"][:, 0] > 0).sum() > 100
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def test_equidistant_pedestrians_keep_index_order(worlds):
     """two (and three) pedestrians at exactly the same distance from a robot: the sort key ties, and the reference's stable
     Python sort keeps them in index order (yaml_env.py:451) -- the register sort's key-only fast path must notice and fall back"""

@@ -74,6 +74,7 @@ for s in range(K):
         elapsed = 0
 want = full.snapshot() if events[-1][0] == "step" else None
 frozen_full = float(((want["is_collisions"] != 0) | (want["is_arrives"] != 0)).mean()) if want else None
+frozen_local = float(((want["is_collisions"][:RL] != 0) | (want["is_arrives"][:RL] != 0)).mean()) if want else None
 full_mode = full.layer_mode()
 full.close()
 
@@ -144,11 +145,16 @@ def run_one():
 
 run_one()
 us_one = 1e6 * sorted(run_one() for _ in range(5))[2] / K
+snap1 = one.snapshot()
+frozen_one = float(((snap1["is_collisions"] != 0) | (snap1["is_arrives"] != 0)).mean())
 one_mode = one.layer_mode()
 one.close()
 line = dict(probe="rank 0 of %d of %s on one GPU" % (N, args.cfg), robots_world=R, robots_local=RL, robots_remote=R - RL, peds=P, policy=args.policy,
             steps=K, time_max=args.time_max, us_per_step_shard=us_shard, us_per_step_unsharded_8192=us_one, ratio=us_shard / us_one,
-            shard_matches_whole_world=ok, frozen_fraction_at_the_end=frozen_full, per_rank_kernel_us=kernel_us, launches_per_step=launches,
+            shard_matches_whole_world=ok, frozen_fraction_at_the_end=frozen_full, frozen_fraction_of_the_shards_robots=frozen_local,
+            frozen_fraction_of_the_unsharded_world=frozen_one,
+            note="a frozen robot (collided or arrived) skips its view: compare the two step times only beside their frozen fractions -- cfg-4's "
+                 "65 536-robot world on 0.5 m cells is dense enough for most robots to stand in another robot's cells from the reset on", per_rank_kernel_us=kernel_us, launches_per_step=launches,
             shard_mode=shard_mode, whole_world_mode=full_mode, unsharded_mode=one_mode, exchange_bytes_per_step=64 * R,
             exchange_stand_in="device-to-device copy of the %d remote records between step_begin and step_end" % (R - RL),
             build_id=build_id)
