@@ -39,7 +39,7 @@ if args.cfg == "cfg4":
     layout.ped_pose[:, :2] = rng.uniform(0.5, 9.5, (P, 2))
     layout.ped_traj[:, :, :2] = rng.uniform(0.5, 9.5, layout.ped_traj[:, :, :2].shape)
     layout.ped_goal[:] = rng.uniform(0.5, 9.5, (P, 2))
-# (time_max far away: the probe never resets, and robots that their time limit has stopped neither move nor rasterise)
+# (time_max far away: the probe never resets)
 w = World(worldgen.make_params(R, P, res=c["res"], view_cells=c["view_cells"], beams=c["beams"], scene=c["scene"], time_max=10 ** 7, **over), grid)
 w.reset(layout)
 a = torch.zeros(R, 3, device="cuda")

@@ -18,8 +18,7 @@ READY = not (len(sys.argv) > 2 and sys.argv[2] == "plain")
 R, P = 8192, 200
 grid = worldgen.make_grid(400, 0)
 layout = worldgen.make_layout(grid, 0.25, R, P, seed=100, clearance=0.7)
-# (time_max far away: with the default 100 every robot is stopped by its time limit after 100 steps -- no move, no raster --
-# and the 2000 warm-up steps below would leave a world of statues to be timed: rounds 1-5's probe numbers were ~2 % flattering)
+# (time_max far away: the probe never resets)
 w = World(dict(worldgen.make_params(R, P, res=0.25, view_cells=48, beams=360, scene="rvoscene", time_max=10 ** 7), flags=FLAGS), grid)
 w.reset(layout)
 a = torch.zeros(R, 3, device="cuda")
