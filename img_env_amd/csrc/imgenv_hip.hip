@@ -1353,6 +1353,7 @@ extern "C" int imgenv_create(const imgenv_cfg* cfg, const uint8_t* static_map, i
         }
         h->gates_work = gates_work == 1;
     }
+    d.view_prio = (P == 0 || (h->early && h->gates_work && h->NA > 0 && h->obs_E >= 1 && h->obs_E <= 4)) ? 1 : 0;  // (world.h)
     HIPCHK_H(hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_H(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK_H(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));

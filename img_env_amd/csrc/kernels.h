@@ -331,15 +331,17 @@ __device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l,
 // Optional per-phase cycle accounting (build with -DIMGENV_PHASE_PROFILE): lane 0 of every wave adds
 // the shader-clock cycles of each phase to w.prof[slot]; tools/phase_profile.py prints the split.
 #if defined(IMGENV_PHASE_PROFILE) || defined(IMGENV_WAVE_TIMELINE)
-#define WAVE_T0() const unsigned long long wave_t0_ = wall_clock64()
+// (IMGENV_WAVE_TIMELINE alone: the phase marks record when THIS wavefront passed them, 10 ns ticks since its start, 16 bits each,
+// in the upper halves of the two hardware-id words: marks 0..3 of the kernel in order)
+#define WAVE_T0() const unsigned long long wave_t0_ = wall_clock64(); unsigned long long wave_ph_ = 0; int wave_nph_ = 0; (void)wave_ph_; (void)wave_nph_
 #define WAVE_DONE(base)                                                                   \
     do {                                                                                  \
         if (lane_id() == 0) {                                                             \
             unsigned long long* p_ = w.prof + 16 + (size_t)(base) * 4 * w.RL + 4 * (size_t)blockIdx.x; \
             p_[0] = wave_t0_;                                                             \
             p_[1] = wall_clock64();                                                       \
-            p_[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));          \
-            p_[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));         \
+            p_[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((wave_ph_ & 0xFFFFFFFFull) << 32);  \
+            p_[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) | (wave_ph_ & 0xFFFFFFFF00000000ull); \
         }                                                                                 \
     } while (0)
 #else
@@ -354,10 +356,30 @@ __device__ __forceinline__ void tail_arrive_obs(const DevWorld& w, int t, int l,
         if (lane_id() == 0) atomicAdd((unsigned long long*)&w.prof[slot], (unsigned long long)(now_ - ph_t_)); \
         ph_t_ = now_;                                                                     \
     } while (0)
+#elif defined(IMGENV_WAVE_TIMELINE)
+#define PHASE_BEGIN() WAVE_T0()
+#define PHASE_MARK(slot)                                                                  \
+    do {                                                                                  \
+        if (wave_nph_ < 4) wave_ph_ |= (unsigned long long)min(wall_clock64() - wave_t0_, 0xFFFFull) << (16 * wave_nph_); \
+        wave_nph_++;                                                                      \
+    } while (0)
 #else
 #define PHASE_BEGIN() WAVE_T0()
 #define PHASE_MARK(slot) (void)0
 #endif
+// k_view's issue priority by phase (world.h: view_prio).  All 8192 wavefronts of a headline launch start within 2 us and the SIMD's
+// arbiter serves the oldest first: the eight wavefronts of a SIMD drift apart -- the first is done after 33 us, the last after 49
+// (tools/wave_timeline.py) -- and for the last third of the kernel the SIMDs run at falling occupancy, where a wavefront is bound
+// by its own round trips.  A wavefront that is BEHIND (in an earlier phase) asks for the issue slot first: collision + crop 3,
+// first hits 2, final pass 1, the resolve 0.  Same work, 50.6 -> 46 us (round 6: 94.7 -> 90.2 us per headline step).
+// (Not in the four-wavefront variant: its launches -- cfg-5, LDS-bound views -- run beside a long k_obs and never set view_prio;
+// the dead branches alone cost cfg-5 2 % in registers spilled elsewhere.)
+#define VIEW_PRIO(level)                                                    \
+    do {                                                                    \
+        if constexpr (NW != 4) {                                            \
+            if (w.view_prio) __builtin_amdgcn_s_setprio(level);             \
+        }                                                                   \
+    } while (0)
 // -DIMGENV_PHASE_PROFILE -DIMGENV_PROFILE_RASTER: the marks inside k_raster's robot blocks instead of k_orca's (they share slots)
 #if defined(IMGENV_PHASE_PROFILE) && defined(IMGENV_PROFILE_RASTER)
 #define RASTER_MARK_BEGIN() long long rm_t_ = clock64()
@@ -2212,6 +2234,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     int* skip_cnt = (int*)(colt + Wv);  // [0] list entries (NW > 1), [1] chunk descriptors, [2] result slots of the final pass
     uint32_t* reach_tab = (uint32_t*)(skip_cnt + 4);  // largest hit word of overlapping blocks of 16 / 32 / 64 beams (filter of (5))
     PHASE_BEGIN();
+    VIEW_PRIO(3);
     EXP_SKEW();
 
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
@@ -2340,6 +2363,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     }
     __syncthreads();
     PHASE_MARK(1);
+    VIEW_PRIO(2);
     EXP_STOP_AFTER(1);  // instruction accounting builds: collision + crop only
 
     // (3) laser (agent.cpp:405-438): first occupied cell on each beam's precomputed Bresenham path
@@ -2405,6 +2429,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
         for (int i = tid; i < n2; i += NT) reach_tab[n0 + n1 + i] = max(reach_tab[n0 + 2 * i], reach_tab[n0 + min(2 * i + 2, n1 - 1)]);
     }
     PHASE_MARK(2);
+    VIEW_PRIO(1);
     EXP_STOP_AFTER(2);  // ... + first hits
 
     // (4) laser_map (agent.cpp:437) per cell from its top beam, the own footprint stamped 100 (agent.cpp:503),
@@ -2509,6 +2534,7 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     } else {
         n_skip = __builtin_amdgcn_readfirstlane(n_skip);  // lane 0 ran every round of the loop above
     }
+    VIEW_PRIO(0);
     if (n_skip > 0) {
         __builtin_amdgcn_s_waitcnt(0);  // the provisional stores of this wave have landed
         __syncthreads();

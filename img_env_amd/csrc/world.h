@@ -200,6 +200,10 @@ struct DevWorld {
     // all while its cells stay.  Local robots count with index l + 1 in the word's index field, remote ones with 0: "the only
     // robot on the cell is me" stays one compare.  No owner layers, no k_compose, no bounding box of the shard.
     int sum_shard;
+    // k_view raises the issue priority of wavefronts that are behind (kernels.h: VIEW_PRIO): on handles whose observation is over when
+    // the views start -- no pedestrians, or early-observation steps with an RVO crowd of at most 256 (headline, cfg-2).  Where k_obs or
+    // the social-force chain run BESIDE the views (cfg-4, cfg-5) it takes the issue slots they need: cfg-4 108 -> 115, cfg-5 275 -> 281 us
+    int view_prio;
     int act_g0;              // first robot (world-wide index) of a raster launch over the robots [act_g0, act_g0 + act_ng)
     int rm_rad;                   // the bitmaps' radius box_rad - 2 when every robot class has the same one, else -1
     unsigned long long* rm_bits;  // [R] the bitmap each robot of ANOTHER rank currently counts itself on ...

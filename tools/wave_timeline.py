@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 so = os.path.join(g.CSRC, "libimgenv_hip_tl.so")
-subprocess.check_call(g.hip_command(so, ["-DIMGENV_WAVE_TIMELINE"]))
+subprocess.check_call(g.hip_command(so, ["-DIMGENV_WAVE_TIMELINE"] + os.environ.get("IMGENV_TL_FLAGS", "").split()))  # (IMGENV_TL_FLAGS: more -D switches)
 from img_env_amd import _cabi, worldgen  # noqa: E402
 _cabi.library_path = lambda: so
 import torch  # noqa: E402
@@ -31,6 +31,8 @@ for s in range(12):
     w.step(a)
 buf = np.zeros(12 * R, dtype=np.uint64)
 w.lib.imgenv_debug_waves(w.h, buf.ctypes.data_as(C.c_void_p))
+if os.path.isdir(os.path.join(ROOT, "gpurun_out")):  # the raw records, for a closer look offline
+    np.savez_compressed(os.path.join(ROOT, "gpurun_out", "wave_timeline.npz"), rec=buf, robot_pose=np.asarray(layout.robot_pose), n_robots=R)
 for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 * R].reshape(R, 4)), ("k_raster", buf[8 * R:].reshape(R, 4))):
     t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
     ok = (t1 > 0) & (t0 > t0.max() - 6000)  # this launch only (60 us back from the last start): frozen robots keep an older record
@@ -45,8 +47,17 @@ for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 *
     print("   starts histogram (5 us bins): " + " ".join(str(int(x)) for x in np.histogram(s, bins=np.arange(0, s.max() + 5, 5))[0]))
     ts = np.linspace(0, e.max(), 11)[1:-1]
     print("   resident waves at " + " ".join("%.0fus:%d" % (t, ((s <= t) & (e > t)).sum()) for t in ts))
-    hw = rec[ok, 2]
+    ph = np.stack([((rec[ok, 2] >> np.uint64(32)) & np.uint64(0xFFFF)), ((rec[ok, 2] >> np.uint64(48)) & np.uint64(0xFFFF)),
+                   ((rec[ok, 3] >> np.uint64(32)) & np.uint64(0xFFFF)), ((rec[ok, 3] >> np.uint64(48)) & np.uint64(0xFFFF))], 1).astype(np.float64) / 100.0
+    if ph.max() > 0:  # when each wavefront passed the kernel's phase marks (us since its start): all, and the slowest / fastest tenth
+        n_ph = int((ph.max(axis=0) > 0).sum())
+        seg = np.diff(np.concatenate([np.zeros((ph.shape[0], 1)), ph[:, :n_ph], d[:, None]], 1), axis=1)
+        order = np.argsort(d)
+        k10 = max(len(d) // 10, 1)
+        for label, idx in (("all", order), ("fastest tenth", order[:k10]), ("slowest tenth", order[-k10:])):
+            print("   phase lengths us (%s): %s | life %.1f" % (label, " ".join("%.1f" % x for x in seg[idx].mean(axis=0)), d[idx].mean()))
+    hw = rec[ok, 2] & np.uint64(0xFFFFFFFF)
     cu = (hw >> 8) & 0xF
     se = (hw >> 13) & 0x7
-    xcc = rec[ok, 3] & 0xF
+    xcc = rec[ok, 3] & np.uint64(0xF)
     print("   distinct (xcc,se,cu): %d" % len(set(zip(xcc.tolist(), se.tolist(), cu.tolist()))))
