@@ -22,18 +22,32 @@ from img_env_amd.world import World  # noqa: E402
 R, P, res = 8192, 200, 0.25
 grid = worldgen.make_grid(400, 0)
 layout = worldgen.make_layout(grid, res, R, P, seed=100, clearance=0.7)
-w = World(worldgen.make_params(R, P, res=res, scene="rvoscene"), grid)
+w = World(dict(worldgen.make_params(R, P, res=res, scene="rvoscene", time_max=10 ** 7), output_guard="none"), grid)  # (no guard: its checks synchronise)
 w.lib.imgenv_debug_waves.argtypes = [C.c_void_p, C.c_void_p]
 w.reset(layout)
 a = torch.zeros(R, 3, device="cuda")
 a[:, 1] = torch.rand(R, device="cuda") * 1.8 - 0.9
-for s in range(12):
+for s in range(400):  # (the host queues far ahead of the device, as in a timed loop: the records are the LAST step's, whose launches were all queued long before)
     w.step(a)
 buf = np.zeros(12 * R, dtype=np.uint64)
 w.lib.imgenv_debug_waves(w.h, buf.ctypes.data_as(C.c_void_p))
 if os.path.isdir(os.path.join(ROOT, "gpurun_out")):  # the raw records, for a closer look offline
     np.savez_compressed(os.path.join(ROOT, "gpurun_out", "wave_timeline.npz"), rec=buf, robot_pose=np.asarray(layout.robot_pose), n_robots=R)
-for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 * R].reshape(R, 4)), ("k_raster", buf[8 * R:].reshape(R, 4))):
+# the three kernels on ONE clock (wall_clock64 is the chip's): who holds the slots when, relative to the observation's first wavefront
+def _span(rec):
+    t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
+    ok = (t1 > 0) & (t0 > t0.max() - 8000)
+    return t0[ok], t1[ok]
+_k = {"k_obs": _span(buf[4 * R:8 * R].reshape(R, 4)), "k_raster": _span(buf[8 * R:12 * R].reshape(R, 4)), "k_view": _span(buf[:4 * R].reshape(R, 4))}
+_base = _k["k_obs"][0].min()
+for nm, (a0, a1) in _k.items():
+    print("%-12s first start %6.1f  p50 start %6.1f  last start %6.1f | first end %6.1f  p50 end %6.1f  last end %6.1f  (us after k_obs's first wavefront)" % (
+        nm, (a0.min() - _base) / 100, (np.median(a0) - _base) / 100, (a0.max() - _base) / 100, (a1.min() - _base) / 100, (np.median(a1) - _base) / 100, (a1.max() - _base) / 100))
+print("resident wavefronts every 4 us: t | " + " ".join(_k))
+for t in range(-8, 100, 4):
+    tt = _base + t * 100
+    print("  %4d | %s" % (t, " ".join("%6d" % (((a0 <= tt) & (a1 > tt)).sum()) for a0, a1 in _k.values())))
+for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 * R].reshape(R, 4)), ("k_raster", buf[8 * R:12 * R].reshape(R, 4))):
     t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
     ok = (t1 > 0) & (t0 > t0.max() - 6000)  # this launch only (60 us back from the last start): frozen robots keep an older record
     xc = (rec[:, 3] & 0xF).astype(np.int64)
