@@ -19,10 +19,11 @@ _cabi.library_path = lambda: so
 import torch  # noqa: E402
 from img_env_amd.world import World  # noqa: E402
 
-R, P, res = 8192, 200, 0.25
+CFG = sys.argv[1] if len(sys.argv) > 1 else "cfg3"  # cfg3 (the headline) | cfg2 (1024 robots, no pedestrians: eight wavefronts per view)
+R, P, res, scene, clearance = (1024, 0, 0.125, "", 1.0) if CFG == "cfg2" else (8192, 200, 0.25, "rvoscene", 0.7)
 grid = worldgen.make_grid(400, 0)
-layout = worldgen.make_layout(grid, res, R, P, seed=100, clearance=0.7)
-w = World(dict(worldgen.make_params(R, P, res=res, scene="rvoscene", time_max=10 ** 7), output_guard="none"), grid)  # (no guard: its checks synchronise)
+layout = worldgen.make_layout(grid, res, R, P, seed=100, clearance=clearance)
+w = World(dict(worldgen.make_params(R, P, res=res, scene=scene, time_max=10 ** 7), output_guard="none"), grid)  # (no guard: its checks synchronise)
 w.lib.imgenv_debug_waves.argtypes = [C.c_void_p, C.c_void_p]
 w.reset(layout)
 a = torch.zeros(R, 3, device="cuda")
@@ -39,9 +40,10 @@ def _span(rec):
     ok = (t1 > 0) & (t0 > t0.max() - 8000)
     return t0[ok], t1[ok]
 _k = {"k_obs": _span(buf[4 * R:8 * R].reshape(R, 4)), "k_raster": _span(buf[8 * R:12 * R].reshape(R, 4)), "k_view": _span(buf[:4 * R].reshape(R, 4))}
-_base = _k["k_obs"][0].min()
+_k = {nm: v for nm, v in _k.items() if len(v[0])}
+_base = min(v[0].min() for v in _k.values()) if "k_obs" not in _k else _k["k_obs"][0].min()
 for nm, (a0, a1) in _k.items():
-    print("%-12s first start %6.1f  p50 start %6.1f  last start %6.1f | first end %6.1f  p50 end %6.1f  last end %6.1f  (us after k_obs's first wavefront)" % (
+    print("%-12s first start %6.1f  p50 start %6.1f  last start %6.1f | first end %6.1f  p50 end %6.1f  last end %6.1f  (us after the first wavefront of k_obs, or of all)" % (
         nm, (a0.min() - _base) / 100, (np.median(a0) - _base) / 100, (a0.max() - _base) / 100, (a1.min() - _base) / 100, (np.median(a1) - _base) / 100, (a1.max() - _base) / 100))
 print("resident wavefronts every 4 us: t | " + " ".join(_k))
 for t in range(-8, 100, 4):
@@ -49,6 +51,8 @@ for t in range(-8, 100, 4):
     print("  %4d | %s" % (t, " ".join("%6d" % (((a0 <= tt) & (a1 > tt)).sum()) for a0, a1 in _k.values())))
 for name, rec in (("k_view", buf[:4 * R].reshape(R, 4)), ("k_obs", buf[4 * R:8 * R].reshape(R, 4)), ("k_raster", buf[8 * R:12 * R].reshape(R, 4))):
     t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
+    if not (t1 > 0).any():
+        continue  # (not launched on this handle)
     ok = (t1 > 0) & (t0 > t0.max() - 6000)  # this launch only (60 us back from the last start): frozen robots keep an older record
     xc = (rec[:, 3] & 0xF).astype(np.int64)
     print("   per-XCC first start (ticks): " + " ".join(str(int(t0[ok & (xc == x)].min() - t0[ok].min())) for x in sorted(set(xc[ok].tolist()))))
