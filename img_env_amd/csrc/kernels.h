@@ -2196,6 +2196,18 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     if ((int)blockIdx.x >= act_count_l(w)) return;
     const int l = act_member(w, w.Rw, blockIdx.x);
     const int lane = lane_id();
+    // The collision test's chain -- how many cells the footprint covers, the cells, their words -- is three dependent round trips
+    // that need nothing but l: on their way from here, underneath the prologue's own (flags, class record, pose), instead of behind them
+    const int n_cov = w.fp_n[l];
+    const uint2* fp_list = w.fp_cells + (size_t)l * w.fp_cap;
+    // (the list entry without waiting for the count -- a lane beyond it reads an old entry or the neighbour's, clamped into the layer;
+    // the four-wavefront variant waits for it: on cfg-5's 800 x 800 layer the stray gathers of four wavefronts cost it 2.5 %)
+    uint2 ce_first = make_uint2(0u, 0u);
+    uint32_t v_first = 0u;
+    if (NW != 4 || lane < n_cov) {
+        ce_first = fp_list[min(lane, w.fp_cap - 1)];
+        v_first = w.cell[min(ce_first.x, (uint32_t)(w.W > 1 ? w.W : 1) * w.Gs - 1u)];
+    }
     // the robot's record as this chain leaves it, where the next step's early k_obs finds it while the move rewrites the original (world.h)
     if (w.rec_snap_out && tid < IMGENV_RECORD_DOUBLES) {
         const double v = w.rec[(size_t)(w.r0 + l) * IMGENV_RECORD_DOUBLES + tid];
@@ -2240,12 +2252,10 @@ __global__ __launch_bounds__(WAVE * NW) __attribute__((amdgpu_waves_per_eu(8, 8)
     // (1) is_collision_ = draw(grid, -1, "world_map", bbox_): the LAST footprint sample that hits decides
     //     the code (agent.cpp:294-326) -> max over (last sample index in the cell, code) of the covered cells
     uint32_t best = 0;
-    const int n_cov = w.fp_n[l];
     if (n_cov >= 0) {
-        const uint2* list = w.fp_cells + (size_t)l * w.fp_cap;
         for (int e = lane; e < n_cov; e += WAVE) {
-            const uint2 ce = list[e];
-            const uint32_t v = w.cell[ce.x];
+            const uint2 ce = e == lane ? ce_first : fp_list[e];
+            const uint32_t v = e == lane ? v_first : w.cell[ce.x];
             const uint32_t cc = layer_sum ? cell_seen_class_sum(w, v, self_w) : cell_seen_class<STAMP>(v, self, stamp_tag_of(w));
             best = max(best, cc <= 2 ? ((ce.y << 2) | (cc + 1)) : 0u);
         }

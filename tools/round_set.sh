@@ -7,7 +7,7 @@
 #   3. the bench line of every config (`roofline.traffic` from those counters: same build id), on the same box
 #   4. rank 0 of the 8-GPU layouts of cfg-4 and cfg-3 (tools/shard_probe.py)
 #   5. the whole GPU test-suite and smoke()
-tag=${1:-r6_97}
+tag=${1:-r6_98}
 set -x
 cd /root/repo
 for c in "cfg3 sq" "cfg2" "cfg4" "cfg5 sq"; do bash tools/profile_cfg.sh $tag $c; done

@@ -7,7 +7,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r6_97"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6_98"
 
 
 def load(path):
